@@ -1,0 +1,127 @@
+/*
+ * wc_hip.h -- C ABI of libwc_hip.so: the MI355X (gfx950) whitening-and-coloring hot path.
+ *
+ * The reference has no FFI boundary for this path: it sits behind the Keras 2.0.8 Layer
+ * protocol.  Each entry point below names the reference call site /
+ * op group it replaces:
+ *
+ *   wc_stats_f32        DecorelationNormalization.call, train mode, the transpose + mean +
+ *                       centre + f f^T/(M-1) part            (class imported generator.py:9,
+ *                       instantiated generator.py:24,26; body in the un-vendored gan/ submodule)
+ *   wc_factor_f64       same call: (1-eps)Sigma+eps I, tf.cholesky, tf.matrix_triangular_solve
+ *                       against I, and the moving_mean / moving_cov add_update ops; eval mode
+ *                       (scorer.py:60,72) takes the moving statistics instead
+ *   wc_color_f32        folds the coloring kernels into the whitening matrix:
+ *                       Conv2D 1x1 (generator.py:50-51), ConditionalConv11 (generator.py:52-60),
+ *                       FactorizedConv11 (generator.py:69-78), CenterScale variants
+ *                       (generator.py:28-40)  ->  A_k = W^T Gamma_k
+ *   wc_apply_f32        W f, the transpose back, and the 1x1-conv coloring + bias + Add
+ *                       (generator.py:83-87 `stack`)            ->  y = (x - mu) A_k + beta_k
+ *   wc_bwd_reduce_f32 / wc_bwd_factor_f64 / wc_bwd_apply_f32
+ *                       the TF graph gradients of all of the above (training via
+ *                       Trainer.train(), run.py:93-94); closed form in SURVEY.md row a10
+ *
+ * Contract (all entry points):
+ *   - return 0 on success, a negative WC_ERR_* on a rejected argument, or a positive
+ *     hipError_t from the launch; nothing throws, nothing aborts.
+ *   - every pointer is DEVICE memory owned by the caller, including the workspace; the
+ *     library allocates nothing and keeps no state between calls.
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*) and never synchronises
+ *     with the host, so calls are graph-capturable and may run concurrently from several
+ *     host threads on different streams/buffers.
+ *   - x, y, gy, dx are row-major (M, C) float32 with C contiguous: an NHWC tensor viewed
+ *     as M = N*H*W rows.  C must be a multiple of 32 with 32 <= C <= 1024 (callers pad
+ *     other widths with zero channels, which leaves the real channels' result unchanged).
+ *   - matrices are row-major, symmetric ones stored in full.  "slot" is an int32 (N,)
+ *     array giving, per SAMPLE, the index into the leading axis of A / bias / gamma
+ *     (NULL = every sample uses slot 0); a sample is HW consecutive rows.
+ */
+#ifndef WC_HIP_H
+#define WC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WC_ABI_VERSION 1
+
+#define WC_OK                 0
+#define WC_ERR_NULL          -1   /* a required pointer is NULL                     */
+#define WC_ERR_SHAPE         -2   /* M/N/HW/Kc not positive, or N*HW overflows       */
+#define WC_ERR_CHANNELS      -3   /* C not a multiple of 32 in [32, 1024]            */
+#define WC_ERR_WORKSPACE     -4   /* workspace smaller than wc_*_workspace_bytes()   */
+#define WC_ERR_ARG           -5   /* eps/momentum/ddof out of range                  */
+
+typedef void* wc_stream_t;        /* hipStream_t */
+
+int         wc_abi_version(void);
+const char* wc_error_string(int code);
+
+/* Bytes of scratch each stage needs for the given problem (16-byte aligned carve inside). */
+size_t wc_stats_workspace_bytes(int64_t M, int C);
+size_t wc_factor_workspace_bytes(int C);
+size_t wc_color_workspace_bytes(int C, int Kc);
+size_t wc_bwd_reduce_workspace_bytes(int64_t N, int64_t HW, int C, int Kc, int has_slot);
+size_t wc_bwd_factor_workspace_bytes(int C, int Kc);
+
+/* K1: raw additive moments of the rows of x:  sum[c] = sum_m x[m,c],  xtx = x^T x  (float64).
+ * These are what a sync-WC data-parallel run all-reduces before wc_factor_f64. */
+int wc_stats_f32(const float* x, int64_t M, int C,
+                 double* sum /*[C]*/, double* xtx /*[C*C]*/,
+                 void* ws, size_t ws_bytes, wc_stream_t stream);
+
+/* K2: moments -> mu, Sigma; T = (1-eps)Sigma + eps I; L = chol(T); W = L^-1 (float64).
+ * training != 0: statistics come from (sum, xtx, M); if moving_mean/moving_cov are non-NULL they
+ *                are updated in place, moving <- momentum*moving + (1-momentum)*batch (un-shrunk Sigma).
+ * training == 0: mu = moving_mean, Sigma = moving_cov (sum/xtx ignored, may be NULL). */
+int wc_factor_f64(const double* sum, const double* xtx, int64_t M, int C,
+                  double eps, double momentum, int ddof, int training,
+                  float* moving_mean /*[C]*/, float* moving_cov /*[C*C]*/,
+                  float* mu /*[C] out*/, double* L /*[C*C] out*/, double* W /*[C*C] out*/,
+                  void* ws, size_t ws_bytes, wc_stream_t stream);
+
+/* A_k = W^T Gamma_k for k < Kc (float32 out), and its transpose At_k = A_k^T (what the backward
+ * apply multiplies by; At may be NULL).  gamma == NULL means Gamma = I (whitening only, Kc = 1). */
+int wc_color_f32(const double* W, const float* gamma /*[Kc,C,C] or NULL*/, int Kc, int C,
+                 float* A /*[Kc,C,C] out*/, float* At /*[Kc,C,C] out, nullable*/,
+                 void* ws, size_t ws_bytes, wc_stream_t stream);
+
+/* K3: y[n] = (x[n] - mu) A[slot[n]] + bias[slot[n]]   (bias NULL = 0; mu NULL = 0). */
+int wc_apply_f32(const float* x, const float* mu, const float* A, const float* bias,
+                 const int32_t* slot, int64_t N, int64_t HW, int C, int Kc,
+                 float* y, wc_stream_t stream);
+
+/* K4: R[k] = sum_{n: slot[n]=k} (x[n]-mu)^T gy[n]  (Kc,C,C),  gsum[k] = sum_{n in k} rows of gy[n]  (Kc,C). */
+int wc_bwd_reduce_f32(const float* x, const float* mu, const float* gy, const int32_t* slot,
+                      int64_t N, int64_t HW, int C, int Kc,
+                      double* R /*[Kc,C,C]*/, double* gsum /*[Kc,C]*/,
+                      void* ws, size_t ws_bytes, wc_stream_t stream);
+
+/* K5: dgamma[k] = W R[k];  and, when training != 0, the statistics path
+ *     Wbar = sum_k Gamma_k R_k^T;  Lbar = -tril(W^T Wbar W^T);  P = Phi(L^T Lbar);
+ *     S = 2(1-eps)/(M-ddof) sym(W^T P W)  (float32, C x C);   gmean = (1/M) sum_k gsum_k A_k^T  (C).
+ * gamma == NULL means Gamma = I.  dgamma / dbeta may be NULL (that output is skipped).  S and gmean are
+ * untouched when training == 0. */
+int wc_bwd_factor_f64(const double* R, const double* gsum, const double* W, const double* L,
+                      const float* gamma, const float* A, int Kc, int C, int64_t M,
+                      double eps, int ddof, int training,
+                      float* dgamma /*[Kc,C,C]*/, float* dbeta /*[Kc,C]*/,
+                      float* S /*[C,C]*/, float* gmean /*[C]*/,
+                      void* ws, size_t ws_bytes, wc_stream_t stream);
+
+/* K6: dx[n] = gy[n] At[slot[n]] + (x[n]-mu) S - gmean     (S, gmean NULL in eval mode: dx = gy A^T).
+ * At[k] = A[k]^T as written by wc_color_f32. */
+int wc_bwd_apply_f32(const float* gy, const float* x, const float* mu, const float* At,
+                     const float* S, const float* gmean, const int32_t* slot,
+                     int64_t N, int64_t HW, int C, int Kc, float* dx, wc_stream_t stream);
+
+/* Bandwidth yardstick used by bench.py: dst[i] = src[i] (float4 grid-stride copy), same stream rules. */
+int wc_stream_copy_f32(const float* src, float* dst, int64_t n, wc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WC_HIP_H */

@@ -1,0 +1,75 @@
+"""ctypes binding of libwc_hip.so -- the only way the Python host reaches the HIP kernels.
+
+There is deliberately no CPU or PyTorch fallback: if the library is missing or a call fails the
+host raises, so a GPU run can never silently pass on something other than the HIP path.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwc_hip.so")
+
+WC_OK = 0
+ERRORS = {-1: "WC_ERR_NULL", -2: "WC_ERR_SHAPE", -3: "WC_ERR_CHANNELS", -4: "WC_ERR_WORKSPACE", -5: "WC_ERR_ARG"}
+
+# name -> (restype, argtypes); mirrors include/wc_hip.h one to one
+SIGNATURES = {
+    "wc_abi_version": (c_int, []),
+    "wc_error_string": (c_char_p, [c_int]),
+    "wc_stats_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "wc_factor_workspace_bytes": (c_size_t, [c_int]),
+    "wc_color_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "wc_bwd_reduce_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int, c_int]),
+    "wc_bwd_factor_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "wc_stats_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wc_factor_f64": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_double, c_double, c_int, c_int,
+                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wc_color_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wc_apply_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,
+                             c_void_p, c_void_p]),
+    "wc_bwd_reduce_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,
+                                  c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wc_bwd_factor_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64,
+                                  c_double, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_size_t, c_void_p]),
+    "wc_bwd_apply_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_int64, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "wc_stream_copy_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+}
+
+_lib = None
+
+
+class WcHipError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load libwc_hip.so (once).  Raises if it has not been built -- no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise WcHipError(
+            f"{LIB_PATH} is missing: build it with `python -m wc_gan_amd.build` "
+            "(or __graft_entry__.build()); the WC path has no non-HIP fallback")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header and library out of sync
+        fn.restype = res
+        fn.argtypes = args
+    if lib.wc_abi_version() != 1:
+        raise WcHipError(f"libwc_hip.so ABI version {lib.wc_abi_version()} != 1")
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    if code == WC_OK:
+        return
+    lib = load()
+    msg = lib.wc_error_string(code)
+    raise WcHipError(f"{what} failed: {ERRORS.get(code, code)} ({msg.decode() if msg else '?'})")

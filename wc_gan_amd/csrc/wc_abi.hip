@@ -1,0 +1,291 @@
+// extern "C" entry points of libwc_hip.so (declared in include/wc_hip.h): argument checks,
+// workspace carving and the launch sequence of each stage.  Nothing here allocates, synchronises
+// or keeps state, so every entry point is stream-ordered and graph-capturable.
+#include "../../include/wc_hip.h"
+#include "wc_common.h"
+
+namespace {
+
+inline bool bad_channels(int C) { return C < 32 || C > 1024 || (C % 32) != 0; }
+
+struct Carver {
+    char* p; size_t left;
+    Carver(void* ws, size_t bytes) : p(static_cast<char*>(ws)), left(bytes) {}
+    template <typename T> T* take(size_t n) {
+        const size_t b = wc_align_up(n * sizeof(T), 256);
+        T* r = reinterpret_cast<T*>(p);
+        p += b; left = (left >= b) ? left - b : 0;
+        return r;
+    }
+};
+inline size_t slot_bytes(size_t n, size_t elem) { return wc_align_up(n * elem, 256); }
+
+#define WC_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int wc_abi_version(void) { return WC_ABI_VERSION; }
+
+const char* wc_error_string(int code)
+{
+    switch (code) {
+        case WC_OK: return "ok";
+        case WC_ERR_NULL: return "required pointer is NULL";
+        case WC_ERR_SHAPE: return "bad shape (M/N/HW/Kc must be positive)";
+        case WC_ERR_CHANNELS: return "C must be a multiple of 32 in [32, 1024]";
+        case WC_ERR_WORKSPACE: return "workspace too small";
+        case WC_ERR_ARG: return "eps/momentum/ddof out of range";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+size_t wc_stats_workspace_bytes(int64_t M, int C)
+{
+    if (M <= 0 || bad_channels(C)) return 0;
+    int nsplit; int64_t rps;
+    const int nslab = wc_xty_plan(1, M, C, 0, 1, &nsplit, &rps);
+    return slot_bytes(C, 4) + slot_bytes(C, 8) + slot_bytes((size_t)nslab * C, 4) + slot_bytes((size_t)nslab * C * C, 4);
+}
+
+int wc_stats_f32(const float* x, int64_t M, int C, double* sum, double* xtx,
+                 void* ws, size_t ws_bytes, wc_stream_t stream)
+{
+    if (!x || !sum || !xtx || !ws) return WC_ERR_NULL;
+    if (M <= 0) return WC_ERR_SHAPE;
+    if (bad_channels(C)) return WC_ERR_CHANNELS;
+    if (ws_bytes < wc_stats_workspace_bytes(M, C)) return WC_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int nsplit; int64_t rps;
+    const int nslab = wc_xty_plan(1, M, C, 0, 1, &nsplit, &rps);
+    Carver cv(ws, ws_bytes);
+    float* shift = cv.take<float>(C);
+    double* Sp = cv.take<double>(C);
+    float* colsum = cv.take<float>((size_t)nslab * C);
+    float* P = cv.take<float>((size_t)nslab * C * C);
+
+    WC_TRY(wc_launch_subsample_mean(x, M, C, shift, st));
+    WcXtyArgs a = {};
+    a.X = x; a.Y = x; a.cx = shift; a.cy = shift; a.N = 1; a.HW = M; a.per_sample = 0; a.nsplit = nsplit;
+    a.rows_per_slab = rps; a.C = C; a.sym = 1; a.P = P; a.colsum = colsum;
+    WC_TRY(wc_launch_xty(a, nslab, st));
+    WC_TRY(wc_launch_stats_finalize(P, colsum, shift, nslab, M, C, Sp, sum, xtx, st));
+    return WC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+size_t wc_factor_workspace_bytes(int C)
+{
+    if (bad_channels(C)) return 0;
+    return slot_bytes((size_t)C * C, 8);
+}
+
+int wc_factor_f64(const double* sum, const double* xtx, int64_t M, int C, double eps, double momentum, int ddof,
+                  int training, float* moving_mean, float* moving_cov, float* mu, double* L, double* W,
+                  void* ws, size_t ws_bytes, wc_stream_t stream)
+{
+    if (!mu || !L || !W || !ws) return WC_ERR_NULL;
+    if (training && (!sum || !xtx)) return WC_ERR_NULL;
+    if (!training && (!moving_mean || !moving_cov)) return WC_ERR_NULL;
+    if (bad_channels(C)) return WC_ERR_CHANNELS;
+    if (training && (M <= ddof || M <= 0)) return WC_ERR_SHAPE;
+    if (!(eps > 0.0) || eps >= 1.0 || momentum < 0.0 || momentum > 1.0 || ddof < 0 || ddof > 1) return WC_ERR_ARG;
+    if (ws_bytes < wc_factor_workspace_bytes(C)) return WC_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Carver cv(ws, ws_bytes);
+    double* tmp = cv.take<double>((size_t)C * C);
+    WC_TRY(wc_launch_factor_prepare(sum, xtx, M, C, eps, momentum, ddof, training, moving_mean, moving_cov, mu, L, st));
+    WC_TRY(wc_launch_cholesky(L, C, st));
+    WC_TRY(wc_launch_tri_inverse(L, W, tmp, C, st));
+    return WC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+size_t wc_color_workspace_bytes(int C, int Kc)
+{
+    (void)Kc;
+    if (bad_channels(C)) return 0;
+    return 256;     // none needed today; kept in the ABI so a caller never has to change
+}
+
+int wc_color_f32(const double* W, const float* gamma, int Kc, int C, float* A, float* At,
+                 void* ws, size_t ws_bytes, wc_stream_t stream)
+{
+    (void)ws; (void)ws_bytes;
+    if (!W || !A) return WC_ERR_NULL;
+    if (bad_channels(C)) return WC_ERR_CHANNELS;
+    if (Kc <= 0 || (!gamma && Kc != 1)) return WC_ERR_SHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!gamma) {
+        WC_TRY(wc_launch_transpose_to_f32(W, C, A, At, st));
+        return WC_OK;
+    }
+    const int64_t CC = (int64_t)C * C;
+    WcGemm g = {};
+    g.A = W; g.a_rs = 1; g.a_cs = C; g.a_bs = 0;                         // W^T
+    g.B = gamma; g.b_is_f32 = 1; g.b_rs = C; g.b_cs = 1; g.b_bs = CC;
+    g.Cm = A; g.c_is_f32 = 1; g.c_rs = C; g.c_cs = 1; g.c_bs = CC;
+    g.Cm2 = At; g.c2_rs = 1; g.c2_cs = C; g.c2_bs = CC;
+    g.m = C; g.n = C; g.k = C; g.batch = Kc; g.nred = 1; g.alpha = 1.0; g.epi = WC_EPI_NONE;
+    WC_TRY(wc_launch_gemm(g, st));
+    return WC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int wc_apply_f32(const float* x, const float* mu, const float* A, const float* bias, const int32_t* slot,
+                 int64_t N, int64_t HW, int C, int Kc, float* y, wc_stream_t stream)
+{
+    if (!x || !A || !y) return WC_ERR_NULL;
+    if (N <= 0 || HW <= 0 || Kc <= 0) return WC_ERR_SHAPE;
+    if (bad_channels(C)) return WC_ERR_CHANNELS;
+    WcRowsGemmArgs a = {};
+    a.in[0] = x; a.center[0] = mu; a.B[0] = A; a.B_slot_stride[0] = (int64_t)C * C;
+    a.bias = bias; a.sub = nullptr; a.slot = slot; a.N = N; a.HW = HW; a.C = C; a.nstreams = 1; a.out = y;
+    WC_TRY(wc_launch_rows_gemm(a, static_cast<hipStream_t>(stream)));
+    return WC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+size_t wc_bwd_reduce_workspace_bytes(int64_t N, int64_t HW, int C, int Kc, int has_slot)
+{
+    (void)Kc;
+    if (N <= 0 || HW <= 0 || bad_channels(C)) return 0;
+    int nsplit; int64_t rps;
+    const int nslab = has_slot ? wc_xty_plan(N, HW, C, 1, 0, &nsplit, &rps) : wc_xty_plan(1, N * HW, C, 0, 0, &nsplit, &rps);
+    return slot_bytes((size_t)nslab * C, 4) + slot_bytes((size_t)nslab * C * C, 4);
+}
+
+int wc_bwd_reduce_f32(const float* x, const float* mu, const float* gy, const int32_t* slot,
+                      int64_t N, int64_t HW, int C, int Kc, double* R, double* gsum,
+                      void* ws, size_t ws_bytes, wc_stream_t stream)
+{
+    if (!x || !gy || !R || !gsum || !ws) return WC_ERR_NULL;
+    if (N <= 0 || HW <= 0 || Kc <= 0 || (!slot && Kc != 1)) return WC_ERR_SHAPE;
+    if (bad_channels(C)) return WC_ERR_CHANNELS;
+    if (ws_bytes < wc_bwd_reduce_workspace_bytes(N, HW, C, Kc, slot != nullptr)) return WC_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int per_sample = slot != nullptr;
+    int nsplit; int64_t rps;
+    const int nslab = per_sample ? wc_xty_plan(N, HW, C, 1, 0, &nsplit, &rps) : wc_xty_plan(1, N * HW, C, 0, 0, &nsplit, &rps);
+    Carver cv(ws, ws_bytes);
+    float* colsum = cv.take<float>((size_t)nslab * C);
+    float* P = cv.take<float>((size_t)nslab * C * C);
+    WcXtyArgs a = {};
+    a.X = x; a.Y = gy; a.cx = mu; a.cy = nullptr;
+    if (per_sample) { a.N = N; a.HW = HW; } else { a.N = 1; a.HW = N * HW; }
+    a.per_sample = per_sample; a.nsplit = nsplit; a.rows_per_slab = rps; a.C = C; a.sym = 0; a.P = P; a.colsum = colsum;
+    WC_TRY(wc_launch_xty(a, nslab, st));
+    WC_TRY(wc_launch_bwd_combine(P, colsum, slot, N, nsplit, per_sample, C, Kc, R, gsum, st));
+    return WC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+size_t wc_bwd_factor_workspace_bytes(int C, int Kc)
+{
+    (void)Kc;
+    if (bad_channels(C)) return 0;
+    return 3 * slot_bytes((size_t)C * C, 8);
+}
+
+int wc_bwd_factor_f64(const double* R, const double* gsum, const double* W, const double* L,
+                      const float* gamma, const float* A, int Kc, int C, int64_t M, double eps, int ddof, int training,
+                      float* dgamma, float* dbeta, float* S, float* gmean,
+                      void* ws, size_t ws_bytes, wc_stream_t stream)
+{
+    if (!R || !gsum || !W || !ws) return WC_ERR_NULL;
+    if (training && (!L || !A || !S || !gmean)) return WC_ERR_NULL;
+    if (bad_channels(C)) return WC_ERR_CHANNELS;
+    if (Kc <= 0 || (!gamma && Kc != 1) || (training && M <= ddof)) return WC_ERR_SHAPE;
+    if (ws_bytes < wc_bwd_factor_workspace_bytes(C, Kc)) return WC_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t CC = (int64_t)C * C;
+    Carver cv(ws, ws_bytes);
+    double* buf0 = cv.take<double>(CC);
+    double* buf1 = cv.take<double>(CC);
+    double* buf2 = cv.take<double>(CC);
+
+    auto sq = [&](const void* Am, int a32, int64_t ars, int64_t acs, const void* Bm, int b32, int64_t brs, int64_t bcs,
+                  void* Cm, int c32, double alpha, int epi) {
+        WcGemm g = {};
+        g.A = Am; g.a_is_f32 = a32; g.a_rs = ars; g.a_cs = acs;
+        g.B = Bm; g.b_is_f32 = b32; g.b_rs = brs; g.b_cs = bcs;
+        g.Cm = Cm; g.c_is_f32 = c32; g.c_rs = C; g.c_cs = 1;
+        g.m = C; g.n = C; g.k = C; g.batch = 1; g.nred = 1; g.alpha = alpha; g.epi = epi;
+        return g;
+    };
+
+    if (dgamma && gamma) {                          // dgamma[k] = W R[k]
+        WcGemm g = sq(W, 0, C, 1, R, 0, C, 1, dgamma, 1, 1.0, WC_EPI_NONE);
+        g.a_bs = 0; g.b_bs = CC; g.c_bs = CC; g.batch = Kc;
+        WC_TRY(wc_launch_gemm(g, st));
+    }
+    if (dbeta) WC_TRY(wc_launch_f64_to_f32(gsum, dbeta, (int64_t)Kc * C, st));
+    if (!training) return WC_OK;
+
+    const double* Wbar; int64_t wb_rs, wb_cs;
+    if (gamma) {                                    // Wbar = sum_k Gamma_k R_k^T
+        WcGemm g = sq(gamma, 1, C, 1, R, 0, 1, C, buf0, 0, 1.0, WC_EPI_NONE);
+        g.a_red = CC; g.b_red = CC; g.nred = Kc;
+        WC_TRY(wc_launch_gemm(g, st));
+        Wbar = buf0; wb_rs = C; wb_cs = 1;
+    } else {                                        // Gamma = I: Wbar = R^T, read through swapped strides
+        Wbar = R; wb_rs = 1; wb_cs = C;
+    }
+    {   // U1 = W^T Wbar
+        WcGemm g = sq(W, 0, 1, C, Wbar, 0, wb_rs, wb_cs, buf1, 0, 1.0, WC_EPI_NONE);
+        WC_TRY(wc_launch_gemm(g, st));
+    }
+    {   // Lbar = -tril(U1 W^T)
+        WcGemm g = sq(buf1, 0, C, 1, W, 0, 1, C, buf2, 0, -1.0, WC_EPI_TRIL);
+        WC_TRY(wc_launch_gemm(g, st));
+    }
+    {   // P = Phi(L^T Lbar)
+        WcGemm g = sq(L, 0, 1, C, buf2, 0, C, 1, buf0, 0, 1.0, WC_EPI_PHI);
+        WC_TRY(wc_launch_gemm(g, st));
+    }
+    {   // Q1 = W^T P
+        WcGemm g = sq(W, 0, 1, C, buf0, 0, C, 1, buf1, 0, 1.0, WC_EPI_NONE);
+        WC_TRY(wc_launch_gemm(g, st));
+    }
+    {   // Q2 = Q1 W
+        WcGemm g = sq(buf1, 0, C, 1, W, 0, C, 1, buf2, 0, 1.0, WC_EPI_NONE);
+        WC_TRY(wc_launch_gemm(g, st));
+    }
+    const double scale = 2.0 * (1.0 - eps) / (double)(M - ddof);
+    WC_TRY(wc_launch_sym_scale_f32(buf2, C, scale, S, st));
+    WC_TRY(wc_launch_gmean(gsum, A, Kc, C, M, gmean, st));
+    return WC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int wc_bwd_apply_f32(const float* gy, const float* x, const float* mu, const float* At, const float* S,
+                     const float* gmean, const int32_t* slot, int64_t N, int64_t HW, int C, int Kc,
+                     float* dx, wc_stream_t stream)
+{
+    if (!gy || !At || !dx) return WC_ERR_NULL;
+    if (S && !x) return WC_ERR_NULL;
+    if (N <= 0 || HW <= 0 || Kc <= 0) return WC_ERR_SHAPE;
+    if (bad_channels(C)) return WC_ERR_CHANNELS;
+    WcRowsGemmArgs a = {};
+    a.in[0] = gy; a.center[0] = nullptr; a.B[0] = At; a.B_slot_stride[0] = (int64_t)C * C;
+    a.nstreams = 1;
+    if (S) {
+        a.in[1] = x; a.center[1] = mu; a.B[1] = S; a.B_slot_stride[1] = 0;
+        a.nstreams = 2;
+    }
+    a.bias = nullptr; a.sub = gmean; a.slot = slot; a.N = N; a.HW = HW; a.C = C; a.out = dx;
+    WC_TRY(wc_launch_rows_gemm(a, static_cast<hipStream_t>(stream)));
+    return WC_OK;
+}
+
+int wc_stream_copy_f32(const float* src, float* dst, int64_t n, wc_stream_t stream)
+{
+    if (!src || !dst) return WC_ERR_NULL;
+    if (n <= 0 || (n % 4) != 0) return WC_ERR_SHAPE;
+    WC_TRY(wc_launch_stream_copy(src, dst, n, static_cast<hipStream_t>(stream)));
+    return WC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,87 @@
+// Shared declarations for the gfx950 WC kernels (internal; the public ABI is include/wc_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+typedef float  f32x4  __attribute__((ext_vector_type(4)));
+typedef float  f32x16 __attribute__((ext_vector_type(16)));
+typedef double f64x4  __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+#define WC_WAVE 64
+
+static inline size_t wc_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ----- big-tensor kernels (wc_rows.hip) ------------------------------------------------------
+
+// out[m,:] = sum_s (in_s[m,:] - center_s) * B_s[slot(m)] + bias[slot(m)] - sub        (K3: 1 stream, K6: 2)
+struct WcRowsGemmArgs {
+    const float* in[2];
+    const float* center[2];     // [C] or nullptr
+    const float* B[2];          // [slots][C][C] row-major (k, n)
+    int64_t      B_slot_stride[2];  // elements between slots (0 = shared)
+    const float* bias;          // [Kc][C] or nullptr
+    const float* sub;           // [C] or nullptr
+    const int32_t* slot;        // [N] or nullptr
+    int64_t N, HW;              // rows = N*HW; a sample is HW consecutive rows
+    int C;
+    int nstreams;
+    float* out;
+};
+hipError_t wc_launch_rows_gemm(const WcRowsGemmArgs& a, hipStream_t st);
+
+// P[z] = sum_{m in slab z} (X[m]-cx)^T (Y[m]-cy)   fp32 partials; sums of X (sym) or Y (non-sym) columns
+struct WcXtyArgs {
+    const float* X; const float* Y;      // Y == X for the symmetric (covariance) case
+    const float* cx; const float* cy;    // centers [C] or nullptr
+    int64_t N, HW;                       // slabs never cross a sample when per_sample != 0
+    int per_sample;                      // 0: slabs tile the whole M = N*HW rows; 1: nsplit slabs per sample
+    int nsplit;                          // per_sample: slabs per sample; else total slabs
+    int64_t rows_per_slab;
+    int C;
+    int sym;                             // 1: only tiles jb >= ib, column sums of X; 0: all tiles, column sums of Y
+    float* P;                            // [nslab][C][C]
+    float* colsum;                       // [nslab][C]
+};
+int  wc_xty_plan(int64_t N, int64_t HW, int C, int per_sample, int sym, int* nsplit, int64_t* rows_per_slab);  // returns nslab
+hipError_t wc_launch_xty(const WcXtyArgs& a, int nslab, hipStream_t st);
+
+hipError_t wc_launch_subsample_mean(const float* x, int64_t M, int C, float* shift, hipStream_t st);
+hipError_t wc_launch_stream_copy(const float* src, float* dst, int64_t n, hipStream_t st);
+
+// ----- small-matrix stage (wc_small.hip) -----------------------------------------------------
+
+// K1 tail: shifted fp32 partials -> raw float64 moments
+hipError_t wc_launch_stats_finalize(const float* P, const float* colsum, const float* shift, int nslab,
+                                    int64_t M, int C, double* Sp /*[C] scratch*/, double* sum, double* xtx, hipStream_t st);
+// K4 tail: per-slab partials -> per-slot float64 R, gsum
+hipError_t wc_launch_bwd_combine(const float* P, const float* colsum, const int32_t* slot, int64_t N, int nsplit,
+                                 int per_sample, int C, int Kc, double* R, double* gsum, hipStream_t st);
+
+hipError_t wc_launch_factor_prepare(const double* sum, const double* xtx, int64_t M, int C, double eps, double momentum,
+                                    int ddof, int training, float* moving_mean, float* moving_cov, float* mu,
+                                    double* T, hipStream_t st);
+hipError_t wc_launch_cholesky(double* T, int C, hipStream_t st);                     // in place: lower factor, upper zeroed
+hipError_t wc_launch_tri_inverse(const double* L, double* W, double* tmp, int C, hipStream_t st);   // W = L^-1 (lower), upper zeroed
+
+// generic small batched GEMM in float64 on the f64 MFMA:  Cm[b] = alpha * sum_r opA[b,r] opB[b,r]  (+ epilogue)
+enum WcEpi { WC_EPI_NONE = 0, WC_EPI_TRIL = 1, WC_EPI_PHI = 2 };
+struct WcGemm {
+    const void* A; int a_is_f32; int64_t a_rs, a_cs, a_bs, a_red;   // element strides: row, col, batch, reduce
+    const void* B; int b_is_f32; int64_t b_rs, b_cs, b_bs, b_red;
+    void* Cm; int c_is_f32; int64_t c_rs, c_cs, c_bs;
+    void* Cm2; int64_t c2_rs, c2_cs, c2_bs;                          // optional second (float) output, e.g. the transpose
+    int m, n, k;            // multiples of 32
+    int batch, nred;
+    double alpha;
+    int epi;
+};
+hipError_t wc_launch_gemm(const WcGemm& g, hipStream_t st);
+
+hipError_t wc_launch_transpose_to_f32(const double* W, int C, float* A, float* At, hipStream_t st);  // A = W^T, At = W
+hipError_t wc_launch_sym_scale_f32(const double* Q, int C, double scale, float* S, hipStream_t st);   // S = scale*(Q+Q^T)/2
+hipError_t wc_launch_gmean(const double* gsum, const float* A, int Kc, int C, int64_t M, float* gmean, hipStream_t st);
+hipError_t wc_launch_f64_to_f32(const double* src, float* dst, int64_t n, hipStream_t st);

@@ -1,0 +1,361 @@
+// Big-tensor kernels of the WC path, exact-fp32 generic versions on the f32-input MFMA
+// (v_mfma_f32_32x32x2_f32: bit-for-bit an fmaf chain, cdna_hip_programming.md section 3).
+//
+//   rows_gemm_kernel   K3 (wc_apply_f32) and K6 (wc_bwd_apply_f32):
+//                      out[m,:] = sum_s (in_s[m,:] - center_s) B_s[slot(m)] + bias[slot(m)] - sub
+//                      replaces  W f -> transpose -> Conv2D 1x1 (+ConditionalConv11/FactorizedConv11 + Add)
+//                      of generator.py:83-87 and their TF gradients.
+//   xty_kernel         K1 (wc_stats_f32) and K4 (wc_bwd_reduce_f32):
+//                      P[z] = sum_{m in slab z} (X[m]-cx)^T (Y[m]-cy), fp32 per-slab partials that the
+//                      small stage combines in float64; replaces transpose + f f^T GEMM of
+//                      DecorelationNormalization.call (generator.py:24) and its gradient reduction.
+//
+// MFMA 32x32x2 f32 operand maps: a = A[i = lane&31][k = lane>>5], b = B[k = lane>>5][j = lane&31],
+// D register r of lane l = D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].
+#include "wc_common.h"
+
+namespace {
+
+constexpr int BM = 128;      // tile rows (rows of x for rows_gemm; channel i for xty)
+constexpr int BN = 128;      // tile cols
+constexpr int BK = 32;       // depth per LDS chunk
+constexpr int AS_LD = BM + 1;   // transposed x tile [k][row]; +1 makes the 4-way-k scatter write conflict-free
+constexpr int BS_LD = BN;
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+__device__ __forceinline__ void mfma_step(const float* __restrict__ As_, int a_ld, const float* __restrict__ Bs_, int b_ld,
+                                          int kk, int lane, int arow, int bcol, bool u0, bool u1, f32x16 (&acc)[2][2])
+{
+    const int kq = kk + (lane >> 5);
+    const int l31 = lane & 31;
+    const float a0 = As_[kq * a_ld + arow + l31];
+    const float a1 = As_[kq * a_ld + arow + 32 + l31];
+    const float b0 = Bs_[kq * b_ld + bcol + l31];
+    const float b1 = Bs_[kq * b_ld + bcol + 32 + l31];
+    if (u0) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+    }
+    if (u1) {
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// rows_gemm: 128 x 128 output tile per 256-thread workgroup, 4 waves as 2 x 2, 64 x 64 per wave.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rows_gemm_kernel(WcRowsGemmArgs a, int ncb)
+{
+    __shared__ float As[BK * AS_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[BK * BS_LD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int C = a.C;
+    const int cb = blockIdx.x % ncb;
+    const int64_t rb = blockIdx.x / ncb;
+
+    int64_t row0; int rows_valid; int slot = 0;
+    if (a.slot) {
+        const int64_t bps = (a.HW + BM - 1) / BM;
+        const int64_t n = rb / bps, r = rb % bps;
+        row0 = n * a.HW + r * BM;
+        const int64_t left = a.HW - r * BM;
+        rows_valid = left < BM ? (int)left : BM;
+        slot = a.slot[n];
+    } else {
+        const int64_t M = a.N * a.HW;
+        row0 = rb * BM;
+        const int64_t left = M - row0;
+        rows_valid = left < BM ? (int)left : BM;
+    }
+    const int col0 = cb * BN;
+
+    // staging coordinates (fixed per thread): x tile 128 rows x 32 k as float4 along k; B tile 32 k x 128 cols
+    const int xkq = tid & 7;            // float4 index along k
+    const int xrow = tid >> 3;          // + 32*p
+    const int bnq = tid & 31;           // float4 index along n
+    const int bk = tid >> 5;            // + 8*p
+    const bool bcol_ok = (col0 + 4 * bnq) < C;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+    const bool u0 = (col0 + wc * 64) < C;
+    const bool u1 = (col0 + wc * 64 + 32) < C;
+
+    const int cpc = C / BK;                       // chunks per stream
+    const int nchunks = a.nstreams * cpc;
+
+    f32x4 xv[4], bv[4], cen;
+    auto load_chunk = [&](int c) {
+        const int s = c / cpc;
+        const int k0 = (c - s * cpc) * BK;
+        const float* in = a.in[s];
+        const float* Bm = a.B[s] + (int64_t)slot * a.B_slot_stride[s];
+        const float* ce = a.center[s];
+        if (ce) cen = ld4(ce + k0 + 4 * xkq); else cen = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = xrow + 32 * p;
+            if (row < rows_valid) xv[p] = ld4(in + (row0 + row) * C + k0 + 4 * xkq) - cen;
+            else xv[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int k = bk + 8 * p;
+            if (bcol_ok) bv[p] = ld4(Bm + (int64_t)(k0 + k) * C + col0 + 4 * bnq);
+            else bv[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+
+    load_chunk(0);
+    for (int c = 0; c < nchunks; ++c) {
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = xrow + 32 * p;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) As[(4 * xkq + j) * AS_LD + row] = xv[p][j];
+            *reinterpret_cast<f32x4*>(&Bs[(bk + 8 * p) * BS_LD + 4 * bnq]) = bv[p];
+        }
+        __syncthreads();
+        if (c + 1 < nchunks) load_chunk(c + 1);
+#pragma unroll 4
+        for (int kk = 0; kk < BK; kk += 2)
+            mfma_step(As, AS_LD, Bs, BS_LD, kk, lane, wr * 64, wc * 64, u0, u1, acc);
+    }
+
+    // epilogue
+    const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int col = col0 + wc * 64 + u * 32 + l31;
+        if (col >= C) continue;
+        float add = 0.f;
+        if (a.bias) add += a.bias[(int64_t)slot * C + col];
+        if (a.sub) add -= a.sub[col];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wr * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < rows_valid) a.out[(row0 + row) * C + col] = acc[t][u][r] + add;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// xty: one 128 x 128 tile of P = Xc^T Yc over one slab of rows per workgroup.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void xty_kernel(WcXtyArgs a, int ntiles, int nb)
+{
+    __shared__ __attribute__((aligned(16))) float Xs[BK * BM];
+    __shared__ __attribute__((aligned(16))) float Ys[BK * BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int C = a.C;
+    const int64_t z = blockIdx.x / ntiles;
+    int t = blockIdx.x % ntiles;
+    int ib, jb;
+    if (a.sym) {            // enumerate the upper triangle row by row
+        ib = 0;
+        while (t >= nb - ib) { t -= nb - ib; ++ib; }
+        jb = ib + t;
+    } else {
+        ib = t / nb; jb = t % nb;
+    }
+    const bool diag = a.sym && ib == jb;
+
+    int64_t r0, r1;
+    if (a.per_sample) {
+        const int64_t n = z / a.nsplit, q = z % a.nsplit;
+        r0 = n * a.HW + q * a.rows_per_slab;
+        r1 = r0 + a.rows_per_slab;
+        const int64_t end = (n + 1) * a.HW;
+        if (r1 > end) r1 = end;
+    } else {
+        const int64_t M = a.N * a.HW;
+        r0 = z * a.rows_per_slab;
+        r1 = r0 + a.rows_per_slab;
+        if (r1 > M) r1 = M;
+    }
+
+    const int q4 = tid & 31;          // float4 column group inside the tile
+    const int rbase = tid >> 5;       // + 8*p
+    const int ci = ib * BM + 4 * q4, cj = jb * BN + 4 * q4;
+    const bool vi = ci < C, vj = cj < C;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 cx = (a.cx && vi) ? ld4(a.cx + ci) : zero4;
+    const f32x4 cy = (a.cy && vj) ? ld4(a.cy + cj) : zero4;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tt][u][r] = 0.f;
+    f32x4 csum = zero4;
+
+    const bool u0 = (jb * BN + wc * 64) < C, u1 = (jb * BN + wc * 64 + 32) < C;
+    const bool t_ok = (ib * BM + wr * 64) < C;     // whole wave row-range outside C -> nothing to do
+
+    f32x4 xv[4], yv[4];
+    auto load_chunk = [&](int64_t m0) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int64_t m = m0 + rbase + 8 * p;
+            const bool ok = m < r1;
+            xv[p] = (ok && vi) ? ld4(a.X + m * C + ci) - cx : zero4;
+            if (!diag) yv[p] = (ok && vj) ? ld4(a.Y + m * C + cj) - cy : zero4;
+        }
+    };
+
+    if (r0 < r1) load_chunk(r0);
+    for (int64_t m0 = r0; m0 < r1; m0 += BK) {
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            *reinterpret_cast<f32x4*>(&Xs[(rbase + 8 * p) * BM + 4 * q4]) = xv[p];
+            if (!diag) *reinterpret_cast<f32x4*>(&Ys[(rbase + 8 * p) * BN + 4 * q4]) = yv[p];
+            csum += a.sym ? xv[p] : yv[p];
+        }
+        __syncthreads();
+        if (m0 + BK < r1) load_chunk(m0 + BK);
+        if (t_ok) {
+            const float* Bsrc = diag ? Xs : Ys;
+#pragma unroll 4
+            for (int kk = 0; kk < BK; kk += 2)
+                mfma_step(Xs, BM, Bsrc, BN, kk, lane, wr * 64, wc * 64, u0, u1, acc);
+        }
+    }
+
+    // partial tile out
+    const int l31 = lane & 31, lh = lane >> 5;
+    float* P = a.P + z * (int64_t)C * C;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int j = jb * BN + wc * 64 + u * 32 + l31;
+        if (j >= C) continue;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = ib * BM + wr * 64 + tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (i < C) P[(int64_t)i * C + j] = acc[tt][u][r];
+            }
+    }
+
+    // column sums: X columns on diagonal tiles (sym), Y columns on the ib == 0 tiles (non-sym)
+    const bool want = a.sym ? diag : (ib == 0);
+    if (want && a.colsum) {
+        __syncthreads();
+        float* red = Xs;                           // [8][128]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[rbase * 128 + 4 * q4 + j] = csum[j];
+        __syncthreads();
+        if (tid < 128) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) s += red[r * 128 + tid];
+            const int col = (a.sym ? ib : jb) * 128 + tid;
+            if (col < C) a.colsum[z * C + col] = s;
+        }
+    }
+}
+
+// shift[c] = mean of a strided sample of <= 1024 rows: removes the mean before fp32 products are summed
+__global__ __launch_bounds__(256) void subsample_mean_kernel(const float* __restrict__ x, int64_t M, int C,
+                                                             float* __restrict__ shift)
+{
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int part = threadIdx.x >> 6;
+    const int64_t nsamp = M < 1024 ? M : 1024;
+    const int64_t stride = M / nsamp;
+    float s = 0.f;
+    if (c < C)
+        for (int64_t r = part; r < nsamp; r += 4) s += x[r * stride * C + c];
+    red[part][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (threadIdx.x < 64 && c < C)
+        shift[c] = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) / (float)nsamp;
+}
+
+__global__ __launch_bounds__(256) void stream_copy_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, int64_t n4)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+}
+
+}  // namespace
+
+hipError_t wc_launch_rows_gemm(const WcRowsGemmArgs& a, hipStream_t st)
+{
+    const int ncb = (a.C + BN - 1) / BN;
+    int64_t nrb;
+    if (a.slot) nrb = a.N * ((a.HW + BM - 1) / BM);
+    else nrb = (a.N * a.HW + BM - 1) / BM;
+    const int64_t grid = nrb * ncb;
+    hipLaunchKernelGGL(rows_gemm_kernel, dim3((unsigned)grid), dim3(256), 0, st, a, ncb);
+    return hipGetLastError();
+}
+
+int wc_xty_plan(int64_t N, int64_t HW, int C, int per_sample, int sym, int* nsplit, int64_t* rows_per_slab)
+{
+    const int nb = (C + BM - 1) / BM;
+    const int64_t target = 768;                       // ~3 workgroups per CU
+    const int64_t min_rows = 256;
+    const int ntiles = sym ? nb * (nb + 1) / 2 : nb * nb;
+    if (per_sample) {
+        int64_t want = (target + N * ntiles - 1) / (N * ntiles);         // slabs per sample
+        int64_t maxs = (HW + min_rows - 1) / min_rows;
+        if (want > maxs) want = maxs;
+        if (want < 1) want = 1;
+        int64_t rps = (HW + want - 1) / want;
+        rps = (rps + BK - 1) / BK * BK;
+        *nsplit = (int)((HW + rps - 1) / rps);
+        *rows_per_slab = rps;
+        return (int)(N * (*nsplit));
+    }
+    const int64_t M = N * HW;
+    int64_t want = (target + ntiles - 1) / ntiles;
+    int64_t maxs = (M + min_rows - 1) / min_rows;
+    if (want > maxs) want = maxs;
+    if (want < 1) want = 1;
+    int64_t rps = (M + want - 1) / want;
+    rps = (rps + BK - 1) / BK * BK;
+    *nsplit = (int)((M + rps - 1) / rps);
+    *rows_per_slab = rps;
+    return *nsplit;
+}
+
+hipError_t wc_launch_xty(const WcXtyArgs& a, int nslab, hipStream_t st)
+{
+    const int nb = (a.C + BM - 1) / BM;
+    const int ntiles = a.sym ? nb * (nb + 1) / 2 : nb * nb;
+    const int64_t grid = (int64_t)nslab * ntiles;
+    hipLaunchKernelGGL(xty_kernel, dim3((unsigned)grid), dim3(256), 0, st, a, ntiles, nb);
+    return hipGetLastError();
+}
+
+hipError_t wc_launch_subsample_mean(const float* x, int64_t M, int C, float* shift, hipStream_t st)
+{
+    hipLaunchKernelGGL(subsample_mean_kernel, dim3((C + 63) / 64), dim3(256), 0, st, x, M, C, shift);
+    return hipGetLastError();
+}
+
+hipError_t wc_launch_stream_copy(const float* src, float* dst, int64_t n, hipStream_t st)
+{
+    const int64_t n4 = n / 4;
+    hipLaunchKernelGGL(stream_copy_kernel, dim3(2048), dim3(256), 0, st,
+                       reinterpret_cast<const f32x4*>(src), reinterpret_cast<f32x4*>(dst), n4);
+    return hipGetLastError();
+}

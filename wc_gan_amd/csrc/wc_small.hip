@@ -1,0 +1,465 @@
+// Small-matrix (C x C) stage of the WC path, float64 throughout.
+//
+// Replaces, inside DecorelationNormalization.call (generator.py:24,26; body in the un-vendored gan/
+// submodule): the covariance normalisation and shrinkage, tf.cholesky, tf.matrix_triangular_solve
+// against I, the moving-statistics add_update ops, and -- for the coloring layers of
+// generator.py:49-78 -- the product A_k = W^T Gamma_k that lets K3 run one fused affine.  The backward
+// half (wc_bwd_factor_f64) is the closed form of SURVEY.md row a10.
+//
+// float64 here is what keeps the path within 1e-4 of the float64 oracle on ill-conditioned batches
+// (hard part 2); the flops are negligible (O(C^3)) next to the M*C^2 kernels.
+#include "wc_common.h"
+
+namespace {
+
+__device__ __forceinline__ double readlane64(double v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1 tail
+// ---------------------------------------------------------------------------------------------
+__global__ void stats_colsum_kernel(const float* __restrict__ colsum, const float* __restrict__ shift, int nslab,
+                                    int64_t M, int C, double* __restrict__ Sp, double* __restrict__ sum)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int z = 0; z < nslab; ++z) s += (double)colsum[(int64_t)z * C + c];
+    Sp[c] = s;
+    sum[c] = s + (double)M * (double)shift[c];
+}
+
+// xtx = G' + s Sp^T + Sp s^T + M s s^T with G' = sum_z P[z]; only block-upper tiles of P were written.
+__global__ void stats_xtx_kernel(const float* __restrict__ P, const float* __restrict__ shift, const double* __restrict__ Sp,
+                                 int nslab, int64_t M, int C, double* __restrict__ xtx)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= C) return;
+    if ((j >> 7) < (i >> 7)) return;              // lower block-triangle is mirrored by the (j,i) thread
+    const int64_t CC = (int64_t)C * C;
+    double g = 0.0;
+    const float* p = P + (int64_t)i * C + j;
+    for (int z = 0; z < nslab; ++z) g += (double)p[z * CC];
+    const double si = shift[i], sj = shift[j];
+    const double v = g + si * Sp[j] + Sp[i] * sj + (double)M * si * sj;
+    xtx[(int64_t)i * C + j] = v;
+    if ((j >> 7) > (i >> 7)) xtx[(int64_t)j * C + i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4 tail: per-slab partials -> per-slot R, gsum
+// ---------------------------------------------------------------------------------------------
+__global__ void bwd_combine_kernel(const float* __restrict__ P, const float* __restrict__ colsum,
+                                   const int32_t* __restrict__ slot, int64_t N, int nsplit, int per_sample,
+                                   int C, double* __restrict__ R, double* __restrict__ gsum)
+{
+    const int64_t CC = (int64_t)C * C;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;    // element of C*C (+ C for gsum)
+    const int k = blockIdx.y;
+    if (e >= CC + C) return;
+    const bool is_sum = e >= CC;
+    const float* src = is_sum ? colsum + (e - CC) : P + e;
+    const int64_t stride = is_sum ? C : CC;
+    double acc = 0.0;
+    if (per_sample) {
+        for (int64_t n = 0; n < N; ++n) {
+            if (slot[n] != k) continue;
+            for (int q = 0; q < nsplit; ++q) acc += (double)src[(n * nsplit + q) * stride];
+        }
+    } else {
+        for (int z = 0; z < nsplit; ++z) acc += (double)src[z * stride];
+    }
+    if (is_sum) gsum[(int64_t)k * C + (e - CC)] = acc;
+    else R[k * CC + e] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2 head: moments -> mu, Sigma, moving statistics, T = (1-eps) Sigma + eps I
+// ---------------------------------------------------------------------------------------------
+__global__ void factor_prepare_kernel(const double* __restrict__ sum, const double* __restrict__ xtx, int64_t M, int C,
+                                      double eps, double momentum, int ddof, int training,
+                                      float* __restrict__ moving_mean, float* __restrict__ moving_cov,
+                                      float* __restrict__ mu, double* __restrict__ T)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= C) return;
+    const int64_t e = (int64_t)i * C + j;
+    double sig;
+    if (training) {
+        const double invM = 1.0 / (double)M;
+        sig = (0.5 * (xtx[e] + xtx[(int64_t)j * C + i]) - sum[i] * sum[j] * invM) / (double)(M - ddof);
+        if (moving_cov) moving_cov[e] = (float)(momentum * (double)moving_cov[e] + (1.0 - momentum) * sig);
+        if (i == 0) {
+            const double m = sum[j] * invM;
+            mu[j] = (float)m;
+            if (moving_mean) moving_mean[j] = (float)(momentum * (double)moving_mean[j] + (1.0 - momentum) * m);
+        }
+    } else {
+        sig = 0.5 * ((double)moving_cov[e] + (double)moving_cov[(int64_t)j * C + i]);
+        if (i == 0) mu[j] = moving_mean[j];
+    }
+    T[e] = (1.0 - eps) * sig + (i == j ? eps : 0.0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cholesky, one 1024-thread workgroup, right-looking with 16-wide panels.
+//   per panel: wave 0 factors the 16x16 diagonal block in registers (lane = row, readlane broadcasts),
+//   every thread solves one row of the panel against it, then 4x4 register micro-tiles apply the
+//   rank-16 update to the trailing lower triangle with the panel held in LDS as [c][row].
+// ---------------------------------------------------------------------------------------------
+constexpr int CH_NB = 16;
+
+__global__ __launch_bounds__(1024) void cholesky_kernel(double* __restrict__ T, int C, int ldp)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double* D = sm;                    // [16][17]
+    double* rdiag = D + 16 * 17;       // [16]
+    double* Pn = rdiag + 16;           // [16][ldp]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    for (int j0 = 0; j0 < C; j0 += CH_NB) {
+        const int rows = C - j0 - CH_NB;
+        if (wave == 0) {
+            double a[CH_NB];
+            const int li = lane & 15;
+#pragma unroll
+            for (int c = 0; c < CH_NB; ++c) a[c] = T[(int64_t)(j0 + li) * C + j0 + c];
+#pragma unroll
+            for (int j = 0; j < CH_NB; ++j) {
+                const double p = readlane64(a[j], j);
+                const double d = sqrt(p);
+                const double rd = 1.0 / d;
+                a[j] = (li == j) ? d : a[j] * rd;
+#pragma unroll
+                for (int k = j + 1; k < CH_NB; ++k) {
+                    const double lkj = readlane64(a[j], k);
+                    a[k] -= a[j] * lkj;
+                }
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int c = 0; c < CH_NB; ++c) {
+                    const double v = (c <= lane) ? a[c] : 0.0;
+                    D[lane * 17 + c] = v;
+                    T[(int64_t)(j0 + lane) * C + j0 + c] = v;
+                    if (c == lane) rdiag[lane] = 1.0 / v;
+                }
+            }
+        }
+        __syncthreads();
+        if (rows <= 0) break;
+        const int g0 = j0 + CH_NB;
+        if (tid < rows) {
+            double x[CH_NB];
+            double* trow = T + (int64_t)(g0 + tid) * C + j0;
+#pragma unroll
+            for (int c = 0; c < CH_NB; ++c) x[c] = trow[c];
+#pragma unroll
+            for (int c = 0; c < CH_NB; ++c) {
+                double s = x[c];
+#pragma unroll
+                for (int k = 0; k < c; ++k) s -= x[k] * D[c * 17 + k];
+                x[c] = s * rdiag[c];
+            }
+#pragma unroll
+            for (int c = 0; c < CH_NB; ++c) { trow[c] = x[c]; Pn[c * ldp + tid] = x[c]; }
+        }
+        __syncthreads();
+        const int nt = rows >> 2;
+        const int count = nt * (nt + 1) / 2;
+        for (int e = tid; e < count; e += 1024) {
+            int ti = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+            while ((ti + 1) * (ti + 2) / 2 <= e) ++ti;
+            while (ti * (ti + 1) / 2 > e) --ti;
+            const int tk = e - ti * (ti + 1) / 2;
+            double acc[4][4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 4; ++y) acc[x][y] = 0.0;
+#pragma unroll 4
+            for (int c = 0; c < CH_NB; ++c) {
+                const double* pi = Pn + c * ldp + 4 * ti;
+                const double* pk = Pn + c * ldp + 4 * tk;
+                const double ai[4] = {pi[0], pi[1], pi[2], pi[3]};
+                const double ak[4] = {pk[0], pk[1], pk[2], pk[3]};
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int y = 0; y < 4; ++y) acc[x][y] += ai[x] * ak[y];
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                double* tr = T + (int64_t)(g0 + 4 * ti + x) * C + g0 + 4 * tk;
+#pragma unroll
+                for (int y = 0; y < 4; ++y) tr[y] -= acc[x][y];
+            }
+        }
+        __syncthreads();
+    }
+    // strict upper triangle := 0
+    for (int64_t e = tid; e < (int64_t)C * C; e += 1024) {
+        const int i = (int)(e / C), j = (int)(e % C);
+        if (j > i) T[e] = 0.0;
+    }
+}
+
+// inverse of each 32 x 32 diagonal block of L (lower): one wave per block, lane = column of the inverse
+__global__ __launch_bounds__(64) void tri_inv_diag_kernel(const double* __restrict__ L, double* __restrict__ W, int C)
+{
+    __shared__ double Lb[32 * 33];
+    const int b0 = blockIdx.x * 32;
+    const int lane = threadIdx.x;
+    for (int e = lane; e < 32 * 32; e += 64) {
+        const int i = e >> 5, k = e & 31;
+        Lb[i * 33 + k] = L[(int64_t)(b0 + i) * C + b0 + k];
+    }
+    __syncthreads();
+    const int c = lane & 31;
+    double w[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        double s = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= Lb[i * 33 + k] * w[k];
+        w[i] = s / Lb[i * 33 + i];
+    }
+    if (lane < 32) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) W[(int64_t)(b0 + i) * C + b0 + c] = w[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic small GEMM on v_mfma_f64_16x16x4_f64.
+//   operand maps: a = A[i = lane&15][k = lane>>4], b = B[k = lane>>4][j = lane&15],
+//   D register r of lane l = D[(l>>4) + 4*r][l&15]   (NOT the f32 row formula).
+// One 32 x 32 output block per 256-thread workgroup; the four waves split K and meet in LDS.
+// ---------------------------------------------------------------------------------------------
+template <typename TA, typename TB>
+__global__ __launch_bounds__(256) void gemm_f64_kernel(WcGemm g)
+{
+    __shared__ double red[4][32 * 32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int bm = blockIdx.x, bn = blockIdx.y, b = blockIdx.z;
+    const int kper = g.k >> 2;
+
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) acc[t][u] = f64x4{0.0, 0.0, 0.0, 0.0};
+
+    for (int r = 0; r < g.nred; ++r) {
+        const TA* A = reinterpret_cast<const TA*>(g.A) + (int64_t)b * g.a_bs + (int64_t)r * g.a_red;
+        const TB* B = reinterpret_cast<const TB*>(g.B) + (int64_t)b * g.b_bs + (int64_t)r * g.b_red;
+        const TA* A0 = A + (int64_t)(bm * 32 + li) * g.a_rs;
+        const TA* A1 = A0 + 16 * g.a_rs;
+        const TB* B0 = B + (int64_t)(bn * 32 + li) * g.b_cs;
+        const TB* B1 = B0 + 16 * g.b_cs;
+#pragma unroll 4
+        for (int kk = wave * kper; kk < (wave + 1) * kper; kk += 4) {
+            const int64_t ka = kk + lq;
+            const double a0 = (double)A0[ka * g.a_cs], a1 = (double)A1[ka * g.a_cs];
+            const double b0 = (double)B0[ka * g.b_rs], b1 = (double)B1[ka * g.b_rs];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][(t * 16 + lq + 4 * r) * 32 + u * 16 + li] = acc[t][u][r];
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int e = tid + 256 * p;
+        const int row = e >> 5, col = e & 31;
+        double v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+        v *= g.alpha;
+        const int gi = bm * 32 + row, gj = bn * 32 + col;
+        if (g.epi != WC_EPI_NONE) {
+            if (gj > gi) v = 0.0;
+            else if (gj == gi && g.epi == WC_EPI_PHI) v *= 0.5;
+        }
+        const int64_t off = (int64_t)b * g.c_bs + (int64_t)gi * g.c_rs + (int64_t)gj * g.c_cs;
+        if (g.c_is_f32) reinterpret_cast<float*>(g.Cm)[off] = (float)v;
+        else reinterpret_cast<double*>(g.Cm)[off] = v;
+        if (g.Cm2)
+            reinterpret_cast<float*>(g.Cm2)[(int64_t)b * g.c2_bs + (int64_t)gi * g.c2_rs + (int64_t)gj * g.c2_cs] = (float)v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// element-wise helpers
+// ---------------------------------------------------------------------------------------------
+__global__ void transpose_to_f32_kernel(const double* __restrict__ W, int C, float* __restrict__ A, float* __restrict__ At)
+{
+    __shared__ double tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 256 threads: ty in 0..7
+    for (int r = ty; r < 32; r += 8) {
+        const double v = W[(int64_t)(by + r) * C + bx + tx];
+        tile[r][tx] = v;
+        if (At) At[(int64_t)(by + r) * C + bx + tx] = (float)v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) A[(int64_t)(bx + r) * C + by + tx] = (float)tile[tx][r];
+}
+
+__global__ void sym_scale_f32_kernel(const double* __restrict__ Q, int C, double scale, float* __restrict__ S)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= C) return;
+    S[(int64_t)i * C + j] = (float)(scale * 0.5 * (Q[(int64_t)i * C + j] + Q[(int64_t)j * C + i]));
+}
+
+// gmean[c] = (1/M) sum_k sum_j gsum[k][j] A[k][c][j]
+__global__ void gmean_kernel(const double* __restrict__ gsum, const float* __restrict__ A, int Kc, int C, int64_t M,
+                             float* __restrict__ gmean)
+{
+    __shared__ double red[256];
+    const int c = blockIdx.x;
+    double s = 0.0;
+    for (int64_t e = threadIdx.x; e < (int64_t)Kc * C; e += 256) {
+        const int64_t k = e / C, j = e % C;
+        s += gsum[e] * (double)A[(k * C + c) * C + j];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) gmean[c] = (float)(red[0] / (double)M);
+}
+
+__global__ void f64_to_f32_kernel(const double* __restrict__ src, float* __restrict__ dst, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (float)src[i];
+}
+
+}  // namespace
+
+hipError_t wc_launch_stats_finalize(const float* P, const float* colsum, const float* shift, int nslab,
+                                    int64_t M, int C, double* Sp, double* sum, double* xtx, hipStream_t st)
+{
+    hipLaunchKernelGGL(stats_colsum_kernel, dim3((C + 63) / 64), dim3(64), 0, st, colsum, shift, nslab, M, C, Sp, sum);
+    hipLaunchKernelGGL(stats_xtx_kernel, dim3((C + 127) / 128, C), dim3(128), 0, st, P, shift, (const double*)Sp, nslab, M, C, xtx);
+    return hipGetLastError();
+}
+
+hipError_t wc_launch_bwd_combine(const float* P, const float* colsum, const int32_t* slot, int64_t N, int nsplit,
+                                 int per_sample, int C, int Kc, double* R, double* gsum, hipStream_t st)
+{
+    const int64_t total = (int64_t)C * C + C;
+    hipLaunchKernelGGL(bwd_combine_kernel, dim3((unsigned)((total + 255) / 256), Kc), dim3(256), 0, st,
+                       P, colsum, slot, N, nsplit, per_sample, C, R, gsum);
+    return hipGetLastError();
+}
+
+hipError_t wc_launch_factor_prepare(const double* sum, const double* xtx, int64_t M, int C, double eps, double momentum,
+                                    int ddof, int training, float* moving_mean, float* moving_cov, float* mu,
+                                    double* T, hipStream_t st)
+{
+    hipLaunchKernelGGL(factor_prepare_kernel, dim3((C + 127) / 128, C), dim3(128), 0, st,
+                       sum, xtx, M, C, eps, momentum, ddof, training, moving_mean, moving_cov, mu, T);
+    return hipGetLastError();
+}
+
+hipError_t wc_launch_cholesky(double* T, int C, hipStream_t st)
+{
+    int ldp = C - CH_NB;
+    if (ldp < 4) ldp = 4;
+    ldp = (ldp + 3) / 4 * 4;
+    const size_t lds = (size_t)(16 * 17 + 16 + 16 * ldp) * sizeof(double);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cholesky_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(cholesky_kernel, dim3(1), dim3(1024), lds, st, T, C, ldp);
+    return hipGetLastError();
+}
+
+hipError_t wc_launch_gemm(const WcGemm& g, hipStream_t st)
+{
+    const dim3 grid(g.m / 32, g.n / 32, g.batch);
+    if (g.a_is_f32 && g.b_is_f32) hipLaunchKernelGGL((gemm_f64_kernel<float, float>), grid, dim3(256), 0, st, g);
+    else if (g.a_is_f32) hipLaunchKernelGGL((gemm_f64_kernel<float, double>), grid, dim3(256), 0, st, g);
+    else if (g.b_is_f32) hipLaunchKernelGGL((gemm_f64_kernel<double, float>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_f64_kernel<double, double>), grid, dim3(256), 0, st, g);
+    return hipGetLastError();
+}
+
+// W = L^-1: invert the 32-wide diagonal blocks, then double the block size level by level:
+//   [L11 0; L21 L22]^-1 = [W11 0; -W22 L21 W11, W22]
+hipError_t wc_launch_tri_inverse(const double* L, double* W, double* tmp, int C, hipStream_t st)
+{
+    hipError_t e = hipMemsetAsync(W, 0, (size_t)C * C * sizeof(double), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(tri_inv_diag_kernel, dim3(C / 32), dim3(64), 0, st, L, W, C);
+    for (int b = 32; b < C; b *= 2) {
+        const int nfull = C / (2 * b);
+        const int rem = C - 2 * b * nfull;
+        for (int pass = 0; pass < 2; ++pass) {
+            // pass 0: the nfull complete pairs (batched); pass 1: a trailing partial pair, if any
+            int start, mrows, batch;
+            if (pass == 0) { if (nfull == 0) continue; start = 0; mrows = b; batch = nfull; }
+            else { if (rem <= b) continue; start = 2 * b * nfull; mrows = rem - b; batch = 1; }
+            const int64_t pair = (int64_t)2 * b * (C + 1);
+            WcGemm g1 = {};
+            g1.A = L + (int64_t)(start + b) * C + start; g1.a_rs = C; g1.a_cs = 1; g1.a_bs = pair;
+            g1.B = W + (int64_t)start * C + start;       g1.b_rs = C; g1.b_cs = 1; g1.b_bs = pair;
+            g1.Cm = tmp; g1.c_rs = b; g1.c_cs = 1; g1.c_bs = (int64_t)b * b;
+            g1.m = mrows; g1.n = b; g1.k = b; g1.batch = batch; g1.nred = 1; g1.alpha = 1.0; g1.epi = WC_EPI_NONE;
+            e = wc_launch_gemm(g1, st);
+            if (e != hipSuccess) return e;
+            WcGemm g2 = {};
+            g2.A = W + (int64_t)(start + b) * C + (start + b); g2.a_rs = C; g2.a_cs = 1; g2.a_bs = pair;
+            g2.B = tmp; g2.b_rs = b; g2.b_cs = 1; g2.b_bs = (int64_t)b * b;
+            g2.Cm = W + (int64_t)(start + b) * C + start; g2.c_rs = C; g2.c_cs = 1; g2.c_bs = pair;
+            g2.m = mrows; g2.n = b; g2.k = mrows; g2.batch = batch; g2.nred = 1; g2.alpha = -1.0; g2.epi = WC_EPI_NONE;
+            e = wc_launch_gemm(g2, st);
+            if (e != hipSuccess) return e;
+        }
+    }
+    return hipGetLastError();
+}
+
+hipError_t wc_launch_transpose_to_f32(const double* W, int C, float* A, float* At, hipStream_t st)
+{
+    hipLaunchKernelGGL(transpose_to_f32_kernel, dim3(C / 32, C / 32), dim3(256), 0, st, W, C, A, At);
+    return hipGetLastError();
+}
+
+hipError_t wc_launch_sym_scale_f32(const double* Q, int C, double scale, float* S, hipStream_t st)
+{
+    hipLaunchKernelGGL(sym_scale_f32_kernel, dim3((C + 127) / 128, C), dim3(128), 0, st, Q, C, scale, S);
+    return hipGetLastError();
+}
+
+hipError_t wc_launch_gmean(const double* gsum, const float* A, int Kc, int C, int64_t M, float* gmean, hipStream_t st)
+{
+    hipLaunchKernelGGL(gmean_kernel, dim3(C), dim3(256), 0, st, gsum, A, Kc, C, M, gmean);
+    return hipGetLastError();
+}
+
+hipError_t wc_launch_f64_to_f32(const double* src, float* dst, int64_t n, hipStream_t st)
+{
+    hipLaunchKernelGGL(f64_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n);
+    return hipGetLastError();
+}

@@ -1,0 +1,96 @@
+"""Autograd function for the fused whitening + coloring transform.
+
+Forward  (SURVEY.md rows a2/a3/a6-a9):  y_n = (x_n - mu) A_{slot(n)} + beta_{slot(n)},  A_k = W^T Gamma_k
+Backward (row a10): one reduction (K4), the small float64 stage (K5), one two-stream apply (K6).
+
+`process_group` turns on sync-WC: the additive moments (K1 output) and the backward reductions
+(K4 output) are all-reduced over RCCL, so every replica whitens with the global-batch statistics.
+Default (None) keeps per-replica statistics, which is the reference's behaviour on each GPU.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+def _allreduce_(tensors, group):
+    flat = torch.cat([t.reshape(-1) for t in tensors])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    off = 0
+    for t in tensors:
+        n = t.numel()
+        t.copy_(flat[off:off + n].view_as(t))
+        off += n
+
+
+class WhitenColorFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, slot, moving_mean, moving_cov, training, eps, momentum, ddof, process_group):
+        # x: (N, ..., C) float32 contiguous (NHWC); gamma (Kc,C,C)|None; beta (Kc,C)|None; slot int32 (N,)|None
+        C = x.shape[-1]
+        M_local = x.numel() // C
+        x = x.contiguous()
+        dev = x.device
+        M = M_local
+        if training:
+            s, xtx = ops.stats(x.view(M_local, C))
+            if process_group is not None:
+                # every replica holds the same number of rows (fixed per-GPU batch): no host sync for the count
+                _allreduce_([s, xtx], process_group)
+                M = M_local * dist.get_world_size(process_group)
+        else:
+            s = xtx = None
+        mm = moving_mean.view(-1) if moving_mean is not None else None
+        mu, L, W = ops.factor(s, xtx, M, C, eps, momentum, ddof, training, mm, moving_cov, dev)
+        g = gamma.contiguous() if gamma is not None else None
+        b = beta.contiguous() if beta is not None else None
+        A, At = ops.color(W, g)
+        y = ops.apply(x, mu, A, b, slot)
+        ctx.save_for_backward(x, mu, L, W, A, At, g if g is not None else torch.empty(0, device=dev),
+                              slot if slot is not None else torch.empty(0, dtype=torch.int32, device=dev))
+        ctx.has_gamma = g is not None
+        ctx.has_beta = b is not None
+        ctx.has_slot = slot is not None
+        ctx.training = bool(training)
+        ctx.eps, ctx.ddof, ctx.M, ctx.group = eps, ddof, M, process_group
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, mu, L, W, A, At, g, slot = ctx.saved_tensors
+        g = g if ctx.has_gamma else None
+        slot = slot if ctx.has_slot else None
+        gy = gy.contiguous()
+        need_x, need_g, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        Kc = A.shape[0]
+        dgamma = dbeta = dx = S = gmean = None
+        stats_path = ctx.training and need_x
+        want_g = ctx.has_gamma and need_g
+        want_b = ctx.has_beta and need_b
+        if want_g or want_b or stats_path:
+            R, gsum = ops.bwd_reduce(x, mu, gy, slot, Kc)
+            if ctx.group is None:
+                dgamma, dbeta, S, gmean = ops.bwd_factor(R, gsum, W, L, g, A, ctx.M, ctx.eps, ctx.ddof, stats_path,
+                                                         want_dgamma=want_g, want_dbeta=want_b)
+            else:
+                # parameter gradients stay per-replica (the DDP-style average happens outside);
+                # the statistics path needs the global reductions under sync-WC
+                if want_g or want_b:
+                    dgamma, dbeta, _, _ = ops.bwd_factor(R, gsum, W, L, g, A, ctx.M, ctx.eps, ctx.ddof, False,
+                                                         want_dgamma=want_g, want_dbeta=want_b)
+                if stats_path:
+                    _allreduce_([R, gsum], ctx.group)
+                    _, _, S, gmean = ops.bwd_factor(R, gsum, W, L, g, A, ctx.M, ctx.eps, ctx.ddof, True,
+                                                    want_dgamma=False, want_dbeta=False)
+        if need_x:
+            dx = ops.bwd_apply(gy, x, mu, At, S, gmean, slot)
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
+
+
+def whiten_color(x, gamma=None, beta=None, slot=None, moving_mean=None, moving_cov=None, training=True,
+                 eps=1e-3, momentum=0.99, ddof=1, process_group=None):
+    """y = coloring(whitening(x)).  x: (N, H, W, C) float32 on the GPU, C % 32 == 0 (see layers for padding)."""
+    return WhitenColorFunction.apply(x, gamma, beta, slot, moving_mean, moving_cov, bool(training),
+                                     float(eps), float(momentum), int(ddof), process_group)

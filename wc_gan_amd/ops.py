@@ -1,0 +1,151 @@
+"""Tensor-level wrappers over the C ABI (include/wc_hip.h).
+
+PyTorch is plumbing here: it owns device memory (caching allocator), the current HIP stream and
+torch.distributed.  Every function checks layouts, allocates outputs/workspace with torch.empty and
+enqueues the HIP stage on torch's current stream.  The six stages mirror the reference's op groups
+(SURVEY.md rows a2/a6/a7/a10):
+
+    stats  -> factor -> color -> apply                       (forward)
+    bwd_reduce -> bwd_factor -> bwd_apply                    (backward)
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need(t, dtype, name, ndim=None):
+    if not t.is_cuda:
+        raise _lib.WcHipError(f"{name} must be a CUDA/HIP tensor (the WC path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    if ndim is not None and t.dim() != ndim:
+        raise ValueError(f"{name} must be {ndim}-D, got shape {tuple(t.shape)}")
+
+
+def _workspace(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def stats(x2d):
+    """K1: x2d (M, C) float32 -> (sum (C,) f64, xtx (C, C) f64), the raw additive moments."""
+    lib = _lib.load()
+    _need(x2d, torch.float32, "x", 2)
+    M, C = x2d.shape
+    s = torch.empty(C, dtype=torch.float64, device=x2d.device)
+    xtx = torch.empty(C, C, dtype=torch.float64, device=x2d.device)
+    nb = lib.wc_stats_workspace_bytes(M, C)
+    if nb == 0:
+        _lib.check(-3, "wc_stats_f32")
+    ws = _workspace(nb, x2d.device)
+    _lib.check(lib.wc_stats_f32(_ptr(x2d), M, C, _ptr(s), _ptr(xtx), _ptr(ws), ws.numel(), _stream()), "wc_stats_f32")
+    return s, xtx
+
+
+def factor(s, xtx, M, C, eps, momentum, ddof, training, moving_mean, moving_cov, device):
+    """K2: -> (mu (C,) f32, L (C,C) f64, W (C,C) f64); updates the moving statistics in place when training."""
+    lib = _lib.load()
+    mu = torch.empty(C, dtype=torch.float32, device=device)
+    L = torch.empty(C, C, dtype=torch.float64, device=device)
+    W = torch.empty(C, C, dtype=torch.float64, device=device)
+    if moving_mean is not None:
+        _need(moving_mean, torch.float32, "moving_mean")
+        _need(moving_cov, torch.float32, "moving_cov", 2)
+    ws = _workspace(lib.wc_factor_workspace_bytes(C), device)
+    _lib.check(lib.wc_factor_f64(_ptr(s), _ptr(xtx), int(M), C, float(eps), float(momentum), int(ddof), int(bool(training)),
+                                 _ptr(moving_mean), _ptr(moving_cov), _ptr(mu), _ptr(L), _ptr(W),
+                                 _ptr(ws), ws.numel(), _stream()), "wc_factor_f64")
+    return mu, L, W
+
+
+def color(W, gamma):
+    """A_k = W^T Gamma_k and At_k = A_k^T.  gamma (Kc, C, C) float32 or None (whitening only)."""
+    lib = _lib.load()
+    C = W.shape[0]
+    Kc = 1 if gamma is None else gamma.shape[0]
+    if gamma is not None:
+        _need(gamma, torch.float32, "gamma", 3)
+    A = torch.empty(Kc, C, C, dtype=torch.float32, device=W.device)
+    At = torch.empty(Kc, C, C, dtype=torch.float32, device=W.device)
+    ws = _workspace(lib.wc_color_workspace_bytes(C, Kc), W.device)
+    _lib.check(lib.wc_color_f32(_ptr(W), _ptr(gamma), Kc, C, _ptr(A), _ptr(At), _ptr(ws), ws.numel(), _stream()),
+               "wc_color_f32")
+    return A, At
+
+
+def apply(x, mu, A, bias, slot, out=None):
+    """K3: y[n] = (x[n] - mu) A[slot[n]] + bias[slot[n]];  x is (N, ..., C) with C contiguous."""
+    lib = _lib.load()
+    _need(x, torch.float32, "x")
+    N, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (N * C)
+    Kc = A.shape[0]
+    if bias is not None:
+        _need(bias, torch.float32, "bias", 2)
+    if slot is not None:
+        _need(slot, torch.int32, "slot", 1)
+    y = torch.empty_like(x) if out is None else out
+    _lib.check(lib.wc_apply_f32(_ptr(x), _ptr(mu), _ptr(A), _ptr(bias), _ptr(slot), N, HW, C, Kc, _ptr(y), _stream()),
+               "wc_apply_f32")
+    return y
+
+
+def bwd_reduce(x, mu, gy, slot, Kc):
+    """K4: -> (R (Kc,C,C) f64, gsum (Kc,C) f64)."""
+    lib = _lib.load()
+    _need(x, torch.float32, "x")
+    _need(gy, torch.float32, "gy")
+    N, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (N * C)
+    R = torch.empty(Kc, C, C, dtype=torch.float64, device=x.device)
+    gsum = torch.empty(Kc, C, dtype=torch.float64, device=x.device)
+    ws = _workspace(lib.wc_bwd_reduce_workspace_bytes(N, HW, C, Kc, int(slot is not None)), x.device)
+    _lib.check(lib.wc_bwd_reduce_f32(_ptr(x), _ptr(mu), _ptr(gy), _ptr(slot), N, HW, C, Kc, _ptr(R), _ptr(gsum),
+                                     _ptr(ws), ws.numel(), _stream()), "wc_bwd_reduce_f32")
+    return R, gsum
+
+
+def bwd_factor(R, gsum, W, L, gamma, A, M, eps, ddof, training, want_dgamma=True, want_dbeta=True):
+    """K5: -> (dgamma (Kc,C,C) f32 | None, dbeta (Kc,C) f32 | None, S (C,C) f32 | None, gmean (C,) f32 | None)."""
+    lib = _lib.load()
+    Kc, C = R.shape[0], R.shape[1]
+    dev = R.device
+    dgamma = torch.empty(Kc, C, C, dtype=torch.float32, device=dev) if (gamma is not None and want_dgamma) else None
+    dbeta = torch.empty(Kc, C, dtype=torch.float32, device=dev) if want_dbeta else None
+    S = torch.empty(C, C, dtype=torch.float32, device=dev) if training else None
+    gmean = torch.empty(C, dtype=torch.float32, device=dev) if training else None
+    ws = _workspace(lib.wc_bwd_factor_workspace_bytes(C, Kc), dev)
+    _lib.check(lib.wc_bwd_factor_f64(_ptr(R), _ptr(gsum), _ptr(W), _ptr(L), _ptr(gamma), _ptr(A), Kc, C, int(M),
+                                     float(eps), int(ddof), int(bool(training)), _ptr(dgamma), _ptr(dbeta),
+                                     _ptr(S), _ptr(gmean), _ptr(ws), ws.numel(), _stream()), "wc_bwd_factor_f64")
+    return dgamma, dbeta, S, gmean
+
+
+def bwd_apply(gy, x, mu, At, S, gmean, slot):
+    """K6: dx[n] = gy[n] At[slot[n]] + (x[n]-mu) S - gmean."""
+    lib = _lib.load()
+    _need(gy, torch.float32, "gy")
+    N, C = gy.shape[0], gy.shape[-1]
+    HW = gy.numel() // (N * C)
+    Kc = At.shape[0]
+    dx = torch.empty_like(gy)
+    _lib.check(lib.wc_bwd_apply_f32(_ptr(gy), _ptr(x), _ptr(mu), _ptr(At), _ptr(S), _ptr(gmean), _ptr(slot),
+                                    N, HW, C, Kc, _ptr(dx), _stream()), "wc_bwd_apply_f32")
+    return dx
+
+
+def stream_copy(src, dst):
+    lib = _lib.load()
+    _lib.check(lib.wc_stream_copy_f32(_ptr(src), _ptr(dst), src.numel(), _stream()), "wc_stream_copy_f32")
+    return dst
