@@ -47,7 +47,7 @@ size_t wc_stats_workspace_bytes(int64_t M, int C)
     if (M <= 0 || bad_channels(C)) return 0;
     int nsplit; int64_t rps;
     const int nslab = wc_xty_plan(1, M, C, 0, 1, &nsplit, &rps);
-    return slot_bytes(C, 4) + slot_bytes(C, 8) + slot_bytes((size_t)nslab * C, 4) + slot_bytes((size_t)nslab * C * C, 4);
+    return slot_bytes(C, 4) + slot_bytes(C, 8) + slot_bytes((size_t)nslab * C, 4) + slot_bytes((size_t)nslab * C * C, 8);
 }
 
 int wc_stats_f32(const float* x, int64_t M, int C, double* sum, double* xtx,
@@ -64,7 +64,7 @@ int wc_stats_f32(const float* x, int64_t M, int C, double* sum, double* xtx,
     float* shift = cv.take<float>(C);
     double* Sp = cv.take<double>(C);
     float* colsum = cv.take<float>((size_t)nslab * C);
-    float* P = cv.take<float>((size_t)nslab * C * C);
+    double* P = cv.take<double>((size_t)nslab * C * C);
 
     WC_TRY(wc_launch_subsample_mean(x, M, C, shift, st));
     WcXtyArgs a = {};
@@ -154,7 +154,7 @@ size_t wc_bwd_reduce_workspace_bytes(int64_t N, int64_t HW, int C, int Kc, int h
     if (N <= 0 || HW <= 0 || bad_channels(C)) return 0;
     int nsplit; int64_t rps;
     const int nslab = has_slot ? wc_xty_plan(N, HW, C, 1, 0, &nsplit, &rps) : wc_xty_plan(1, N * HW, C, 0, 0, &nsplit, &rps);
-    return slot_bytes((size_t)nslab * C, 4) + slot_bytes((size_t)nslab * C * C, 4);
+    return slot_bytes((size_t)nslab * C, 4) + slot_bytes((size_t)nslab * C * C, 8);
 }
 
 int wc_bwd_reduce_f32(const float* x, const float* mu, const float* gy, const int32_t* slot,
@@ -171,7 +171,7 @@ int wc_bwd_reduce_f32(const float* x, const float* mu, const float* gy, const in
     const int nslab = per_sample ? wc_xty_plan(N, HW, C, 1, 0, &nsplit, &rps) : wc_xty_plan(1, N * HW, C, 0, 0, &nsplit, &rps);
     Carver cv(ws, ws_bytes);
     float* colsum = cv.take<float>((size_t)nslab * C);
-    float* P = cv.take<float>((size_t)nslab * C * C);
+    double* P = cv.take<double>((size_t)nslab * C * C);
     WcXtyArgs a = {};
     a.X = x; a.Y = gy; a.cx = mu; a.cy = nullptr;
     if (per_sample) { a.N = N; a.HW = HW; } else { a.N = 1; a.HW = N * HW; }

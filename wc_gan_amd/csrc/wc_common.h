@@ -33,7 +33,7 @@ struct WcRowsGemmArgs {
 };
 hipError_t wc_launch_rows_gemm(const WcRowsGemmArgs& a, hipStream_t st);
 
-// P[z] = sum_{m in slab z} (X[m]-cx)^T (Y[m]-cy)   fp32 partials; sums of X (sym) or Y (non-sym) columns
+// P[z] = sum_{m in slab z} (X[m]-cx)^T (Y[m]-cy)   float64 partials; sums of X (sym) or Y (non-sym) columns
 struct WcXtyArgs {
     const float* X; const float* Y;      // Y == X for the symmetric (covariance) case
     const float* cx; const float* cy;    // centers [C] or nullptr
@@ -43,7 +43,7 @@ struct WcXtyArgs {
     int64_t rows_per_slab;
     int C;
     int sym;                             // 1: only tiles jb >= ib, column sums of X; 0: all tiles, column sums of Y
-    float* P;                            // [nslab][C][C]
+    double* P;                           // [nslab][C][C] float64 partials
     float* colsum;                       // [nslab][C]
 };
 int  wc_xty_plan(int64_t N, int64_t HW, int C, int per_sample, int sym, int* nsplit, int64_t* rows_per_slab);  // returns nslab
@@ -55,10 +55,10 @@ hipError_t wc_launch_stream_copy(const float* src, float* dst, int64_t n, hipStr
 // ----- small-matrix stage (wc_small.hip) -----------------------------------------------------
 
 // K1 tail: shifted fp32 partials -> raw float64 moments
-hipError_t wc_launch_stats_finalize(const float* P, const float* colsum, const float* shift, int nslab,
+hipError_t wc_launch_stats_finalize(const double* P, const float* colsum, const float* shift, int nslab,
                                     int64_t M, int C, double* Sp /*[C] scratch*/, double* sum, double* xtx, hipStream_t st);
 // K4 tail: per-slab partials -> per-slot float64 R, gsum
-hipError_t wc_launch_bwd_combine(const float* P, const float* colsum, const int32_t* slot, int64_t N, int nsplit,
+hipError_t wc_launch_bwd_combine(const double* P, const float* colsum, const int32_t* slot, int64_t N, int nsplit,
                                  int per_sample, int C, int Kc, double* R, double* gsum, hipStream_t st);
 
 hipError_t wc_launch_factor_prepare(const double* sum, const double* xtx, int64_t M, int C, double eps, double momentum,

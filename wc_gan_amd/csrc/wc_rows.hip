@@ -21,6 +21,7 @@ constexpr int BN = 128;      // tile cols
 constexpr int BK = 32;       // depth per LDS chunk
 constexpr int AS_LD = BM + 1;   // transposed x tile [k][row]; +1 makes the 4-way-k scatter write conflict-free
 constexpr int BS_LD = BN;
+constexpr int64_t WC_EXACT_ROWS = 16384;   // M at or below this: exact float64-MFMA reductions
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
@@ -195,13 +196,17 @@ __global__ __launch_bounds__(256) void xty_kernel(WcXtyArgs a, int ntiles, int n
     const f32x4 cx = (a.cx && vi) ? ld4(a.cx + ci) : zero4;
     const f32x4 cy = (a.cy && vj) ? ld4(a.cy + cj) : zero4;
 
+    // fp32 MFMA accumulators are flushed into float64 registers after every 32-row chunk: the fp32
+    // rounding chain is 16 steps long instead of rows_per_slab/2, which is what keeps the covariance
+    // (and hence the Cholesky factor of an ill-conditioned batch) at ~1e-8 instead of ~1e-6.
     f32x16 acc[2][2];
+    double acc64[2][2][16];
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[tt][u][r] = 0.f;
+            for (int r = 0; r < 16; ++r) { acc[tt][u][r] = 0.f; acc64[tt][u][r] = 0.0; }
     f32x4 csum = zero4;
 
     const bool u0 = (jb * BN + wc * 64) < C, u1 = (jb * BN + wc * 64 + 32) < C;
@@ -234,12 +239,18 @@ __global__ __launch_bounds__(256) void xty_kernel(WcXtyArgs a, int ntiles, int n
 #pragma unroll 4
             for (int kk = 0; kk < BK; kk += 2)
                 mfma_step(Xs, BM, Bsrc, BN, kk, lane, wr * 64, wc * 64, u0, u1, acc);
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { acc64[tt][u][r] += (double)acc[tt][u][r]; acc[tt][u][r] = 0.f; }
         }
     }
 
     // partial tile out
     const int l31 = lane & 31, lh = lane >> 5;
-    float* P = a.P + z * (int64_t)C * C;
+    double* P = a.P + z * (int64_t)C * C;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int j = jb * BN + wc * 64 + u * 32 + l31;
@@ -249,7 +260,7 @@ __global__ __launch_bounds__(256) void xty_kernel(WcXtyArgs a, int ntiles, int n
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i = ib * BM + wr * 64 + tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (i < C) P[(int64_t)i * C + j] = acc[tt][u][r];
+                if (i < C) P[(int64_t)i * C + j] = acc64[tt][u][r];
             }
     }
 
@@ -267,6 +278,137 @@ __global__ __launch_bounds__(256) void xty_kernel(WcXtyArgs a, int ntiles, int n
             for (int r = 0; r < 8; ++r) s += red[r * 128 + tid];
             const int col = (a.sym ? ib : jb) * 128 + tid;
             if (col < C) a.colsum[z * C + col] = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// xty, exact variant for small M: products of float32 values are exact in float64, and the float64
+// MFMA (v_mfma_f64_16x16x4_f64) accumulates them in float64, so the partials carry no fp32 rounding
+// at all.  Half the rate of the f32 MFMA -- used only when M <= WC_EXACT_ROWS, where the statistics
+// of few rows get no help from averaging and the whole reduction is a few microseconds anyway.
+//   a = A[i = lane&15][k = lane>>4], b = B[k = lane>>4][j = lane&15], D reg r = D[(lane>>4) + 4r][lane&15]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void xty_f64_kernel(WcXtyArgs a, int ntiles, int nb)
+{
+    __shared__ __attribute__((aligned(16))) float Xs[BK * BM];
+    __shared__ __attribute__((aligned(16))) float Ys[BK * BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int C = a.C;
+    const int64_t z = blockIdx.x / ntiles;
+    int t = blockIdx.x % ntiles;
+    int ib, jb;
+    if (a.sym) {
+        ib = 0;
+        while (t >= nb - ib) { t -= nb - ib; ++ib; }
+        jb = ib + t;
+    } else {
+        ib = t / nb; jb = t % nb;
+    }
+    const bool diag = a.sym && ib == jb;
+
+    int64_t r0, r1;
+    if (a.per_sample) {
+        const int64_t n = z / a.nsplit, q = z % a.nsplit;
+        r0 = n * a.HW + q * a.rows_per_slab;
+        r1 = r0 + a.rows_per_slab;
+        const int64_t end = (n + 1) * a.HW;
+        if (r1 > end) r1 = end;
+    } else {
+        const int64_t M = a.N * a.HW;
+        r0 = z * a.rows_per_slab;
+        r1 = r0 + a.rows_per_slab;
+        if (r1 > M) r1 = M;
+    }
+
+    const int q4 = tid & 31;
+    const int rbase = tid >> 5;
+    const int ci = ib * BM + 4 * q4, cj = jb * BN + 4 * q4;
+    const bool vi = ci < C, vj = cj < C;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 cx = (a.cx && vi) ? ld4(a.cx + ci) : zero4;
+    const f32x4 cy = (a.cy && vj) ? ld4(a.cy + cj) : zero4;
+
+    f64x4 acc[4][4];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[tt][u] = f64x4{0.0, 0.0, 0.0, 0.0};
+    f32x4 csum = zero4;
+
+    const bool t_ok = (ib * BM + wr * 64) < C && (jb * BN + wc * 64) < C;
+    const int li = lane & 15, lq = lane >> 4;
+
+    f32x4 xv[4], yv[4];
+    auto load_chunk = [&](int64_t m0) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int64_t m = m0 + rbase + 8 * p;
+            const bool ok = m < r1;
+            xv[p] = (ok && vi) ? ld4(a.X + m * C + ci) - cx : zero4;
+            if (!diag) yv[p] = (ok && vj) ? ld4(a.Y + m * C + cj) - cy : zero4;
+        }
+    };
+
+    if (r0 < r1) load_chunk(r0);
+    for (int64_t m0 = r0; m0 < r1; m0 += BK) {
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            *reinterpret_cast<f32x4*>(&Xs[(rbase + 8 * p) * BM + 4 * q4]) = xv[p];
+            if (!diag) *reinterpret_cast<f32x4*>(&Ys[(rbase + 8 * p) * BN + 4 * q4]) = yv[p];
+            csum += a.sym ? xv[p] : yv[p];
+        }
+        __syncthreads();
+        if (m0 + BK < r1) load_chunk(m0 + BK);
+        if (t_ok) {
+            const float* Bsrc = diag ? Xs : Ys;
+#pragma unroll 2
+            for (int kk = 0; kk < BK; kk += 4) {
+                double av[4], bv[4];
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                    av[tt] = (double)Xs[(kk + lq) * BM + wr * 64 + tt * 16 + li];
+                    bv[tt] = (double)Bsrc[(kk + lq) * BN + wc * 64 + tt * 16 + li];
+                }
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        acc[tt][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[tt], bv[u], acc[tt][u], 0, 0, 0);
+            }
+        }
+    }
+
+    double* P = a.P + z * (int64_t)C * C;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int j = jb * BN + wc * 64 + u * 16 + li;
+        if (j >= C) continue;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = ib * BM + wr * 64 + tt * 16 + lq + 4 * r;
+                if (i < C) P[(int64_t)i * C + j] = acc[tt][u][r];
+            }
+    }
+
+    const bool want = a.sym ? diag : (ib == 0);
+    if (want && a.colsum) {
+        __syncthreads();
+        float* red = Xs;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[rbase * 128 + 4 * q4 + j] = csum[j];
+        __syncthreads();
+        if (tid < 128) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) sacc += red[r * 128 + tid];
+            const int col = (a.sym ? ib : jb) * 128 + tid;
+            if (col < C) a.colsum[z * C + col] = sacc;
         }
     }
 }
@@ -311,7 +453,7 @@ hipError_t wc_launch_rows_gemm(const WcRowsGemmArgs& a, hipStream_t st)
 int wc_xty_plan(int64_t N, int64_t HW, int C, int per_sample, int sym, int* nsplit, int64_t* rows_per_slab)
 {
     const int nb = (C + BM - 1) / BM;
-    const int64_t target = 768;                       // ~3 workgroups per CU
+    const int64_t target = 512;                       // ~2 workgroups per CU (the fp64 flush registers cap it at 2)
     const int64_t min_rows = 256;
     const int ntiles = sym ? nb * (nb + 1) / 2 : nb * nb;
     if (per_sample) {
@@ -342,7 +484,10 @@ hipError_t wc_launch_xty(const WcXtyArgs& a, int nslab, hipStream_t st)
     const int nb = (a.C + BM - 1) / BM;
     const int ntiles = a.sym ? nb * (nb + 1) / 2 : nb * nb;
     const int64_t grid = (int64_t)nslab * ntiles;
-    hipLaunchKernelGGL(xty_kernel, dim3((unsigned)grid), dim3(256), 0, st, a, ntiles, nb);
+    if (a.N * a.HW <= WC_EXACT_ROWS)
+        hipLaunchKernelGGL(xty_f64_kernel, dim3((unsigned)grid), dim3(256), 0, st, a, ntiles, nb);
+    else
+        hipLaunchKernelGGL(xty_kernel, dim3((unsigned)grid), dim3(256), 0, st, a, ntiles, nb);
     return hipGetLastError();
 }
 

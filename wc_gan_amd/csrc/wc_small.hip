@@ -34,27 +34,27 @@ __global__ void stats_colsum_kernel(const float* __restrict__ colsum, const floa
 }
 
 // xtx = G' + s Sp^T + Sp s^T + M s s^T with G' = sum_z P[z]; only block-upper tiles of P were written.
-__global__ void stats_xtx_kernel(const float* __restrict__ P, const float* __restrict__ shift, const double* __restrict__ Sp,
+__global__ void stats_xtx_kernel(const double* __restrict__ P, const float* __restrict__ shift, const double* __restrict__ Sp,
                                  int nslab, int64_t M, int C, double* __restrict__ xtx)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y;
     if (j >= C) return;
-    if ((j >> 7) < (i >> 7)) return;              // lower block-triangle is mirrored by the (j,i) thread
+    if (j < i) return;                            // the lower triangle is mirrored by the (j,i) thread: exact symmetry
     const int64_t CC = (int64_t)C * C;
     double g = 0.0;
-    const float* p = P + (int64_t)i * C + j;
-    for (int z = 0; z < nslab; ++z) g += (double)p[z * CC];
+    const double* p = P + (int64_t)i * C + j;
+    for (int z = 0; z < nslab; ++z) g += p[z * CC];
     const double si = shift[i], sj = shift[j];
     const double v = g + si * Sp[j] + Sp[i] * sj + (double)M * si * sj;
     xtx[(int64_t)i * C + j] = v;
-    if ((j >> 7) > (i >> 7)) xtx[(int64_t)j * C + i] = v;
+    if (j != i) xtx[(int64_t)j * C + i] = v;
 }
 
 // ---------------------------------------------------------------------------------------------
 // K4 tail: per-slab partials -> per-slot R, gsum
 // ---------------------------------------------------------------------------------------------
-__global__ void bwd_combine_kernel(const float* __restrict__ P, const float* __restrict__ colsum,
+__global__ void bwd_combine_kernel(const double* __restrict__ P, const float* __restrict__ colsum,
                                    const int32_t* __restrict__ slot, int64_t N, int nsplit, int per_sample,
                                    int C, double* __restrict__ R, double* __restrict__ gsum)
 {
@@ -63,16 +63,15 @@ __global__ void bwd_combine_kernel(const float* __restrict__ P, const float* __r
     const int k = blockIdx.y;
     if (e >= CC + C) return;
     const bool is_sum = e >= CC;
-    const float* src = is_sum ? colsum + (e - CC) : P + e;
-    const int64_t stride = is_sum ? C : CC;
     double acc = 0.0;
+    auto term = [&](int64_t z) { return is_sum ? (double)colsum[z * C + (e - CC)] : P[z * CC + e]; };
     if (per_sample) {
         for (int64_t n = 0; n < N; ++n) {
             if (slot[n] != k) continue;
-            for (int q = 0; q < nsplit; ++q) acc += (double)src[(n * nsplit + q) * stride];
+            for (int q = 0; q < nsplit; ++q) acc += term(n * nsplit + q);
         }
     } else {
-        for (int z = 0; z < nsplit; ++z) acc += (double)src[z * stride];
+        for (int z = 0; z < nsplit; ++z) acc += term(z);
     }
     if (is_sum) gsum[(int64_t)k * C + (e - CC)] = acc;
     else R[k * CC + e] = acc;
@@ -354,7 +353,7 @@ __global__ void f64_to_f32_kernel(const double* __restrict__ src, float* __restr
 
 }  // namespace
 
-hipError_t wc_launch_stats_finalize(const float* P, const float* colsum, const float* shift, int nslab,
+hipError_t wc_launch_stats_finalize(const double* P, const float* colsum, const float* shift, int nslab,
                                     int64_t M, int C, double* Sp, double* sum, double* xtx, hipStream_t st)
 {
     hipLaunchKernelGGL(stats_colsum_kernel, dim3((C + 63) / 64), dim3(64), 0, st, colsum, shift, nslab, M, C, Sp, sum);
@@ -362,7 +361,7 @@ hipError_t wc_launch_stats_finalize(const float* P, const float* colsum, const f
     return hipGetLastError();
 }
 
-hipError_t wc_launch_bwd_combine(const float* P, const float* colsum, const int32_t* slot, int64_t N, int nsplit,
+hipError_t wc_launch_bwd_combine(const double* P, const float* colsum, const int32_t* slot, int64_t N, int nsplit,
                                  int per_sample, int C, int Kc, double* R, double* gsum, hipStream_t st)
 {
     const int64_t total = (int64_t)C * C + C;
