@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of the G+D training step, CIFAR-10 ResNet-SN + WC, batch 64 per GPU.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched through
+torch.distributed.run, one rank per GPU over RCCL.  Rank 0 prints ONE JSON line.
+
+  step      one "G+D step" = training_ratio critic updates (64 real + 64 generated, generator forward in
+            train mode) + one generator update at batch 64 x 2 (run.py:101,293-294); images/sec = 64 x steps/s
+            per GPU (weak scaling: every GPU keeps batch 64).
+  roofline  the dominant hand-written kernel, the fused WC apply (K3) at the headline site
+            128 x 32 x 32 x 256: algorithmic bytes 2*M*C*4 + (C*C + C)*4 per launch over the launch time
+            measured here with HIP events on the launching stream, against the 8 TB/s HBM3E peak.
+  cpu_baseline  the float64 numpy oracle (kind "port") timed on this box's host cores over the WC sites of
+            one G+D step -- the hot path only, the convolutions are not part of it.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.setdefault("PYTORCH_MIOPEN_SUGGEST_NHWC", "1")
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+TRAINING_RATIO = 5             # default of the missing gan.cmd parser [UPSTREAM-RECALL]; ratio 1 also reported
+
+# WC sites of the CIFAR-10 unconditional generator: (H=W, C) per site
+CIFAR_SITES = [(4, 256), (8, 256), (8, 256), (16, 256), (16, 256), (32, 256), (32, 256)]
+
+
+def time_kernel(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()                       # torch's current stream == the stream the C ABI launches on
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def roofline_apply(dev):
+    from wc_gan_amd import ops
+    N, H, C = 128, 32, 256
+    M = N * H * H
+    g = torch.Generator(device="cpu"); g.manual_seed(1234)
+    x = torch.randn(N, H, H, C, generator=g).to(dev)
+    A = (torch.randn(1, C, C, generator=g) / C ** 0.5).to(dev)
+    mu = (0.2 * torch.ones(C)).to(dev); b = (0.1 * torch.randn(1, C, generator=g)).to(dev)
+    y = torch.empty_like(x)
+    t = time_kernel(lambda: ops.apply(x, mu, A, b, None, out=y))
+    alg_bytes = 2 * M * C * 4 + (C * C + C) * 4
+    y2 = torch.empty_like(x)
+    t_copy = time_kernel(lambda: ops.stream_copy(x, y2))
+    achieved = alg_bytes / t / 1e9
+    return {"bound": "hbm", "kernel": "rows_gemm_kernel (wc_apply_f32, 128x32x32x256 fp32)",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "launch_us": round(t * 1e6, 2), "algorithmic_bytes": alg_bytes,
+            "stream_copy_GBs": round(2 * M * C * 4 / t_copy / 1e9, 1),
+            "frac_of_stream_copy": round(achieved / (2 * M * C * 4 / t_copy / 1e9), 4)}
+
+
+def wc_sites_gpu(dev, ratio):
+    """GPU time of the WC sites of one G+D step (what cpu_baseline times on the host)."""
+    from wc_gan_amd.functional import whiten_color
+    g = torch.Generator(device="cpu"); g.manual_seed(1234)
+    work = []
+    for H, C in CIFAR_SITES:
+        G = (torch.randn(1, C, C, generator=g) / C ** 0.5).to(dev).requires_grad_(True)
+        B = torch.zeros(1, C, device=dev, requires_grad=True)
+        x64 = torch.randn(64, H, H, C, generator=g).to(dev)
+        x128 = torch.randn(128, H, H, C, generator=g).to(dev).requires_grad_(True)
+        work.append((x64, x128, G, B, torch.randn(128, H, H, C, generator=g).to(dev)))
+
+    def one():
+        for x64, x128, G, B, gy in work:
+            with torch.no_grad():
+                for _ in range(ratio):
+                    whiten_color(x64, G, B)
+            whiten_color(x128, G, B).backward(gy)
+    return time_kernel(one, iters=5, warm=2)
+
+
+def cpu_baseline(ratio):
+    import numpy as np
+    from oracle import wc_oracle as o
+    rng = np.random.default_rng(1234)
+    t_total = 0.0
+    for H, C in CIFAR_SITES:
+        G, B = o.synth_coloring(rng, C, 1)
+        x64 = rng.standard_normal((64, H, H, C)).astype(np.float32)
+        x128 = rng.standard_normal((128, H, H, C)).astype(np.float32)
+        gy = rng.standard_normal((128, H, H, C)).astype(np.float32)
+        t0 = time.perf_counter()
+        for _ in range(ratio):
+            o.wc_forward(x64, G, B)
+        y, cache = o.wc_forward(x128, G, B)
+        o.wc_backward(gy, cache)
+        t_total += time.perf_counter() - t0
+    cores = os.cpu_count() or 1
+    return {"value": round(64.0 / t_total, 3), "unit": "images/sec (WC sites of one G+D step only)",
+            "cores": cores, "kind": "port",
+            "sample": f"float64 numpy oracle, 7 generator WC sites, {ratio} forward passes at N=64 + 1 forward+backward "
+                      f"at N=128 = the WC work of one G+D step ({t_total:.1f} s), BLAS threads = {cores}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--training-ratio", type=int, default=TRAINING_RATIO)
+    ap.add_argument("--sync-wc", action="store_true", help="all-reduce WC statistics across replicas")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the WC path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    group = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        group = dist.group.WORLD
+
+    from wc_gan_amd import _lib
+    from wc_gan_amd.train import CIFAR10_UNCOND, build_trainer
+    _lib.load()
+    torch.manual_seed(1234)
+    trainer = build_trainer(CIFAR10_UNCOND, dev, process_group=group, sync_wc=args.sync_wc,
+                            training_ratio=args.training_ratio, seed=1234 + rank)
+    g = torch.Generator(device="cpu"); g.manual_seed(1234 + rank)
+    reals = [(torch.rand(64, 32, 32, 3, generator=g) * 2 - 1).to(dev) for _ in range(args.training_ratio)]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(reals)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.step(reals)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    extra = {}
+    if rank == 0:
+        roof = roofline_apply(dev)
+        wc_gpu = wc_sites_gpu(dev, args.training_ratio)
+        extra["wc_sites_gpu"] = {"value": round(64.0 / wc_gpu, 1), "unit": "images/sec (WC sites of one G+D step only)",
+                                 "ms": round(wc_gpu * 1e3, 3)}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args.training_ratio)
+        out = {
+            "metric": "images/sec G+D step, CIFAR-10 ResNet-SN+WC, batch 64",
+            "value": round(64.0 * world * args.steps / dt, 2), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "CIFAR-10 ResNet SN uncond + WC (scripts/cifar10_resnet_sn_uncond.sh), batch 64/GPU, "
+                                   f"training_ratio {args.training_ratio}, generator_batch_multiple 2",
+                       "parallelism": f"dp{world}", "wc_statistics": "sync" if args.sync_wc else "per-replica"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        out.update(extra)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

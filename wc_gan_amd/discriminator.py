@@ -1,0 +1,107 @@
+"""`make_discriminator` with the reference's keyword surface (discriminator.py:15-20).
+
+The discriminator holds NO whitening-and-coloring site in any shipped recipe (`--discriminator_norm`
+defaults to 'n', run.py:298), so it is the stock-torch part of the surrounding step: SN-ResNet blocks
+on MIOpen convolutions with torch's spectral-norm parametrisation standing in for gan.SNConv2D /
+SNDense / SNEmbeding (discriminator.py:26-33).  Three heads as in discriminator.py:73-85.
+"""
+from __future__ import annotations
+
+from functools import partial
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .generator import Conv2D, create_norm, to_nchw_view, to_nhwc
+
+
+def downsample2x(x):
+    return to_nhwc(F.avg_pool2d(to_nchw_view(x), 2))
+
+
+class ResBlockDown(nn.Module):
+    def __init__(self, in_ch, nfilters, resample, name, norm, conv_layer, is_first):
+        super().__init__()
+        assert resample in ('DOWN', 'SAME')
+        self.resample, self.is_first = resample, is_first
+        self.bn1 = norm(axis=-1, name=name + '.bn1', channels=in_ch)
+        self.conv1 = conv_layer(in_ch, nfilters, (3, 3), name=name + '.conv1')
+        self.bn2 = norm(axis=-1, name=name + '.bn2', channels=nfilters)
+        self.conv2 = conv_layer(nfilters, nfilters, (3, 3), name=name + '.conv2')
+        self.has_shortcut = (in_ch != nfilters) or resample == 'DOWN'
+        if self.has_shortcut:
+            self.shortcut = conv_layer(in_ch, nfilters, (1, 1), name=name + '.shortcut')
+
+    def forward(self, x, cls):
+        h = x
+        if not self.is_first:
+            h = F.relu(self.bn1(h, cls))
+        h = self.conv1(h)
+        h = F.relu(self.bn2(h, cls))
+        h = self.conv2(h)
+        s = x
+        if self.resample == 'DOWN':
+            h = downsample2x(h)
+            s = downsample2x(s)
+        if self.has_shortcut:
+            s = self.shortcut(s)
+        return h + s
+
+
+class Discriminator(nn.Module):
+    def __init__(self, in_ch, block_sizes, resamples, norm_layer, conv_layer, dense, emb, number_of_classes, type,
+                 sum_pool, dropout):
+        super().__init__()
+        blocks = []
+        ch = in_ch
+        for i, (bs, rs) in enumerate(zip(block_sizes, resamples)):
+            bs = int(bs)
+            blocks.append(ResBlockDown(ch, bs, rs, 'Discriminator.' + str(i), norm_layer, conv_layer, is_first=(i == 0)))
+            ch = bs
+        self.blocks = nn.ModuleList(blocks)
+        self.sum_pool, self.type = sum_pool, type
+        self.dropout = nn.Dropout(dropout) if dropout else None
+        self.out = dense(ch, 1)
+        if type == 'AC_GAN':
+            self.cls_out = dense(ch, number_of_classes)
+        elif type == 'PROJECTIVE':
+            self.emb = emb(number_of_classes, ch)
+
+    def forward(self, x, cls=None):
+        y = x
+        for blk in self.blocks:
+            y = blk(y, cls)
+        y = F.relu(y)
+        y = y.sum(dim=(1, 2)) if self.sum_pool else y.mean(dim=(1, 2))
+        if self.dropout is not None:
+            y = self.dropout(y)
+        out = self.out(y)
+        if self.type == 'AC_GAN':
+            return out, self.cls_out(y)
+        if self.type == 'PROJECTIVE':
+            out = out + (self.emb(cls.reshape(-1).long()) * y).sum(dim=1, keepdim=True)
+        return out
+
+
+def make_discriminator(input_image_shape=(32, 32, 3), input_cls_shape=(1,), block_sizes=(128, 128, 128, 128),
+                       resamples=('DOWN', 'DOWN', 'SAME', 'SAME'), number_of_classes=10,
+                       type=None, norm='n', after_norm='n', spectral=True,
+                       fully_diff_spectral=False, spectral_iterations=1, conv_singular=True,
+                       sum_pool=True, dropout=False, arch='res', filters_emb=10):
+    assert arch == 'res', "only the ResNet critic is built for the harness (dcgan critic: out of the WC path)"
+    assert type in [None, 'AC_GAN', 'PROJECTIVE']
+    conv_layer = partial(Conv2D, spectral=bool(spectral))
+
+    def dense(i, o):
+        lin = nn.Linear(i, o)
+        nn.init.xavier_uniform_(lin.weight); nn.init.zeros_(lin.bias)
+        return nn.utils.parametrizations.spectral_norm(lin) if spectral else lin
+
+    def emb(k, d):
+        e = nn.Embedding(k, d)
+        return nn.utils.parametrizations.spectral_norm(e) if spectral else e
+
+    norm_layer = create_norm(norm, after_norm, number_of_classes=number_of_classes, filters_emb=filters_emb)
+    return Discriminator(int(input_image_shape[-1]), block_sizes, resamples, norm_layer, conv_layer, dense, emb,
+                         number_of_classes, type, sum_pool, dropout)

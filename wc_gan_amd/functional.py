@@ -94,3 +94,100 @@ def whiten_color(x, gamma=None, beta=None, slot=None, moving_mean=None, moving_c
     """y = coloring(whitening(x)).  x: (N, H, W, C) float32 on the GPU, C % 32 == 0 (see layers for padding)."""
     return WhitenColorFunction.apply(x, gamma, beta, slot, moving_mean, moving_cov, bool(training),
                                      float(eps), float(momentum), int(ddof), process_group)
+
+
+# ---------------------------------------------------------------------------------------------
+# Modular pieces: the same HIP kernels exposed as two differentiable ops, so that a C x C stage
+# written in torch (ZCA's eigendecomposition, renorm's constant factor) can sit between them.
+# ---------------------------------------------------------------------------------------------
+class MomentsFunction(torch.autograd.Function):
+    """(sum, xtx) = K1(x).  backward: dx[m] = gsum + x[m] (gxtx + gxtx^T)  -- one K3 launch."""
+
+    @staticmethod
+    def forward(ctx, x):
+        C = x.shape[-1]
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return ops.stats(x.view(-1, C))
+
+    @staticmethod
+    def backward(ctx, gs, gxtx):
+        (x,) = ctx.saved_tensors
+        C = x.shape[-1]
+        A = (gxtx + gxtx.t()).to(torch.float32).reshape(1, C, C).contiguous()
+        b = gs.to(torch.float32).reshape(1, C).contiguous()
+        return ops.apply(x, None, A, b, None)
+
+
+class AffineRowsFunction(torch.autograd.Function):
+    """y[n] = (x[n] - mu) A[slot[n]] + b[slot[n]] with gradients to x, mu, A and b (K3 / K4 / K6)."""
+
+    @staticmethod
+    def forward(ctx, x, mu, A, b, slot):
+        x = x.contiguous()
+        A = A.contiguous()
+        mu_c = mu.contiguous() if mu is not None else None
+        b_c = b.contiguous() if b is not None else None
+        ctx.save_for_backward(x, A, mu_c if mu_c is not None else torch.empty(0, device=x.device),
+                              slot if slot is not None else torch.empty(0, dtype=torch.int32, device=x.device))
+        ctx.has_mu, ctx.has_b, ctx.has_slot = mu is not None, b is not None, slot is not None
+        return ops.apply(x, mu_c, A, b_c, slot)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, A, mu, slot = ctx.saved_tensors
+        mu = mu if ctx.has_mu else None
+        slot = slot if ctx.has_slot else None
+        gy = gy.contiguous()
+        Kc = A.shape[0]
+        need_x, need_mu, need_A, need_b = ctx.needs_input_grad[:4]
+        dx = dmu = dA = db = None
+        At = A.transpose(1, 2).contiguous()
+        if need_x:
+            dx = ops.bwd_apply(gy, None, None, At, None, None, slot)
+        if need_A or need_b or need_mu:
+            R, gsum = ops.bwd_reduce(x, mu, gy, slot, Kc)
+            if need_A:
+                dA = R.to(torch.float32)
+            if need_b and ctx.has_b:
+                db = gsum.to(torch.float32)
+            if need_mu and ctx.has_mu:
+                dmu = -torch.einsum('kj,kcj->c', gsum, A.to(torch.float64)).to(torch.float32)
+        return dx, dmu, dA, db, None
+
+
+def whiten_color_modular(x, gamma=None, beta=None, slot=None, moving_mean=None, moving_cov=None, training=True,
+                         eps=1e-3, momentum=0.99, ddof=1, decomposition='zca'):
+    """Unfused composition moments -> torch C x C stage -> affine, for decompositions without a fused kernel.
+
+    decomposition='zca' (generator.py:24, commented alternative): W = U diag(S^-1/2) U^T of Sigma + eps I;
+    torch.linalg.eigh supplies the (reportedly unstable) gradient, as tf.svd did upstream.
+    """
+    C = x.shape[-1]
+    M = x.numel() // C
+    if training:
+        s, xtx = MomentsFunction.apply(x)
+        mu64 = s / M
+        sigma = (xtx - torch.outer(s, s) / M) / (M - ddof)
+        sigma = 0.5 * (sigma + sigma.t())
+        if moving_mean is not None:
+            with torch.no_grad():
+                moving_mean.mul_(momentum).add_((1 - momentum) * mu64.to(torch.float32).view_as(moving_mean))
+                moving_cov.mul_(momentum).add_((1 - momentum) * sigma.to(torch.float32))
+    else:
+        mu64 = moving_mean.view(-1).to(torch.float64)
+        sigma = moving_cov.to(torch.float64)
+    eye = torch.eye(C, dtype=torch.float64, device=x.device)
+    if decomposition == 'zca':
+        S, U = torch.linalg.eigh(sigma + eps * eye)
+        W = (U * S.rsqrt()) @ U.t()
+    elif decomposition == 'cholesky':
+        L = torch.linalg.cholesky((1 - eps) * sigma + eps * eye)
+        W = torch.linalg.solve_triangular(L, eye, upper=False)
+    else:
+        raise ValueError(f"unknown decomposition {decomposition!r}")
+    if gamma is None:
+        A = W.t().unsqueeze(0)
+    else:
+        A = torch.matmul(W.t().unsqueeze(0), gamma.to(torch.float64))
+    return AffineRowsFunction.apply(x, mu64.to(torch.float32), A.to(torch.float32), beta, slot)

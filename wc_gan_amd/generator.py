@@ -1,0 +1,244 @@
+"""`create_norm` and `make_generator` with the reference's signatures (generator.py:13-17, 93-98).
+
+`create_norm(norm, after_norm, ...)` returns `result_norm(axis, name)` exactly as in the reference
+(generator.py:82-90); calling that gives the `stack` callable.  Differences forced by define-by-run
+PyTorch: `stack(inp, cls)` receives the class tensor at call time (the reference closes over the
+symbolic `cls` Input, generator.py:102,131-139), and a stack is an nn.Module so its weights register.
+
+Whenever norm is 'd' / 'dr' the stack is the fused `WhiteningColoring` (one statistics pass, one
+float64 C x C stage, one affine pass).  Sub-layer naming follows generator.py:85-86 and 36-38, 55-58:
+`<name>_npart`, `<name>_repart`, `<name>_repart_c`, `<name>_repart_u`.
+
+The ResNet block body (`gan.layer_utils.resblock`) is in the un-vendored submodule; the block here is
+the SN-GAN generator block it implements [UPSTREAM-RECALL]: norm -> relu -> upsample -> conv3x3 ->
+norm -> relu -> conv3x3, plus an upsample -> conv1x1 shortcut (SURVEY.md row a2 site list).
+"""
+from __future__ import annotations
+
+from functools import partial
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .layers import (CenterScale, ConditionalCenterScale, ConditionalConv11, Conv11, DecorelationNormalization,
+                     FactorizedConv11, WhiteningColoring)
+
+NORMS = ['n', 'b', 'd', 'dr']
+AFTER_NORMS = ['ucs', 'ccs', 'uccs', 'uconv', 'fconv', 'ufconv', 'cconv', 'ucconv', 'ccsuconv', 'n']
+
+
+# ---------------------------------------------------------------------------------------------
+# NHWC plumbing around torch's convolutions (the surrounding step is stock torch / MIOpen)
+# ---------------------------------------------------------------------------------------------
+def to_nchw_view(x):
+    return x.permute(0, 3, 1, 2)          # NHWC-contiguous -> channels_last NCHW view, zero copy
+
+
+def to_nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()   # no copy when x is channels_last
+
+
+class Conv2D(nn.Module):
+    """Keras-style Conv2D on NHWC tensors (padding='same'); glorot-uniform kernel, zero bias."""
+
+    def __init__(self, in_channels, filters, kernel_size=(3, 3), use_bias=True, name=None, spectral=False):
+        super().__init__()
+        k = kernel_size if isinstance(kernel_size, int) else kernel_size[0]
+        self.conv = nn.Conv2d(in_channels, filters, k, padding=k // 2, bias=use_bias)
+        nn.init.xavier_uniform_(self.conv.weight)
+        if use_bias:
+            nn.init.zeros_(self.conv.bias)
+        self.conv = self.conv.to(memory_format=torch.channels_last)
+        if spectral:
+            self.conv = nn.utils.parametrizations.spectral_norm(self.conv)
+        self.layer_name = name
+
+    def forward(self, x):
+        return to_nhwc(self.conv(to_nchw_view(x)))
+
+
+def upsample2x(x):
+    return to_nhwc(F.interpolate(to_nchw_view(x), scale_factor=2, mode='nearest'))
+
+
+class _BatchNormNoAffine(nn.Module):
+    """norm == 'b': BatchNormalization(center=False, scale=False) (generator.py:22) on NHWC."""
+
+    def __init__(self, name=None):
+        super().__init__()
+        self.bn = None
+        self.layer_name = name
+
+    def forward(self, x):
+        if self.bn is None:
+            self.bn = nn.BatchNorm2d(x.shape[-1], eps=1e-3, momentum=0.01, affine=False).to(x.device)
+        return to_nhwc(self.bn(to_nchw_view(x)))
+
+
+class _UnfusedStack(nn.Module):
+    """norm in {'n','b'}: normalisation then the coloring branches applied on their own and added."""
+
+    def __init__(self, norm_layer, branches):
+        super().__init__()
+        self.norm_layer = norm_layer
+        self.branches = nn.ModuleList(branches)
+
+    def forward(self, x, cls=None):
+        if isinstance(x, (list, tuple)):
+            x, cls = x
+        out = self.norm_layer(x) if self.norm_layer is not None else x
+        if len(self.branches) == 0:
+            return out
+        total = None
+        for br in self.branches:
+            y = br([out, cls]) if br.conditional else br(out)
+            total = y if total is None else total + y
+        return total
+
+
+def create_norm(norm, after_norm, cls=None, number_of_classes=None, filters_emb=10,
+                uncoditional_conv_layer=Conv11, conditional_conv_layer=ConditionalConv11,
+                factor_conv_layer=FactorizedConv11, process_group=None):
+    """Factory of generator.py:13-90: returns result_norm(axis, name) -> stack(inp, cls)."""
+    assert norm in NORMS
+    assert after_norm in AFTER_NORMS
+    K = number_of_classes
+
+    def branches(axis, name, ch):
+        if after_norm == 'ccs':
+            return [ConditionalCenterScale(number_of_classes=K, axis=axis, name=name, channels=ch)]
+        if after_norm == 'ucs':
+            return [CenterScale(axis=axis, name=name, channels=ch)]
+        if after_norm == 'uccs':
+            return [ConditionalCenterScale(number_of_classes=K, axis=axis, name=name + '_c', channels=ch),
+                    CenterScale(axis=axis, name=name + '_u', channels=ch)]
+        if after_norm == 'cconv':
+            return [conditional_conv_layer(number_of_classes=K, name=name, channels=ch)]
+        if after_norm == 'fconv':
+            return [factor_conv_layer(number_of_classes=K, name=name + '_c', filters_emb=filters_emb, use_bias=False, channels=ch)]
+        if after_norm == 'uconv':
+            return [uncoditional_conv_layer(kernel_size=(1, 1), name=name, channels=ch)]
+        if after_norm == 'ucconv':
+            return [conditional_conv_layer(number_of_classes=K, name=name + '_c', channels=ch),
+                    uncoditional_conv_layer(kernel_size=(1, 1), name=name + '_u', channels=ch)]
+        if after_norm == 'ccsuconv':
+            return [ConditionalCenterScale(number_of_classes=K, axis=axis, name=name + '_c', channels=ch),
+                    uncoditional_conv_layer(kernel_size=(1, 1), name=name + '_u', channels=ch)]
+        if after_norm == 'ufconv':
+            return [factor_conv_layer(number_of_classes=K, name=name + '_c', filters_emb=filters_emb, use_bias=False, channels=ch),
+                    uncoditional_conv_layer(kernel_size=(1, 1), name=name + '_u', channels=ch)]
+        return []                                           # 'n'
+
+    def result_norm(axis, name, channels=None):
+        # channels=None keeps the Keras behaviour (build on first call); giving it builds the weights now
+        br = branches(axis, name + '_repart', channels)
+        if norm in ('d', 'dr'):
+            npart = DecorelationNormalization(name=name + '_npart', renorm=(norm == 'dr'), channels=channels,
+                                              process_group=process_group)
+            return WhiteningColoring(npart, br)
+        norm_layer = _BatchNormNoAffine(name=name + '_npart') if norm == 'b' else None
+        return _UnfusedStack(norm_layer, br)
+
+    return result_norm
+
+
+# ---------------------------------------------------------------------------------------------
+# generator
+# ---------------------------------------------------------------------------------------------
+class ResBlockUp(nn.Module):
+    def __init__(self, in_ch, nfilters, resample, name, norm, conv_layer):
+        super().__init__()
+        assert resample in ('UP', 'SAME')
+        self.resample = resample
+        self.bn1 = norm(axis=-1, name=name + '.bn1', channels=in_ch)
+        self.conv1 = conv_layer(in_ch, nfilters, (3, 3), name=name + '.conv1')
+        self.bn2 = norm(axis=-1, name=name + '.bn2', channels=nfilters)
+        self.conv2 = conv_layer(nfilters, nfilters, (3, 3), name=name + '.conv2')
+        self.shortcut = conv_layer(in_ch, nfilters, (1, 1), name=name + '.shortcut')
+
+    def forward(self, x, cls):
+        h = F.relu(self.bn1(x, cls))
+        s = x
+        if self.resample == 'UP':
+            h = upsample2x(h)
+            s = upsample2x(s)
+        h = self.conv1(h)
+        h = F.relu(self.bn2(h, cls))
+        h = self.conv2(h)
+        return h + self.shortcut(s)
+
+
+class DCBlockUp(nn.Module):
+    def __init__(self, in_ch, nfilters, resample, name, norm):
+        super().__init__()
+        self.deconv = nn.ConvTranspose2d(in_ch, nfilters, 4, stride=2 if resample == 'UP' else 1,
+                                         padding=1 if resample == 'UP' else 0).to(memory_format=torch.channels_last)
+        self.bn = norm(axis=-1, name=name + '.bn', channels=nfilters)
+
+    def forward(self, x, cls):
+        h = to_nhwc(self.deconv(to_nchw_view(x)))
+        return F.relu(self.bn(h, cls))
+
+
+class Generator(nn.Module):
+    def __init__(self, input_noise_shape, output_channels, first_block_shape, block_sizes, resamples,
+                 block_norm_layer, last_norm_layer, conv_layer, dense_spectral, concat_cls, number_of_classes, arch,
+                 conditional):
+        super().__init__()
+        self.first_block_shape = tuple(int(v) for v in first_block_shape)
+        self.conditional = conditional
+        in_dim = int(np.prod(input_noise_shape))
+        self.emb = None
+        if concat_cls:
+            self.emb = nn.Embedding(number_of_classes, self.first_block_shape[-1])
+            in_dim += self.first_block_shape[-1]
+        self.dense = nn.Linear(in_dim, int(np.prod(self.first_block_shape)))
+        nn.init.xavier_uniform_(self.dense.weight); nn.init.zeros_(self.dense.bias)
+        if dense_spectral:
+            self.dense = nn.utils.parametrizations.spectral_norm(self.dense)
+        blocks = []
+        ch = self.first_block_shape[-1]
+        for i, (bs, rs) in enumerate(zip(block_sizes, resamples)):
+            bs = int(bs)
+            name = 'Generator.' + str(i)
+            if arch == 'res':
+                blocks.append(ResBlockUp(ch, bs, rs, name, block_norm_layer, conv_layer))
+            else:
+                blocks.append(DCBlockUp(ch, bs, rs, name, block_norm_layer))
+            ch = bs
+        self.blocks = nn.ModuleList(blocks)
+        self.final_norm = last_norm_layer(axis=-1, name='Generator.BN.Final', channels=ch)
+        self.final_conv = conv_layer(ch, output_channels, (3, 3), name='Generator.Final')
+
+    def forward(self, z, cls=None):
+        y = z
+        if self.emb is not None:
+            y = torch.cat([self.emb(cls.reshape(-1).long()), z], dim=-1)
+        y = self.dense(y).view(-1, *self.first_block_shape)
+        for blk in self.blocks:
+            y = blk(y, cls)
+        y = F.relu(self.final_norm(y, cls))
+        return torch.tanh(self.final_conv(y))
+
+
+def make_generator(input_noise_shape=(128,), output_channels=3, input_cls_shape=(1,),
+                   block_sizes=(128, 128, 128), resamples=("UP", "UP", "UP"),
+                   first_block_shape=(4, 4, 128), number_of_classes=10, concat_cls=False,
+                   block_norm='u', block_after_norm='cs', filters_emb=10,
+                   last_norm='u', last_after_norm='cs', gan_type=None, arch='res',
+                   spectral=False, fully_diff_spectral=False, spectral_iterations=1, conv_singular=True,
+                   process_group=None):
+    """Same keyword surface as generator.py:93-98; returns an nn.Module called as G(z) or G(z, cls)."""
+    assert arch in ['res', 'dcgan']
+    if spectral and (block_after_norm not in ('uconv', 'ucs', 'n') or last_after_norm not in ('uconv', 'ucs', 'n')):
+        raise NotImplementedError("spectral-normalised conditional coloring (SNConditionalConv11/SNFactorizedConv11) "
+                                  "is outside the WC hot path; no shipped recipe sets --generator_spectral")
+    conv_layer = partial(Conv2D, spectral=bool(spectral))
+    mk = partial(create_norm, number_of_classes=number_of_classes, filters_emb=filters_emb, process_group=process_group)
+    block_norm_layer = mk(block_norm, block_after_norm)
+    last_norm_layer = mk(last_norm, last_after_norm)
+    return Generator(input_noise_shape, output_channels, first_block_shape, block_sizes, resamples,
+                     block_norm_layer, last_norm_layer, conv_layer, bool(spectral), concat_cls, number_of_classes, arch,
+                     conditional=gan_type is not None)

@@ -1,0 +1,314 @@
+"""Host-side mirror of the reference's layer surface for the WC path (torch.nn.Module based).
+
+Names, constructor kwargs and NHWC semantics follow the call sites in the reference:
+
+    DecorelationNormalization(name=, renorm=, decomposition=)      generator.py:24,26
+    CenterScale(axis=, name=)                                      generator.py:32,37
+    ConditionalCenterScale(number_of_classes=, axis=, name=)([x, cls])     generator.py:29-30,36
+    ConditionalConv11(filters=, number_of_classes=, name=)([x, cls])       generator.py:42-44,55-57
+    FactorizedConv11(number_of_classes=, filters=, filters_emb=, use_bias=, name=)([x, cls])   generator.py:46-48,72-76
+    Conv11(filters=, name=)  -- the Keras Conv2D(kernel_size=(1,1)) coloring of generator.py:50-51
+
+The classes themselves live in the reference's un-vendored `gan/` submodule, so weight shapes,
+initialisers, epsilon and momentum are [UPSTREAM-RECALL] and exposed as constructor arguments.
+
+Tensors are NHWC (Keras `axis=-1`); `cls` is the int (N, 1) class input of generator.py:102.
+Modules build lazily on the first call (Keras `build(input_shape)`) unless `channels=` is given.
+
+`WhiteningColoring` is the fused hot path `create_norm` substitutes whenever norm is 'd'/'dr':
+it owns a DecorelationNormalization (`<name>_npart`) and the coloring layers (`<name>_repart*`)
+and runs them as ONE statistics pass, one small float64 stage and ONE affine pass over x.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import functional as WF
+
+
+def _glorot_uniform_(t, fan_in, fan_out):
+    limit = math.sqrt(6.0 / (fan_in + fan_out))
+    with torch.no_grad():
+        return t.uniform_(-limit, limit)
+
+
+def _cls_index(cls):
+    return cls.reshape(-1).to(torch.int32).contiguous()
+
+
+def _pad_channels(x, mult=32):
+    C = x.shape[-1]
+    Cp = (C + mult - 1) // mult * mult
+    if Cp == C:
+        return x, C
+    return F.pad(x, (0, Cp - C)), C
+
+
+class _Lazy(nn.Module):
+    """Keras-style deferred build: parameters are created on the first call, from the input's channel count."""
+
+    def __init__(self, name=None, channels=None):
+        super().__init__()
+        self.layer_name = name
+        self.channels = None
+        if channels is not None:
+            self._build(int(channels))
+
+    def _build(self, C, device=None):
+        self.channels = C
+        self.build(C, device)
+
+    def _ensure(self, x):
+        if self.channels is None:
+            self._build(x.shape[-1], x.device)
+        elif x.shape[-1] != self.channels:
+            raise ValueError(f"{self.layer_name}: built for {self.channels} channels, got {x.shape[-1]}")
+
+
+# ---------------------------------------------------------------------------------------------
+# whitening
+# ---------------------------------------------------------------------------------------------
+class DecorelationNormalization(_Lazy):
+    """Batch whitening.  State: moving_mean (C,1), moving_cov (C,C)."""
+
+    def __init__(self, name=None, renorm=False, decomposition='cholesky', momentum=0.99, epsilon=1e-3, axis=-1,
+                 channels=None, process_group=None):
+        if decomposition not in ('cholesky', 'zca'):
+            raise ValueError("decomposition must be 'cholesky' or 'zca'")
+        if axis not in (-1, 3):
+            raise ValueError("the WC path is NHWC: axis must be -1")
+        self.renorm, self.decomposition = bool(renorm), decomposition
+        self.momentum, self.epsilon, self.process_group = float(momentum), float(epsilon), process_group
+        super().__init__(name, channels)
+
+    def build(self, C, device=None):
+        self.register_buffer('moving_mean', torch.zeros(C, 1, device=device))
+        self.register_buffer('moving_cov', torch.eye(C, device=device))
+
+    def transform(self, x, gamma=None, beta=None, slot=None):
+        """Whitening fused with an optional coloring table (gamma (Kc,C,C), beta (Kc,C), slot (N,))."""
+        self._ensure(x)
+        C = self.channels
+        if C % 32 != 0:
+            return self._padded(x, gamma, beta, slot)
+        if self.decomposition == 'zca':
+            if self.renorm:
+                raise NotImplementedError("renorm is defined for decomposition='cholesky' only")
+            return WF.whiten_color_modular(x, gamma, beta, slot, self.moving_mean, self.moving_cov, self.training,
+                                           self.epsilon, self.momentum, 1, 'zca')
+        if self.renorm and self.training:
+            gamma = self._renorm_gamma(x, gamma)
+        return WF.whiten_color(x, gamma, beta, slot, self.moving_mean, self.moving_cov, self.training,
+                               self.epsilon, self.momentum, 1, self.process_group)
+
+    def _renorm_gamma(self, x, gamma):
+        # W_eff = L_mov^-1 . stop_grad(L_batch) . L_batch^-1 (row a4): the batch factor carries the gradient,
+        # the value is the moving-statistics whitening.  Folded into the coloring: Gamma' = (L_mov^-1 L_batch)^T Gamma.
+        C = self.channels
+        with torch.no_grad():
+            from . import ops
+            s, xtx = ops.stats(x.contiguous().view(-1, C))
+            M = x.numel() // C
+            _, Lb, _ = ops.factor(s, xtx, M, C, self.epsilon, self.momentum, 1, True, None, None, x.device)
+            _, _, Wm = ops.factor(None, None, M, C, self.epsilon, self.momentum, 1, False,
+                                  self.moving_mean.view(-1), self.moving_cov, x.device)
+            C0t = (Wm @ Lb).t().to(torch.float32)
+        if gamma is None:
+            return C0t.unsqueeze(0).contiguous()
+        return torch.matmul(C0t.unsqueeze(0), gamma)
+
+    def _padded(self, x, gamma, beta, slot):
+        # zero channels whiten to zero and leave the real channels' Cholesky rows untouched
+        C = self.channels
+        xp, _ = _pad_channels(x)
+        Cp = xp.shape[-1]
+        if not hasattr(self, '_pad_mean'):
+            self.register_buffer('_pad_mean', torch.zeros(Cp, 1, device=x.device), persistent=False)
+            self.register_buffer('_pad_cov', torch.eye(Cp, device=x.device), persistent=False)
+        self._pad_mean.zero_(); self._pad_mean[:C] = self.moving_mean
+        self._pad_cov.copy_(torch.eye(Cp, device=x.device)); self._pad_cov[:C, :C] = self.moving_cov
+        Kc = 1 if gamma is None else gamma.shape[0]
+        g = torch.eye(Cp, device=x.device).repeat(Kc, 1, 1)
+        g[:, :C, :C] = gamma if gamma is not None else torch.eye(C, device=x.device)
+        b = None if beta is None else F.pad(beta, (0, Cp - C))
+        y = WF.whiten_color(xp.contiguous(), g, b, slot, self._pad_mean, self._pad_cov, self.training,
+                            self.epsilon, self.momentum, 1, self.process_group)
+        with torch.no_grad():
+            self.moving_mean.copy_(self._pad_mean[:C]); self.moving_cov.copy_(self._pad_cov[:C, :C])
+        return y[..., :C]
+
+    def forward(self, x):
+        return self.transform(x)
+
+
+# ---------------------------------------------------------------------------------------------
+# coloring layers.  Each exposes table(cls) -> (gamma (Kc,C,C), beta (Kc,C) | None, slot (N,) | None),
+# which is what the fused path consumes; forward() applies the layer on its own (unfused use).
+# ---------------------------------------------------------------------------------------------
+class _Coloring(_Lazy):
+    conditional = False
+
+    def table(self, cls=None):
+        raise NotImplementedError
+
+    def forward(self, inputs):
+        x, cls = (inputs if isinstance(inputs, (list, tuple)) else (inputs, None))
+        self._ensure(x)
+        gamma, beta, slot = self.table(cls)
+        xp, C = _pad_channels(x)
+        if xp.shape[-1] != C:
+            Cp = xp.shape[-1]
+            g = torch.zeros(gamma.shape[0], Cp, Cp, device=x.device); g[:, :C, :C] = gamma
+            beta = None if beta is None else F.pad(beta, (0, Cp - C))
+            gamma = g
+        y = WF.AffineRowsFunction.apply(xp.contiguous(), None, gamma, beta, slot)
+        return y[..., :C] if xp.shape[-1] != C else y
+
+
+class Conv11(_Coloring):
+    """Keras Conv2D(kernel_size=(1,1), filters=C): kernel (1,1,C_in,C_out), bias (C).  generator.py:50-51."""
+
+    def __init__(self, filters=None, name=None, use_bias=True, kernel_size=(1, 1), channels=None):
+        assert tuple(kernel_size) == (1, 1)
+        self.use_bias = use_bias
+        super().__init__(name, channels if channels is not None else filters)
+
+    def build(self, C, device=None):
+        self.kernel = nn.Parameter(_glorot_uniform_(torch.empty(1, 1, C, C, device=device), C, C))
+        self.bias = nn.Parameter(torch.zeros(C, device=device)) if self.use_bias else None
+
+    def table(self, cls=None):
+        C = self.channels
+        return self.kernel.view(1, C, C), (self.bias.view(1, C) if self.bias is not None else None), None
+
+
+class ConditionalConv11(_Coloring):
+    """Per-class 1x1 convolution: kernel (K, C_in, C_out), bias (K, C).  generator.py:42-44,55-57."""
+    conditional = True
+
+    def __init__(self, filters=None, number_of_classes=10, name=None, use_bias=True, channels=None):
+        self.number_of_classes, self.use_bias = int(number_of_classes), use_bias
+        super().__init__(name, channels if channels is not None else filters)
+
+    def build(self, C, device=None):
+        K = self.number_of_classes
+        self.kernel = nn.Parameter(_glorot_uniform_(torch.empty(K, C, C, device=device), C, C))
+        self.bias = nn.Parameter(torch.zeros(K, C, device=device)) if self.use_bias else None
+
+    def table(self, cls=None):
+        return self.kernel, self.bias, _cls_index(cls)
+
+
+class FactorizedConv11(_Coloring):
+    """Soft-assignment coloring (cWC_sa): Gamma_y = sum_e alpha[y,e] Gamma_e.  generator.py:46-48,72-76."""
+    conditional = True
+
+    def __init__(self, number_of_classes=10, filters=None, filters_emb=10, use_bias=False, name=None, channels=None):
+        self.number_of_classes, self.filters_emb, self.use_bias = int(number_of_classes), int(filters_emb), use_bias
+        super().__init__(name, channels if channels is not None else filters)
+
+    def build(self, C, device=None):
+        K, E = self.number_of_classes, self.filters_emb
+        self.kernel = nn.Parameter(_glorot_uniform_(torch.empty(E, C, C, device=device), C, C))
+        self.class_matrix = nn.Parameter(_glorot_uniform_(torch.empty(K, E, device=device), K, E))
+        self.bias = nn.Parameter(torch.zeros(K, C, device=device)) if self.use_bias else None
+
+    def table(self, cls=None):
+        E, C = self.filters_emb, self.channels
+        gamma = (self.class_matrix @ self.kernel.view(E, C * C)).view(self.number_of_classes, C, C)
+        return gamma, self.bias, _cls_index(cls)
+
+
+class CenterScale(_Coloring):
+    """Per-channel gamma * x + beta (diagonal coloring, "WC-diag").  generator.py:32,37."""
+
+    def __init__(self, axis=-1, name=None, channels=None):
+        super().__init__(name, channels)
+
+    def build(self, C, device=None):
+        self.gamma = nn.Parameter(torch.ones(C, device=device))
+        self.beta = nn.Parameter(torch.zeros(C, device=device))
+
+    def table(self, cls=None):
+        return torch.diag(self.gamma).unsqueeze(0), self.beta.view(1, -1), None
+
+    def forward(self, inputs):
+        x = inputs[0] if isinstance(inputs, (list, tuple)) else inputs
+        self._ensure(x)
+        return x * self.gamma + self.beta
+
+
+class ConditionalCenterScale(_Coloring):
+    """Per-class, per-channel gamma_y * x + beta_y.  generator.py:29-30,36."""
+    conditional = True
+
+    def __init__(self, number_of_classes=10, axis=-1, name=None, channels=None):
+        self.number_of_classes = int(number_of_classes)
+        super().__init__(name, channels)
+
+    def build(self, C, device=None):
+        K = self.number_of_classes
+        self.gamma = nn.Parameter(torch.ones(K, C, device=device))
+        self.beta = nn.Parameter(torch.zeros(K, C, device=device))
+
+    def table(self, cls=None):
+        return torch.diag_embed(self.gamma), self.beta, _cls_index(cls)
+
+    def forward(self, inputs):
+        x, cls = inputs
+        self._ensure(x)
+        idx = cls.reshape(-1).long()
+        shape = (x.shape[0],) + (1,) * (x.dim() - 2) + (x.shape[-1],)
+        return x * self.gamma[idx].view(shape) + self.beta[idx].view(shape)
+
+
+# ---------------------------------------------------------------------------------------------
+# the fused hot path
+# ---------------------------------------------------------------------------------------------
+class WhiteningColoring(nn.Module):
+    """`stack(inp)` of generator.py:83-87 as one fused op: y = coloring(whitening(x)).
+
+    `branches` are coloring layers whose outputs the reference adds (`Add`, generator.py:39,58,66,77);
+    their tables add too, so any after_norm value is a single (Gamma_eff, beta_eff, slot) for K3/K5.
+    """
+
+    def __init__(self, npart: DecorelationNormalization, branches):
+        super().__init__()
+        self.npart = npart
+        self.branches = nn.ModuleList(branches)
+
+    def coloring_table(self, x, cls):
+        gamma = beta = slot = None
+        for br in self.branches:
+            br._ensure(x)
+            g, b, s = br.table(cls)
+            if s is not None:
+                slot = s
+            gamma = g if gamma is None else gamma + g          # (1,C,C) broadcasts against (K,C,C)
+            if b is not None:
+                beta = b if beta is None else beta + b
+        if gamma is not None and slot is not None:
+            K, N = gamma.shape[0], x.shape[0]
+            if K > N:                                           # more classes than samples: per-sample slots
+                idx = slot.long()
+                gamma = gamma.expand(K, -1, -1)[idx] if gamma.shape[0] == K else gamma
+                if beta is not None:
+                    beta = beta.expand(K, -1)[idx]
+                slot = torch.arange(N, dtype=torch.int32, device=x.device)
+        if gamma is not None and beta is not None and beta.shape[0] != gamma.shape[0]:
+            beta = beta.expand(gamma.shape[0], -1)
+        return gamma, beta, slot
+
+    def forward(self, x, cls=None):
+        if isinstance(x, (list, tuple)):
+            x, cls = x
+        gamma, beta, slot = self.coloring_table(x, cls)
+        if gamma is not None:
+            gamma = gamma.contiguous()
+        if beta is not None:
+            beta = beta.contiguous()
+        return self.npart.transform(x, gamma, beta, slot)

@@ -1,0 +1,133 @@
+"""Minimal G+D training step around the WC generator: hinge loss, Adam(beta1=0, beta2=0.9)
+(run.py:58-59,255-256), `training_ratio` critic updates per generator update (run.py:101), the
+generator update at batch_size x generator_batch_multiple (run.py:293-294).
+
+Data parallelism is new design (the reference is single-process): one process per
+GPU, per-replica WC statistics by default, and ONE flat gradient bucket per network that is
+all-reduced (mean) over RCCL after each backward.  The bucket is zero-copy: every parameter's .grad
+is a view into it, so there is no pack/unpack around the collective.  xGMI is point-to-point
+(7 links per GPU) and these messages are small (G ~19 MB, D ~4 MB fp32), i.e. latency-bound; a single
+large all-reduce per network is the shape RCCL handles best there.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+
+class FlatGradBucket:
+    """All gradients of one network in one contiguous buffer; .grad tensors are views into it."""
+
+    def __init__(self, params, process_group=None):
+        self.params = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+
+    def zero(self):
+        self.flat.zero_()
+
+    def allreduce_mean(self):
+        if self.world > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat.mul_(1.0 / self.world)
+
+
+def broadcast_state(module, src=0, group=None):
+    """Rank 0's parameters and buffers (incl. moving_mean / moving_cov) to every replica at start-up."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src, group=group)
+
+
+class GanTrainer:
+    def __init__(self, generator, discriminator, batch_size=64, generator_batch_multiple=2, training_ratio=5,
+                 lr=2e-4, beta1=0.0, beta2=0.9, noise_dim=128, number_of_classes=10, conditional=False,
+                 process_group=None, seed=1234):
+        self.G, self.D = generator, discriminator
+        self.batch_size, self.gbm, self.training_ratio = batch_size, generator_batch_multiple, training_ratio
+        self.noise_dim, self.K, self.conditional = noise_dim, number_of_classes, conditional
+        self.dev = next(generator.parameters()).device
+        self.g_bucket = FlatGradBucket(self.G.parameters(), process_group)
+        self.d_bucket = FlatGradBucket(self.D.parameters(), process_group)
+        self.opt_g = torch.optim.Adam(self.g_bucket.params, lr=lr, betas=(beta1, beta2))
+        self.opt_d = torch.optim.Adam(self.d_bucket.params, lr=lr, betas=(beta1, beta2))
+        self.gen = torch.Generator(device=self.dev)
+        self.gen.manual_seed(seed)
+
+    def _noise(self, n):
+        z = torch.randn(n, self.noise_dim, device=self.dev, generator=self.gen)
+        cls = torch.randint(0, self.K, (n, 1), device=self.dev, generator=self.gen, dtype=torch.int32)
+        return z, cls
+
+    def _d(self, x, cls):
+        out = self.D(x, cls if self.conditional else None)
+        return out[0] if isinstance(out, tuple) else out
+
+    def d_step(self, real, real_cls=None):
+        z, cls = self._noise(self.batch_size)
+        with torch.no_grad():
+            fake = self.G(z, cls)                      # train-mode WC forward (batch statistics), no graph
+        self.d_bucket.zero()
+        loss = F.relu(1.0 - self._d(real, real_cls if real_cls is not None else cls)).mean() + \
+            F.relu(1.0 + self._d(fake, cls)).mean()
+        loss.backward()
+        self.d_bucket.allreduce_mean()
+        self.opt_d.step()
+        return loss.detach()
+
+    def g_step(self):
+        z, cls = self._noise(self.batch_size * self.gbm)
+        self.g_bucket.zero()
+        for p in self.d_bucket.params:
+            p.requires_grad_(False)
+        loss = -self._d(self.G(z, cls), cls).mean()
+        loss.backward()
+        for p in self.d_bucket.params:
+            p.requires_grad_(True)
+        self.g_bucket.allreduce_mean()
+        self.opt_g.step()
+        return loss.detach()
+
+    def step(self, real_batches):
+        """One G+D step: training_ratio critic updates, then one generator update."""
+        for r in range(self.training_ratio):
+            d_loss = self.d_step(real_batches[r % len(real_batches)])
+        g_loss = self.g_step()
+        return d_loss, g_loss
+
+
+CIFAR10_UNCOND = dict(          # scripts/cifar10_resnet_sn_uncond.sh:4-7 + run.py:147-193
+    generator=dict(block_sizes=(256, 256, 256), resamples=("UP", "UP", "UP"), first_block_shape=(4, 4, 256),
+                   number_of_classes=10, block_norm='d', block_after_norm='uconv', last_norm='d',
+                   last_after_norm='uconv', gan_type=None),
+    discriminator=dict(input_image_shape=(32, 32, 3), block_sizes=(128, 128, 128, 128),
+                       resamples=('DOWN', 'DOWN', 'SAME', 'SAME'), number_of_classes=10, type=None, spectral=True),
+    image_shape=(32, 32, 3), conditional=False)
+
+CIFAR10_COND = dict(            # scripts/cifar10_resnet_sn_cond.sh:5-8
+    generator=dict(block_sizes=(128, 128, 128), resamples=("UP", "UP", "UP"), first_block_shape=(4, 4, 128),
+                   number_of_classes=10, block_norm='d', block_after_norm='ucconv', last_norm='d',
+                   last_after_norm='uconv', gan_type='PROJECTIVE'),
+    discriminator=dict(input_image_shape=(32, 32, 3), block_sizes=(256, 256, 256, 256),
+                       resamples=('DOWN', 'DOWN', 'SAME', 'SAME'), number_of_classes=10, type='PROJECTIVE', spectral=True),
+    image_shape=(32, 32, 3), conditional=True)
+
+
+def build_trainer(config=CIFAR10_UNCOND, device='cuda', process_group=None, sync_wc=False, **kw):
+    from .discriminator import make_discriminator
+    from .generator import make_generator
+    G = make_generator(process_group=process_group if sync_wc else None, **config['generator']).to(device)
+    D = make_discriminator(**config['discriminator']).to(device)
+    broadcast_state(G, group=process_group)
+    broadcast_state(D, group=process_group)
+    return GanTrainer(G, D, number_of_classes=config['generator']['number_of_classes'],
+                      conditional=config['conditional'], process_group=process_group, **kw)
