@@ -23,7 +23,6 @@ import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 os.environ.setdefault("PYTORCH_MIOPEN_SUGGEST_NHWC", "1")
-os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
 
 import torch
 import torch.distributed as dist

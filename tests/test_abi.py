@@ -1,0 +1,71 @@
+"""CPU tests of the C-ABI boundary: the shared library loads, exports every symbol include/wc_hip.h
+declares, and its host-side argument checks and workspace sizing behave -- no kernel is launched."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "wc_hip.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from wc_gan_amd import _lib, build
+    if not os.path.exists(_lib.LIB_PATH):
+        build.build(verbose=False)
+    return _lib.load()
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(wc_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_binding_table_agree():
+    from wc_gan_amd import _lib
+    assert declared_symbols() == sorted(_lib.SIGNATURES)
+
+
+def test_every_declared_symbol_is_exported(lib):
+    for name in declared_symbols():
+        assert hasattr(lib, name), name
+
+
+def test_abi_version_and_error_strings(lib):
+    assert lib.wc_abi_version() == 1
+    assert b"multiple of 32" in lib.wc_error_string(-3)
+    assert lib.wc_error_string(0) == b"ok"
+
+
+def test_workspace_sizes(lib):
+    assert lib.wc_stats_workspace_bytes(131072, 256) > 256 * 256 * 8
+    assert lib.wc_stats_workspace_bytes(131072, 48) == 0          # C not a multiple of 32
+    assert lib.wc_stats_workspace_bytes(0, 64) == 0
+    assert lib.wc_factor_workspace_bytes(256) >= 256 * 256 * 8
+    assert lib.wc_bwd_factor_workspace_bytes(128, 10) >= 3 * 128 * 128 * 8
+    per_sample = lib.wc_bwd_reduce_workspace_bytes(128, 1024, 128, 10, 1)
+    whole = lib.wc_bwd_reduce_workspace_bytes(128, 1024, 128, 1, 0)
+    assert per_sample >= 128 * 128 * 128 * 8 and whole > 0
+
+
+def test_argument_checks_return_codes_without_touching_the_gpu(lib):
+    one = ctypes.c_void_p(16)      # never dereferenced: every call below is rejected first
+    assert lib.wc_apply_f32(None, None, None, None, None, 1, 1, 32, 1, None, None) == -1
+    assert lib.wc_apply_f32(one, None, one, None, None, 0, 1, 32, 1, one, None) == -2
+    assert lib.wc_apply_f32(one, None, one, None, None, 1, 1, 40, 1, one, None) == -3
+    assert lib.wc_stats_f32(one, 64, 64, one, one, one, 16, None) == -4
+    assert lib.wc_factor_f64(one, one, 64, 64, 0.0, 0.99, 1, 1, None, None, one, one, one, one, 1 << 30, None) == -5
+    assert lib.wc_factor_f64(one, one, 1, 64, 1e-3, 0.99, 1, 1, None, None, one, one, one, one, 1 << 30, None) == -2
+    assert lib.wc_color_f32(one, None, 2, 64, one, None, None, 0, None) == -2
+    assert lib.wc_bwd_reduce_f32(one, None, one, None, 4, 16, 64, 3, one, one, one, 1 << 30, None) == -2
+    assert lib.wc_stream_copy_f32(one, one, 6, None) == -2
+
+
+def test_host_wrappers_refuse_cpu_tensors():
+    import torch
+    from wc_gan_amd import _lib, ops
+    with pytest.raises(_lib.WcHipError):
+        ops.stats(torch.zeros(64, 32))

@@ -1,0 +1,126 @@
+"""CPU tests of the Python host mirror: create_norm alphabets, sub-layer naming, coloring tables."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import wc_oracle as o
+from wc_gan_amd.generator import AFTER_NORMS, NORMS, create_norm, make_generator
+from wc_gan_amd.layers import (ConditionalConv11, Conv11, DecorelationNormalization, FactorizedConv11,
+                               WhiteningColoring)
+from wc_gan_amd.train import CIFAR10_COND, CIFAR10_UNCOND, FlatGradBucket
+
+
+def test_alphabets_match_reference():
+    # generator.py:16-17
+    assert NORMS == ['n', 'b', 'd', 'dr']
+    assert AFTER_NORMS == ['ucs', 'ccs', 'uccs', 'uconv', 'fconv', 'ufconv', 'cconv', 'ucconv', 'ccsuconv', 'n']
+    with pytest.raises(AssertionError):
+        create_norm('x', 'uconv')
+    with pytest.raises(AssertionError):
+        create_norm('d', 'cs')
+
+
+@pytest.mark.parametrize("after_norm", AFTER_NORMS)
+def test_fused_stack_builds_for_every_after_norm(after_norm):
+    stack = create_norm('d', after_norm, number_of_classes=7, filters_emb=3)(axis=-1, name='Generator.0.bn1', channels=32)
+    assert isinstance(stack, WhiteningColoring)
+    assert stack.npart.layer_name == 'Generator.0.bn1_npart'          # generator.py:85
+    assert stack.npart.moving_mean.shape == (32, 1) and stack.npart.moving_cov.shape == (32, 32)
+    names = [b.layer_name for b in stack.branches]
+    assert all(n.startswith('Generator.0.bn1_repart') for n in names)  # generator.py:86
+    if after_norm in ('ucconv', 'ufconv', 'uccs', 'ccsuconv'):
+        assert names == ['Generator.0.bn1_repart_c', 'Generator.0.bn1_repart_u']   # generator.py:55-57
+
+
+@pytest.mark.parametrize("after_norm", AFTER_NORMS)
+def test_coloring_table_equals_oracle_table(after_norm):
+    C, K, E, N = 32, 5, 3, 9
+    stack = create_norm('d', after_norm, number_of_classes=K, filters_emb=E)(axis=-1, name='s', channels=C)
+    rng = np.random.default_rng(0)
+    params = {}
+    for br in stack.branches:
+        for pn, p in br.named_parameters():
+            with torch.no_grad():
+                p.copy_(torch.tensor(rng.standard_normal(tuple(p.shape)), dtype=torch.float32))
+        kind = type(br).__name__
+        if kind == 'Conv11':
+            params['u_kernel'] = br.kernel.detach().numpy().reshape(C, C).astype(np.float64)
+            params['u_bias'] = br.bias.detach().numpy().astype(np.float64)
+        elif kind == 'ConditionalConv11':
+            params['c_kernel'] = br.kernel.detach().numpy().astype(np.float64)
+            params['c_bias'] = br.bias.detach().numpy().astype(np.float64)
+        elif kind == 'FactorizedConv11':
+            params['f_kernel'] = br.kernel.detach().numpy().astype(np.float64)
+            params['f_alpha'] = br.class_matrix.detach().numpy().astype(np.float64)
+        elif kind == 'CenterScale':
+            params['u_gamma'] = br.gamma.detach().numpy().astype(np.float64)
+            params['u_beta'] = br.beta.detach().numpy().astype(np.float64)
+        elif kind == 'ConditionalCenterScale':
+            params['c_gamma'] = br.gamma.detach().numpy().astype(np.float64)
+            params['c_beta'] = br.beta.detach().numpy().astype(np.float64)
+    x = torch.zeros(N, 2, 2, C)
+    cls = torch.tensor(rng.integers(0, K, (N, 1)), dtype=torch.int32)
+    gamma, beta, slot = stack.coloring_table(x, cls)
+    G_ref, B_ref = o.coloring_table(after_norm, C, params, K)
+    if after_norm == 'n':
+        assert gamma is None and beta is None
+        return
+    assert np.abs(gamma.detach().numpy() - G_ref).max() < 1e-5
+    if beta is not None:
+        assert np.abs(beta.detach().numpy() - B_ref).max() < 1e-6
+    else:
+        assert np.abs(B_ref).max() == 0
+    if gamma.shape[0] > 1:
+        assert slot.dtype == torch.int32 and torch.equal(slot, cls.reshape(-1))
+
+
+def test_more_classes_than_samples_switches_to_per_sample_slots():
+    C, K, N = 32, 50, 4
+    stack = create_norm('d', 'ucconv', number_of_classes=K)(axis=-1, name='s', channels=C)
+    cls = torch.tensor([[3], [49], [3], [0]], dtype=torch.int32)
+    gamma, beta, slot = stack.coloring_table(torch.zeros(N, 1, 1, C), cls)
+    assert gamma.shape == (N, C, C) and beta.shape == (N, C)
+    assert torch.equal(slot, torch.arange(N, dtype=torch.int32))
+    full = stack.branches[0].kernel + stack.branches[1].kernel.view(1, C, C)
+    assert torch.allclose(gamma, full[cls.reshape(-1).long()])
+
+
+def test_generator_matches_recipe_shapes():
+    G = make_generator(**CIFAR10_UNCOND['generator'])
+    nparams = sum(p.numel() for p in G.parameters())
+    assert abs(nparams - 4.73e6) < 0.02e6                  # SURVEY.md section 8e estimate
+    sites = [m for m in G.modules() if isinstance(m, WhiteningColoring)]
+    assert len(sites) == 7 and all(s.npart.channels == 256 for s in sites)     # row a2 site list
+    assert sites[-1].npart.layer_name == 'Generator.BN.Final_npart'            # generator.py:154
+    Gc = make_generator(**CIFAR10_COND['generator'])
+    kinds = [type(b).__name__ for b in Gc.blocks[0].bn1.branches]
+    assert kinds == ['ConditionalConv11', 'Conv11']                             # ucconv, generator.py:52-60
+    assert [type(b).__name__ for b in Gc.final_norm.branches] == ['Conv11']     # last site is always uconv
+
+
+def test_layer_constructor_surface():
+    d = DecorelationNormalization(name='x_npart', renorm=True)
+    assert d.renorm and d.decomposition == 'cholesky' and d.momentum == 0.99 and d.epsilon == 1e-3
+    with pytest.raises(ValueError):
+        DecorelationNormalization(decomposition='svd')
+    c = ConditionalConv11(filters=32, number_of_classes=10, name='c')
+    assert c.kernel.shape == (10, 32, 32) and c.bias.shape == (10, 32)
+    f = FactorizedConv11(number_of_classes=10, filters=32, filters_emb=4, use_bias=False, name='f')
+    assert f.kernel.shape == (4, 32, 32) and f.class_matrix.shape == (10, 4) and f.bias is None
+    u = Conv11(kernel_size=(1, 1), filters=32, name='u')
+    assert u.kernel.shape == (1, 1, 32, 32) and u.bias.shape == (32,)
+    lazy = Conv11(kernel_size=(1, 1), name='lazy')
+    assert lazy.channels is None                                                # Keras-style deferred build
+
+
+def test_flat_grad_bucket_views_track_backward():
+    lin = torch.nn.Linear(4, 3)
+    conv = torch.nn.Conv2d(2, 2, 3).to(memory_format=torch.channels_last)
+    params = list(lin.parameters()) + list(conv.parameters())
+    b = FlatGradBucket(params)
+    assert conv.weight.grad.stride() == conv.weight.stride()
+    (lin(torch.ones(2, 4)).sum() + conv(torch.ones(1, 2, 5, 5)).sum()).backward()
+    assert b.flat.abs().sum() > 0
+    assert all(p.grad.data_ptr() >= b.flat.data_ptr() for p in params)
+    b.zero()
+    assert float(lin.weight.grad.abs().sum()) == 0.0

@@ -1,0 +1,161 @@
+"""GPU tests of the layer surface and the committed golden fixtures, all through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import wc_oracle as o
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "wc_golden.npz")
+TOL = 1e-4     # north_star: 1e-4 relative, float32 path
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def dev(a, dtype=torch.float32):
+    return torch.tensor(np.ascontiguousarray(a), dtype=dtype, device="cuda")
+
+
+def test_golden_fixtures():
+    from wc_gan_amd.functional import whiten_color
+    g = np.load(GOLDEN)
+    for n in sorted({k.split('/')[0] for k in g.files}):
+        a = {k.split('/')[1]: g[k] for k in g.files if k.startswith(n + '/')}
+        training = bool(a['training']); C = a['x'].shape[-1]
+        x = dev(a['x']).requires_grad_(True); G = dev(a['gamma']).requires_grad_(True); B = dev(a['beta']).requires_grad_(True)
+        mm = dev(a['mm0']).view(C, 1).clone(); mc = dev(a['mc0']).clone()
+        slot = dev(a['slot'], torch.int32) if a['gamma'].shape[0] > 1 else None
+        y = whiten_color(x, G, B, slot, mm, mc, training)
+        y.backward(dev(a['gy']))
+        errs = dict(y=rel(y.detach().cpu(), a['y']), dx=rel(x.grad.cpu(), a['dx']), dG=rel(G.grad.cpu(), a['dgamma']),
+                    dB=rel(B.grad.cpu(), a['dbeta']))
+        if training:
+            errs['mc'] = rel(mc.cpu(), a['mc1'])
+        assert all(v < TOL for v in errs.values()), (n, errs)
+
+
+@pytest.mark.parametrize("after_norm", ['uconv', 'ucconv', 'ufconv', 'uccs', 'n'])
+def test_fused_stack_matches_oracle(after_norm):
+    from wc_gan_amd.generator import create_norm
+    C, K, E, N = 64, 6, 3, 10
+    torch.manual_seed(0)
+    stack = create_norm('d', after_norm, number_of_classes=K, filters_emb=E)(axis=-1, name='s', channels=C).cuda()
+    for p in stack.parameters():
+        torch.nn.init.normal_(p, std=0.3)
+    rng = np.random.default_rng(1)
+    x = o.synth_activation(rng, (N, 6, 6, C), "well").astype(np.float32)
+    cls = rng.integers(0, K, (N, 1)).astype(np.int32)
+    xt = dev(x).requires_grad_(True)
+    y = stack(xt, dev(cls, torch.int32))
+    gy = rng.standard_normal(x.shape).astype(np.float32)
+    y.backward(dev(gy))
+    gamma, beta, slot = stack.coloring_table(xt, dev(cls, torch.int32))
+    Gn = None if gamma is None else gamma.detach().cpu().numpy()
+    Bn = None if beta is None else beta.detach().cpu().numpy()
+    sn = None if slot is None else slot.cpu().numpy()
+    y_ref, cache = o.wc_forward(x, Gn, Bn, sn)
+    dx_ref, _, _ = o.wc_backward(gy, cache)
+    assert rel(y.detach().cpu(), y_ref) < TOL and rel(xt.grad.cpu(), dx_ref) < TOL
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in stack.parameters())
+
+
+def test_channel_padding_path():
+    """C = 48 is not a multiple of 32: zero-channel padding must leave the real channels' result unchanged."""
+    from wc_gan_amd.generator import create_norm
+    C, N = 48, 8
+    stack = create_norm('d', 'uconv')(axis=-1, name='s', channels=C).cuda()
+    rng = np.random.default_rng(2)
+    x = o.synth_activation(rng, (N, 5, 5, C), "well").astype(np.float32)
+    xt = dev(x).requires_grad_(True)
+    y = stack(xt)
+    gy = rng.standard_normal(x.shape).astype(np.float32)
+    y.backward(dev(gy))
+    br = stack.branches[0]
+    y_ref, cache = o.wc_forward(x, br.kernel.detach().cpu().numpy().reshape(C, C), br.bias.detach().cpu().numpy(),
+                                moving_mean=np.zeros(C), moving_cov=np.eye(C))
+    dx_ref, dG_ref, _ = o.wc_backward(gy, cache)
+    assert rel(y.detach().cpu(), y_ref) < TOL and rel(xt.grad.cpu(), dx_ref) < TOL
+    assert rel(br.kernel.grad.cpu().numpy().reshape(C, C), dG_ref[0]) < TOL
+    assert rel(stack.npart.moving_cov.cpu(), cache['moving_cov']) < 1e-5
+
+
+def test_eval_mode_switch_and_state():
+    from wc_gan_amd.layers import DecorelationNormalization
+    C = 32
+    layer = DecorelationNormalization(name='w', channels=C).cuda()
+    rng = np.random.default_rng(3)
+    x = o.synth_activation(rng, (16, 4, 4, C), "well").astype(np.float32)
+    layer.train()
+    layer(dev(x))
+    mm1, mc1 = layer.moving_mean.clone(), layer.moving_cov.clone()
+    _, cache = o.wc_forward(x, moving_mean=np.zeros(C), moving_cov=np.eye(C))
+    assert rel(mc1.cpu(), cache['moving_cov']) < 1e-5
+    layer.eval()
+    y = layer(dev(x))
+    assert torch.equal(layer.moving_mean, mm1) and torch.equal(layer.moving_cov, mc1)
+    y_ref, _ = o.wc_forward(x, training=False, moving_mean=mm1.cpu().numpy().reshape(-1), moving_cov=mc1.cpu().numpy())
+    assert rel(y.cpu(), y_ref) < TOL
+    assert set(layer.state_dict()) == {'moving_mean', 'moving_cov'}
+
+
+def test_zca_decomposition_modular_path():
+    from wc_gan_amd.layers import DecorelationNormalization
+    C = 32
+    layer = DecorelationNormalization(name='z', decomposition='zca', channels=C).cuda()
+    rng = np.random.default_rng(4)
+    x = o.synth_activation(rng, (16, 6, 6, C), "well").astype(np.float32)
+    xt = dev(x).requires_grad_(True)
+    y = layer(xt)
+    y_ref, _ = o.wc_forward(x, decomposition='zca')
+    assert rel(y.detach().cpu(), y_ref) < TOL
+    gy = rng.standard_normal(x.shape).astype(np.float32)
+    y.backward(dev(gy))
+    # gradient check against float64 torch autograd of the same math on the CPU
+    xc = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    X = xc.reshape(-1, C); M = X.shape[0]
+    mu = X.mean(0); f = X - mu
+    sig = f.T @ f / (M - 1)
+    S, U = torch.linalg.eigh(sig + 1e-3 * torch.eye(C, dtype=torch.float64))
+    W = (U * S.rsqrt()) @ U.T
+    (f @ W.T).backward(torch.tensor(gy, dtype=torch.float64).reshape(-1, C))
+    assert rel(xt.grad.cpu(), xc.grad.numpy()) < 1e-3      # eigh gradient is ill-conditioned ("unstable", poster)
+
+
+def test_renorm_value_is_moving_statistics_whitening():
+    from wc_gan_amd.layers import DecorelationNormalization
+    C = 32
+    layer = DecorelationNormalization(name='r', renorm=True, channels=C).cuda()
+    rng = np.random.default_rng(5)
+    ref = o.synth_activation(rng, (2000, C), "well")
+    mm, mc = o.moments_to_stats(*o.batch_moments(ref))
+    layer.moving_mean.copy_(dev(mm).view(C, 1)); layer.moving_cov.copy_(dev(mc))
+    x = o.synth_activation(rng, (16, 4, 4, C), "well").astype(np.float32)
+    xt = dev(x).requires_grad_(True)
+    y = layer(xt)
+    # value: W_mov (x - mu_batch)   (row a4: W_eff = L_mov^-1 sg(L_b) L_b^-1)
+    X = x.reshape(-1, C).astype(np.float64)
+    _, Wm = o.whitening_matrix(mc)
+    y_ref = (X - X.mean(0)) @ Wm.T
+    assert rel(y.detach().cpu().numpy().reshape(-1, C), y_ref) < TOL
+    y.sum().backward()
+    assert torch.isfinite(xt.grad).all()
+
+
+def test_generator_step_runs_and_trains():
+    from wc_gan_amd.train import CIFAR10_COND, build_trainer
+    cfg = dict(CIFAR10_COND)
+    cfg['generator'] = dict(cfg['generator'], block_sizes=(64, 64, 64), first_block_shape=(4, 4, 64))
+    cfg['discriminator'] = dict(cfg['discriminator'], block_sizes=(32, 32, 32, 32))
+    tr = build_trainer(cfg, 'cuda', batch_size=8, training_ratio=1)
+    real = torch.rand(8, 32, 32, 3, device='cuda') * 2 - 1
+    before = [p.detach().clone() for p in tr.G.parameters()]
+    d, g = tr.step([real])
+    assert torch.isfinite(d) and torch.isfinite(g)
+    assert any(not torch.equal(a, b) for a, b in zip(before, tr.G.parameters()))
+    img = tr.G(torch.randn(4, 128, device='cuda'), torch.zeros(4, 1, dtype=torch.int32, device='cuda'))
+    assert img.shape == (4, 32, 32, 3) and float(img.abs().max()) <= 1.0

@@ -52,6 +52,9 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: libwc_hip.so must bind to the HIP runtime torch has loaded (same streams, same
+    # allocations); loading it before torch pulls in a second runtime that sees no device
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise WcHipError(
             f"{LIB_PATH} is missing: build it with `python -m wc_gan_amd.build` "

@@ -26,7 +26,12 @@ class FlatGradBucket:
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
         off = 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            seg = self.flat[off:off + p.numel()]
+            if p.dim() == 4 and not p.is_contiguous() and p.is_contiguous(memory_format=torch.channels_last):
+                o, i, kh, kw = p.shape                      # same strides as the channels_last weight
+                p.grad = seg.view(o, kh, kw, i).permute(0, 3, 1, 2)
+            else:
+                p.grad = seg.view_as(p)
             off += p.numel()
         self.group = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
