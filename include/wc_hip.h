@@ -66,6 +66,8 @@ size_t wc_factor_workspace_bytes(int C);
 size_t wc_color_workspace_bytes(int C, int Kc);
 size_t wc_bwd_reduce_workspace_bytes(int64_t N, int64_t HW, int C, int Kc, int has_slot);
 size_t wc_bwd_factor_workspace_bytes(int C, int Kc);
+size_t wc_apply_workspace_bytes(int64_t N, int64_t HW, int C, int Kc);
+size_t wc_bwd_apply_workspace_bytes(int64_t N, int64_t HW, int C, int Kc);
 
 /* K1: raw additive moments of the rows of x:  sum[c] = sum_m x[m,c],  xtx = x^T x  (float64).
  * These are what a sync-WC data-parallel run all-reduces before wc_factor_f64. */
@@ -89,10 +91,14 @@ int wc_color_f32(const double* W, const float* gamma /*[Kc,C,C] or NULL*/, int K
                  float* A /*[Kc,C,C] out*/, float* At /*[Kc,C,C] out, nullable*/,
                  void* ws, size_t ws_bytes, wc_stream_t stream);
 
-/* K3: y[n] = (x[n] - mu) A[slot[n]] + bias[slot[n]]   (bias NULL = 0; mu NULL = 0). */
+/* K3: y[n] = (x[n] - mu) A[slot[n]] + bias[slot[n]]   (bias NULL = 0; mu NULL = 0).
+ * With a workspace of wc_apply_workspace_bytes() the split-fp16 MFMA fast path runs when the shape allows
+ * (C in {32,64,128,256}, N*HW >= 16384, HW a multiple of the row tile when slot != NULL); ws == NULL
+ * always takes the exact f32-MFMA kernel.  Both give fp32-GEMM accuracy; an fp16-range overflow inside
+ * the fast path is detected on the device and the exact kernel redoes the call in the same stream. */
 int wc_apply_f32(const float* x, const float* mu, const float* A, const float* bias,
                  const int32_t* slot, int64_t N, int64_t HW, int C, int Kc,
-                 float* y, wc_stream_t stream);
+                 float* y, void* ws, size_t ws_bytes, wc_stream_t stream);
 
 /* K4: R[k] = sum_{n: slot[n]=k} (x[n]-mu)^T gy[n]  (Kc,C,C),  gsum[k] = sum_{n in k} rows of gy[n]  (Kc,C). */
 int wc_bwd_reduce_f32(const float* x, const float* mu, const float* gy, const int32_t* slot,
@@ -116,7 +122,8 @@ int wc_bwd_factor_f64(const double* R, const double* gsum, const double* W, cons
  * At[k] = A[k]^T as written by wc_color_f32. */
 int wc_bwd_apply_f32(const float* gy, const float* x, const float* mu, const float* At,
                      const float* S, const float* gmean, const int32_t* slot,
-                     int64_t N, int64_t HW, int C, int Kc, float* dx, wc_stream_t stream);
+                     int64_t N, int64_t HW, int C, int Kc, float* dx,
+                     void* ws, size_t ws_bytes, wc_stream_t stream);
 
 /* Bandwidth yardstick used by bench.py: dst[i] = src[i] (float4 grid-stride copy), same stream rules. */
 int wc_stream_copy_f32(const float* src, float* dst, int64_t n, wc_stream_t stream);

@@ -1,0 +1,89 @@
+"""GPU parity of the split-fp16 fast affine path (wc_fast.hip) against float64, and of its overflow gate."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def dev(a, dtype=torch.float32):
+    return torch.tensor(np.ascontiguousarray(a), dtype=dtype, device="cuda")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from wc_gan_amd import ops as _ops
+    return _ops
+
+
+def _ref_apply(x, mu, A, b, slot):
+    N, C = x.shape[0], x.shape[-1]
+    f = x.astype(np.float64).reshape(N, -1, C) - mu.astype(np.float64)
+    return np.einsum('npc,nco->npo', f, A.astype(np.float64)[slot]) + b.astype(np.float64)[slot][:, None, :]
+
+
+CASES = [((16, 32, 32, 256), 1), ((17, 32, 32, 256), 1), ((16, 32, 32, 128), 3), ((64, 16, 16, 64), 4), ((4, 64, 64, 32), 2),
+         ((33, 24, 24, 128), 1)]
+
+
+@pytest.mark.parametrize("shape,Kc", CASES)
+def test_fast_apply_matches_float64(ops, shape, Kc):
+    rng = np.random.default_rng(11)
+    N, C = shape[0], shape[-1]
+    chan_scale = np.exp(rng.uniform(-6, 6, C))                      # channels of wildly different magnitude
+    x = (rng.standard_normal(shape) * chan_scale + 3 * chan_scale).astype(np.float32)
+    mu = (3 * chan_scale).astype(np.float32)
+    A = (rng.standard_normal((Kc, C, C)) / np.sqrt(C) / chan_scale[None, :, None]).astype(np.float32)
+    b = rng.standard_normal((Kc, C)).astype(np.float32)
+    slot = rng.integers(0, Kc, N).astype(np.int32)
+    st = dev(slot, torch.int32) if Kc > 1 else None
+    y_fast = ops.apply(dev(x), dev(mu), dev(A), dev(b), st, fast=True)
+    y_exact = ops.apply(dev(x), dev(mu), dev(A), dev(b), st, fast=False)
+    ref = _ref_apply(x, mu, A, b, slot)
+    e_fast, e_exact = rel(y_fast.cpu().numpy().reshape(ref.shape), ref), rel(y_exact.cpu().numpy().reshape(ref.shape), ref)
+    print(shape, Kc, "fast", e_fast, "exact f32-MFMA", e_exact)
+    assert e_fast < 3e-6 and e_exact < 3e-6
+
+
+def test_fast_apply_overflow_is_caught_by_the_exact_redo(ops):
+    rng = np.random.default_rng(12)
+    shape = (16, 32, 32, 128); N, C = 16, 128
+    x = rng.standard_normal(shape).astype(np.float32)
+    x[5, 7, 9, 3] = 3.0e7            # 3e7 sigma: far outside fp16 after scaling, and not on the sampled rows
+    x[11, 1, 2, 77] = -5.0e8
+    mu = np.zeros(C, np.float32)
+    A = (rng.standard_normal((1, C, C)) / np.sqrt(C)).astype(np.float32)
+    b = np.zeros((1, C), np.float32)
+    y = ops.apply(dev(x), dev(mu), dev(A), dev(b), None, fast=True)
+    ref = _ref_apply(x, mu, A, b, np.zeros(N, int))
+    assert torch.isfinite(y).all()
+    assert rel(y.cpu().numpy().reshape(ref.shape), ref) < 3e-6
+
+
+@pytest.mark.parametrize("shape,Kc,train", [((16, 32, 32, 256), 1, True), ((16, 32, 32, 128), 3, True), ((32, 32, 32, 64), 1, False)])
+def test_fast_bwd_apply_matches_float64(ops, shape, Kc, train):
+    rng = np.random.default_rng(13)
+    N, C = shape[0], shape[-1]
+    x = rng.standard_normal(shape).astype(np.float32) + 0.5
+    gy = (rng.standard_normal(shape) * 1e-3).astype(np.float32)
+    mu = np.full(C, 0.5, np.float32)
+    A = (rng.standard_normal((Kc, C, C)) / np.sqrt(C)).astype(np.float32)
+    At = np.ascontiguousarray(np.transpose(A, (0, 2, 1)))
+    S = rng.standard_normal((C, C)).astype(np.float32) * 1e-4; S = (S + S.T) / 2
+    gm = (rng.standard_normal(C) * 1e-4).astype(np.float32)
+    slot = rng.integers(0, Kc, N).astype(np.int32)
+    st = dev(slot, torch.int32) if Kc > 1 else None
+    args = (dev(gy), dev(x), dev(mu), dev(At), dev(S) if train else None, dev(gm) if train else None, st)
+    dx_fast = ops.bwd_apply(*args, fast=True)
+    dx_exact = ops.bwd_apply(*args, fast=False)
+    g3 = gy.astype(np.float64).reshape(N, -1, C)
+    ref = np.einsum('npc,nco->npo', g3, At.astype(np.float64)[slot])
+    if train:
+        ref = ref + (x.astype(np.float64).reshape(N, -1, C) - mu) @ S.astype(np.float64) - gm.astype(np.float64)
+    assert rel(dx_fast.cpu().numpy().reshape(ref.shape), ref) < 3e-6
+    assert rel(dx_exact.cpu().numpy().reshape(ref.shape), ref) < 3e-6

@@ -134,16 +134,32 @@ int wc_color_f32(const double* W, const float* gamma, int Kc, int C, float* A, f
 }
 
 // ---------------------------------------------------------------------------------------------
+size_t wc_apply_workspace_bytes(int64_t N, int64_t HW, int C, int Kc)
+{
+    if (N <= 0 || HW <= 0 || Kc <= 0 || bad_channels(C)) return 0;
+    if (!wc_fast_affine_supported(N, HW, C, Kc > 1)) return 256;
+    return wc_fast_affine_workspace(C, Kc);
+}
+
 int wc_apply_f32(const float* x, const float* mu, const float* A, const float* bias, const int32_t* slot,
-                 int64_t N, int64_t HW, int C, int Kc, float* y, wc_stream_t stream)
+                 int64_t N, int64_t HW, int C, int Kc, float* y, void* ws, size_t ws_bytes, wc_stream_t stream)
 {
     if (!x || !A || !y) return WC_ERR_NULL;
     if (N <= 0 || HW <= 0 || Kc <= 0) return WC_ERR_SHAPE;
     if (bad_channels(C)) return WC_ERR_CHANNELS;
+    hipStream_t st = static_cast<hipStream_t>(stream);
     WcRowsGemmArgs a = {};
     a.in[0] = x; a.center[0] = mu; a.B[0] = A; a.B_slot_stride[0] = (int64_t)C * C;
     a.bias = bias; a.sub = nullptr; a.slot = slot; a.N = N; a.HW = HW; a.C = C; a.nstreams = 1; a.out = y;
-    WC_TRY(wc_launch_rows_gemm(a, static_cast<hipStream_t>(stream)));
+    const bool fast = ws && wc_fast_affine_supported(N, HW, C, slot != nullptr) && ws_bytes >= wc_fast_affine_workspace(C, Kc);
+    if (fast) {
+        int* gate = static_cast<int*>(ws);
+        WC_TRY(hipMemsetAsync(gate, 0, 256, st));
+        WC_TRY(wc_launch_fast_affine(x, mu, A, Kc, false, bias, nullptr, slot, N, HW, C, 0, y,
+                                     static_cast<char*>(ws) + 256, gate, st));
+        a.gate = gate;                       // exact f32-MFMA redo, a no-op unless the fp16 range was exceeded
+    }
+    WC_TRY(wc_launch_rows_gemm(a, st));
     return WC_OK;
 }
 
@@ -260,14 +276,20 @@ int wc_bwd_factor_f64(const double* R, const double* gsum, const double* W, cons
 }
 
 // ---------------------------------------------------------------------------------------------
+size_t wc_bwd_apply_workspace_bytes(int64_t N, int64_t HW, int C, int Kc)
+{
+    return wc_apply_workspace_bytes(N, HW, C, Kc);
+}
+
 int wc_bwd_apply_f32(const float* gy, const float* x, const float* mu, const float* At, const float* S,
                      const float* gmean, const int32_t* slot, int64_t N, int64_t HW, int C, int Kc,
-                     float* dx, wc_stream_t stream)
+                     float* dx, void* ws, size_t ws_bytes, wc_stream_t stream)
 {
     if (!gy || !At || !dx) return WC_ERR_NULL;
     if (S && !x) return WC_ERR_NULL;
     if (N <= 0 || HW <= 0 || Kc <= 0) return WC_ERR_SHAPE;
     if (bad_channels(C)) return WC_ERR_CHANNELS;
+    hipStream_t st = static_cast<hipStream_t>(stream);
     WcRowsGemmArgs a = {};
     a.in[0] = gy; a.center[0] = nullptr; a.B[0] = At; a.B_slot_stride[0] = (int64_t)C * C;
     a.nstreams = 1;
@@ -276,7 +298,18 @@ int wc_bwd_apply_f32(const float* gy, const float* x, const float* mu, const flo
         a.nstreams = 2;
     }
     a.bias = nullptr; a.sub = gmean; a.slot = slot; a.N = N; a.HW = HW; a.C = C; a.out = dx;
-    WC_TRY(wc_launch_rows_gemm(a, static_cast<hipStream_t>(stream)));
+    const bool fast = ws && wc_fast_affine_supported(N, HW, C, slot != nullptr) && ws_bytes >= wc_fast_affine_workspace(C, Kc);
+    if (fast) {
+        // two passes over dx (the B' fragments of both streams do not fit one wave's registers at C = 256):
+        //   dx  = gy At[slot] - gmean ;   dx += (x - mu) S
+        int* gate = static_cast<int*>(ws);
+        char* wsp = static_cast<char*>(ws) + 256;
+        WC_TRY(hipMemsetAsync(gate, 0, 256, st));
+        WC_TRY(wc_launch_fast_affine(gy, nullptr, At, Kc, false, nullptr, gmean, slot, N, HW, C, 0, dx, wsp, gate, st));
+        if (S) WC_TRY(wc_launch_fast_affine(x, mu, S, 1, true, nullptr, nullptr, nullptr, N, HW, C, 1, dx, wsp, gate, st));
+        a.gate = gate;
+    }
+    WC_TRY(wc_launch_rows_gemm(a, st));
     return WC_OK;
 }
 

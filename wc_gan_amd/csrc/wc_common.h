@@ -30,6 +30,7 @@ struct WcRowsGemmArgs {
     int C;
     int nstreams;
     float* out;
+    const int* gate;            // optional device flag: when non-null and *gate == 0 the kernel does nothing
 };
 hipError_t wc_launch_rows_gemm(const WcRowsGemmArgs& a, hipStream_t st);
 
@@ -51,6 +52,15 @@ hipError_t wc_launch_xty(const WcXtyArgs& a, int nslab, hipStream_t st);
 
 hipError_t wc_launch_subsample_mean(const float* x, int64_t M, int C, float* shift, hipStream_t st);
 hipError_t wc_launch_stream_copy(const float* src, float* dst, int64_t n, hipStream_t st);
+
+// ----- fast split-fp16 affine (wc_fast.hip) ---------------------------------------------------
+constexpr int64_t WC_FAST_MIN_ROWS = 16384;     // below this the launch-count overhead of the fast path is not repaid
+bool   wc_fast_affine_supported(int64_t N, int64_t HW, int C, bool has_slot);
+size_t wc_fast_affine_workspace(int C, int Kc);
+hipError_t wc_launch_fast_affine(const float* in, const float* center, const float* B, int Kc, bool shared_table,
+                                 const float* bias, const float* sub, const int32_t* slot,
+                                 int64_t N, int64_t HW, int C, int accumulate, float* out,
+                                 void* ws, int* gate, hipStream_t st);
 
 // ----- small-matrix stage (wc_small.hip) -----------------------------------------------------
 

@@ -1,0 +1,368 @@
+// Fast path of the fused WC affine (K3 wc_apply_f32, K6 wc_bwd_apply_f32) for C in {32,64,128,256}:
+//   out[m,:] (+)= ((in[m,:] - center) .* s) B'[slot(m)] .* colscale[slot(m)] + bias[slot(m)] - sub
+//
+// Why not the f32 MFMA: at C = 256 the contraction has 64 flop/B, so v_mfma_f32_32x32x2_f32 (157 TF/s)
+// caps the kernel at ~30 % of the HBM roofline and gfx950 has no xf32 MFMA.  Each fp32 operand is split
+// into two fp16 terms, v = hi + lo * 2^-11 (22 significant bits), and the product runs as three
+// v_mfma_f32_32x32x16_f16 (hi*hi into one accumulator, hi*lo + lo*hi into a second): 3/16 of the
+// f32-MFMA time at fp32-GEMM accuracy.  fp16's narrow range is handled by exact power-of-two scalings:
+// per input channel (s, from a row subsample), per output column (colscale, from the table itself);
+// an element that still exceeds the fp16 range raises a device flag and the exact f32-MFMA kernel,
+// queued behind with that flag as its gate, redoes the call -- the result never depends on the guess.
+//
+// Structure: one persistent 512-thread workgroup per CU.  Each of the 8 waves keeps the B' fragments of
+// its 32 output columns for ALL of K in registers (128 VGPRs at C = 256), so the only LDS traffic is the
+// activation tile: fp32 rows are loaded once from HBM (16 B per lane, whole rows per wave), centred,
+// scaled, split and written as XOR-swizzled fp16 hi/lo images that every wave reads with ds_read_b128.
+// Tiles are double-buffered; the loads of tile t+2 are in flight while tile t is on the matrix pipe.
+#include "wc_common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));
+
+constexpr float kLoScale = 2048.0f;            // 2^11
+constexpr float kLoInv = 1.0f / 2048.0f;
+constexpr float kF16Guard = 60000.0f;          // |scaled element| above this -> gate the exact path
+
+__device__ __forceinline__ f32x4 ld4f(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// --------------------------------------------------------------------------------------------
+// per-input-channel power-of-two scale from <= 256 sampled rows: s_k = 2^(4 - ceil(log2(max|in - c|)))
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void channel_scale_kernel(const float* __restrict__ in, const float* __restrict__ center,
+                                                             int64_t M, int C, float* __restrict__ scale)
+{
+    __shared__ float red[16][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int part = threadIdx.x >> 6;
+    const int64_t nsamp = M < 256 ? M : 256;
+    const int64_t stride = M / nsamp;
+    float mx = 0.f;
+    if (c < C) {
+        const float ce = center ? center[c] : 0.f;
+        for (int64_t r = part; r < nsamp; r += 16) mx = fmaxf(mx, fabsf(in[r * stride * C + c] - ce));
+    }
+    red[part][threadIdx.x & 63] = mx;
+    __syncthreads();
+    if (threadIdx.x < 64 && c < C) {
+        float m = 0.f;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) m = fmaxf(m, red[p][threadIdx.x]);
+        float s = 1.0f;
+        if (m > 0.f && m < 3.0e38f) {
+            int e;
+            frexpf(m, &e);                       // m = f * 2^e, f in [0.5, 1)  ->  m <= 2^e
+            s = ldexpf(1.0f, 4 - e);             // sampled max lands in [8, 16]
+        }
+        scale[c] = s;
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// B table split: B[slot][k][n] fp32 (row-major, as wc_color_f32 writes A / At) -> transposed fp16 hi/lo
+// images T[slot][n][k] of  B[k][n] / s_k / colscale[n]   (k contiguous: one 16-B load per MFMA fragment).
+// one wave per (slot, n)
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void split_table_kernel(const float* __restrict__ B, const float* __restrict__ scale,
+                                                         int C, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
+                                                         float* __restrict__ colscale)
+{
+    const int64_t row = blockIdx.x;                 // slot * C + n
+    const float* src = B + (row / C) * (int64_t)C * C + (row % C);     // column n of B[slot]
+    const int lane = threadIdx.x;
+    float v[16];
+    float mx = 0.f;
+    const int per = C / 64 > 0 ? C / 64 : 1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        v[i] = 0.f;
+        const int k = lane + 64 * i;
+        if (i < per && k < C) { v[i] = src[(int64_t)k * C] / scale[k]; mx = fmaxf(mx, fabsf(v[i])); }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    float cs = 1.0f;
+    if (mx > 0.f && mx < 3.0e38f) { int e; frexpf(mx, &e); cs = ldexpf(1.0f, e); }     // |v / cs| <= 1
+    const float inv = 1.0f / cs;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int k = lane + 64 * i;
+        if (i < per && k < C) {
+            const float w = v[i] * inv;
+            const _Float16 h = (_Float16)w;
+            const _Float16 l = (_Float16)((w - (float)h) * kLoScale);
+            hi[row * C + k] = h;
+            lo[row * C + k] = l;
+        }
+    }
+    if (lane == 0) colscale[row] = cs;
+}
+
+struct FastArgs {
+    const float* in; const float* center; const float* scale;       // [M,C], [C]|null, [C]
+    const _Float16* Bhi; const _Float16* Blo; const float* colscale; // [slots][C(n)][C(k)], [slots][C]
+    int64_t slot_stride;                                             // C*C, or 0 when the table is shared
+    const float* bias; const float* sub; const int32_t* slot;
+    int64_t M, HW;
+    int accumulate;
+    int* flag;
+    float* out;
+    int ntiles, tiles_per_wg;
+};
+
+// M must be a multiple of the row tile (the caller checks): every load and store below is unconditional, which is
+// what lets hipcc keep counted vmcnt waits instead of draining the memory queue at every masked access.
+template <int C, bool ACC, bool HAS_SLOT>
+__global__ __launch_bounds__(512, 2) void affine_f16x3_kernel(FastArgs a)
+{
+    constexpr int BM = 64 * 256 / C;          // rows per tile: 64 KiB of fp32 activations
+    constexpr int CPR = C / 8;                // 16-byte chunks per fp16 row
+    constexpr int KS = C / 16;                // MFMA k-steps
+    constexpr int CG = C / 32;                // column groups (one wave each)
+    constexpr int RG = 8 / CG;                // row groups of waves
+    constexpr int SUB = BM / 32 / RG;         // 32-row sub-tiles per wave per tile (= 2)
+    constexpr int C4 = C / 4;                 // float4 per row
+    constexpr int IMG = BM * C * 2;           // bytes of one fp16 image
+    constexpr int RSTEP = 512 / C4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][hi | lo]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cg = wave % CG, rg = wave / CG;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const int t_begin = blockIdx.x * a.tiles_per_wg;
+    int t_end = t_begin + a.tiles_per_wg;
+    if (t_end > a.ntiles) t_end = a.ntiles;
+    if (t_begin >= t_end) return;
+
+    // staging coordinates: thread handles float4 #c4 of rows srow + RSTEP*p, p = 0..7
+    const int c4 = tid % C4;
+    const int srow = tid / C4;
+    const f32x4 scl = ld4f(a.scale + 4 * c4);
+    f32x4 ncs = {0.f, 0.f, 0.f, 0.f};
+    if (a.center) { const f32x4 ce = ld4f(a.center + 4 * c4); ncs = -ce * scl; }
+
+    auto swz = [](int row) -> int {
+        if (CPR >= 16) return row & 15;
+        return (row / (16 / CPR)) & (CPR - 1);
+    };
+    const int in_off = srow * C + 4 * c4;                 // element offset inside a tile (fits 32 bits)
+    // LDS byte offsets of this thread's 8 staging stores (tile-invariant)
+    int st_off[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int row = srow + RSTEP * p;
+        st_off[p] = row * (C * 2) + (((c4 >> 1) ^ swz(row)) * 16) + (c4 & 1) * 8;
+    }
+
+    f32x4 xr[8];
+    auto load_chunk = [&](int tile, int p) {
+        const float* base = a.in + (int64_t)tile * (BM * C);          // wave-uniform
+        xr[p] = ld4f(base + in_off + p * (RSTEP * C));
+    };
+    auto stage_load = [&](int tile) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) load_chunk(tile, p);
+    };
+    bool overflow = false;
+    auto write_chunk = [&](int buf, int p) {
+        char* hi_img = smem + buf * 2 * IMG;
+        char* lo_img = hi_img + IMG;
+        {
+            const f32x4 g = xr[p] * scl + ncs;
+            overflow |= (fabsf(g[0]) > kF16Guard) | (fabsf(g[1]) > kF16Guard) | (fabsf(g[2]) > kF16Guard) | (fabsf(g[3]) > kF16Guard);
+            const h16x2 h01 = __builtin_amdgcn_cvt_pkrtz(g[0], g[1]);
+            const h16x2 h23 = __builtin_amdgcn_cvt_pkrtz(g[2], g[3]);
+            const float r0 = (g[0] - (float)h01[0]) * kLoScale, r1 = (g[1] - (float)h01[1]) * kLoScale;
+            const float r2 = (g[2] - (float)h23[0]) * kLoScale, r3 = (g[3] - (float)h23[1]) * kLoScale;
+            const h16x2 l01 = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+            const h16x2 l23 = __builtin_amdgcn_cvt_pkrtz(r2, r3);
+            *reinterpret_cast<uint2*>(hi_img + st_off[p]) = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+            *reinterpret_cast<uint2*>(lo_img + st_off[p]) = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+        }
+    };
+    auto stage_write = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) write_chunk(buf, p);
+    };
+
+    // B' fragments of this wave's 32 columns, all of K, in registers
+    f16x8 bhi[KS], blo[KS];
+    float cscale = 1.f, addv = 0.f;
+    int cur_slot = -1;
+    const int col = cg * 32 + l31;
+    auto load_b = [&](int slot) {
+        const _Float16* ph = a.Bhi + (int64_t)slot * a.slot_stride + (col * C + 8 * lh);
+        const _Float16* pl = a.Blo + (int64_t)slot * a.slot_stride + (col * C + 8 * lh);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            bhi[s] = *reinterpret_cast<const f16x8*>(ph + 16 * s);
+            blo[s] = *reinterpret_cast<const f16x8*>(pl + 16 * s);
+        }
+        const int64_t srow_ = a.slot_stride ? slot : 0;
+        cscale = a.colscale[srow_ * C + col];
+        addv = 0.f;
+        if (a.bias) addv += a.bias[(int64_t)slot * C + col];
+        if (a.sub) addv -= a.sub[col];
+        cur_slot = slot;
+    };
+
+    stage_load(t_begin);
+    if (!HAS_SLOT) load_b(0);
+    stage_write(0);
+    if (t_begin + 1 < t_end) stage_load(t_begin + 1);
+    __syncthreads();
+
+    // per-lane output offset inside a tile: rows (4*lh + ...) and this wave's column; the rest is compile-time
+    const int out_lane = (4 * lh) * C + col;
+    const int rd_lane = l31 * (C * 2);
+
+    // One tile: [convert + LDS-write tile t+1] [issue the loads of tile t+2] [MFMA + store tile t] [LDS barrier].
+    // The steady-state loop calls it with both stages unconditional (the last two tiles are peeled below), so the
+    // body has no control-flow merge and hipcc emits COUNTED vmcnt waits: the 32 stores of a tile stay in flight
+    // across the barrier and under the next tile's staging instead of being drained.
+    auto tile_body = [&](int t, auto do_write, auto do_load) {
+        const int cur = (t - t_begin) & 1;
+        constexpr bool W_ = decltype(do_write)::value, L_ = decltype(do_load)::value;
+
+        if (HAS_SLOT) {
+            const int slot = a.slot[((int64_t)t * BM) / a.HW];
+            if (slot != cur_slot) load_b(slot);
+        }
+        float* out_tile = a.out + (int64_t)t * (BM * C);                // wave-uniform
+        const char* hi_img = smem + cur * 2 * IMG;
+        const char* lo_img = hi_img + IMG;
+#pragma unroll
+        for (int sb = 0; sb < SUB; ++sb) {
+            const int rbase = (rg * SUB + sb) * 32;
+            const int sw = swz(rbase + l31);
+            const char* hrow = hi_img + rbase * (C * 2) + rd_lane;
+            const char* lrow = lo_img + rbase * (C * 2) + rd_lane;
+            f32x16 acc1, acc2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc1[r] = 0.f; acc2[r] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                // staging of the NEXT tile rides in the gaps of this tile's first sub-tile: one 16-B chunk per
+                // STEP k-steps is centred/split/written to the other LDS buffer and its register refilled from t+2
+                constexpr int STEP = (KS >= 8) ? KS / 8 : 1;
+                if (sb == 0 && (s % STEP) == 0 && (s / STEP) < 8) {
+                    if (KS >= 8) {
+                        if (W_) write_chunk(cur ^ 1, s / STEP);
+                        if (L_) load_chunk(t + 2, s / STEP);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 8 / KS; ++q) {
+                            if (W_) write_chunk(cur ^ 1, s * (8 / KS) + q);
+                            if (L_) load_chunk(t + 2, s * (8 / KS) + q);
+                        }
+                    }
+                }
+                const int chunk = (2 * s + lh) ^ sw;
+                const f16x8 ah = *reinterpret_cast<const f16x8*>(hrow + chunk * 16);
+                const f16x8 al = *reinterpret_cast<const f16x8*>(lrow + chunk * 16);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bhi[s], acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, blo[s], acc2, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bhi[s], acc2, 0, 0, 0);
+            }
+            float* po = out_tile + rbase * C + out_lane;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ro = ((r & 3) + 8 * (r >> 2)) * C;
+                float v = (acc1[r] + acc2[r] * kLoInv) * cscale + addv;
+                if (ACC) v += po[ro];
+                po[ro] = v;
+            }
+        }
+        // LDS hand-off only: a raw barrier behind lgkmcnt(0).  __syncthreads() would also drain vmcnt.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    using T_ = std::integral_constant<bool, true>;
+    using F_ = std::integral_constant<bool, false>;
+    int t = t_begin;
+    for (; t + 2 < t_end; ++t) tile_body(t, T_{}, T_{});
+    if (t + 1 < t_end) { tile_body(t, T_{}, F_{}); ++t; }
+    tile_body(t, F_{}, F_{});
+    if (overflow) atomicOr(a.flag, 1);
+}
+
+template <int C>
+hipError_t launch_affine(const FastArgs& a, hipStream_t st)
+{
+    constexpr int BM = 64 * 256 / C;
+    constexpr size_t lds = (size_t)4 * BM * C * 2;          // 128 KiB
+    FastArgs b = a;
+    b.ntiles = (int)(a.M / BM);
+    int nwg = b.ntiles < 256 ? b.ntiles : 256;
+    b.tiles_per_wg = (b.ntiles + nwg - 1) / nwg;
+    nwg = (b.ntiles + b.tiles_per_wg - 1) / b.tiles_per_wg;
+#define WC_LAUNCH_AFFINE(ACC_, SLOT_)                                                                                   \
+    do {                                                                                                                \
+        static bool attr_set = false;                                                                                   \
+        if (!attr_set) {                                                                                                \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(affine_f16x3_kernel<C, ACC_, SLOT_>),      \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
+            if (e != hipSuccess) return e;                                                                              \
+            attr_set = true;                                                                                            \
+        }                                                                                                               \
+        hipLaunchKernelGGL((affine_f16x3_kernel<C, ACC_, SLOT_>), dim3(nwg), dim3(512), lds, st, b);                    \
+    } while (0)
+    const bool has_slot = b.slot != nullptr;
+    if (b.accumulate) { if (has_slot) WC_LAUNCH_AFFINE(true, true); else WC_LAUNCH_AFFINE(true, false); }
+    else { if (has_slot) WC_LAUNCH_AFFINE(false, true); else WC_LAUNCH_AFFINE(false, false); }
+#undef WC_LAUNCH_AFFINE
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool wc_fast_affine_supported(int64_t N, int64_t HW, int C, bool has_slot)
+{
+    if (!(C == 32 || C == 64 || C == 128 || C == 256)) return false;
+    const int64_t M = N * HW;
+    if (M < WC_FAST_MIN_ROWS) return false;
+    const int BM = 64 * 256 / C;
+    if (has_slot && (HW % BM) != 0) return false;            // a tile must not straddle two samples
+    if ((M % BM) != 0) return false;                         // whole tiles only (keeps the kernel free of masked accesses)
+    return true;
+}
+
+size_t wc_fast_affine_workspace(int C, int Kc)
+{
+    // flag | scale[C] | colscale[Kc*C] | hi[Kc*C*C] | lo[Kc*C*C]
+    return 256 + wc_align_up((size_t)C * 4, 256) + wc_align_up((size_t)Kc * C * 4, 256) +
+           2 * wc_align_up((size_t)Kc * C * C * 2, 256);
+}
+
+// One stream of the affine on the fast path.  B is [slot][k][n] row-major.
+// `gate` (device int, zeroed by the caller before the first pass) collects fp16-range overflows.
+hipError_t wc_launch_fast_affine(const float* in, const float* center, const float* B, int Kc, bool shared_table,
+                                 const float* bias, const float* sub, const int32_t* slot,
+                                 int64_t N, int64_t HW, int C, int accumulate, float* out,
+                                 void* ws, int* gate, hipStream_t st)
+{
+    char* p = static_cast<char*>(ws);
+    float* scale = reinterpret_cast<float*>(p); p += wc_align_up((size_t)C * 4, 256);
+    float* colscale = reinterpret_cast<float*>(p); p += wc_align_up((size_t)Kc * C * 4, 256);
+    _Float16* hi = reinterpret_cast<_Float16*>(p); p += wc_align_up((size_t)Kc * C * C * 2, 256);
+    _Float16* lo = reinterpret_cast<_Float16*>(p);
+    const int64_t M = N * HW;
+    hipLaunchKernelGGL(channel_scale_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, in, center, M, C, scale);
+    hipLaunchKernelGGL(split_table_kernel, dim3((unsigned)(Kc * C)), dim3(64), 0, st, B, (const float*)scale, C, hi, lo, colscale);
+    FastArgs a = {};
+    a.in = in; a.center = center; a.scale = scale; a.Bhi = hi; a.Blo = lo; a.colscale = colscale;
+    a.slot_stride = shared_table ? 0 : (int64_t)C * C;
+    a.bias = bias; a.sub = sub; a.slot = shared_table ? nullptr : slot; a.M = M; a.HW = HW;
+    a.accumulate = accumulate; a.flag = gate; a.out = out;
+    switch (C) {
+        case 32: return launch_affine<32>(a, st);
+        case 64: return launch_affine<64>(a, st);
+        case 128: return launch_affine<128>(a, st);
+        case 256: return launch_affine<256>(a, st);
+    }
+    return hipErrorInvalidValue;
+}

@@ -52,6 +52,7 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(WcRowsGemmArgs a, int nc
     __shared__ float As[BK * AS_LD];
     __shared__ __attribute__((aligned(16))) float Bs[BK * BS_LD];
 
+    if (a.gate && *a.gate == 0) return;      // exact redo of a fast-path call: only when it flagged an overflow
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int C = a.C;
@@ -413,22 +414,27 @@ __global__ __launch_bounds__(256) void xty_f64_kernel(WcXtyArgs a, int ntiles, i
     }
 }
 
-// shift[c] = mean of a strided sample of <= 1024 rows: removes the mean before fp32 products are summed
-__global__ __launch_bounds__(256) void subsample_mean_kernel(const float* __restrict__ x, int64_t M, int C,
-                                                             float* __restrict__ shift)
+// shift[c] = mean of a strided sample of <= 256 rows: removes the mean before fp32 products are summed.
+// 16 row groups x 64 channels per 1024-thread block, so no thread walks more than 16 dependent loads.
+__global__ __launch_bounds__(1024) void subsample_mean_kernel(const float* __restrict__ x, int64_t M, int C,
+                                                              float* __restrict__ shift)
 {
-    __shared__ float red[4][64];
+    __shared__ float red[16][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int part = threadIdx.x >> 6;
-    const int64_t nsamp = M < 1024 ? M : 1024;
+    const int64_t nsamp = M < 256 ? M : 256;
     const int64_t stride = M / nsamp;
     float s = 0.f;
     if (c < C)
-        for (int64_t r = part; r < nsamp; r += 4) s += x[r * stride * C + c];
+        for (int64_t r = part; r < nsamp; r += 16) s += x[r * stride * C + c];
     red[part][threadIdx.x & 63] = s;
     __syncthreads();
-    if (threadIdx.x < 64 && c < C)
-        shift[c] = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) / (float)nsamp;
+    if (threadIdx.x < 64 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) t += red[p][threadIdx.x];
+        shift[c] = t / (float)nsamp;
+    }
 }
 
 __global__ __launch_bounds__(256) void stream_copy_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, int64_t n4)
@@ -493,7 +499,7 @@ hipError_t wc_launch_xty(const WcXtyArgs& a, int nslab, hipStream_t st)
 
 hipError_t wc_launch_subsample_mean(const float* x, int64_t M, int C, float* shift, hipStream_t st)
 {
-    hipLaunchKernelGGL(subsample_mean_kernel, dim3((C + 63) / 64), dim3(256), 0, st, x, M, C, shift);
+    hipLaunchKernelGGL(subsample_mean_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, x, M, C, shift);
     return hipGetLastError();
 }
 

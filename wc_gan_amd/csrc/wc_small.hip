@@ -22,59 +22,92 @@ __device__ __forceinline__ double readlane64(double v, int l)
 // ---------------------------------------------------------------------------------------------
 // K1 tail
 // ---------------------------------------------------------------------------------------------
-__global__ void stats_colsum_kernel(const float* __restrict__ colsum, const float* __restrict__ shift, int nslab,
-                                    int64_t M, int C, double* __restrict__ Sp, double* __restrict__ sum)
+// 16 slab groups x 64 channels per block; partial sums meet in LDS (fixed order: deterministic)
+__global__ __launch_bounds__(1024) void stats_colsum_kernel(const float* __restrict__ colsum, const float* __restrict__ shift,
+                                                            int nslab, int64_t M, int C, double* __restrict__ Sp,
+                                                            double* __restrict__ sum)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double red[16][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int part = threadIdx.x >> 6;
     double s = 0.0;
-    for (int z = 0; z < nslab; ++z) s += (double)colsum[(int64_t)z * C + c];
-    Sp[c] = s;
-    sum[c] = s + (double)M * (double)shift[c];
+    if (c < C)
+        for (int z = part; z < nslab; z += 16) s += (double)colsum[(int64_t)z * C + c];
+    red[part][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (threadIdx.x < 64 && c < C) {
+        double t = 0.0;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) t += red[p][threadIdx.x];
+        Sp[c] = t;
+        sum[c] = t + (double)M * (double)shift[c];
+    }
 }
 
 // xtx = G' + s Sp^T + Sp s^T + M s s^T with G' = sum_z P[z]; only block-upper tiles of P were written.
-__global__ void stats_xtx_kernel(const double* __restrict__ P, const float* __restrict__ shift, const double* __restrict__ Sp,
-                                 int nslab, int64_t M, int C, double* __restrict__ xtx)
+// block = 64 columns x 4 slab groups, one row i per blockIdx.y
+__global__ __launch_bounds__(256) void stats_xtx_kernel(const double* __restrict__ P, const float* __restrict__ shift,
+                                                        const double* __restrict__ Sp, int nslab, int64_t M, int C,
+                                                        double* __restrict__ xtx)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ double red[4][64];
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int part = threadIdx.x >> 6;
     const int i = blockIdx.y;
-    if (j >= C) return;
-    if (j < i) return;                            // the lower triangle is mirrored by the (j,i) thread: exact symmetry
+    if (blockIdx.x * 64 + 63 < i) return;          // whole block below the diagonal
     const int64_t CC = (int64_t)C * C;
     double g = 0.0;
-    const double* p = P + (int64_t)i * C + j;
-    for (int z = 0; z < nslab; ++z) g += p[z * CC];
-    const double si = shift[i], sj = shift[j];
-    const double v = g + si * Sp[j] + Sp[i] * sj + (double)M * si * sj;
-    xtx[(int64_t)i * C + j] = v;
-    if (j != i) xtx[(int64_t)j * C + i] = v;
+    if (j < C && j >= i) {
+        const double* p = P + (int64_t)i * C + j;
+#pragma unroll 4
+        for (int z = part; z < nslab; z += 4) g += p[z * CC];
+    }
+    red[part][threadIdx.x & 63] = g;
+    __syncthreads();
+    if (threadIdx.x < 64 && j < C && j >= i) {
+        g = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        const double si = shift[i], sj = shift[j];
+        const double v = g + si * Sp[j] + Sp[i] * sj + (double)M * si * sj;
+        xtx[(int64_t)i * C + j] = v;
+        if (j != i) xtx[(int64_t)j * C + i] = v;   // mirrored by the same thread: exact symmetry
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
-// K4 tail: per-slab partials -> per-slot R, gsum
+// K4 tail: per-slab partials -> per-slot R, gsum.  block = 64 elements x 4 slab groups.
 // ---------------------------------------------------------------------------------------------
-__global__ void bwd_combine_kernel(const double* __restrict__ P, const float* __restrict__ colsum,
-                                   const int32_t* __restrict__ slot, int64_t N, int nsplit, int per_sample,
-                                   int C, double* __restrict__ R, double* __restrict__ gsum)
+__global__ __launch_bounds__(256) void bwd_combine_kernel(const double* __restrict__ P, const float* __restrict__ colsum,
+                                                          const int32_t* __restrict__ slot, int64_t N, int nsplit,
+                                                          int per_sample, int C, double* __restrict__ R,
+                                                          double* __restrict__ gsum)
 {
+    __shared__ double red[4][64];
     const int64_t CC = (int64_t)C * C;
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;    // element of C*C (+ C for gsum)
+    const int64_t e = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);    // element of C*C (+ C for gsum)
+    const int part = threadIdx.x >> 6;
     const int k = blockIdx.y;
-    if (e >= CC + C) return;
+    const bool live = e < CC + C;
     const bool is_sum = e >= CC;
     double acc = 0.0;
     auto term = [&](int64_t z) { return is_sum ? (double)colsum[z * C + (e - CC)] : P[z * CC + e]; };
-    if (per_sample) {
-        for (int64_t n = 0; n < N; ++n) {
-            if (slot[n] != k) continue;
-            for (int q = 0; q < nsplit; ++q) acc += term(n * nsplit + q);
+    if (live) {
+        if (per_sample) {
+            for (int64_t n = 0; n < N; ++n) {
+                if (slot[n] != k) continue;
+                for (int q = part; q < nsplit; q += 4) acc += term(n * nsplit + q);
+            }
+        } else {
+#pragma unroll 4
+            for (int z = part; z < nsplit; z += 4) acc += term(z);
         }
-    } else {
-        for (int z = 0; z < nsplit; ++z) acc += term(z);
     }
-    if (is_sum) gsum[(int64_t)k * C + (e - CC)] = acc;
-    else R[k * CC + e] = acc;
+    red[part][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (threadIdx.x < 64 && live) {
+        acc = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        if (is_sum) gsum[(int64_t)k * C + (e - CC)] = acc;
+        else R[k * CC + e] = acc;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -356,8 +389,8 @@ __global__ void f64_to_f32_kernel(const double* __restrict__ src, float* __restr
 hipError_t wc_launch_stats_finalize(const double* P, const float* colsum, const float* shift, int nslab,
                                     int64_t M, int C, double* Sp, double* sum, double* xtx, hipStream_t st)
 {
-    hipLaunchKernelGGL(stats_colsum_kernel, dim3((C + 63) / 64), dim3(64), 0, st, colsum, shift, nslab, M, C, Sp, sum);
-    hipLaunchKernelGGL(stats_xtx_kernel, dim3((C + 127) / 128, C), dim3(128), 0, st, P, shift, (const double*)Sp, nslab, M, C, xtx);
+    hipLaunchKernelGGL(stats_colsum_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, colsum, shift, nslab, M, C, Sp, sum);
+    hipLaunchKernelGGL(stats_xtx_kernel, dim3((C + 63) / 64, C), dim3(256), 0, st, P, shift, (const double*)Sp, nslab, M, C, xtx);
     return hipGetLastError();
 }
 
@@ -365,7 +398,7 @@ hipError_t wc_launch_bwd_combine(const double* P, const float* colsum, const int
                                  int per_sample, int C, int Kc, double* R, double* gsum, hipStream_t st)
 {
     const int64_t total = (int64_t)C * C + C;
-    hipLaunchKernelGGL(bwd_combine_kernel, dim3((unsigned)((total + 255) / 256), Kc), dim3(256), 0, st,
+    hipLaunchKernelGGL(bwd_combine_kernel, dim3((unsigned)((total + 63) / 64), Kc), dim3(256), 0, st,
                        P, colsum, slot, N, nsplit, per_sample, C, R, gsum);
     return hipGetLastError();
 }

@@ -84,7 +84,7 @@ def color(W, gamma):
     return A, At
 
 
-def apply(x, mu, A, bias, slot, out=None):
+def apply(x, mu, A, bias, slot, out=None, fast=True):
     """K3: y[n] = (x[n] - mu) A[slot[n]] + bias[slot[n]];  x is (N, ..., C) with C contiguous."""
     lib = _lib.load()
     _need(x, torch.float32, "x")
@@ -96,8 +96,9 @@ def apply(x, mu, A, bias, slot, out=None):
     if slot is not None:
         _need(slot, torch.int32, "slot", 1)
     y = torch.empty_like(x) if out is None else out
-    _lib.check(lib.wc_apply_f32(_ptr(x), _ptr(mu), _ptr(A), _ptr(bias), _ptr(slot), N, HW, C, Kc, _ptr(y), _stream()),
-               "wc_apply_f32")
+    ws = _workspace(lib.wc_apply_workspace_bytes(N, HW, C, Kc), x.device) if fast else None
+    _lib.check(lib.wc_apply_f32(_ptr(x), _ptr(mu), _ptr(A), _ptr(bias), _ptr(slot), N, HW, C, Kc, _ptr(y),
+                                _ptr(ws), ws.numel() if ws is not None else 0, _stream()), "wc_apply_f32")
     return y
 
 
@@ -132,7 +133,7 @@ def bwd_factor(R, gsum, W, L, gamma, A, M, eps, ddof, training, want_dgamma=True
     return dgamma, dbeta, S, gmean
 
 
-def bwd_apply(gy, x, mu, At, S, gmean, slot):
+def bwd_apply(gy, x, mu, At, S, gmean, slot, fast=True):
     """K6: dx[n] = gy[n] At[slot[n]] + (x[n]-mu) S - gmean."""
     lib = _lib.load()
     _need(gy, torch.float32, "gy")
@@ -140,8 +141,10 @@ def bwd_apply(gy, x, mu, At, S, gmean, slot):
     HW = gy.numel() // (N * C)
     Kc = At.shape[0]
     dx = torch.empty_like(gy)
+    ws = _workspace(lib.wc_bwd_apply_workspace_bytes(N, HW, C, Kc), gy.device) if fast else None
     _lib.check(lib.wc_bwd_apply_f32(_ptr(gy), _ptr(x), _ptr(mu), _ptr(At), _ptr(S), _ptr(gmean), _ptr(slot),
-                                    N, HW, C, Kc, _ptr(dx), _stream()), "wc_bwd_apply_f32")
+                                    N, HW, C, Kc, _ptr(dx), _ptr(ws), ws.numel() if ws is not None else 0, _stream()),
+               "wc_bwd_apply_f32")
     return dx
 
 
