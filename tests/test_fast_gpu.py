@@ -28,7 +28,7 @@ def _ref_apply(x, mu, A, b, slot):
 
 
 CASES = [((16, 32, 32, 256), 1), ((17, 32, 32, 256), 1), ((16, 32, 32, 128), 3), ((64, 16, 16, 64), 4), ((4, 64, 64, 32), 2),
-         ((33, 24, 24, 128), 1)]
+         ((33, 24, 24, 128), 1), ((128, 32, 32, 256), 1), ((128, 32, 32, 128), 10), ((96, 32, 32, 64), 5)]
 
 
 @pytest.mark.parametrize("shape,Kc", CASES)
@@ -42,7 +42,8 @@ def test_fast_apply_matches_float64(ops, shape, Kc):
     b = rng.standard_normal((Kc, C)).astype(np.float32)
     slot = rng.integers(0, Kc, N).astype(np.int32)
     st = dev(slot, torch.int32) if Kc > 1 else None
-    y_fast = ops.apply(dev(x), dev(mu), dev(A), dev(b), st, fast=True)
+    y_fast, gate = ops.apply(dev(x), dev(mu), dev(A), dev(b), st, fast=True, return_gate=True)
+    assert gate == 0, "the exact redo fired on in-range data: the fast kernel's own result was never checked"
     y_exact = ops.apply(dev(x), dev(mu), dev(A), dev(b), st, fast=False)
     ref = _ref_apply(x, mu, A, b, slot)
     e_fast, e_exact = rel(y_fast.cpu().numpy().reshape(ref.shape), ref), rel(y_exact.cpu().numpy().reshape(ref.shape), ref)
@@ -59,13 +60,15 @@ def test_fast_apply_overflow_is_caught_by_the_exact_redo(ops):
     mu = np.zeros(C, np.float32)
     A = (rng.standard_normal((1, C, C)) / np.sqrt(C)).astype(np.float32)
     b = np.zeros((1, C), np.float32)
-    y = ops.apply(dev(x), dev(mu), dev(A), dev(b), None, fast=True)
+    y, gate = ops.apply(dev(x), dev(mu), dev(A), dev(b), None, fast=True, return_gate=True)
+    assert gate == 1, "the out-of-range elements must raise the gate"
     ref = _ref_apply(x, mu, A, b, np.zeros(N, int))
     assert torch.isfinite(y).all()
     assert rel(y.cpu().numpy().reshape(ref.shape), ref) < 3e-6
 
 
-@pytest.mark.parametrize("shape,Kc,train", [((16, 32, 32, 256), 1, True), ((16, 32, 32, 128), 3, True), ((32, 32, 32, 64), 1, False)])
+@pytest.mark.parametrize("shape,Kc,train", [((16, 32, 32, 256), 1, True), ((16, 32, 32, 128), 3, True), ((32, 32, 32, 64), 1, False),
+                                            ((128, 32, 32, 256), 1, True), ((128, 32, 32, 128), 10, True)])
 def test_fast_bwd_apply_matches_float64(ops, shape, Kc, train):
     rng = np.random.default_rng(13)
     N, C = shape[0], shape[-1]
@@ -79,7 +82,8 @@ def test_fast_bwd_apply_matches_float64(ops, shape, Kc, train):
     slot = rng.integers(0, Kc, N).astype(np.int32)
     st = dev(slot, torch.int32) if Kc > 1 else None
     args = (dev(gy), dev(x), dev(mu), dev(At), dev(S) if train else None, dev(gm) if train else None, st)
-    dx_fast = ops.bwd_apply(*args, fast=True)
+    dx_fast, gate = ops.bwd_apply(*args, fast=True, return_gate=True)
+    assert gate == 0
     dx_exact = ops.bwd_apply(*args, fast=False)
     g3 = gy.astype(np.float64).reshape(N, -1, C)
     ref = np.einsum('npc,nco->npo', g3, At.astype(np.float64)[slot])

@@ -3,9 +3,10 @@
 //
 // Why not the f32 MFMA: at C = 256 the contraction has 64 flop/B, so v_mfma_f32_32x32x2_f32 (157 TF/s)
 // caps the kernel at ~30 % of the HBM roofline and gfx950 has no xf32 MFMA.  Each fp32 operand is split
-// into two fp16 terms, v = hi + lo * 2^-11 (22 significant bits), and the product runs as three
-// v_mfma_f32_32x32x16_f16 (hi*hi into one accumulator, hi*lo + lo*hi into a second): 3/16 of the
-// f32-MFMA time at fp32-GEMM accuracy.  fp16's narrow range is handled by exact power-of-two scalings:
+// into two fp16 terms, v = hi + lo with lo = fp16(v - hi) (22 significant bits while lo is a normal fp16,
+// an absolute error <= 2^-25 of the scaled range once it is subnormal), and the product runs as three
+// v_mfma_f32_32x32x16_f16 into ONE fp32 accumulator (lo*hi + hi*lo + hi*hi; lo*lo <= 2^-22 is dropped):
+// 3/16 of the f32-MFMA time at fp32-GEMM accuracy.  fp16's narrow range is handled by exact power-of-two scalings:
 // per input channel (s, from a row subsample), per output column (colscale, from the table itself);
 // an element that still exceeds the fp16 range raises a device flag and the exact f32-MFMA kernel,
 // queued behind with that flag as its gate, redoes the call -- the result never depends on the guess.
@@ -23,8 +24,6 @@ namespace {
 
 typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));
 
-constexpr float kLoScale = 2048.0f;            // 2^11
-constexpr float kLoInv = 1.0f / 2048.0f;
 constexpr float kF16Guard = 60000.0f;          // |scaled element| above this -> gate the exact path
 
 __device__ __forceinline__ f32x4 ld4f(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -93,7 +92,7 @@ __global__ __launch_bounds__(64) void split_table_kernel(const float* __restrict
         if (i < per && k < C) {
             const float w = v[i] * inv;
             const _Float16 h = (_Float16)w;
-            const _Float16 l = (_Float16)((w - (float)h) * kLoScale);
+            const _Float16 l = (_Float16)(w - (float)h);
             hi[row * C + k] = h;
             lo[row * C + k] = l;
         }
@@ -133,10 +132,21 @@ __global__ __launch_bounds__(512, 2) void affine_f16x3_kernel(FastArgs a)
     const int cg = wave % CG, rg = wave / CG;
     const int l31 = lane & 31, lh = lane >> 5;
 
-    const int t_begin = blockIdx.x * a.tiles_per_wg;
-    int t_end = t_begin + a.tiles_per_wg;
-    if (t_end > a.ntiles) t_end = a.ntiles;
-    if (t_begin >= t_end) return;
+    // Tile order.  Without slots the workgroups interleave (tile = block + i*grid): at any moment the chip then
+    // streams one contiguous window of HBM instead of 256 windows half a megabyte apart, whose identical low
+    // address bits march through the same memory channels in lockstep.  With slots a workgroup keeps a contiguous
+    // run of tiles so that its B' registers are reloaded only when the sample's slot changes.
+    int t_first, t_stride, t_count;
+    if (HAS_SLOT) {
+        t_first = blockIdx.x * a.tiles_per_wg; t_stride = 1;
+        t_count = a.ntiles - t_first; if (t_count > a.tiles_per_wg) t_count = a.tiles_per_wg;
+    } else {
+        t_first = blockIdx.x; t_stride = gridDim.x;
+        t_count = (a.ntiles - t_first + t_stride - 1) / t_stride;
+    }
+    if (t_count <= 0) return;
+    const int t_begin = 0, t_end = t_count;              // the loops below count tiles i; tile_of(i) maps to memory
+    auto tile_of = [&](int i) { return t_first + i * t_stride; };
 
     // staging coordinates: thread handles float4 #c4 of rows srow + RSTEP*p, p = 0..7
     const int c4 = tid % C4;
@@ -151,21 +161,32 @@ __global__ __launch_bounds__(512, 2) void affine_f16x3_kernel(FastArgs a)
     };
     const int in_off = srow * C + 4 * c4;                 // element offset inside a tile (fits 32 bits)
     // LDS byte offsets of this thread's 8 staging stores (tile-invariant)
-    int st_off[8];
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
+    auto st_off_fn = [&](int p) {
         const int row = srow + RSTEP * p;
-        st_off[p] = row * (C * 2) + (((c4 >> 1) ^ swz(row)) * 16) + (c4 & 1) * 8;
-    }
+        return row * (C * 2) + (((c4 >> 1) ^ swz(row)) * 16) + (c4 & 1) * 8;
+    };
+    // the swizzle term repeats with period 16/gcd(RSTEP,16) in p: keep the distinct bases, add the row stride as a constant
+    constexpr int NB = (RSTEP % 16 == 0) ? 1 : 16 / RSTEP;
+    int st_base[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) st_base[q] = st_off_fn(q) - q * RSTEP * (C * 2);
 
     f32x4 xr[8];
-    auto load_chunk = [&](int tile, int p) {
-        const float* base = a.in + (int64_t)tile * (BM * C);          // wave-uniform
-        xr[p] = ld4f(base + in_off + p * (RSTEP * C));
+    // In the non-accumulating kernels the steady-state loads are inline asm, invisible to hipcc's waitcnt pass:
+    // with compiler-visible loads it drains vmcnt to 0 before every use (loads and stores share the counter and
+    // it treats the mix as unordered), which also waits for the previous tile's 32 stores.  The waits are counted
+    // by hand instead (wait_chunk): between a chunk's load and its use one iteration later exactly
+    // (7-p) loads + 32 stores + p loads = 39 younger VMEM ops are issued.
+    constexpr bool ASM_LOADS = !ACC;
+    const int in_off_b = in_off * 4;
+    auto load_chunk = [&](int ti, int p) {
+        const float* base = a.in + (int64_t)tile_of(ti) * (BM * C) + p * (RSTEP * C);     // wave-uniform
+        if (ASM_LOADS) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(xr[p]) : "v"(in_off_b), "s"(base) : "memory");
+        else xr[p] = ld4f(base + in_off);
     };
-    auto stage_load = [&](int tile) {
+    auto stage_load = [&](int ti) {
 #pragma unroll
-        for (int p = 0; p < 8; ++p) load_chunk(tile, p);
+        for (int p = 0; p < 8; ++p) load_chunk(ti, p);
     };
     bool overflow = false;
     auto write_chunk = [&](int buf, int p) {
@@ -176,12 +197,12 @@ __global__ __launch_bounds__(512, 2) void affine_f16x3_kernel(FastArgs a)
             overflow |= (fabsf(g[0]) > kF16Guard) | (fabsf(g[1]) > kF16Guard) | (fabsf(g[2]) > kF16Guard) | (fabsf(g[3]) > kF16Guard);
             const h16x2 h01 = __builtin_amdgcn_cvt_pkrtz(g[0], g[1]);
             const h16x2 h23 = __builtin_amdgcn_cvt_pkrtz(g[2], g[3]);
-            const float r0 = (g[0] - (float)h01[0]) * kLoScale, r1 = (g[1] - (float)h01[1]) * kLoScale;
-            const float r2 = (g[2] - (float)h23[0]) * kLoScale, r3 = (g[3] - (float)h23[1]) * kLoScale;
+            const float r0 = g[0] - (float)h01[0], r1 = g[1] - (float)h01[1];
+            const float r2 = g[2] - (float)h23[0], r3 = g[3] - (float)h23[1];
             const h16x2 l01 = __builtin_amdgcn_cvt_pkrtz(r0, r1);
             const h16x2 l23 = __builtin_amdgcn_cvt_pkrtz(r2, r3);
-            *reinterpret_cast<uint2*>(hi_img + st_off[p]) = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
-            *reinterpret_cast<uint2*>(lo_img + st_off[p]) = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+            *reinterpret_cast<uint2*>(hi_img + st_base[p % NB] + p * RSTEP * (C * 2)) = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+            *reinterpret_cast<uint2*>(lo_img + st_base[p % NB] + p * RSTEP * (C * 2)) = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
         }
     };
     auto stage_write = [&](int buf) {
@@ -212,6 +233,9 @@ __global__ __launch_bounds__(512, 2) void affine_f16x3_kernel(FastArgs a)
 
     stage_load(t_begin);
     if (!HAS_SLOT) load_b(0);
+    if (ASM_LOADS)          // asm loads are not tracked by the compiler: wait for the first tile by hand
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]),
+                                            "+v"(xr[4]), "+v"(xr[5]), "+v"(xr[6]), "+v"(xr[7]) :: "memory");
     stage_write(0);
     if (t_begin + 1 < t_end) stage_load(t_begin + 1);
     __syncthreads();
@@ -227,12 +251,20 @@ __global__ __launch_bounds__(512, 2) void affine_f16x3_kernel(FastArgs a)
     auto tile_body = [&](int t, auto do_write, auto do_load) {
         const int cur = (t - t_begin) & 1;
         constexpr bool W_ = decltype(do_write)::value, L_ = decltype(do_load)::value;
+        if (ASM_LOADS && t == t_begin)       // the prologue's loads have no stores behind them: drain once, counts hold after
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]),
+                                                "+v"(xr[4]), "+v"(xr[5]), "+v"(xr[6]), "+v"(xr[7]) :: "memory");
 
         if (HAS_SLOT) {
-            const int slot = a.slot[((int64_t)t * BM) / a.HW];
-            if (slot != cur_slot) load_b(slot);
+            const int slot = a.slot[((int64_t)tile_of(t) * BM) / a.HW];
+            if (slot != cur_slot) {
+                load_b(slot);
+                if (ASM_LOADS)     // the table reload put extra loads in the queue: drain, after which every count is conservative again
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]),
+                                                        "+v"(xr[4]), "+v"(xr[5]), "+v"(xr[6]), "+v"(xr[7]) :: "memory");
+            }
         }
-        float* out_tile = a.out + (int64_t)t * (BM * C);                // wave-uniform
+        float* out_tile = a.out + (int64_t)tile_of(t) * (BM * C);       // wave-uniform
         const char* hi_img = smem + cur * 2 * IMG;
         const char* lo_img = hi_img + IMG;
 #pragma unroll
@@ -241,38 +273,47 @@ __global__ __launch_bounds__(512, 2) void affine_f16x3_kernel(FastArgs a)
             const int sw = swz(rbase + l31);
             const char* hrow = hi_img + rbase * (C * 2) + rd_lane;
             const char* lrow = lo_img + rbase * (C * 2) + rd_lane;
-            f32x16 acc1, acc2;
+            f32x16 acc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc1[r] = 0.f; acc2[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            // fragments are fetched one k-step ahead of the MFMAs that consume them (LDS latency off the critical path)
+            f16x8 ah = *reinterpret_cast<const f16x8*>(hrow + ((0 + lh) ^ sw) * 16);
+            f16x8 al = *reinterpret_cast<const f16x8*>(lrow + ((0 + lh) ^ sw) * 16);
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                // staging of the NEXT tile rides in the gaps of this tile's first sub-tile: one 16-B chunk per
-                // STEP k-steps is centred/split/written to the other LDS buffer and its register refilled from t+2
-                constexpr int STEP = (KS >= 8) ? KS / 8 : 1;
-                if (sb == 0 && (s % STEP) == 0 && (s / STEP) < 8) {
-                    if (KS >= 8) {
-                        if (W_) write_chunk(cur ^ 1, s / STEP);
-                        if (L_) load_chunk(t + 2, s / STEP);
-                    } else {
+                f16x8 nh = ah, nl = al;
+                if (s + 1 < KS) {
+                    const int chunk = (2 * (s + 1) + lh) ^ sw;
+                    nh = *reinterpret_cast<const f16x8*>(hrow + chunk * 16);
+                    nl = *reinterpret_cast<const f16x8*>(lrow + chunk * 16);
+                }
+                // staging of the NEXT tile rides in the gaps of this tile's MFMAs: one 16-B chunk per STEP k-steps
+                // is centred/split/written to the other LDS buffer and its register refilled from tile t+2.
+                // Chunks 0-3 ride in sub-tile 0 and 4-7 in sub-tile 1; the hand count of younger VMEM ops is 39 for all.
+                constexpr int STEP = (KS >= 4) ? KS / 4 : 1;        // k-steps per chunk inside one sub-tile
+                constexpr int PER = (KS >= 4) ? 1 : 4 / KS;          // chunks per k-step when K is short
+                if ((s % STEP) == 0 && (s / STEP) < 4) {
 #pragma unroll
-                        for (int q = 0; q < 8 / KS; ++q) {
-                            if (W_) write_chunk(cur ^ 1, s * (8 / KS) + q);
-                            if (L_) load_chunk(t + 2, s * (8 / KS) + q);
+                    for (int q = 0; q < PER; ++q) {
+                        const int p = sb * 4 + (s / STEP) * PER + q;
+                        if (W_ && ASM_LOADS) {
+                            if (L_) asm volatile("s_waitcnt vmcnt(39)" : "+v"(xr[p]) :: "memory");
+                            else asm volatile("s_waitcnt vmcnt(16)" : "+v"(xr[p]) :: "memory");   // <= every tail count
                         }
+                        if (W_) write_chunk(cur ^ 1, p);
+                        if (L_) load_chunk(t + 2, p);
                     }
                 }
-                const int chunk = (2 * s + lh) ^ sw;
-                const f16x8 ah = *reinterpret_cast<const f16x8*>(hrow + chunk * 16);
-                const f16x8 al = *reinterpret_cast<const f16x8*>(lrow + chunk * 16);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bhi[s], acc1, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, blo[s], acc2, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bhi[s], acc2, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bhi[s], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, blo[s], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bhi[s], acc, 0, 0, 0);
+                ah = nh; al = nl;
             }
             float* po = out_tile + rbase * C + out_lane;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ro = ((r & 3) + 8 * (r >> 2)) * C;
-                float v = (acc1[r] + acc2[r] * kLoInv) * cscale + addv;
+                float v = acc[r] * cscale + addv;
                 if (ACC) v += po[ro];
                 po[ro] = v;
             }

@@ -84,7 +84,7 @@ def color(W, gamma):
     return A, At
 
 
-def apply(x, mu, A, bias, slot, out=None, fast=True):
+def apply(x, mu, A, bias, slot, out=None, fast=True, return_gate=False):
     """K3: y[n] = (x[n] - mu) A[slot[n]] + bias[slot[n]];  x is (N, ..., C) with C contiguous."""
     lib = _lib.load()
     _need(x, torch.float32, "x")
@@ -99,6 +99,8 @@ def apply(x, mu, A, bias, slot, out=None, fast=True):
     ws = _workspace(lib.wc_apply_workspace_bytes(N, HW, C, Kc), x.device) if fast else None
     _lib.check(lib.wc_apply_f32(_ptr(x), _ptr(mu), _ptr(A), _ptr(bias), _ptr(slot), N, HW, C, Kc, _ptr(y),
                                 _ptr(ws), ws.numel() if ws is not None else 0, _stream()), "wc_apply_f32")
+    if return_gate:      # first word of the workspace = the fast path's fp16-overflow gate (tests only: forces a sync)
+        return y, (int(ws[:4].view(torch.int32).item()) if (ws is not None and ws.numel() > 256) else 0)
     return y
 
 
@@ -133,7 +135,7 @@ def bwd_factor(R, gsum, W, L, gamma, A, M, eps, ddof, training, want_dgamma=True
     return dgamma, dbeta, S, gmean
 
 
-def bwd_apply(gy, x, mu, At, S, gmean, slot, fast=True):
+def bwd_apply(gy, x, mu, At, S, gmean, slot, fast=True, return_gate=False):
     """K6: dx[n] = gy[n] At[slot[n]] + (x[n]-mu) S - gmean."""
     lib = _lib.load()
     _need(gy, torch.float32, "gy")
@@ -145,6 +147,8 @@ def bwd_apply(gy, x, mu, At, S, gmean, slot, fast=True):
     _lib.check(lib.wc_bwd_apply_f32(_ptr(gy), _ptr(x), _ptr(mu), _ptr(At), _ptr(S), _ptr(gmean), _ptr(slot),
                                     N, HW, C, Kc, _ptr(dx), _ptr(ws), ws.numel() if ws is not None else 0, _stream()),
                "wc_bwd_apply_f32")
+    if return_gate:
+        return dx, (int(ws[:4].view(torch.int32).item()) if (ws is not None and ws.numel() > 256) else 0)
     return dx
 
 
