@@ -91,3 +91,46 @@ def test_fast_bwd_apply_matches_float64(ops, shape, Kc, train):
         ref = ref + (x.astype(np.float64).reshape(N, -1, C) - mu) @ S.astype(np.float64) - gm.astype(np.float64)
     assert rel(dx_fast.cpu().numpy().reshape(ref.shape), ref) < 3e-6
     assert rel(dx_exact.cpu().numpy().reshape(ref.shape), ref) < 3e-6
+
+
+# ---- fast reductions (wc_fast_xty.hip) -------------------------------------------------------------------------
+XTY_CASES = [((16, 32, 32, 256), 1), ((128, 32, 32, 256), 1), ((32, 32, 32, 128), 1), ((16, 64, 64, 64), 1), ((8, 64, 64, 32), 1)]
+
+
+@pytest.mark.parametrize("shape,_k", XTY_CASES)
+def test_fast_stats_matches_float64(ops, shape, _k):
+    from oracle import wc_oracle as o
+    rng = np.random.default_rng(21)
+    C = shape[-1]
+    x = o.synth_activation(rng, shape, "ill").astype(np.float32)
+    X = x.reshape(-1, C).astype(np.float64)
+    s, xtx = ops.stats(dev(x).view(-1, C))
+    s_ref, xtx_ref, M = o.batch_moments(X)
+    _, cov_ref = o.moments_to_stats(s_ref, xtx_ref, M)
+    _, cov = o.moments_to_stats(s.cpu().numpy(), xtx.cpu().numpy(), M)
+    assert rel(s.cpu().numpy(), s_ref) < 1e-5
+    e = rel(cov, cov_ref)
+    print(shape, "cov rel err", e)
+    # float64-flushed split-fp16 products.  What remains is the dropped lo*lo term: a ~3e-8 relative, nearly uniform
+    # inflation of the diagonal (a ridge 4 orders below eps) -- an fp32-accumulated covariance sits at 1e-6.
+    assert e < 1e-7, e
+    assert np.abs(xtx.cpu().numpy() - xtx.cpu().numpy().T).max() == 0.0
+
+
+@pytest.mark.parametrize("shape,Kc", [((16, 32, 32, 256), 1), ((32, 32, 32, 128), 5), ((128, 32, 32, 128), 10), ((16, 64, 64, 64), 3)])
+def test_fast_bwd_reduce_matches_float64(ops, shape, Kc):
+    rng = np.random.default_rng(22)
+    N, C = shape[0], shape[-1]
+    x = (rng.standard_normal(shape) * np.exp(rng.uniform(-3, 3, C)) + 0.3).astype(np.float32)
+    gy = (rng.standard_normal(shape) * 1e-3 * np.exp(rng.uniform(-3, 3, C))).astype(np.float32)
+    mu = x.reshape(-1, C).mean(0).astype(np.float32)
+    slot = rng.integers(0, Kc, N).astype(np.int32)
+    R, gsum = ops.bwd_reduce(dev(x), dev(mu), dev(gy), dev(slot, torch.int32) if Kc > 1 else None, Kc)
+    f = x.astype(np.float64).reshape(N, -1, C) - mu.astype(np.float64)
+    g = gy.astype(np.float64).reshape(N, -1, C)
+    for k in range(Kc):
+        sel = slot == k if Kc > 1 else np.ones(N, bool)
+        R_ref = np.einsum('npi,npj->ij', f[sel], g[sel])
+        scale = np.sqrt(np.outer((f[sel] ** 2).sum((0, 1)), (g[sel] ** 2).sum((0, 1)))) + 1e-300   # per-entry natural scale
+        assert np.abs((R[k].cpu().numpy() - R_ref) / scale).max() < 1e-7
+        assert rel(gsum[k].cpu().numpy(), g[sel].sum((0, 1))) < 1e-5

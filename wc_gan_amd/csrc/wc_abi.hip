@@ -42,12 +42,24 @@ const char* wc_error_string(int code)
 }
 
 // ---------------------------------------------------------------------------------------------
+namespace {
+struct XtyPlan { int fast; int nslab; int nsplit; int64_t rps; int ntypes; };
+// one plan per call shape: the fast kernel and its gated exact redo must write the same slab layout
+XtyPlan plan_xty(int64_t N, int64_t HW, int C, int per_sample, int sym)
+{
+    XtyPlan p = {};
+    p.nslab = wc_fast_xty_plan(N, HW, C, per_sample, !sym, &p.nsplit, &p.rps, &p.ntypes);
+    p.fast = p.nslab > 0;
+    if (!p.fast) p.nslab = wc_xty_plan(N, HW, C, per_sample, sym, &p.nsplit, &p.rps);
+    return p;
+}
+}  // namespace
+
 size_t wc_stats_workspace_bytes(int64_t M, int C)
 {
     if (M <= 0 || bad_channels(C)) return 0;
-    int nsplit; int64_t rps;
-    const int nslab = wc_xty_plan(1, M, C, 0, 1, &nsplit, &rps);
-    return slot_bytes(C, 4) + slot_bytes(C, 8) + slot_bytes((size_t)nslab * C, 4) + slot_bytes((size_t)nslab * C * C, 8);
+    const XtyPlan p = plan_xty(1, M, C, 0, 1);
+    return 256 + 2 * slot_bytes(C, 4) + slot_bytes(C, 8) + slot_bytes((size_t)p.nslab * C, 4) + slot_bytes((size_t)p.nslab * C * C, 8);
 }
 
 int wc_stats_f32(const float* x, int64_t M, int C, double* sum, double* xtx,
@@ -58,20 +70,28 @@ int wc_stats_f32(const float* x, int64_t M, int C, double* sum, double* xtx,
     if (bad_channels(C)) return WC_ERR_CHANNELS;
     if (ws_bytes < wc_stats_workspace_bytes(M, C)) return WC_ERR_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    int nsplit; int64_t rps;
-    const int nslab = wc_xty_plan(1, M, C, 0, 1, &nsplit, &rps);
+    const XtyPlan p = plan_xty(1, M, C, 0, 1);
     Carver cv(ws, ws_bytes);
+    int* gate = cv.take<int>(64);
     float* shift = cv.take<float>(C);
+    float* scale = cv.take<float>(C);
     double* Sp = cv.take<double>(C);
-    float* colsum = cv.take<float>((size_t)nslab * C);
-    double* P = cv.take<double>((size_t)nslab * C * C);
+    float* colsum = cv.take<float>((size_t)p.nslab * C);
+    double* P = cv.take<double>((size_t)p.nslab * C * C);
 
     WC_TRY(wc_launch_subsample_mean(x, M, C, shift, st));
     WcXtyArgs a = {};
-    a.X = x; a.Y = x; a.cx = shift; a.cy = shift; a.N = 1; a.HW = M; a.per_sample = 0; a.nsplit = nsplit;
-    a.rows_per_slab = rps; a.C = C; a.sym = 1; a.P = P; a.colsum = colsum;
-    WC_TRY(wc_launch_xty(a, nslab, st));
-    WC_TRY(wc_launch_stats_finalize(P, colsum, shift, nslab, M, C, Sp, sum, xtx, st));
+    a.X = x; a.Y = x; a.cx = shift; a.cy = shift; a.N = 1; a.HW = M; a.per_sample = 0; a.nsplit = p.nsplit;
+    a.rows_per_slab = p.rps; a.C = C; a.sym = 1; a.P = P; a.colsum = colsum;
+    if (p.fast) {
+        WC_TRY(hipMemsetAsync(gate, 0, 256, st));
+        WC_TRY(wc_launch_channel_scale(x, shift, M, C, scale, st));
+        WC_TRY(wc_launch_fast_xty(x, x, shift, shift, scale, scale, 1, M, C, 0, p.nsplit, p.rps, p.nslab, p.ntypes,
+                                  P, colsum, gate, st));
+        a.gate = gate;                       // exact redo, a no-op unless the fp16 range was exceeded
+    }
+    WC_TRY(wc_launch_xty(a, p.nslab, st));
+    WC_TRY(wc_launch_stats_finalize(P, colsum, shift, p.nslab, M, C, Sp, sum, xtx, st));
     return WC_OK;
 }
 
@@ -168,9 +188,8 @@ size_t wc_bwd_reduce_workspace_bytes(int64_t N, int64_t HW, int C, int Kc, int h
 {
     (void)Kc;
     if (N <= 0 || HW <= 0 || bad_channels(C)) return 0;
-    int nsplit; int64_t rps;
-    const int nslab = has_slot ? wc_xty_plan(N, HW, C, 1, 0, &nsplit, &rps) : wc_xty_plan(1, N * HW, C, 0, 0, &nsplit, &rps);
-    return slot_bytes((size_t)nslab * C, 4) + slot_bytes((size_t)nslab * C * C, 8);
+    const XtyPlan p = has_slot ? plan_xty(N, HW, C, 1, 0) : plan_xty(1, N * HW, C, 0, 0);
+    return 256 + 2 * slot_bytes(C, 4) + slot_bytes((size_t)p.nslab * C, 4) + slot_bytes((size_t)p.nslab * C * C, 8);
 }
 
 int wc_bwd_reduce_f32(const float* x, const float* mu, const float* gy, const int32_t* slot,
@@ -183,17 +202,27 @@ int wc_bwd_reduce_f32(const float* x, const float* mu, const float* gy, const in
     if (ws_bytes < wc_bwd_reduce_workspace_bytes(N, HW, C, Kc, slot != nullptr)) return WC_ERR_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int per_sample = slot != nullptr;
-    int nsplit; int64_t rps;
-    const int nslab = per_sample ? wc_xty_plan(N, HW, C, 1, 0, &nsplit, &rps) : wc_xty_plan(1, N * HW, C, 0, 0, &nsplit, &rps);
+    const int64_t Ns = per_sample ? N : 1, HWs = per_sample ? HW : N * HW;
+    const XtyPlan p = plan_xty(Ns, HWs, C, per_sample, 0);
     Carver cv(ws, ws_bytes);
-    float* colsum = cv.take<float>((size_t)nslab * C);
-    double* P = cv.take<double>((size_t)nslab * C * C);
+    int* gate = cv.take<int>(64);
+    float* sx = cv.take<float>(C);
+    float* sy = cv.take<float>(C);
+    float* colsum = cv.take<float>((size_t)p.nslab * C);
+    double* P = cv.take<double>((size_t)p.nslab * C * C);
     WcXtyArgs a = {};
-    a.X = x; a.Y = gy; a.cx = mu; a.cy = nullptr;
-    if (per_sample) { a.N = N; a.HW = HW; } else { a.N = 1; a.HW = N * HW; }
-    a.per_sample = per_sample; a.nsplit = nsplit; a.rows_per_slab = rps; a.C = C; a.sym = 0; a.P = P; a.colsum = colsum;
-    WC_TRY(wc_launch_xty(a, nslab, st));
-    WC_TRY(wc_launch_bwd_combine(P, colsum, slot, N, nsplit, per_sample, C, Kc, R, gsum, st));
+    a.X = x; a.Y = gy; a.cx = mu; a.cy = nullptr; a.N = Ns; a.HW = HWs;
+    a.per_sample = per_sample; a.nsplit = p.nsplit; a.rows_per_slab = p.rps; a.C = C; a.sym = 0; a.P = P; a.colsum = colsum;
+    if (p.fast) {
+        WC_TRY(hipMemsetAsync(gate, 0, 256, st));
+        WC_TRY(wc_launch_channel_scale(x, mu, N * HW, C, sx, st));
+        WC_TRY(wc_launch_channel_scale(gy, nullptr, N * HW, C, sy, st));
+        WC_TRY(wc_launch_fast_xty(x, gy, mu, nullptr, sx, sy, Ns, HWs, C, per_sample, p.nsplit, p.rps, p.nslab, p.ntypes,
+                                  P, colsum, gate, st));
+        a.gate = gate;
+    }
+    WC_TRY(wc_launch_xty(a, p.nslab, st));
+    WC_TRY(wc_launch_bwd_combine(P, colsum, slot, N, p.nsplit, per_sample, C, Kc, R, gsum, st));
     return WC_OK;
 }
 

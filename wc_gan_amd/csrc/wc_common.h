@@ -46,6 +46,7 @@ struct WcXtyArgs {
     int sym;                             // 1: only tiles jb >= ib, column sums of X; 0: all tiles, column sums of Y
     double* P;                           // [nslab][C][C] float64 partials
     float* colsum;                       // [nslab][C]
+    const int* gate;                     // optional: run only when *gate != 0 (exact redo of a fast-path call)
 };
 int  wc_xty_plan(int64_t N, int64_t HW, int C, int per_sample, int sym, int* nsplit, int64_t* rows_per_slab);  // returns nslab
 hipError_t wc_launch_xty(const WcXtyArgs& a, int nslab, hipStream_t st);
@@ -61,6 +62,14 @@ hipError_t wc_launch_fast_affine(const float* in, const float* center, const flo
                                  const float* bias, const float* sub, const int32_t* slot,
                                  int64_t N, int64_t HW, int C, int accumulate, float* out,
                                  void* ws, int* gate, hipStream_t st);
+
+// fast reductions (wc_fast_xty.hip)
+int wc_fast_xty_plan(int64_t N, int64_t HW, int C, int per_sample, int two, int* nsplit, int64_t* rows_per_slab, int* ntypes);
+hipError_t wc_launch_fast_xty(const float* X, const float* Y, const float* cx, const float* cy,
+                              const float* sx, const float* sy, int64_t N, int64_t HW, int C,
+                              int per_sample, int nsplit, int64_t rows_per_slab, int nslab, int ntypes,
+                              double* P, float* colsum, int* gate, hipStream_t st);
+hipError_t wc_launch_channel_scale(const float* in, const float* center, int64_t M, int C, float* scale, hipStream_t st);
 
 // ----- small-matrix stage (wc_small.hip) -----------------------------------------------------
 

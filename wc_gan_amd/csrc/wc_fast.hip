@@ -23,6 +23,14 @@
 namespace {
 
 typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
+// round-to-nearest pack (v_cvt_pk_f16_f32) for the low terms: a truncating convert there biases every element
+// toward zero by ~2^-23 and shows up as a uniform 3e-7 shrink of the covariance
+__device__ __forceinline__ unsigned pk_rne(float a, float b)
+{
+    const f32x2_ v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+}
 
 constexpr float kF16Guard = 60000.0f;          // |scaled element| above this -> gate the exact path
 
@@ -195,14 +203,14 @@ __global__ __launch_bounds__(512, 2) void affine_f16x3_kernel(FastArgs a)
         {
             const f32x4 g = xr[p] * scl + ncs;
             overflow |= (fabsf(g[0]) > kF16Guard) | (fabsf(g[1]) > kF16Guard) | (fabsf(g[2]) > kF16Guard) | (fabsf(g[3]) > kF16Guard);
-            const h16x2 h01 = __builtin_amdgcn_cvt_pkrtz(g[0], g[1]);
-            const h16x2 h23 = __builtin_amdgcn_cvt_pkrtz(g[2], g[3]);
+            const unsigned hw01 = pk_rne(g[0], g[1]), hw23 = pk_rne(g[2], g[3]);
+            const f16x2 h01 = __builtin_bit_cast(f16x2, hw01), h23 = __builtin_bit_cast(f16x2, hw23);
             const float r0 = g[0] - (float)h01[0], r1 = g[1] - (float)h01[1];
             const float r2 = g[2] - (float)h23[0], r3 = g[3] - (float)h23[1];
-            const h16x2 l01 = __builtin_amdgcn_cvt_pkrtz(r0, r1);
-            const h16x2 l23 = __builtin_amdgcn_cvt_pkrtz(r2, r3);
-            *reinterpret_cast<uint2*>(hi_img + st_base[p % NB] + p * RSTEP * (C * 2)) = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
-            *reinterpret_cast<uint2*>(lo_img + st_base[p % NB] + p * RSTEP * (C * 2)) = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+            const unsigned l01 = pk_rne(r0, r1);
+            const unsigned l23 = pk_rne(r2, r3);
+            *reinterpret_cast<uint2*>(hi_img + st_base[p % NB] + p * RSTEP * (C * 2)) = make_uint2(hw01, hw23);
+            *reinterpret_cast<uint2*>(lo_img + st_base[p % NB] + p * RSTEP * (C * 2)) = make_uint2(l01, l23);
         }
     };
     auto stage_write = [&](int buf) {
@@ -377,6 +385,12 @@ size_t wc_fast_affine_workspace(int C, int Kc)
     // flag | scale[C] | colscale[Kc*C] | hi[Kc*C*C] | lo[Kc*C*C]
     return 256 + wc_align_up((size_t)C * 4, 256) + wc_align_up((size_t)Kc * C * 4, 256) +
            2 * wc_align_up((size_t)Kc * C * C * 2, 256);
+}
+
+hipError_t wc_launch_channel_scale(const float* in, const float* center, int64_t M, int C, float* scale, hipStream_t st)
+{
+    hipLaunchKernelGGL(channel_scale_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, in, center, M, C, scale);
+    return hipGetLastError();
 }
 
 // One stream of the affine on the fast path.  B is [slot][k][n] row-major.

@@ -1,0 +1,306 @@
+// Fast path of the two big reductions, K1 (covariance moments, wc_stats_f32) and K4 (R = f^T gbar, wc_bwd_reduce_f32):
+//   P[slab] = sum_{m in slab} ((X[m]-cx).*sx)^T ((Y[m]-cy).*sy)  / (sx_i sy_j)          (+ column sums)
+// on the split-fp16 scheme of wc_fast.hip: v = hi + lo, three v_mfma_f32_32x32x16_f16 per 32x32 block and
+// 16 rows, 3/16 of the f32-MFMA time.  What is specific here:
+//
+//  * Both MFMA operands are indexed [channel][row] (the contraction runs over rows), so the activation tile is
+//    transposed while it is staged: a thread loads 16 B (4 channels) from each of 8 consecutive rows and then
+//    holds, per channel, 8 consecutive rows = one 16-byte fp16 fragment chunk -- written with ds_write_b128 into an
+//    XOR-swizzled [C][R] image.  No transposed LDS read, no shuffles.
+//  * Accuracy of the covariance decides parity on ill-conditioned batches, so the fp32 MFMA
+//    accumulators are flushed into FLOAT64 registers after every stage (64 rows: a 12-step fp32 chain).  That
+//    costs 48 VGPRs per block, so a wave owns only 2 of the C/32 x C/32 blocks and the blocks of one slab are
+//    spread over `ntypes` workgroups that stream the same rows (co-scheduled on one XCD: L2 serves the re-reads).
+//  * fp16 range: per-channel power-of-two scales from a row subsample, undone exactly in the float64 flush; an
+//    out-of-range element raises the same device gate as in wc_fast.hip and the exact kernel redoes the call.
+#include "wc_common.h"
+#include <type_traits>
+
+namespace {
+
+typedef __fp16 h16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
+// round-to-nearest pack (v_cvt_pk_f16_f32) for the low terms: a truncating convert there biases every element
+// toward zero by ~2^-23 and shows up as a uniform 3e-7 shrink of the covariance
+__device__ __forceinline__ unsigned pk_rne(float a, float b)
+{
+    const f32x2_ v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+}
+constexpr float kGuard = 60000.0f;
+constexpr int BW = 2;                      // 32x32 blocks per wave
+
+__device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+struct FastXtyArgs {
+    const float* X; const float* Y;        // Y == X (and TWO == false) for the covariance
+    const float* cx; const float* cy;      // centers [C] or nullptr
+    const float* sx; const float* sy;      // power-of-two scales [C]
+    int64_t N, HW;
+    int per_sample, nsplit;
+    int64_t rows_per_slab;
+    int nslab, ntypes;
+    double* P;                             // [nslab][C][C]
+    float* colsum;                         // [nslab][C]: sum of (X-cx) (covariance) or of (Y-cy) (two-operand)
+    int* flag;
+};
+
+template <int C, bool TWO>
+__global__ __launch_bounds__(512, 2) void xty_f16x3_kernel(FastXtyArgs a)
+{
+    constexpr int C4 = C / 4;
+    constexpr int RGRP = 512 / C4;                    // 8-row groups covered by the 512 threads
+    constexpr int R = TWO ? RGRP * 4 : RGRP * 8;      // rows per stage and operand (TWO: half the threads per operand)
+    constexpr int CPR = R / 8;                        // 16-byte chunks per channel row of an image
+    constexpr int KS = R / 16;                        // MFMA k-steps per stage
+    constexpr int IMG = C * R * 2;                    // bytes of one fp16 image
+    constexpr int NOP = TWO ? 2 : 1;
+    constexpr int NB = C / 32;
+    constexpr int NBLK = TWO ? NB * NB : NB * (NB + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // [2 buffers][operand][hi | lo]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // workgroup -> (slab, type): the ntypes workgroups of a slab sit 8 apart in block order (same XCD, speed only)
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int type = q % a.ntypes;
+    const int64_t z = (int64_t)(q / a.ntypes) * 8 + xcd;
+    if (z >= a.nslab) return;
+
+    int64_t r0, r1;
+    if (a.per_sample) {
+        const int64_t n = z / a.nsplit, qq = z % a.nsplit;
+        r0 = n * a.HW + qq * a.rows_per_slab;
+        r1 = r0 + a.rows_per_slab;
+        const int64_t end = (n + 1) * a.HW;
+        if (r1 > end) r1 = end;
+    } else {
+        const int64_t M = a.N * a.HW;
+        r0 = z * a.rows_per_slab;
+        r1 = r0 + a.rows_per_slab;
+        if (r1 > M) r1 = M;
+    }
+    const int nst = (int)((r1 - r0) / R);             // whole stages only (the launcher guarantees it)
+
+    // this wave's blocks
+    int ib[BW], jb[BW]; bool live[BW];
+#pragma unroll
+    for (int b = 0; b < BW; ++b) {
+        int L = (type * 8 + wave) * BW + b;
+        live[b] = L < NBLK;
+        if (!live[b]) L = 0;
+        if (TWO) { ib[b] = L / NB; jb[b] = L % NB; }
+        else { int i = 0; while (L >= NB - i) { L -= NB - i; ++i; } ib[b] = i; jb[b] = i + L; }
+    }
+
+    // staging: thread -> operand op, float4 column c4, 8-row group rgrp
+    const int op = TWO ? (tid >= 256) : 0;
+    const int tl = TWO ? (tid & 255) : tid;
+    const int c4 = tl % C4, rgrp = tl / C4;
+    const float* src = (TWO && op) ? a.Y : a.X;
+    const float* cen = (TWO && op) ? a.cy : a.cx;
+    const float* scp = (TWO && op) ? a.sy : a.sx;
+    const f32x4 scl = ldg4(scp + 4 * c4);
+    f32x4 ncs = {0.f, 0.f, 0.f, 0.f};
+    if (cen) ncs = -ldg4(cen + 4 * c4) * scl;
+
+    auto swz = [](int c) -> int {
+        if (CPR >= 16) return c & 15;
+        return (c / (16 / CPR)) & (CPR - 1);
+    };
+    int st_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = 4 * c4 + j;
+        st_off[j] = op * 2 * IMG + c * (R * 2) + ((rgrp ^ swz(c)) * 16);
+    }
+
+    f32x4 xr[8];
+    auto stage_load = [&](int st) {
+        const float* base = src + (r0 + (int64_t)st * R + rgrp * 8) * C + 4 * c4;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) xr[p] = ldg4(base + p * C);
+    };
+    bool overflow = false;
+    f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+    auto stage_write = [&](int buf) {
+        char* img = smem + buf * (NOP * 2 * IMG);
+        f32x4 g[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            g[p] = xr[p] * scl + ncs;
+            csum += g[p];
+            overflow |= (fabsf(g[p][0]) > kGuard) | (fabsf(g[p][1]) > kGuard) | (fabsf(g[p][2]) > kGuard) | (fabsf(g[p][3]) > kGuard);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned hw[4], lw[4];
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+                const float v0 = g[2 * pp][j], v1 = g[2 * pp + 1][j];
+                hw[pp] = pk_rne(v0, v1);
+                const f16x2 h = __builtin_bit_cast(f16x2, hw[pp]);
+                lw[pp] = pk_rne(v0 - (float)h[0], v1 - (float)h[1]);
+            }
+            *reinterpret_cast<uint4*>(img + st_off[j]) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+            *reinterpret_cast<uint4*>(img + st_off[j] + IMG) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+        }
+    };
+
+    f32x16 acc[BW];
+    double acc64[BW][16];
+#pragma unroll
+    for (int b = 0; b < BW; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[b][r] = 0.f; acc64[b][r] = 0.0; }
+
+    // per-lane fragment addressing: channel row (block*32 + l31), chunk (2*ks + lh) ^ swz(channel)
+    int a_off[BW], b_off[BW], a_sw[BW], b_sw[BW];
+#pragma unroll
+    for (int b = 0; b < BW; ++b) {
+        const int ca = ib[b] * 32 + l31, cb = jb[b] * 32 + l31;
+        a_off[b] = ca * (R * 2); a_sw[b] = swz(ca);
+        b_off[b] = (TWO ? 2 * IMG : 0) + cb * (R * 2); b_sw[b] = swz(cb);
+    }
+
+    if (nst > 0) {
+        stage_load(0);
+        stage_write(0);
+        if (nst > 1) stage_load(1);
+    }
+    __syncthreads();
+    for (int st = 0; st < nst; ++st) {
+        const int cur = st & 1;
+        if (st + 1 < nst) stage_write(cur ^ 1);
+        if (st + 2 < nst) stage_load(st + 2);
+        const char* img = smem + cur * (NOP * 2 * IMG);
+#pragma unroll 4
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int b = 0; b < BW; ++b) {
+                if (!live[b]) continue;
+                const int cha = ((2 * ks + lh) ^ a_sw[b]) * 16, chb = ((2 * ks + lh) ^ b_sw[b]) * 16;
+                const f16x8 ah = *reinterpret_cast<const f16x8*>(img + a_off[b] + cha);
+                const f16x8 al = *reinterpret_cast<const f16x8*>(img + a_off[b] + cha + IMG);
+                const f16x8 bh = *reinterpret_cast<const f16x8*>(img + b_off[b] + chb);
+                const f16x8 bl = *reinterpret_cast<const f16x8*>(img + b_off[b] + chb + IMG);
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[b], 0, 0, 0);
+            }
+        }
+        // float64 flush: the fp32 rounding chain never exceeds one stage (3*KS MFMA accumulations)
+#pragma unroll
+        for (int b = 0; b < BW; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc64[b][r] += (double)acc[b][r]; acc[b][r] = 0.f; }
+        __syncthreads();
+    }
+
+    // partial blocks out, scales undone exactly (powers of two)
+    double* P = a.P + z * (int64_t)C * C;
+#pragma unroll
+    for (int b = 0; b < BW; ++b) {
+        if (!live[b]) continue;
+        const int j = jb[b] * 32 + l31;
+        const double isj = 1.0 / (double)(TWO ? a.sy[j] : a.sx[j]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = ib[b] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            P[(int64_t)i * C + j] = acc64[b][r] * isj / (double)a.sx[i];
+        }
+    }
+    // column sums (type-0 workgroups): of the single operand, or of Y when there are two
+    if (type == 0 && a.colsum && (!TWO || op == 1)) {
+        // csum holds sums of SCALED values of channels 4*c4.. over this thread's rows; reduce over the row groups in LDS
+        float* red = reinterpret_cast<float*>(smem);            // [row groups][C], free after the last barrier
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[rgrp * C + 4 * c4 + j] = csum[j];
+    }
+    __syncthreads();
+    if (type == 0 && a.colsum) {
+        constexpr int RG_USED = TWO ? RGRP / 2 : RGRP;
+        const float* red = reinterpret_cast<const float*>(smem);
+        for (int c = tid; c < C; c += 512) {
+            float s = 0.f;
+            for (int g = 0; g < RG_USED; ++g) s += red[g * C + c];
+            a.colsum[z * C + c] = s / (TWO ? a.sy[c] : a.sx[c]);
+        }
+    }
+    if (overflow) atomicOr(a.flag, 1);
+}
+
+template <int C, bool TWO>
+constexpr int stage_rows() { return TWO ? (512 / (C / 4)) * 4 : (512 / (C / 4)) * 8; }
+
+template <int C, bool TWO>
+hipError_t launch_xty_fast(const FastXtyArgs& a, hipStream_t st)
+{
+    constexpr int R = stage_rows<C, TWO>();
+    constexpr size_t lds = (size_t)2 * (TWO ? 2 : 1) * 2 * C * R * 2;       // 128 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(xty_f16x3_kernel<C, TWO>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int slab_groups = (a.nslab + 7) / 8;
+    const int grid = slab_groups * a.ntypes * 8;
+    hipLaunchKernelGGL((xty_f16x3_kernel<C, TWO>), dim3(grid), dim3(512), lds, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+static int xty_stage_rows(int C, bool two)
+{
+    const int rg = 512 / (C / 4);
+    return two ? rg * 4 : rg * 8;
+}
+
+// Plan: slabs of whole stages; total workgroups ~ one per CU.  Returns nslab (0 = shape not eligible).
+int wc_fast_xty_plan(int64_t N, int64_t HW, int C, int per_sample, int two, int* nsplit, int64_t* rows_per_slab, int* ntypes)
+{
+    if (!(C == 32 || C == 64 || C == 128 || C == 256)) return 0;
+    const int64_t M = N * HW;
+    if (M < WC_FAST_MIN_ROWS) return 0;
+    const int R = xty_stage_rows(C, two != 0);
+    const int64_t seg = per_sample ? HW : M;                  // rows of one segment (slabs never cross segments)
+    if (seg % R != 0) return 0;
+    const int nb = C / 32;
+    const int nblk = two ? nb * nb : nb * (nb + 1) / 2;
+    *ntypes = (nblk + 8 * BW - 1) / (8 * BW);
+    const int64_t nseg = per_sample ? N : 1;
+    // 128 KiB of LDS = one workgroup per CU: keep the grid (slab groups of 8 x ntypes) within the 256 CUs when the
+    // segment count allows, or the surplus workgroups would run as a second, mostly idle round
+    const int64_t target = (256 / (8 * *ntypes)) * 8;
+    int64_t per_seg = (target + nseg - 1) / nseg;
+    if (per_seg < 1) per_seg = 1;
+    const int64_t stages = seg / R;
+    if (per_seg > stages) per_seg = stages;
+    int64_t st_per_slab = (stages + per_seg - 1) / per_seg;
+    *rows_per_slab = st_per_slab * R;
+    *nsplit = (int)((seg + *rows_per_slab - 1) / *rows_per_slab);
+    return (int)(nseg * (*nsplit));
+}
+
+hipError_t wc_launch_fast_xty(const float* X, const float* Y, const float* cx, const float* cy,
+                              const float* sx, const float* sy, int64_t N, int64_t HW, int C,
+                              int per_sample, int nsplit, int64_t rows_per_slab, int nslab, int ntypes,
+                              double* P, float* colsum, int* gate, hipStream_t st)
+{
+    FastXtyArgs a = {};
+    a.X = X; a.Y = Y; a.cx = cx; a.cy = cy; a.sx = sx; a.sy = sy; a.N = N; a.HW = HW;
+    a.per_sample = per_sample; a.nsplit = nsplit; a.rows_per_slab = rows_per_slab; a.nslab = nslab; a.ntypes = ntypes;
+    a.P = P; a.colsum = colsum; a.flag = gate;
+    const bool two = (Y != X);
+    switch (C) {
+        case 32: return two ? launch_xty_fast<32, true>(a, st) : launch_xty_fast<32, false>(a, st);
+        case 64: return two ? launch_xty_fast<64, true>(a, st) : launch_xty_fast<64, false>(a, st);
+        case 128: return two ? launch_xty_fast<128, true>(a, st) : launch_xty_fast<128, false>(a, st);
+        case 256: return two ? launch_xty_fast<256, true>(a, st) : launch_xty_fast<256, false>(a, st);
+    }
+    return hipErrorInvalidValue;
+}

@@ -160,6 +160,7 @@ __global__ __launch_bounds__(256) void xty_kernel(WcXtyArgs a, int ntiles, int n
     __shared__ __attribute__((aligned(16))) float Xs[BK * BM];
     __shared__ __attribute__((aligned(16))) float Ys[BK * BN];
 
+    if (a.gate && *a.gate == 0) return;      // exact redo of a fast-path call: only when it flagged an overflow
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int C = a.C;
@@ -295,6 +296,7 @@ __global__ __launch_bounds__(256) void xty_f64_kernel(WcXtyArgs a, int ntiles, i
     __shared__ __attribute__((aligned(16))) float Xs[BK * BM];
     __shared__ __attribute__((aligned(16))) float Ys[BK * BN];
 
+    if (a.gate && *a.gate == 0) return;      // exact redo of a fast-path call: only when it flagged an overflow
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int C = a.C;
