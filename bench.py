@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--training-ratio", type=int, default=TRAINING_RATIO)
     ap.add_argument("--sync-wc", action="store_true", help="all-reduce WC statistics across replicas")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -153,12 +154,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    step = lambda: trainer.step(reals)
     for _ in range(args.warmup):
-        trainer.step(reals)
+        step()
+    launch_mode = "eager"
+    if not args.no_graph:
+        try:
+            step = trainer.capture(reals)        # the whole G+D step as one hipGraph: the host leaves the loop
+            launch_mode = "hipgraph"
+            step()
+        except Exception as exc:                 # e.g. a collective that refuses capture: fall back, say so
+            print(f"[bench] graph capture failed ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
+            torch.cuda.synchronize()
+            step = lambda: trainer.step(reals)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        trainer.step(reals)
+        step()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -183,7 +195,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "CIFAR-10 ResNet SN uncond + WC (scripts/cifar10_resnet_sn_uncond.sh), batch 64/GPU, "
                                    f"training_ratio {args.training_ratio}, generator_batch_multiple 2",
-                       "parallelism": f"dp{world}", "wc_statistics": "sync" if args.sync_wc else "per-replica"},
+                       "parallelism": f"dp{world}", "wc_statistics": "sync" if args.sync_wc else "per-replica",
+                       "launch": launch_mode},
             "roofline": roof, "cpu_baseline": cpu,
         }
         out.update(extra)

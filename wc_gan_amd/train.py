@@ -63,14 +63,17 @@ class GanTrainer:
         self.dev = next(generator.parameters()).device
         self.g_bucket = FlatGradBucket(self.G.parameters(), process_group)
         self.d_bucket = FlatGradBucket(self.D.parameters(), process_group)
-        self.opt_g = torch.optim.Adam(self.g_bucket.params, lr=lr, betas=(beta1, beta2))
-        self.opt_d = torch.optim.Adam(self.d_bucket.params, lr=lr, betas=(beta1, beta2))
-        self.gen = torch.Generator(device=self.dev)
-        self.gen.manual_seed(seed)
+        # capturable: the step counters live on the device, so a whole G+D step can be recorded into one hipGraph
+        cap = self.dev.type == 'cuda'
+        self.opt_g = torch.optim.Adam(self.g_bucket.params, lr=lr, betas=(beta1, beta2), capturable=cap)
+        self.opt_d = torch.optim.Adam(self.d_bucket.params, lr=lr, betas=(beta1, beta2), capturable=cap)
+        if cap:
+            torch.cuda.manual_seed(seed)         # the default device generator: its Philox offset is graph-safe
+        self._graph = None
 
     def _noise(self, n):
-        z = torch.randn(n, self.noise_dim, device=self.dev, generator=self.gen)
-        cls = torch.randint(0, self.K, (n, 1), device=self.dev, generator=self.gen, dtype=torch.int32)
+        z = torch.randn(n, self.noise_dim, device=self.dev)
+        cls = torch.randint(0, self.K, (n, 1), device=self.dev, dtype=torch.int32)
         return z, cls
 
     def _d(self, x, cls):
@@ -82,8 +85,13 @@ class GanTrainer:
         with torch.no_grad():
             fake = self.G(z, cls)                      # train-mode WC forward (batch statistics), no graph
         self.d_bucket.zero()
-        loss = F.relu(1.0 - self._d(real, real_cls if real_cls is not None else cls)).mean() + \
-            F.relu(1.0 + self._d(fake, cls)).mean()
+        # real and generated images go through the critic as ONE batch of 128: the critic has no batch-dependent
+        # layer (discriminator_norm is 'n' in every recipe), so this equals two applications with shared weights,
+        # with one spectral-norm power iteration per update and convolutions at twice the batch
+        n = real.shape[0]
+        both_cls = torch.cat([real_cls if real_cls is not None else cls, cls], dim=0)
+        out = self._d(torch.cat([real, fake], dim=0), both_cls)
+        loss = F.relu(1.0 - out[:n]).mean() + F.relu(1.0 + out[n:]).mean()
         loss.backward()
         self.d_bucket.allreduce_mean()
         self.opt_d.step()
@@ -108,6 +116,29 @@ class GanTrainer:
             d_loss = self.d_step(real_batches[r % len(real_batches)])
         g_loss = self.g_step()
         return d_loss, g_loss
+
+    def capture(self, real_batches, warmup=3):
+        """Record one whole G+D step (~5000 kernel launches, the collectives included) into a hipGraph.
+
+        The C-ABI stages never synchronise or allocate and the gate of the fast path is a device flag, so the
+        step is capturable as is; `real_batches` become the graph's static inputs (copy new data into them).
+        Returns a callable that replays the step.  Every replay draws fresh noise and updates the weights."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.step(real_batches)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._static_losses = self.step(real_batches)
+        self._graph = graph
+
+        def replay():
+            graph.replay()
+            return self._static_losses
+        return replay
 
 
 CIFAR10_UNCOND = dict(          # scripts/cifar10_resnet_sn_uncond.sh:4-7 + run.py:147-193
