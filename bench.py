@@ -55,16 +55,23 @@ def roofline_apply(dev):
     N, H, C = 128, 32, 256
     M = N * H * H
     g = torch.Generator(device="cpu"); g.manual_seed(1234)
-    x = torch.randn(N, H, H, C, generator=g).to(dev)
-    A = (torch.randn(1, C, C, generator=g) / C ** 0.5).to(dev)
-    mu = (0.2 * torch.ones(C)).to(dev); b = (0.1 * torch.randn(1, C, generator=g)).to(dev)
+    # SURVEY section 8d kernel-bench input: x = z Mix + 0.2 (cond ~1e6), Gamma = randn/sqrt(C), beta = 0.1 randn
+    z = torch.randn(M, C, generator=g)
+    mix = torch.randn(C, C, generator=g) / C ** 0.5 + 0.3 * (torch.randn(C, 8, generator=g) @ torch.randn(8, C, generator=g)) / 8 ** 0.5
+    x = (z @ mix + 0.2).view(N, H, H, C).to(dev)
+    gamma = (torch.randn(1, C, C, generator=g) / C ** 0.5).to(dev)
+    b = (0.1 * torch.randn(1, C, generator=g)).to(dev)
+    # the apply exactly as the layer runs it: statistics -> factor -> color (which prepares the plan) -> K3
+    s, xtx = ops.stats(x.view(M, C))
+    mu, L, W, cs = ops.factor(s, xtx, M, C, 1e-3, 0.99, 1, True, None, None, dev, want_scale=True)
+    A, At, plan = ops.color(W, gamma, cs)
     y = torch.empty_like(x)
-    t = time_kernel(lambda: ops.apply(x, mu, A, b, None, out=y))
+    t = time_kernel(lambda: ops.apply(x, mu, A, b, None, out=y, plan=plan))
     alg_bytes = 2 * M * C * 4 + (C * C + C) * 4
     y2 = torch.empty_like(x)
     t_copy = time_kernel(lambda: ops.stream_copy(x, y2))
     achieved = alg_bytes / t / 1e9
-    return {"bound": "hbm", "kernel": "rows_gemm_kernel (wc_apply_f32, 128x32x32x256 fp32)",
+    return {"bound": "hbm", "kernel": "affine_f16x3_kernel<256> (wc_apply_f32 with plan, 128x32x32x256 fp32)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
             "launch_us": round(t * 1e6, 2), "algorithmic_bytes": alg_bytes,

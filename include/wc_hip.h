@@ -67,6 +67,7 @@ size_t wc_color_workspace_bytes(int C, int Kc);
 size_t wc_bwd_reduce_workspace_bytes(int64_t N, int64_t HW, int C, int Kc, int has_slot);
 size_t wc_bwd_factor_workspace_bytes(int C, int Kc);
 size_t wc_apply_workspace_bytes(int64_t N, int64_t HW, int C, int Kc);
+size_t wc_apply_plan_bytes(int C, int Kc);
 size_t wc_bwd_apply_workspace_bytes(int64_t N, int64_t HW, int C, int Kc);
 
 /* K1: raw additive moments of the rows of x:  sum[c] = sum_m x[m,c],  xtx = x^T x  (float64).
@@ -82,23 +83,28 @@ int wc_stats_f32(const float* x, int64_t M, int C,
 int wc_factor_f64(const double* sum, const double* xtx, int64_t M, int C,
                   double eps, double momentum, int ddof, int training,
                   float* moving_mean /*[C]*/, float* moving_cov /*[C*C]*/,
-                  float* mu /*[C] out*/, double* L /*[C*C] out*/, double* W /*[C*C] out*/,
+                  float* mu /*[C] out*/, float* chan_scale /*[C] out, nullable: power-of-two 1/sigma for the fp16 path*/,
+                  double* L /*[C*C] out*/, double* W /*[C*C] out*/,
                   void* ws, size_t ws_bytes, wc_stream_t stream);
 
 /* A_k = W^T Gamma_k for k < Kc (float32 out), and its transpose At_k = A_k^T (what the backward
- * apply multiplies by; At may be NULL).  gamma == NULL means Gamma = I (whitening only, Kc = 1). */
+ * apply multiplies by; At may be NULL).  gamma == NULL means Gamma = I (whitening only, Kc = 1).
+ * With chan_scale (from wc_factor_f64) and a buffer of wc_apply_plan_bytes(C, Kc) it also prepares the
+ * "plan" of A -- split-fp16 tables of the fast apply -- so that wc_apply_f32 is a single kernel launch. */
 int wc_color_f32(const double* W, const float* gamma /*[Kc,C,C] or NULL*/, int Kc, int C,
                  float* A /*[Kc,C,C] out*/, float* At /*[Kc,C,C] out, nullable*/,
+                 const float* chan_scale /*[C], nullable*/, void* plan /*out, nullable*/,
                  void* ws, size_t ws_bytes, wc_stream_t stream);
 
 /* K3: y[n] = (x[n] - mu) A[slot[n]] + bias[slot[n]]   (bias NULL = 0; mu NULL = 0).
  * With a workspace of wc_apply_workspace_bytes() the split-fp16 MFMA fast path runs when the shape allows
  * (C in {32,64,128,256}, N*HW >= 16384, HW a multiple of the row tile when slot != NULL); ws == NULL
- * always takes the exact f32-MFMA kernel.  Both give fp32-GEMM accuracy; an fp16-range overflow inside
- * the fast path is detected on the device and the exact kernel redoes the call in the same stream. */
+ * (and no plan) always takes the exact f32-MFMA kernel.  Both give fp32-GEMM accuracy; a row tile holding an
+ * element outside the fp16 range is detected on the device and recomputed in fp32 by the same kernel. */
 int wc_apply_f32(const float* x, const float* mu, const float* A, const float* bias,
                  const int32_t* slot, int64_t N, int64_t HW, int C, int Kc,
-                 float* y, void* ws, size_t ws_bytes, wc_stream_t stream);
+                 float* y, const void* plan /*from wc_color_f32, nullable*/,
+                 void* ws, size_t ws_bytes, wc_stream_t stream);
 
 /* K4: R[k] = sum_{n: slot[n]=k} (x[n]-mu)^T gy[n]  (Kc,C,C),  gsum[k] = sum_{n in k} rows of gy[n]  (Kc,C). */
 int wc_bwd_reduce_f32(const float* x, const float* mu, const float* gy, const int32_t* slot,

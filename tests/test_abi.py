@@ -53,13 +53,13 @@ def test_workspace_sizes(lib):
 
 def test_argument_checks_return_codes_without_touching_the_gpu(lib):
     one = ctypes.c_void_p(16)      # never dereferenced: every call below is rejected first
-    assert lib.wc_apply_f32(None, None, None, None, None, 1, 1, 32, 1, None, None, 0, None) == -1
-    assert lib.wc_apply_f32(one, None, one, None, None, 0, 1, 32, 1, one, None, 0, None) == -2
-    assert lib.wc_apply_f32(one, None, one, None, None, 1, 1, 40, 1, one, None, 0, None) == -3
+    assert lib.wc_apply_f32(None, None, None, None, None, 1, 1, 32, 1, None, None, None, 0, None) == -1
+    assert lib.wc_apply_f32(one, None, one, None, None, 0, 1, 32, 1, one, None, None, 0, None) == -2
+    assert lib.wc_apply_f32(one, None, one, None, None, 1, 1, 40, 1, one, None, None, 0, None) == -3
     assert lib.wc_stats_f32(one, 64, 64, one, one, one, 16, None) == -4
-    assert lib.wc_factor_f64(one, one, 64, 64, 0.0, 0.99, 1, 1, None, None, one, one, one, one, 1 << 30, None) == -5
-    assert lib.wc_factor_f64(one, one, 1, 64, 1e-3, 0.99, 1, 1, None, None, one, one, one, one, 1 << 30, None) == -2
-    assert lib.wc_color_f32(one, None, 2, 64, one, None, None, 0, None) == -2
+    assert lib.wc_factor_f64(one, one, 64, 64, 0.0, 0.99, 1, 1, None, None, one, None, one, one, one, 1 << 30, None) == -5
+    assert lib.wc_factor_f64(one, one, 1, 64, 1e-3, 0.99, 1, 1, None, None, one, None, one, one, one, 1 << 30, None) == -2
+    assert lib.wc_color_f32(one, None, 2, 64, one, None, None, None, None, 0, None) == -2
     assert lib.wc_bwd_reduce_f32(one, None, one, None, 4, 16, 64, 3, one, one, one, 1 << 30, None) == -2
     assert lib.wc_stream_copy_f32(one, one, 6, None) == -2
 

@@ -11,6 +11,6 @@ def t(fn, it=20):
     e0.record()
     for _ in range(it): fn()
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / it * 1e3
-for v in [0, 1, 2, 3, 4, 8, 12, 15, 7, 11]:
+for v in [0]:
     os.environ['WC_FAST_VARIANT'] = str(v)
     print('variant', v, '%.1f us' % t(lambda: ops.apply(x, mu, A, b, None, out=y, fast=True)), flush=True)

@@ -16,8 +16,8 @@ gamma = (torch.randn(Kc, C, C, generator=g) / C ** 0.5).cuda(); beta = torch.zer
 slot = torch.randint(0, Kc, (N,), generator=g).to(torch.int32).cuda() if Kc > 1 else None
 M = N * H * H
 mm = torch.zeros(C).cuda(); mc = torch.eye(C).cuda()
-s, xtx = ops.stats(x.view(M, C)); mu, L, W = ops.factor(s, xtx, M, C, 1e-3, 0.99, 1, True, mm, mc, x.device)
-A, At = ops.color(W, gamma); y = torch.empty_like(x)
+s, xtx = ops.stats(x.view(M, C)); mu, L, W, cs = ops.factor(s, xtx, M, C, 1e-3, 0.99, 1, True, mm, mc, x.device, want_scale=True)
+A, At, plan = ops.color(W, gamma, cs); y = torch.empty_like(x)
 R, gsum = ops.bwd_reduce(x, mu, gy, slot, Kc)
 dg, db, S, gm = ops.bwd_factor(R, gsum, W, L, gamma, A, M, 1e-3, 1, True)
 by = 2 * M * C * 4
@@ -25,7 +25,8 @@ res = {
  'stream_copy': t(lambda: ops.stream_copy(x, y)),
  'stats(K1)': t(lambda: ops.stats(x.view(M, C))),
  'factor(K2)': t(lambda: ops.factor(s, xtx, M, C, 1e-3, 0.99, 1, True, mm, mc, x.device)),
- 'color': t(lambda: ops.color(W, gamma)),
+ 'color(+plan)': t(lambda: ops.color(W, gamma, cs)),
+ 'apply planned(K3)': t(lambda: ops.apply(x, mu, A, beta, slot, out=y, plan=plan)),
  'apply fast(K3)': t(lambda: ops.apply(x, mu, A, beta, slot, out=y, fast=True)),
  'apply exact(K3)': t(lambda: ops.apply(x, mu, A, beta, slot, out=y, fast=False)),
  'bwd_reduce(K4)': t(lambda: ops.bwd_reduce(x, mu, gy, slot, Kc)),

@@ -25,13 +25,15 @@ SIGNATURES = {
     "wc_bwd_reduce_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int, c_int]),
     "wc_bwd_factor_workspace_bytes": (c_size_t, [c_int, c_int]),
     "wc_apply_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int]),
+    "wc_apply_plan_bytes": (c_size_t, [c_int, c_int]),
     "wc_bwd_apply_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int]),
     "wc_stats_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wc_factor_f64": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_double, c_double, c_int, c_int,
-                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "wc_color_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wc_color_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                             c_void_p, c_size_t, c_void_p]),
     "wc_apply_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,
-                             c_void_p, c_void_p, c_size_t, c_void_p]),
+                             c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wc_bwd_reduce_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,
                                   c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wc_bwd_factor_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64,

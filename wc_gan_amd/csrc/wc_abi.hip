@@ -103,7 +103,7 @@ size_t wc_factor_workspace_bytes(int C)
 }
 
 int wc_factor_f64(const double* sum, const double* xtx, int64_t M, int C, double eps, double momentum, int ddof,
-                  int training, float* moving_mean, float* moving_cov, float* mu, double* L, double* W,
+                  int training, float* moving_mean, float* moving_cov, float* mu, float* chan_scale, double* L, double* W,
                   void* ws, size_t ws_bytes, wc_stream_t stream)
 {
     if (!mu || !L || !W || !ws) return WC_ERR_NULL;
@@ -116,7 +116,7 @@ int wc_factor_f64(const double* sum, const double* xtx, int64_t M, int C, double
     hipStream_t st = static_cast<hipStream_t>(stream);
     Carver cv(ws, ws_bytes);
     double* tmp = cv.take<double>((size_t)C * C);
-    WC_TRY(wc_launch_factor_prepare(sum, xtx, M, C, eps, momentum, ddof, training, moving_mean, moving_cov, mu, L, st));
+    WC_TRY(wc_launch_factor_prepare(sum, xtx, M, C, eps, momentum, ddof, training, moving_mean, moving_cov, mu, chan_scale, L, st));
     WC_TRY(wc_launch_cholesky(L, C, st));
     WC_TRY(wc_launch_tri_inverse(L, W, tmp, C, st));
     return WC_OK;
@@ -130,16 +130,27 @@ size_t wc_color_workspace_bytes(int C, int Kc)
     return 256;     // none needed today; kept in the ABI so a caller never has to change
 }
 
+size_t wc_apply_plan_bytes(int C, int Kc)
+{
+    if (Kc <= 0 || bad_channels(C)) return 0;
+    return wc_fast_affine_workspace(C, Kc);
+}
+
 int wc_color_f32(const double* W, const float* gamma, int Kc, int C, float* A, float* At,
-                 void* ws, size_t ws_bytes, wc_stream_t stream)
+                 const float* chan_scale, void* plan, void* ws, size_t ws_bytes, wc_stream_t stream)
 {
     (void)ws; (void)ws_bytes;
     if (!W || !A) return WC_ERR_NULL;
     if (bad_channels(C)) return WC_ERR_CHANNELS;
     if (Kc <= 0 || (!gamma && Kc != 1)) return WC_ERR_SHAPE;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool want_plan = plan && chan_scale && (C == 32 || C == 64 || C == 128 || C == 256);
     if (!gamma) {
         WC_TRY(wc_launch_transpose_to_f32(W, C, A, At, st));
+        if (want_plan) {
+            WC_TRY(hipMemcpyAsync(wc_fast_plan_scale(plan), chan_scale, (size_t)C * 4, hipMemcpyDeviceToDevice, st));
+            WC_TRY(wc_launch_fast_plan_tables(A, Kc, C, plan, st));
+        }
         return WC_OK;
     }
     const int64_t CC = (int64_t)C * C;
@@ -150,6 +161,10 @@ int wc_color_f32(const double* W, const float* gamma, int Kc, int C, float* A, f
     g.Cm2 = At; g.c2_rs = 1; g.c2_cs = C; g.c2_bs = CC;
     g.m = C; g.n = C; g.k = C; g.batch = Kc; g.nred = 1; g.alpha = 1.0; g.epi = WC_EPI_NONE;
     WC_TRY(wc_launch_gemm(g, st));
+    if (want_plan) {     // the apply's fp16 tables, built once here instead of inside every wc_apply_f32 call
+        WC_TRY(hipMemcpyAsync(wc_fast_plan_scale(plan), chan_scale, (size_t)C * 4, hipMemcpyDeviceToDevice, st));
+        WC_TRY(wc_launch_fast_plan_tables(A, Kc, C, plan, st));
+    }
     return WC_OK;
 }
 
@@ -162,7 +177,8 @@ size_t wc_apply_workspace_bytes(int64_t N, int64_t HW, int C, int Kc)
 }
 
 int wc_apply_f32(const float* x, const float* mu, const float* A, const float* bias, const int32_t* slot,
-                 int64_t N, int64_t HW, int C, int Kc, float* y, void* ws, size_t ws_bytes, wc_stream_t stream)
+                 int64_t N, int64_t HW, int C, int Kc, float* y, const void* plan,
+                 void* ws, size_t ws_bytes, wc_stream_t stream)
 {
     if (!x || !A || !y) return WC_ERR_NULL;
     if (N <= 0 || HW <= 0 || Kc <= 0) return WC_ERR_SHAPE;
@@ -171,13 +187,14 @@ int wc_apply_f32(const float* x, const float* mu, const float* A, const float* b
     WcRowsGemmArgs a = {};
     a.in[0] = x; a.center[0] = mu; a.B[0] = A; a.B_slot_stride[0] = (int64_t)C * C;
     a.bias = bias; a.sub = nullptr; a.slot = slot; a.N = N; a.HW = HW; a.C = C; a.nstreams = 1; a.out = y;
-    const bool fast = ws && wc_fast_affine_supported(N, HW, C, slot != nullptr) && ws_bytes >= wc_fast_affine_workspace(C, Kc);
-    if (fast) {
-        int* gate = static_cast<int*>(ws);
-        WC_TRY(hipMemsetAsync(gate, 0, 256, st));
-        WC_TRY(wc_launch_fast_affine(x, mu, A, Kc, false, bias, nullptr, slot, N, HW, C, 0, y,
-                                     static_cast<char*>(ws) + 256, gate, st));
-        a.gate = gate;                       // exact f32-MFMA redo, a no-op unless the fp16 range was exceeded
+    const bool eligible = wc_fast_affine_supported(N, HW, C, slot != nullptr);
+    if (eligible && plan) {                  // tables prepared by wc_color_f32: one launch
+        WC_TRY(wc_launch_fast_affine_planned(x, mu, A, Kc, false, bias, nullptr, slot, N, HW, C, 0, y, plan, st));
+        return WC_OK;
+    }
+    if (eligible && ws && ws_bytes >= wc_fast_affine_workspace(C, Kc)) {
+        WC_TRY(wc_launch_fast_affine(x, mu, A, Kc, false, bias, nullptr, slot, N, HW, C, 0, y, ws, st));
+        return WC_OK;
     }
     WC_TRY(wc_launch_rows_gemm(a, st));
     return WC_OK;
@@ -331,12 +348,9 @@ int wc_bwd_apply_f32(const float* gy, const float* x, const float* mu, const flo
     if (fast) {
         // two passes over dx (the B' fragments of both streams do not fit one wave's registers at C = 256):
         //   dx  = gy At[slot] - gmean ;   dx += (x - mu) S
-        int* gate = static_cast<int*>(ws);
-        char* wsp = static_cast<char*>(ws) + 256;
-        WC_TRY(hipMemsetAsync(gate, 0, 256, st));
-        WC_TRY(wc_launch_fast_affine(gy, nullptr, At, Kc, false, nullptr, gmean, slot, N, HW, C, 0, dx, wsp, gate, st));
-        if (S) WC_TRY(wc_launch_fast_affine(x, mu, S, 1, true, nullptr, nullptr, nullptr, N, HW, C, 1, dx, wsp, gate, st));
-        a.gate = gate;
+        WC_TRY(wc_launch_fast_affine(gy, nullptr, At, Kc, false, nullptr, gmean, slot, N, HW, C, 0, dx, ws, st));
+        if (S) WC_TRY(wc_launch_fast_affine(x, mu, S, 1, true, nullptr, nullptr, nullptr, N, HW, C, 1, dx, ws, st));
+        return WC_OK;
     }
     WC_TRY(wc_launch_rows_gemm(a, st));
     return WC_OK;

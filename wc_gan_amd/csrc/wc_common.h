@@ -61,7 +61,7 @@ size_t wc_fast_affine_workspace(int C, int Kc);
 hipError_t wc_launch_fast_affine(const float* in, const float* center, const float* B, int Kc, bool shared_table,
                                  const float* bias, const float* sub, const int32_t* slot,
                                  int64_t N, int64_t HW, int C, int accumulate, float* out,
-                                 void* ws, int* gate, hipStream_t st);
+                                 void* ws, hipStream_t st);
 
 // fast reductions (wc_fast_xty.hip)
 int wc_fast_xty_plan(int64_t N, int64_t HW, int C, int per_sample, int two, int* nsplit, int64_t* rows_per_slab, int* ntypes);
@@ -69,6 +69,12 @@ hipError_t wc_launch_fast_xty(const float* X, const float* Y, const float* cx, c
                               const float* sx, const float* sy, int64_t N, int64_t HW, int C,
                               int per_sample, int nsplit, int64_t rows_per_slab, int nslab, int ntypes,
                               double* P, float* colsum, int* gate, hipStream_t st);
+hipError_t wc_launch_fast_plan_tables(const float* B, int Kc, int C, void* plan, hipStream_t st);
+float* wc_fast_plan_scale(void* plan);
+hipError_t wc_launch_fast_affine_planned(const float* in, const float* center, const float* B, int Kc, bool shared_table,
+                                         const float* bias, const float* sub, const int32_t* slot,
+                                         int64_t N, int64_t HW, int C, int accumulate, float* out,
+                                         const void* plan, hipStream_t st);
 hipError_t wc_launch_channel_scale(const float* in, const float* center, int64_t M, int C, float* scale, hipStream_t st);
 
 // ----- small-matrix stage (wc_small.hip) -----------------------------------------------------
@@ -82,7 +88,7 @@ hipError_t wc_launch_bwd_combine(const double* P, const float* colsum, const int
 
 hipError_t wc_launch_factor_prepare(const double* sum, const double* xtx, int64_t M, int C, double eps, double momentum,
                                     int ddof, int training, float* moving_mean, float* moving_cov, float* mu,
-                                    double* T, hipStream_t st);
+                                    float* chan_scale, double* T, hipStream_t st);
 hipError_t wc_launch_cholesky(double* T, int C, hipStream_t st);                     // in place: lower factor, upper zeroed
 hipError_t wc_launch_tri_inverse(const double* L, double* W, double* tmp, int C, hipStream_t st);   // W = L^-1 (lower), upper zeroed
 

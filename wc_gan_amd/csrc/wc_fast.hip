@@ -8,8 +8,8 @@
 // v_mfma_f32_32x32x16_f16 into ONE fp32 accumulator (lo*hi + hi*lo + hi*hi; lo*lo <= 2^-22 is dropped):
 // 3/16 of the f32-MFMA time at fp32-GEMM accuracy.  fp16's narrow range is handled by exact power-of-two scalings:
 // per input channel (s, from a row subsample), per output column (colscale, from the table itself);
-// an element that still exceeds the fp16 range raises a device flag and the exact f32-MFMA kernel,
-// queued behind with that flag as its gate, redoes the call -- the result never depends on the guess.
+// a tile holding an element that still exceeds the fp16 range is recomputed by the same workgroup with plain fp32
+// FMAs from global memory (tagged in LDS while it is staged) -- the result never depends on the scale guess.
 //
 // Structure: one persistent 512-thread workgroup per CU.  Each of the 8 waves keeps the B' fragments of
 // its 32 output columns for ALL of K in registers (128 VGPRs at C = 256), so the only LDS traffic is the
@@ -18,6 +18,13 @@
 // Tiles are double-buffered; the loads of tile t+2 are in flight while tile t is on the matrix pipe.
 #include "wc_common.h"
 #include <stdlib.h>
+#ifndef WC_STAMPS
+#define WC_STAMPS 0
+#endif
+#define WC_STAMP(i) do { if (WC_STAMPS && stamp_on) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ts[i] = t_; } } while (0)
+#ifndef WC_ABL
+#define WC_ABL 0      // development ablation bits: 1 no stores, 2 no MFMA, 4 no staging writes, 8 no loads
+#endif
 #include <type_traits>
 
 namespace {
@@ -32,7 +39,7 @@ __device__ __forceinline__ unsigned pk_rne(float a, float b)
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
 }
 
-constexpr float kF16Guard = 60000.0f;          // |scaled element| above this -> gate the exact path
+constexpr float kF16Guard = 60000.0f;          // |scaled element| above this -> the tile takes the exact path
 
 __device__ __forceinline__ f32x4 ld4f(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
@@ -115,9 +122,10 @@ struct FastArgs {
     const float* bias; const float* sub; const int32_t* slot;
     int64_t M, HW;
     int accumulate;
-    int* flag;
+    const float* Bf; int64_t bf_stride;                             // the fp32 table [slot][k][n] for the exact path
     float* out;
     int ntiles, tiles_per_wg;
+    unsigned long long* dbg;      // WC_STAMPS builds only: s_memtime stamps of one steady-state tile
 };
 
 // M must be a multiple of the row tile (the caller checks): every load and store below is unconditional, which is
@@ -134,7 +142,8 @@ __global__ __launch_bounds__(512, 2) void affine_f16x3_kernel(FastArgs a)
     constexpr int C4 = C / 4;                 // float4 per row
     constexpr int IMG = BM * C * 2;           // bytes of one fp16 image
     constexpr int RSTEP = 512 / C4;
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][hi | lo]
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][hi | lo] + 2 dirty tags
+    volatile int* dirty = reinterpret_cast<volatile int*>(smem + 4 * IMG);      // dirty[buf] == tile+1: exact path
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cg = wave % CG, rg = wave / CG;
@@ -196,13 +205,13 @@ __global__ __launch_bounds__(512, 2) void affine_f16x3_kernel(FastArgs a)
 #pragma unroll
         for (int p = 0; p < 8; ++p) load_chunk(ti, p);
     };
-    bool overflow = false;
-    auto write_chunk = [&](int buf, int p) {
+    auto write_chunk = [&](int buf, int p, int tag) {
         char* hi_img = smem + buf * 2 * IMG;
         char* lo_img = hi_img + IMG;
         {
             const f32x4 g = xr[p] * scl + ncs;
-            overflow |= (fabsf(g[0]) > kF16Guard) | (fabsf(g[1]) > kF16Guard) | (fabsf(g[2]) > kF16Guard) | (fabsf(g[3]) > kF16Guard);
+            if ((fabsf(g[0]) > kF16Guard) | (fabsf(g[1]) > kF16Guard) | (fabsf(g[2]) > kF16Guard) | (fabsf(g[3]) > kF16Guard))
+                dirty[buf] = tag;                      // rare; every reader compares against its own tile's tag
             const unsigned hw01 = pk_rne(g[0], g[1]), hw23 = pk_rne(g[2], g[3]);
             const f16x2 h01 = __builtin_bit_cast(f16x2, hw01), h23 = __builtin_bit_cast(f16x2, hw23);
             const float r0 = g[0] - (float)h01[0], r1 = g[1] - (float)h01[1];
@@ -213,9 +222,9 @@ __global__ __launch_bounds__(512, 2) void affine_f16x3_kernel(FastArgs a)
             *reinterpret_cast<uint2*>(lo_img + st_base[p % NB] + p * RSTEP * (C * 2)) = make_uint2(l01, l23);
         }
     };
-    auto stage_write = [&](int buf) {
+    auto stage_write = [&](int buf, int tag) {
 #pragma unroll
-        for (int p = 0; p < 8; ++p) write_chunk(buf, p);
+        for (int p = 0; p < 8; ++p) write_chunk(buf, p, tag);
     };
 
     // B' fragments of this wave's 32 columns, all of K, in registers
@@ -239,12 +248,14 @@ __global__ __launch_bounds__(512, 2) void affine_f16x3_kernel(FastArgs a)
         cur_slot = slot;
     };
 
+    if (tid < 2) dirty[tid] = 0;
+    __syncthreads();
     stage_load(t_begin);
     if (!HAS_SLOT) load_b(0);
     if (ASM_LOADS)          // asm loads are not tracked by the compiler: wait for the first tile by hand
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]),
                                             "+v"(xr[4]), "+v"(xr[5]), "+v"(xr[6]), "+v"(xr[7]) :: "memory");
-    stage_write(0);
+    stage_write(0, t_begin + 1);
     if (t_begin + 1 < t_end) stage_load(t_begin + 1);
     __syncthreads();
 
@@ -252,6 +263,11 @@ __global__ __launch_bounds__(512, 2) void affine_f16x3_kernel(FastArgs a)
     const int out_lane = (4 * lh) * C + col;
     const int rd_lane = l31 * (C * 2);
 
+    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool stamp_on = false;
+    using T_ = std::integral_constant<bool, true>;
+    using F_ = std::integral_constant<bool, false>;
+    const int chunk_sb = (__builtin_amdgcn_readfirstlane(wave) >= 4) ? 1 : 0;      // wave-uniform (SGPR)
     // One tile: [convert + LDS-write tile t+1] [issue the loads of tile t+2] [MFMA + store tile t] [LDS barrier].
     // The steady-state loop calls it with both stages unconditional (the last two tiles are peeled below), so the
     // body has no control-flow merge and hipcc emits COUNTED vmcnt waits: the 32 stores of a tile stay in flight
@@ -259,6 +275,8 @@ __global__ __launch_bounds__(512, 2) void affine_f16x3_kernel(FastArgs a)
     auto tile_body = [&](int t, auto do_write, auto do_load) {
         const int cur = (t - t_begin) & 1;
         constexpr bool W_ = decltype(do_write)::value, L_ = decltype(do_load)::value;
+        stamp_on = WC_STAMPS && (t == t_begin + 3);
+        WC_STAMP(0);
         if (ASM_LOADS && t == t_begin)       // the prologue's loads have no stores behind them: drain once, counts hold after
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]),
                                                 "+v"(xr[4]), "+v"(xr[5]), "+v"(xr[6]), "+v"(xr[7]) :: "memory");
@@ -275,8 +293,11 @@ __global__ __launch_bounds__(512, 2) void affine_f16x3_kernel(FastArgs a)
         float* out_tile = a.out + (int64_t)tile_of(t) * (BM * C);       // wave-uniform
         const char* hi_img = smem + cur * 2 * IMG;
         const char* lo_img = hi_img + IMG;
-#pragma unroll
-        for (int sb = 0; sb < SUB; ++sb) {
+        // One 32-row sub-tile: 3*KS MFMAs, and -- in exactly one of the wave's two sub-tiles -- the staging of the
+        // NEXT tile in the MFMA gaps: every other k-step one 16-B chunk is centred/split/written to the other LDS
+        // buffer and its register refilled from tile t+2.  Hand count of younger VMEM ops at each use: 39.
+        auto sub_tile = [&](int sb) {
+            const bool CH = (sb == chunk_sb);
             const int rbase = (rg * SUB + sb) * 32;
             const int sw = swz(rbase + l31);
             const char* hrow = hi_img + rbase * (C * 2) + rd_lane;
@@ -284,7 +305,7 @@ __global__ __launch_bounds__(512, 2) void affine_f16x3_kernel(FastArgs a)
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            // fragments are fetched one k-step ahead of the MFMAs that consume them (LDS latency off the critical path)
+            // fragments are fetched one k-step ahead of the MFMAs that consume them
             f16x8 ah = *reinterpret_cast<const f16x8*>(hrow + ((0 + lh) ^ sw) * 16);
             f16x8 al = *reinterpret_cast<const f16x8*>(lrow + ((0 + lh) ^ sw) * 16);
 #pragma unroll
@@ -295,55 +316,97 @@ __global__ __launch_bounds__(512, 2) void affine_f16x3_kernel(FastArgs a)
                     nh = *reinterpret_cast<const f16x8*>(hrow + chunk * 16);
                     nl = *reinterpret_cast<const f16x8*>(lrow + chunk * 16);
                 }
-                // staging of the NEXT tile rides in the gaps of this tile's MFMAs: one 16-B chunk per STEP k-steps
-                // is centred/split/written to the other LDS buffer and its register refilled from tile t+2.
-                // Chunks 0-3 ride in sub-tile 0 and 4-7 in sub-tile 1; the hand count of younger VMEM ops is 39 for all.
-                constexpr int STEP = (KS >= 4) ? KS / 4 : 1;        // k-steps per chunk inside one sub-tile
-                constexpr int PER = (KS >= 4) ? 1 : 4 / KS;          // chunks per k-step when K is short
-                if ((s % STEP) == 0 && (s / STEP) < 4) {
+                constexpr int STEP = (KS >= 8) ? KS / 8 : 1;         // k-steps per chunk
+                constexpr int PER = (KS >= 8) ? 1 : 8 / KS;          // chunks per k-step when K is short
+                if (CH && (s % STEP) == 0 && (s / STEP) < 8) {
 #pragma unroll
                     for (int q = 0; q < PER; ++q) {
-                        const int p = sb * 4 + (s / STEP) * PER + q;
-                        if (W_ && ASM_LOADS) {
+                        const int p = (s / STEP) * PER + q;
+                        if (W_ && ASM_LOADS && !(WC_ABL & 8)) {
                             if (L_) asm volatile("s_waitcnt vmcnt(39)" : "+v"(xr[p]) :: "memory");
                             else asm volatile("s_waitcnt vmcnt(16)" : "+v"(xr[p]) :: "memory");   // <= every tail count
                         }
-                        if (W_) write_chunk(cur ^ 1, p);
-                        if (L_) load_chunk(t + 2, p);
+                        if (W_ && !(WC_ABL & 4)) write_chunk(cur ^ 1, p, t + 2);
+                        if (L_ && !(WC_ABL & 8)) load_chunk(t + 2, p);
                     }
                 }
+                if (WC_ABL & 2) { asm volatile("" :: "v"(ah), "v"(al)); }
+                else {
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bhi[s], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, blo[s], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bhi[s], acc, 0, 0, 0);
+                }
                 ah = nh; al = nl;
             }
+            WC_STAMP(1 + 2 * sb);
             float* po = out_tile + rbase * C + out_lane;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ro = ((r & 3) + 8 * (r >> 2)) * C;
                 float v = acc[r] * cscale + addv;
                 if (ACC) v += po[ro];
+                if (WC_ABL & 1) asm volatile("" :: "v"(v)); else
                 po[ro] = v;
             }
+            WC_STAMP(2 + 2 * sb);
+        };
+        // The two waves that share a SIMD (w and w+4) take the staging in opposite halves of the tile: while one is
+        // exposed to its vmcnt waits the other is in a pure MFMA stretch, so the matrix pipe keeps running under
+        // the memory stalls.  Both orders issue the same 39 younger VMEM ops between a chunk's load and its use.
+        if (dirty[cur] == t + 1) {
+            // Exact path (rare): this tile holds an element outside the fp16 range.  Stage the next tile first
+            // (drain the queue: the hand counts assume the regular order), then recompute this one in fp32 straight
+            // from global memory -- same rows, same columns, same epilogue as the MFMA path.
+            if (W_) {
+                if (ASM_LOADS)
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]),
+                                                        "+v"(xr[4]), "+v"(xr[5]), "+v"(xr[6]), "+v"(xr[7]) :: "memory");
+                stage_write(cur ^ 1, t + 2);
+            }
+            if (L_) stage_load(t + 2);
+            const float* xin = a.in + (int64_t)tile_of(t) * (BM * C);
+            const float* Bf = a.Bf + (int64_t)(cur_slot < 0 ? 0 : cur_slot) * a.bf_stride + col;
+            for (int sb = 0; sb < SUB; ++sb) {
+                const int rbase = (rg * SUB + sb) * 32;
+                for (int i = 0; i < 16; ++i) {
+                    const int row = rbase + (i & 3) + 8 * (i >> 2) + 4 * lh;
+                    const float* xrow = xin + row * C;
+                    float accf = 0.f;
+                    for (int k = 0; k < C; ++k) {
+                        const float ce = a.center ? a.center[k] : 0.f;
+                        accf = fmaf(xrow[k] - ce, Bf[(int64_t)k * C], accf);
+                    }
+                    float* po = out_tile + row * C + col;
+                    float v = accf + addv;
+                    if (ACC) v += *po;
+                    *po = v;
+                }
+            }
+        } else {
+#pragma unroll
+        for (int sb = 0; sb < SUB; ++sb) sub_tile(sb);
         }
         // LDS hand-off only: a raw barrier behind lgkmcnt(0).  __syncthreads() would also drain vmcnt.
+        WC_STAMP(5);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        WC_STAMP(6);
     };
-    using T_ = std::integral_constant<bool, true>;
-    using F_ = std::integral_constant<bool, false>;
     int t = t_begin;
     for (; t + 2 < t_end; ++t) tile_body(t, T_{}, T_{});
     if (t + 1 < t_end) { tile_body(t, T_{}, F_{}); ++t; }
     tile_body(t, F_{}, F_{});
-    if (overflow) atomicOr(a.flag, 1);
+    if (WC_STAMPS && a.dbg && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 100)) {
+        unsigned long long* d = a.dbg + ((blockIdx.x ? 1 : 0) * 8 + wave) * 8;
+        for (int i = 0; i < 8; ++i) d[i] = ts[i];
+    }
 }
 
 template <int C>
 hipError_t launch_affine(const FastArgs& a, hipStream_t st)
 {
     constexpr int BM = 64 * 256 / C;
-    constexpr size_t lds = (size_t)4 * BM * C * 2;          // 128 KiB
+    constexpr size_t lds = (size_t)4 * BM * C * 2 + 16;     // 128 KiB of images + the two dirty tags
     FastArgs b = a;
     b.ntiles = (int)(a.M / BM);
     int nwg = b.ntiles < 256 ? b.ntiles : 256;
@@ -382,9 +445,9 @@ bool wc_fast_affine_supported(int64_t N, int64_t HW, int C, bool has_slot)
 
 size_t wc_fast_affine_workspace(int C, int Kc)
 {
-    // flag | scale[C] | colscale[Kc*C] | hi[Kc*C*C] | lo[Kc*C*C]
-    return 256 + wc_align_up((size_t)C * 4, 256) + wc_align_up((size_t)Kc * C * 4, 256) +
-           2 * wc_align_up((size_t)Kc * C * C * 2, 256);
+    // scale[C] | colscale[Kc*C] | hi[Kc*C*C] | lo[Kc*C*C]
+    return wc_align_up((size_t)C * 4, 256) + wc_align_up((size_t)Kc * C * 4, 256) +
+           2 * wc_align_up((size_t)Kc * C * C * 2, 256) + 2048;     // + stamp area of WC_STAMPS builds
 }
 
 hipError_t wc_launch_channel_scale(const float* in, const float* center, int64_t M, int C, float* scale, hipStream_t st)
@@ -393,26 +456,42 @@ hipError_t wc_launch_channel_scale(const float* in, const float* center, int64_t
     return hipGetLastError();
 }
 
-// One stream of the affine on the fast path.  B is [slot][k][n] row-major.
-// `gate` (device int, zeroed by the caller before the first pass) collects fp16-range overflows.
-hipError_t wc_launch_fast_affine(const float* in, const float* center, const float* B, int Kc, bool shared_table,
-                                 const float* bias, const float* sub, const int32_t* slot,
-                                 int64_t N, int64_t HW, int C, int accumulate, float* out,
-                                 void* ws, int* gate, hipStream_t st)
+// Plan layout (also the layout of the per-call workspace): scale[C] | colscale[Kc*C] | hi[Kc*C*C] | lo[Kc*C*C] | stamps
+struct PlanView { float* scale; float* colscale; _Float16* hi; _Float16* lo; unsigned long long* dbg; };
+static PlanView plan_view(void* plan, int C, int Kc)
 {
-    char* p = static_cast<char*>(ws);
-    float* scale = reinterpret_cast<float*>(p); p += wc_align_up((size_t)C * 4, 256);
-    float* colscale = reinterpret_cast<float*>(p); p += wc_align_up((size_t)Kc * C * 4, 256);
-    _Float16* hi = reinterpret_cast<_Float16*>(p); p += wc_align_up((size_t)Kc * C * C * 2, 256);
-    _Float16* lo = reinterpret_cast<_Float16*>(p);
-    const int64_t M = N * HW;
-    hipLaunchKernelGGL(channel_scale_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, in, center, M, C, scale);
-    hipLaunchKernelGGL(split_table_kernel, dim3((unsigned)(Kc * C)), dim3(64), 0, st, B, (const float*)scale, C, hi, lo, colscale);
+    char* p = static_cast<char*>(plan);
+    PlanView v;
+    v.scale = reinterpret_cast<float*>(p); p += wc_align_up((size_t)C * 4, 256);
+    v.colscale = reinterpret_cast<float*>(p); p += wc_align_up((size_t)Kc * C * 4, 256);
+    v.hi = reinterpret_cast<_Float16*>(p); p += wc_align_up((size_t)Kc * C * C * 2, 256);
+    v.lo = reinterpret_cast<_Float16*>(p); p += wc_align_up((size_t)Kc * C * C * 2, 256);
+    v.dbg = reinterpret_cast<unsigned long long*>(p);
+    return v;
+}
+
+// Build the fp16 tables of B ([slot][k][n] fp32) for the per-channel scales already stored in plan.scale.
+hipError_t wc_launch_fast_plan_tables(const float* B, int Kc, int C, void* plan, hipStream_t st)
+{
+    const PlanView v = plan_view(plan, C, Kc);
+    hipLaunchKernelGGL(split_table_kernel, dim3((unsigned)(Kc * C)), dim3(64), 0, st, B, (const float*)v.scale, C, v.hi, v.lo, v.colscale);
+    return hipGetLastError();
+}
+
+float* wc_fast_plan_scale(void* plan) { return reinterpret_cast<float*>(plan); }
+
+// The main kernel alone, on a prepared plan.  B is still needed: tiles outside the fp16 range are recomputed from it.
+hipError_t wc_launch_fast_affine_planned(const float* in, const float* center, const float* B, int Kc, bool shared_table,
+                                         const float* bias, const float* sub, const int32_t* slot,
+                                         int64_t N, int64_t HW, int C, int accumulate, float* out,
+                                         const void* plan, hipStream_t st)
+{
+    const PlanView v = plan_view(const_cast<void*>(plan), C, Kc);
     FastArgs a = {};
-    a.in = in; a.center = center; a.scale = scale; a.Bhi = hi; a.Blo = lo; a.colscale = colscale;
+    a.in = in; a.center = center; a.scale = v.scale; a.Bhi = v.hi; a.Blo = v.lo; a.colscale = v.colscale;
     a.slot_stride = shared_table ? 0 : (int64_t)C * C;
-    a.bias = bias; a.sub = sub; a.slot = shared_table ? nullptr : slot; a.M = M; a.HW = HW;
-    a.accumulate = accumulate; a.flag = gate; a.out = out;
+    a.bias = bias; a.sub = sub; a.slot = shared_table ? nullptr : slot; a.M = N * HW; a.HW = HW;
+    a.accumulate = accumulate; a.Bf = B; a.bf_stride = shared_table ? 0 : (int64_t)C * C; a.out = out; a.dbg = v.dbg;
     switch (C) {
         case 32: return launch_affine<32>(a, st);
         case 64: return launch_affine<64>(a, st);
@@ -420,4 +499,16 @@ hipError_t wc_launch_fast_affine(const float* in, const float* center, const flo
         case 256: return launch_affine<256>(a, st);
     }
     return hipErrorInvalidValue;
+}
+
+// One stream of the affine on the fast path with no prepared plan: sample the channel scales, build the tables, run.
+hipError_t wc_launch_fast_affine(const float* in, const float* center, const float* B, int Kc, bool shared_table,
+                                 const float* bias, const float* sub, const int32_t* slot,
+                                 int64_t N, int64_t HW, int C, int accumulate, float* out,
+                                 void* ws, hipStream_t st)
+{
+    hipLaunchKernelGGL(channel_scale_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, in, center, N * HW, C, wc_fast_plan_scale(ws));
+    hipError_t e = wc_launch_fast_plan_tables(B, Kc, C, ws, st);
+    if (e != hipSuccess) return e;
+    return wc_launch_fast_affine_planned(in, center, B, Kc, shared_table, bias, sub, slot, N, HW, C, accumulate, out, ws, st);
 }

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void bwd_combine_kernel(const double* __restri
 __global__ void factor_prepare_kernel(const double* __restrict__ sum, const double* __restrict__ xtx, int64_t M, int C,
                                       double eps, double momentum, int ddof, int training,
                                       float* __restrict__ moving_mean, float* __restrict__ moving_cov,
-                                      float* __restrict__ mu, double* __restrict__ T)
+                                      float* __restrict__ mu, float* __restrict__ chan_scale, double* __restrict__ T)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y;
@@ -136,7 +136,15 @@ __global__ void factor_prepare_kernel(const double* __restrict__ sum, const doub
         sig = 0.5 * ((double)moving_cov[e] + (double)moving_cov[(int64_t)j * C + i]);
         if (i == 0) mu[j] = moving_mean[j];
     }
-    T[e] = (1.0 - eps) * sig + (i == j ? eps : 0.0);
+    const double t = (1.0 - eps) * sig + (i == j ? eps : 0.0);
+    T[e] = t;
+    if (chan_scale && i == j) {
+        // power-of-two scale for the fp16 fast path: (x - mu) * s has a standard deviation in [4, 8), which leaves
+        // 7500 sigma of head-room below the fp16 guard and is exact to undo
+        int ex;
+        frexp(sqrt(t), &ex);
+        chan_scale[j] = (float)ldexp(1.0, 3 - ex);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -405,10 +413,10 @@ hipError_t wc_launch_bwd_combine(const double* P, const float* colsum, const int
 
 hipError_t wc_launch_factor_prepare(const double* sum, const double* xtx, int64_t M, int C, double eps, double momentum,
                                     int ddof, int training, float* moving_mean, float* moving_cov, float* mu,
-                                    double* T, hipStream_t st)
+                                    float* chan_scale, double* T, hipStream_t st)
 {
     hipLaunchKernelGGL(factor_prepare_kernel, dim3((C + 127) / 128, C), dim3(128), 0, st,
-                       sum, xtx, M, C, eps, momentum, ddof, training, moving_mean, moving_cov, mu, T);
+                       sum, xtx, M, C, eps, momentum, ddof, training, moving_mean, moving_cov, mu, chan_scale, T);
     return hipGetLastError();
 }
 

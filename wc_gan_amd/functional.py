@@ -43,11 +43,11 @@ class WhitenColorFunction(torch.autograd.Function):
         else:
             s = xtx = None
         mm = moving_mean.view(-1) if moving_mean is not None else None
-        mu, L, W = ops.factor(s, xtx, M, C, eps, momentum, ddof, training, mm, moving_cov, dev)
+        mu, L, W, chan_scale = ops.factor(s, xtx, M, C, eps, momentum, ddof, training, mm, moving_cov, dev, want_scale=True)
         g = gamma.contiguous() if gamma is not None else None
         b = beta.contiguous() if beta is not None else None
-        A, At = ops.color(W, g)
-        y = ops.apply(x, mu, A, b, slot)
+        A, At, plan = ops.color(W, g, chan_scale)      # plan: the apply's fp16 tables, so K3 is one launch
+        y = ops.apply(x, mu, A, b, slot, plan=plan)
         ctx.save_for_backward(x, mu, L, W, A, At, g if g is not None else torch.empty(0, device=dev),
                               slot if slot is not None else torch.empty(0, dtype=torch.int32, device=dev))
         ctx.has_gamma = g is not None

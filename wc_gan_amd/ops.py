@@ -53,10 +53,12 @@ def stats(x2d):
     return s, xtx
 
 
-def factor(s, xtx, M, C, eps, momentum, ddof, training, moving_mean, moving_cov, device):
-    """K2: -> (mu (C,) f32, L (C,C) f64, W (C,C) f64); updates the moving statistics in place when training."""
+def factor(s, xtx, M, C, eps, momentum, ddof, training, moving_mean, moving_cov, device, want_scale=False):
+    """K2: -> (mu (C,) f32, L (C,C) f64, W (C,C) f64); updates the moving statistics in place when training.
+    With want_scale=True also returns chan_scale (C,) f32, the power-of-two 1/sigma the fp16 fast path uses."""
     lib = _lib.load()
     mu = torch.empty(C, dtype=torch.float32, device=device)
+    chan_scale = torch.empty(C, dtype=torch.float32, device=device) if want_scale else None
     L = torch.empty(C, C, dtype=torch.float64, device=device)
     W = torch.empty(C, C, dtype=torch.float64, device=device)
     if moving_mean is not None:
@@ -64,13 +66,16 @@ def factor(s, xtx, M, C, eps, momentum, ddof, training, moving_mean, moving_cov,
         _need(moving_cov, torch.float32, "moving_cov", 2)
     ws = _workspace(lib.wc_factor_workspace_bytes(C), device)
     _lib.check(lib.wc_factor_f64(_ptr(s), _ptr(xtx), int(M), C, float(eps), float(momentum), int(ddof), int(bool(training)),
-                                 _ptr(moving_mean), _ptr(moving_cov), _ptr(mu), _ptr(L), _ptr(W),
+                                 _ptr(moving_mean), _ptr(moving_cov), _ptr(mu), _ptr(chan_scale), _ptr(L), _ptr(W),
                                  _ptr(ws), ws.numel(), _stream()), "wc_factor_f64")
+    if want_scale:
+        return mu, L, W, chan_scale
     return mu, L, W
 
 
-def color(W, gamma):
-    """A_k = W^T Gamma_k and At_k = A_k^T.  gamma (Kc, C, C) float32 or None (whitening only)."""
+def color(W, gamma, chan_scale=None):
+    """A_k = W^T Gamma_k and At_k = A_k^T.  gamma (Kc, C, C) float32 or None (whitening only).
+    With chan_scale also returns the apply plan (opaque uint8 tensor) -> (A, At, plan)."""
     lib = _lib.load()
     C = W.shape[0]
     Kc = 1 if gamma is None else gamma.shape[0]
@@ -79,12 +84,17 @@ def color(W, gamma):
     A = torch.empty(Kc, C, C, dtype=torch.float32, device=W.device)
     At = torch.empty(Kc, C, C, dtype=torch.float32, device=W.device)
     ws = _workspace(lib.wc_color_workspace_bytes(C, Kc), W.device)
-    _lib.check(lib.wc_color_f32(_ptr(W), _ptr(gamma), Kc, C, _ptr(A), _ptr(At), _ptr(ws), ws.numel(), _stream()),
-               "wc_color_f32")
+    plan = None
+    if chan_scale is not None and C in (32, 64, 128, 256):
+        plan = _workspace(lib.wc_apply_plan_bytes(C, Kc), W.device)
+    _lib.check(lib.wc_color_f32(_ptr(W), _ptr(gamma), Kc, C, _ptr(A), _ptr(At), _ptr(chan_scale), _ptr(plan),
+                                _ptr(ws), ws.numel(), _stream()), "wc_color_f32")
+    if chan_scale is not None:
+        return A, At, plan
     return A, At
 
 
-def apply(x, mu, A, bias, slot, out=None, fast=True, return_gate=False):
+def apply(x, mu, A, bias, slot, out=None, fast=True, plan=None):
     """K3: y[n] = (x[n] - mu) A[slot[n]] + bias[slot[n]];  x is (N, ..., C) with C contiguous."""
     lib = _lib.load()
     _need(x, torch.float32, "x")
@@ -96,11 +106,10 @@ def apply(x, mu, A, bias, slot, out=None, fast=True, return_gate=False):
     if slot is not None:
         _need(slot, torch.int32, "slot", 1)
     y = torch.empty_like(x) if out is None else out
-    ws = _workspace(lib.wc_apply_workspace_bytes(N, HW, C, Kc), x.device) if fast else None
+    ws = _workspace(lib.wc_apply_workspace_bytes(N, HW, C, Kc), x.device) if (fast and plan is None) else None
     _lib.check(lib.wc_apply_f32(_ptr(x), _ptr(mu), _ptr(A), _ptr(bias), _ptr(slot), N, HW, C, Kc, _ptr(y),
-                                _ptr(ws), ws.numel() if ws is not None else 0, _stream()), "wc_apply_f32")
-    if return_gate:      # first word of the workspace = the fast path's fp16-overflow gate (tests only: forces a sync)
-        return y, (int(ws[:4].view(torch.int32).item()) if (ws is not None and ws.numel() > 256) else 0)
+                                _ptr(plan) if fast else None, _ptr(ws), ws.numel() if ws is not None else 0, _stream()),
+               "wc_apply_f32")
     return y
 
 
@@ -135,7 +144,7 @@ def bwd_factor(R, gsum, W, L, gamma, A, M, eps, ddof, training, want_dgamma=True
     return dgamma, dbeta, S, gmean
 
 
-def bwd_apply(gy, x, mu, At, S, gmean, slot, fast=True, return_gate=False):
+def bwd_apply(gy, x, mu, At, S, gmean, slot, fast=True):
     """K6: dx[n] = gy[n] At[slot[n]] + (x[n]-mu) S - gmean."""
     lib = _lib.load()
     _need(gy, torch.float32, "gy")
@@ -147,8 +156,6 @@ def bwd_apply(gy, x, mu, At, S, gmean, slot, fast=True, return_gate=False):
     _lib.check(lib.wc_bwd_apply_f32(_ptr(gy), _ptr(x), _ptr(mu), _ptr(At), _ptr(S), _ptr(gmean), _ptr(slot),
                                     N, HW, C, Kc, _ptr(dx), _ptr(ws), ws.numel() if ws is not None else 0, _stream()),
                "wc_bwd_apply_f32")
-    if return_gate:
-        return dx, (int(ws[:4].view(torch.int32).item()) if (ws is not None and ws.numel() > 256) else 0)
     return dx
 
 
