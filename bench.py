@@ -71,9 +71,13 @@ def roofline_apply(dev):
     y2 = torch.empty_like(x)
     t_copy = time_kernel(lambda: ops.stream_copy(x, y2))
     achieved = alg_bytes / t / 1e9
+    traffic = None          # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see the file)
+    pmc = os.path.join(ROOT, "profiles", "r1_apply_k3_pmc.json")
+    if os.path.exists(pmc):
+        traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
     return {"bound": "hbm", "kernel": "affine_f16x3_kernel<256> (wc_apply_f32 with plan, 128x32x32x256 fp32)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "launch_us": round(t * 1e6, 2), "algorithmic_bytes": alg_bytes,
             "stream_copy_GBs": round(2 * M * C * 4 / t_copy / 1e9, 1),
             "frac_of_stream_copy": round(achieved / (2 * M * C * 4 / t_copy / 1e9), 4)}
