@@ -61,8 +61,8 @@ int         wc_abi_version(void);
 const char* wc_error_string(int code);
 
 /* Bytes of scratch each stage needs for the given problem (16-byte aligned carve inside). */
-size_t wc_stats_workspace_bytes(int64_t M, int C);
-size_t wc_factor_workspace_bytes(int C);
+size_t wc_stats_workspace_bytes(int64_t M, int C, int groups);
+size_t wc_factor_workspace_bytes(int C, int groups);
 size_t wc_color_workspace_bytes(int C, int Kc);
 size_t wc_bwd_reduce_workspace_bytes(int64_t N, int64_t HW, int C, int Kc, int has_slot);
 size_t wc_bwd_factor_workspace_bytes(int C, int Kc);
@@ -71,16 +71,20 @@ size_t wc_apply_plan_bytes(int C, int Kc);
 size_t wc_bwd_apply_workspace_bytes(int64_t N, int64_t HW, int C, int Kc);
 
 /* K1: raw additive moments of the rows of x:  sum[c] = sum_m x[m,c],  xtx = x^T x  (float64).
- * These are what a sync-WC data-parallel run all-reduces before wc_factor_f64. */
-int wc_stats_f32(const float* x, int64_t M, int C,
-                 double* sum /*[C]*/, double* xtx /*[C*C]*/,
+ * These are what a sync-WC data-parallel run all-reduces before wc_factor_f64.
+ * groups > 1: the M rows are `groups` independent batches of M/groups consecutive rows, each with its own
+ * statistics (sum [groups,C], xtx [groups,C,C]) -- several forward passes of the same layer in one call. */
+int wc_stats_f32(const float* x, int64_t M, int C, int groups,
+                 double* sum /*[groups,C]*/, double* xtx /*[groups,C,C]*/,
                  void* ws, size_t ws_bytes, wc_stream_t stream);
 
 /* K2: moments -> mu, Sigma; T = (1-eps)Sigma + eps I; L = chol(T); W = L^-1 (float64).
  * training != 0: statistics come from (sum, xtx, M); if moving_mean/moving_cov are non-NULL they
  *                are updated in place, moving <- momentum*moving + (1-momentum)*batch (un-shrunk Sigma).
- * training == 0: mu = moving_mean, Sigma = moving_cov (sum/xtx ignored, may be NULL). */
-int wc_factor_f64(const double* sum, const double* xtx, int64_t M, int C,
+ * training == 0: mu = moving_mean, Sigma = moving_cov (sum/xtx ignored, may be NULL).
+ * groups > 1: mu [groups,C], L/W [groups,C,C]; the moving statistics receive the groups' updates one after the
+ * other (as separate calls would); chan_scale stays [C] (the largest variance over the groups decides). */
+int wc_factor_f64(const double* sum, const double* xtx, int64_t M /*rows per group*/, int C, int groups,
                   double eps, double momentum, int ddof, int training,
                   float* moving_mean /*[C]*/, float* moving_cov /*[C*C]*/,
                   float* mu /*[C] out*/, float* chan_scale /*[C] out, nullable: power-of-two 1/sigma for the fp16 path*/,
@@ -91,10 +95,16 @@ int wc_factor_f64(const double* sum, const double* xtx, int64_t M, int C,
  * apply multiplies by; At may be NULL).  gamma == NULL means Gamma = I (whitening only, Kc = 1).
  * With chan_scale (from wc_factor_f64) and a buffer of wc_apply_plan_bytes(C, Kc) it also prepares the
  * "plan" of A -- split-fp16 tables of the fast apply -- so that wc_apply_f32 is a single kernel launch. */
-int wc_color_f32(const double* W, const float* gamma /*[Kc,C,C] or NULL*/, int Kc, int C,
-                 float* A /*[Kc,C,C] out*/, float* At /*[Kc,C,C] out, nullable*/,
+int wc_color_f32(const double* W /*[groups,C,C]*/, const float* gamma /*[Kc,C,C] or NULL*/, int Kc, int C, int groups,
+                 float* A /*[groups*Kc,C,C] out, index g*Kc+k*/, float* At /*same shape, nullable*/,
                  const float* chan_scale /*[C], nullable*/, void* plan /*out, nullable*/,
                  void* ws, size_t ws_bytes, wc_stream_t stream);
+
+/* Grouped forward glue: center[c] = mean_g mu[g,c] and bias[g*Kc+k] = beta[k] - (mu[g] - center) A[g*Kc+k], so that
+ * wc_apply_f32(x, center, A, bias, slot = g*Kc + k) equals (x - mu_g) A[g*Kc+k] + beta[k] for every group. */
+int wc_group_bias_f32(const float* mu /*[groups,C]*/, const float* A /*[groups*Kc,C,C]*/, const float* beta /*[Kc,C] nullable*/,
+                      int groups, int Kc, int C, float* center /*[C] out*/, float* bias /*[groups*Kc,C] out*/,
+                      wc_stream_t stream);
 
 /* K3: y[n] = (x[n] - mu) A[slot[n]] + bias[slot[n]]   (bias NULL = 0; mu NULL = 0).
  * With a workspace of wc_apply_workspace_bytes() the split-fp16 MFMA fast path runs when the shape allows

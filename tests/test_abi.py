@@ -41,10 +41,10 @@ def test_abi_version_and_error_strings(lib):
 
 
 def test_workspace_sizes(lib):
-    assert lib.wc_stats_workspace_bytes(131072, 256) > 256 * 256 * 8
-    assert lib.wc_stats_workspace_bytes(131072, 48) == 0          # C not a multiple of 32
-    assert lib.wc_stats_workspace_bytes(0, 64) == 0
-    assert lib.wc_factor_workspace_bytes(256) >= 256 * 256 * 8
+    assert lib.wc_stats_workspace_bytes(131072, 256, 1) > 256 * 256 * 8
+    assert lib.wc_stats_workspace_bytes(131072, 48, 1) == 0          # C not a multiple of 32
+    assert lib.wc_stats_workspace_bytes(0, 64, 1) == 0
+    assert lib.wc_factor_workspace_bytes(256, 1) >= 256 * 256 * 8
     assert lib.wc_bwd_factor_workspace_bytes(128, 10) >= 3 * 128 * 128 * 8
     per_sample = lib.wc_bwd_reduce_workspace_bytes(128, 1024, 128, 10, 1)
     whole = lib.wc_bwd_reduce_workspace_bytes(128, 1024, 128, 1, 0)
@@ -56,10 +56,10 @@ def test_argument_checks_return_codes_without_touching_the_gpu(lib):
     assert lib.wc_apply_f32(None, None, None, None, None, 1, 1, 32, 1, None, None, None, 0, None) == -1
     assert lib.wc_apply_f32(one, None, one, None, None, 0, 1, 32, 1, one, None, None, 0, None) == -2
     assert lib.wc_apply_f32(one, None, one, None, None, 1, 1, 40, 1, one, None, None, 0, None) == -3
-    assert lib.wc_stats_f32(one, 64, 64, one, one, one, 16, None) == -4
-    assert lib.wc_factor_f64(one, one, 64, 64, 0.0, 0.99, 1, 1, None, None, one, None, one, one, one, 1 << 30, None) == -5
-    assert lib.wc_factor_f64(one, one, 1, 64, 1e-3, 0.99, 1, 1, None, None, one, None, one, one, one, 1 << 30, None) == -2
-    assert lib.wc_color_f32(one, None, 2, 64, one, None, None, None, None, 0, None) == -2
+    assert lib.wc_stats_f32(one, 64, 64, 1, one, one, one, 16, None) == -4
+    assert lib.wc_factor_f64(one, one, 64, 64, 1, 0.0, 0.99, 1, 1, None, None, one, None, one, one, one, 1 << 30, None) == -5
+    assert lib.wc_factor_f64(one, one, 1, 64, 1, 1e-3, 0.99, 1, 1, None, None, one, None, one, one, one, 1 << 30, None) == -2
+    assert lib.wc_color_f32(one, None, 2, 64, 1, one, None, None, None, None, 0, None) == -2
     assert lib.wc_bwd_reduce_f32(one, None, one, None, 4, 16, 64, 3, one, one, one, 1 << 30, None) == -2
     assert lib.wc_stream_copy_f32(one, one, 6, None) == -2
 

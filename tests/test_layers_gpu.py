@@ -159,3 +159,32 @@ def test_generator_step_runs_and_trains():
     assert any(not torch.equal(a, b) for a, b in zip(before, tr.G.parameters()))
     img = tr.G(torch.randn(4, 128, device='cuda'), torch.zeros(4, 1, dtype=torch.int32, device='cuda'))
     assert img.shape == (4, 32, 32, 3) and float(img.abs().max()) <= 1.0
+
+
+@pytest.mark.parametrize("shape,Kc,G", [((20, 8, 8, 64), 1, 5), ((30, 16, 16, 128), 4, 5), ((320, 8, 8, 256), 1, 5), ((128, 32, 32, 128), 3, 2)])
+def test_statistic_groups_equal_separate_passes(shape, Kc, G):
+    """One grouped call == G separate training-mode calls: outputs and the sequentially updated moving statistics."""
+    from wc_gan_amd.functional import whiten_color, whiten_color_grouped
+    rng = np.random.default_rng(31)
+    N, C = shape[0], shape[-1]
+    x = np.concatenate([o.synth_activation(rng, (N // G,) + shape[1:], "well") * (1 + 0.2 * g) + 0.3 * g for g in range(G)]).astype(np.float32)
+    Gm, B = o.synth_coloring(rng, C, Kc)
+    Gm = Gm.astype(np.float32); B = B.astype(np.float32)
+    slot = rng.integers(0, Kc, N).astype(np.int32)
+    st = dev(slot, torch.int32) if Kc > 1 else None
+    mm1 = torch.zeros(C, 1, device="cuda"); mc1 = torch.eye(C, device="cuda")
+    mm2 = torch.zeros(C, 1, device="cuda"); mc2 = torch.eye(C, device="cuda")
+    with torch.no_grad():
+        y_grouped = whiten_color_grouped(dev(x), G, dev(Gm), dev(B), st, mm1, mc1)
+        parts = []
+        n = N // G
+        for g in range(G):
+            sg = st[g * n:(g + 1) * n].contiguous() if st is not None else None
+            parts.append(whiten_color(dev(x[g * n:(g + 1) * n]), dev(Gm), dev(B), sg, mm2, mc2, True))
+    y_sep = torch.cat(parts)
+    assert rel(y_grouped.cpu(), y_sep.cpu()) < 2e-5
+    assert rel(mm1.cpu(), mm2.cpu()) < 1e-6 and rel(mc1.cpu(), mc2.cpu()) < 1e-6
+    # and against the oracle, group by group
+    for g in range(G):
+        y_ref, _ = o.wc_forward(x[g * n:(g + 1) * n], Gm, B, slot[g * n:(g + 1) * n])
+        assert rel(y_grouped[g * n:(g + 1) * n].cpu(), y_ref) < TOL

@@ -175,4 +175,4 @@ def test_abi_rejects_bad_arguments(ops):
     with pytest.raises(_lib.WcHipError):
         ops.stats(x)                              # C = 48 is not a multiple of 32
     assert lib.wc_apply_f32(None, None, None, None, None, 1, 1, 32, 1, None, None, None, 0, None) == -1
-    assert lib.wc_stats_f32(x.data_ptr(), 64, 64, x.data_ptr(), x.data_ptr(), x.data_ptr(), 16, None) == -4
+    assert lib.wc_stats_f32(x.data_ptr(), 64, 64, 1, x.data_ptr(), x.data_ptr(), x.data_ptr(), 16, None) == -4

@@ -19,18 +19,19 @@ ERRORS = {-1: "WC_ERR_NULL", -2: "WC_ERR_SHAPE", -3: "WC_ERR_CHANNELS", -4: "WC_
 SIGNATURES = {
     "wc_abi_version": (c_int, []),
     "wc_error_string": (c_char_p, [c_int]),
-    "wc_stats_workspace_bytes": (c_size_t, [c_int64, c_int]),
-    "wc_factor_workspace_bytes": (c_size_t, [c_int]),
+    "wc_stats_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "wc_factor_workspace_bytes": (c_size_t, [c_int, c_int]),
     "wc_color_workspace_bytes": (c_size_t, [c_int, c_int]),
     "wc_bwd_reduce_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int, c_int]),
     "wc_bwd_factor_workspace_bytes": (c_size_t, [c_int, c_int]),
     "wc_apply_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int]),
     "wc_apply_plan_bytes": (c_size_t, [c_int, c_int]),
     "wc_bwd_apply_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int]),
-    "wc_stats_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "wc_factor_f64": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_double, c_double, c_int, c_int,
+    "wc_stats_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wc_group_bias_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "wc_factor_f64": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_double, c_double, c_int, c_int,
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "wc_color_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+    "wc_color_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_void_p, c_size_t, c_void_p]),
     "wc_apply_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,
                              c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -55,54 +55,58 @@ XtyPlan plan_xty(int64_t N, int64_t HW, int C, int per_sample, int sym)
 }
 }  // namespace
 
-size_t wc_stats_workspace_bytes(int64_t M, int C)
+size_t wc_stats_workspace_bytes(int64_t M, int C, int groups)
 {
-    if (M <= 0 || bad_channels(C)) return 0;
-    const XtyPlan p = plan_xty(1, M, C, 0, 1);
-    return 256 + 2 * slot_bytes(C, 4) + slot_bytes(C, 8) + slot_bytes((size_t)p.nslab * C, 4) + slot_bytes((size_t)p.nslab * C * C, 8);
+    if (M <= 0 || groups <= 0 || (M % groups) != 0 || bad_channels(C)) return 0;
+    const XtyPlan p = plan_xty(groups, M / groups, C, groups > 1, 1);
+    return 256 + 2 * slot_bytes(C, 4) + slot_bytes((size_t)groups * C, 8) + slot_bytes((size_t)p.nslab * C, 4) +
+           slot_bytes((size_t)p.nslab * C * C, 8);
 }
 
-int wc_stats_f32(const float* x, int64_t M, int C, double* sum, double* xtx,
+int wc_stats_f32(const float* x, int64_t M, int C, int groups, double* sum, double* xtx,
                  void* ws, size_t ws_bytes, wc_stream_t stream)
 {
     if (!x || !sum || !xtx || !ws) return WC_ERR_NULL;
-    if (M <= 0) return WC_ERR_SHAPE;
+    if (M <= 0 || groups <= 0 || (M % groups) != 0) return WC_ERR_SHAPE;
     if (bad_channels(C)) return WC_ERR_CHANNELS;
-    if (ws_bytes < wc_stats_workspace_bytes(M, C)) return WC_ERR_WORKSPACE;
+    if (ws_bytes < wc_stats_workspace_bytes(M, C, groups)) return WC_ERR_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const XtyPlan p = plan_xty(1, M, C, 0, 1);
+    // a statistic group is a run of M/groups consecutive rows; slabs never cross groups (the per-sample machinery)
+    const int per_seg = groups > 1;
+    const int64_t Ns = groups, HWs = M / groups;
+    const XtyPlan p = plan_xty(Ns, HWs, C, per_seg, 1);
     Carver cv(ws, ws_bytes);
     int* gate = cv.take<int>(64);
     float* shift = cv.take<float>(C);
     float* scale = cv.take<float>(C);
-    double* Sp = cv.take<double>(C);
+    double* Sp = cv.take<double>((size_t)groups * C);
     float* colsum = cv.take<float>((size_t)p.nslab * C);
     double* P = cv.take<double>((size_t)p.nslab * C * C);
 
     WC_TRY(wc_launch_subsample_mean(x, M, C, shift, st));
     WcXtyArgs a = {};
-    a.X = x; a.Y = x; a.cx = shift; a.cy = shift; a.N = 1; a.HW = M; a.per_sample = 0; a.nsplit = p.nsplit;
+    a.X = x; a.Y = x; a.cx = shift; a.cy = shift; a.N = Ns; a.HW = HWs; a.per_sample = per_seg; a.nsplit = p.nsplit;
     a.rows_per_slab = p.rps; a.C = C; a.sym = 1; a.P = P; a.colsum = colsum;
     if (p.fast) {
         WC_TRY(hipMemsetAsync(gate, 0, 256, st));
         WC_TRY(wc_launch_channel_scale(x, shift, M, C, scale, st));
-        WC_TRY(wc_launch_fast_xty(x, x, shift, shift, scale, scale, 1, M, C, 0, p.nsplit, p.rps, p.nslab, p.ntypes,
+        WC_TRY(wc_launch_fast_xty(x, x, shift, shift, scale, scale, Ns, HWs, C, per_seg, p.nsplit, p.rps, p.nslab, p.ntypes,
                                   P, colsum, gate, st));
         a.gate = gate;                       // exact redo, a no-op unless the fp16 range was exceeded
     }
     WC_TRY(wc_launch_xty(a, p.nslab, st));
-    WC_TRY(wc_launch_stats_finalize(P, colsum, shift, p.nslab, M, C, Sp, sum, xtx, st));
+    WC_TRY(wc_launch_stats_finalize(P, colsum, shift, p.nslab / groups, HWs, C, groups, Sp, sum, xtx, st));
     return WC_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
-size_t wc_factor_workspace_bytes(int C)
+size_t wc_factor_workspace_bytes(int C, int groups)
 {
-    if (bad_channels(C)) return 0;
-    return slot_bytes((size_t)C * C, 8);
+    if (bad_channels(C) || groups <= 0) return 0;
+    return slot_bytes((size_t)groups * C * C, 8);
 }
 
-int wc_factor_f64(const double* sum, const double* xtx, int64_t M, int C, double eps, double momentum, int ddof,
+int wc_factor_f64(const double* sum, const double* xtx, int64_t M, int C, int groups, double eps, double momentum, int ddof,
                   int training, float* moving_mean, float* moving_cov, float* mu, float* chan_scale, double* L, double* W,
                   void* ws, size_t ws_bytes, wc_stream_t stream)
 {
@@ -110,15 +114,15 @@ int wc_factor_f64(const double* sum, const double* xtx, int64_t M, int C, double
     if (training && (!sum || !xtx)) return WC_ERR_NULL;
     if (!training && (!moving_mean || !moving_cov)) return WC_ERR_NULL;
     if (bad_channels(C)) return WC_ERR_CHANNELS;
-    if (training && (M <= ddof || M <= 0)) return WC_ERR_SHAPE;
+    if (groups <= 0 || (training && (M <= ddof || M <= 0))) return WC_ERR_SHAPE;
     if (!(eps > 0.0) || eps >= 1.0 || momentum < 0.0 || momentum > 1.0 || ddof < 0 || ddof > 1) return WC_ERR_ARG;
-    if (ws_bytes < wc_factor_workspace_bytes(C)) return WC_ERR_WORKSPACE;
+    if (ws_bytes < wc_factor_workspace_bytes(C, groups)) return WC_ERR_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     Carver cv(ws, ws_bytes);
-    double* tmp = cv.take<double>((size_t)C * C);
-    WC_TRY(wc_launch_factor_prepare(sum, xtx, M, C, eps, momentum, ddof, training, moving_mean, moving_cov, mu, chan_scale, L, st));
-    WC_TRY(wc_launch_cholesky(L, C, st));
-    WC_TRY(wc_launch_tri_inverse(L, W, tmp, C, st));
+    double* tmp = cv.take<double>((size_t)groups * C * C);
+    WC_TRY(wc_launch_factor_prepare(sum, xtx, M, C, eps, momentum, ddof, training, groups, moving_mean, moving_cov, mu, chan_scale, L, st));
+    WC_TRY(wc_launch_cholesky(L, C, groups, st));
+    WC_TRY(wc_launch_tri_inverse(L, W, tmp, C, groups, st));
     return WC_OK;
 }
 
@@ -136,20 +140,23 @@ size_t wc_apply_plan_bytes(int C, int Kc)
     return wc_fast_affine_workspace(C, Kc);
 }
 
-int wc_color_f32(const double* W, const float* gamma, int Kc, int C, float* A, float* At,
+int wc_color_f32(const double* W, const float* gamma, int Kc, int C, int groups, float* A, float* At,
                  const float* chan_scale, void* plan, void* ws, size_t ws_bytes, wc_stream_t stream)
 {
     (void)ws; (void)ws_bytes;
     if (!W || !A) return WC_ERR_NULL;
     if (bad_channels(C)) return WC_ERR_CHANNELS;
-    if (Kc <= 0 || (!gamma && Kc != 1)) return WC_ERR_SHAPE;
+    if (Kc <= 0 || groups <= 0 || (!gamma && Kc != 1)) return WC_ERR_SHAPE;
+    const int slots = groups * Kc;                    // table index = group * Kc + class slot
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool want_plan = plan && chan_scale && (C == 32 || C == 64 || C == 128 || C == 256);
     if (!gamma) {
-        WC_TRY(wc_launch_transpose_to_f32(W, C, A, At, st));
+        for (int g = 0; g < groups; ++g)
+            WC_TRY(wc_launch_transpose_to_f32(W + (int64_t)g * C * C, C, A + (int64_t)g * C * C,
+                                              At ? At + (int64_t)g * C * C : nullptr, st));
         if (want_plan) {
             WC_TRY(hipMemcpyAsync(wc_fast_plan_scale(plan), chan_scale, (size_t)C * 4, hipMemcpyDeviceToDevice, st));
-            WC_TRY(wc_launch_fast_plan_tables(A, Kc, C, plan, st));
+            WC_TRY(wc_launch_fast_plan_tables(A, slots, C, plan, st));
         }
         return WC_OK;
     }
@@ -160,11 +167,24 @@ int wc_color_f32(const double* W, const float* gamma, int Kc, int C, float* A, f
     g.Cm = A; g.c_is_f32 = 1; g.c_rs = C; g.c_cs = 1; g.c_bs = CC;
     g.Cm2 = At; g.c2_rs = 1; g.c2_cs = C; g.c2_bs = CC;
     g.m = C; g.n = C; g.k = C; g.batch = Kc; g.nred = 1; g.alpha = 1.0; g.epi = WC_EPI_NONE;
+    g.batch2 = groups; g.a_b2s = CC; g.b_b2s = 0; g.c_b2s = (int64_t)Kc * CC;      // A[g*Kc + k] = W_g^T Gamma_k
     WC_TRY(wc_launch_gemm(g, st));
     if (want_plan) {     // the apply's fp16 tables, built once here instead of inside every wc_apply_f32 call
         WC_TRY(hipMemcpyAsync(wc_fast_plan_scale(plan), chan_scale, (size_t)C * 4, hipMemcpyDeviceToDevice, st));
-        WC_TRY(wc_launch_fast_plan_tables(A, Kc, C, plan, st));
+        WC_TRY(wc_launch_fast_plan_tables(A, slots, C, plan, st));
     }
+    return WC_OK;
+}
+
+// grouped forward: one common centre + per-slot bias so that y = (x - center) A[s] + bias[s] equals
+// (x - mu_g) A[g*Kc+k] + beta_k for every sample of group g and class slot k
+int wc_group_bias_f32(const float* mu, const float* A, const float* beta, int groups, int Kc, int C,
+                      float* center, float* bias, wc_stream_t stream)
+{
+    if (!mu || !A || !center || !bias) return WC_ERR_NULL;
+    if (groups <= 0 || Kc <= 0) return WC_ERR_SHAPE;
+    if (bad_channels(C)) return WC_ERR_CHANNELS;
+    WC_TRY(wc_launch_group_bias(mu, A, beta, groups, Kc, C, center, bias, static_cast<hipStream_t>(stream)));
     return WC_OK;
 }
 

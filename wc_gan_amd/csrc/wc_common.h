@@ -81,16 +81,16 @@ hipError_t wc_launch_channel_scale(const float* in, const float* center, int64_t
 
 // K1 tail: shifted fp32 partials -> raw float64 moments
 hipError_t wc_launch_stats_finalize(const double* P, const float* colsum, const float* shift, int nslab,
-                                    int64_t M, int C, double* Sp /*[C] scratch*/, double* sum, double* xtx, hipStream_t st);
+                                    int64_t M, int C, int groups, double* Sp /*[groups*C] scratch*/, double* sum, double* xtx, hipStream_t st);
 // K4 tail: per-slab partials -> per-slot float64 R, gsum
 hipError_t wc_launch_bwd_combine(const double* P, const float* colsum, const int32_t* slot, int64_t N, int nsplit,
                                  int per_sample, int C, int Kc, double* R, double* gsum, hipStream_t st);
 
 hipError_t wc_launch_factor_prepare(const double* sum, const double* xtx, int64_t M, int C, double eps, double momentum,
-                                    int ddof, int training, float* moving_mean, float* moving_cov, float* mu,
+                                    int ddof, int training, int groups, float* moving_mean, float* moving_cov, float* mu,
                                     float* chan_scale, double* T, hipStream_t st);
-hipError_t wc_launch_cholesky(double* T, int C, hipStream_t st);                     // in place: lower factor, upper zeroed
-hipError_t wc_launch_tri_inverse(const double* L, double* W, double* tmp, int C, hipStream_t st);   // W = L^-1 (lower), upper zeroed
+hipError_t wc_launch_cholesky(double* T, int C, int groups, hipStream_t st);                     // in place: lower factor, upper zeroed
+hipError_t wc_launch_tri_inverse(const double* L, double* W, double* tmp, int C, int groups, hipStream_t st);   // W = L^-1 (lower), upper zeroed
 
 // generic small batched GEMM in float64 on the f64 MFMA:  Cm[b] = alpha * sum_r opA[b,r] opB[b,r]  (+ epilogue)
 enum WcEpi { WC_EPI_NONE = 0, WC_EPI_TRIL = 1, WC_EPI_PHI = 2 };
@@ -101,6 +101,7 @@ struct WcGemm {
     void* Cm2; int64_t c2_rs, c2_cs, c2_bs;                          // optional second (float) output, e.g. the transpose
     int m, n, k;            // multiples of 32
     int batch, nred;
+    int batch2; int64_t a_b2s, b_b2s, c_b2s;        // optional outer batch level (0 = none); c_b2s also strides Cm2
     double alpha;
     int epi;
 };
@@ -109,4 +110,6 @@ hipError_t wc_launch_gemm(const WcGemm& g, hipStream_t st);
 hipError_t wc_launch_transpose_to_f32(const double* W, int C, float* A, float* At, hipStream_t st);  // A = W^T, At = W
 hipError_t wc_launch_sym_scale_f32(const double* Q, int C, double scale, float* S, hipStream_t st);   // S = scale*(Q+Q^T)/2
 hipError_t wc_launch_gmean(const double* gsum, const float* A, int Kc, int C, int64_t M, float* gmean, hipStream_t st);
+hipError_t wc_launch_group_bias(const float* mu, const float* A, const float* beta, int G, int Kc, int C,
+                                float* center, float* bias, hipStream_t st);
 hipError_t wc_launch_f64_to_f32(const double* src, float* dst, int64_t n, hipStream_t st);

@@ -28,6 +28,8 @@ __global__ __launch_bounds__(1024) void stats_colsum_kernel(const float* __restr
                                                             double* __restrict__ sum)
 {
     __shared__ double red[16][64];
+    // statistic group = blockIdx.y: its nslab partial slabs, its Sp / sum rows (shift is common to all groups)
+    colsum += (int64_t)blockIdx.y * nslab * C; Sp += (int64_t)blockIdx.y * C; sum += (int64_t)blockIdx.y * C;
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int part = threadIdx.x >> 6;
     double s = 0.0;
@@ -56,6 +58,7 @@ __global__ __launch_bounds__(256) void stats_xtx_kernel(const double* __restrict
     const int i = blockIdx.y;
     if (blockIdx.x * 64 + 63 < i) return;          // whole block below the diagonal
     const int64_t CC = (int64_t)C * C;
+    P += (int64_t)blockIdx.z * nslab * CC; Sp += (int64_t)blockIdx.z * C; xtx += (int64_t)blockIdx.z * CC;   // group
     double g = 0.0;
     if (j < C && j >= i) {
         const double* p = P + (int64_t)i * C + j;
@@ -114,35 +117,43 @@ __global__ __launch_bounds__(256) void bwd_combine_kernel(const double* __restri
 // K2 head: moments -> mu, Sigma, moving statistics, T = (1-eps) Sigma + eps I
 // ---------------------------------------------------------------------------------------------
 __global__ void factor_prepare_kernel(const double* __restrict__ sum, const double* __restrict__ xtx, int64_t M, int C,
-                                      double eps, double momentum, int ddof, int training,
+                                      double eps, double momentum, int ddof, int training, int groups,
                                       float* __restrict__ moving_mean, float* __restrict__ moving_cov,
                                       float* __restrict__ mu, float* __restrict__ chan_scale, double* __restrict__ T)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y;
     if (j >= C) return;
-    const int64_t e = (int64_t)i * C + j;
-    double sig;
-    if (training) {
-        const double invM = 1.0 / (double)M;
-        sig = (0.5 * (xtx[e] + xtx[(int64_t)j * C + i]) - sum[i] * sum[j] * invM) / (double)(M - ddof);
-        if (moving_cov) moving_cov[e] = (float)(momentum * (double)moving_cov[e] + (1.0 - momentum) * sig);
-        if (i == 0) {
-            const double m = sum[j] * invM;
-            mu[j] = (float)m;
-            if (moving_mean) moving_mean[j] = (float)(momentum * (double)moving_mean[j] + (1.0 - momentum) * m);
+    const int64_t e = (int64_t)i * C + j, CC = (int64_t)C * C;
+    double tmax = 0.0;
+    // statistic groups are independent batches; their moving-statistics updates are applied one after the other,
+    // exactly as `groups` separate calls would
+    for (int g = 0; g < groups; ++g) {
+        double sig;
+        if (training) {
+            const double* sg = sum + (int64_t)g * C;
+            const double* xg = xtx + g * CC;
+            const double invM = 1.0 / (double)M;
+            sig = (0.5 * (xg[e] + xg[(int64_t)j * C + i]) - sg[i] * sg[j] * invM) / (double)(M - ddof);
+            if (moving_cov) moving_cov[e] = (float)(momentum * (double)moving_cov[e] + (1.0 - momentum) * sig);
+            if (i == 0) {
+                const double m = sg[j] * invM;
+                mu[(int64_t)g * C + j] = (float)m;
+                if (moving_mean) moving_mean[j] = (float)(momentum * (double)moving_mean[j] + (1.0 - momentum) * m);
+            }
+        } else {
+            sig = 0.5 * ((double)moving_cov[e] + (double)moving_cov[(int64_t)j * C + i]);
+            if (i == 0) mu[(int64_t)g * C + j] = moving_mean[j];
         }
-    } else {
-        sig = 0.5 * ((double)moving_cov[e] + (double)moving_cov[(int64_t)j * C + i]);
-        if (i == 0) mu[j] = moving_mean[j];
+        const double t = (1.0 - eps) * sig + (i == j ? eps : 0.0);
+        T[g * CC + e] = t;
+        tmax = t > tmax ? t : tmax;
     }
-    const double t = (1.0 - eps) * sig + (i == j ? eps : 0.0);
-    T[e] = t;
     if (chan_scale && i == j) {
-        // power-of-two scale for the fp16 fast path: (x - mu) * s has a standard deviation in [4, 8), which leaves
-        // 7500 sigma of head-room below the fp16 guard and is exact to undo
+        // power-of-two scale for the fp16 fast path (common to all groups: the largest variance decides):
+        // (x - mu) * s has a standard deviation in [4, 8), 7500 sigma below the fp16 guard, exact to undo
         int ex;
-        frexp(sqrt(t), &ex);
+        frexp(sqrt(tmax), &ex);
         chan_scale[j] = (float)ldexp(1.0, 3 - ex);
     }
 }
@@ -162,6 +173,7 @@ __global__ __launch_bounds__(1024) void cholesky_kernel(double* __restrict__ T, 
     double* rdiag = D + 16 * 17;       // [16]
     double* Pn = rdiag + 16;           // [16][ldp]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    T += (int64_t)blockIdx.x * C * C;  // one matrix (statistic group) per workgroup
 
     for (int j0 = 0; j0 < C; j0 += CH_NB) {
         const int rows = C - j0 - CH_NB;
@@ -256,6 +268,7 @@ __global__ __launch_bounds__(64) void tri_inv_diag_kernel(const double* __restri
     __shared__ double Lb[32 * 33];
     const int b0 = blockIdx.x * 32;
     const int lane = threadIdx.x;
+    L += (int64_t)blockIdx.y * C * C; W += (int64_t)blockIdx.y * C * C;      // group
     for (int e = lane; e < 32 * 32; e += 64) {
         const int i = e >> 5, k = e & 31;
         Lb[i * 33 + k] = L[(int64_t)(b0 + i) * C + b0 + k];
@@ -288,7 +301,8 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(WcGemm g)
     __shared__ double red[4][32 * 32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
-    const int bm = blockIdx.x, bn = blockIdx.y, b = blockIdx.z;
+    const int bm = blockIdx.x, bn = blockIdx.y;
+    const int b = blockIdx.z % g.batch, b2 = blockIdx.z / g.batch;       // two batch levels (e.g. class x group)
     const int kper = g.k >> 2;
 
     f64x4 acc[2][2];
@@ -298,8 +312,8 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(WcGemm g)
         for (int u = 0; u < 2; ++u) acc[t][u] = f64x4{0.0, 0.0, 0.0, 0.0};
 
     for (int r = 0; r < g.nred; ++r) {
-        const TA* A = reinterpret_cast<const TA*>(g.A) + (int64_t)b * g.a_bs + (int64_t)r * g.a_red;
-        const TB* B = reinterpret_cast<const TB*>(g.B) + (int64_t)b * g.b_bs + (int64_t)r * g.b_red;
+        const TA* A = reinterpret_cast<const TA*>(g.A) + (int64_t)b * g.a_bs + (int64_t)b2 * g.a_b2s + (int64_t)r * g.a_red;
+        const TB* B = reinterpret_cast<const TB*>(g.B) + (int64_t)b * g.b_bs + (int64_t)b2 * g.b_b2s + (int64_t)r * g.b_red;
         const TA* A0 = A + (int64_t)(bm * 32 + li) * g.a_rs;
         const TA* A1 = A0 + 16 * g.a_rs;
         const TB* B0 = B + (int64_t)(bn * 32 + li) * g.b_cs;
@@ -333,11 +347,11 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(WcGemm g)
             if (gj > gi) v = 0.0;
             else if (gj == gi && g.epi == WC_EPI_PHI) v *= 0.5;
         }
-        const int64_t off = (int64_t)b * g.c_bs + (int64_t)gi * g.c_rs + (int64_t)gj * g.c_cs;
+        const int64_t off = (int64_t)b * g.c_bs + (int64_t)b2 * g.c_b2s + (int64_t)gi * g.c_rs + (int64_t)gj * g.c_cs;
         if (g.c_is_f32) reinterpret_cast<float*>(g.Cm)[off] = (float)v;
         else reinterpret_cast<double*>(g.Cm)[off] = v;
         if (g.Cm2)
-            reinterpret_cast<float*>(g.Cm2)[(int64_t)b * g.c2_bs + (int64_t)gi * g.c2_rs + (int64_t)gj * g.c2_cs] = (float)v;
+            reinterpret_cast<float*>(g.Cm2)[(int64_t)b * g.c2_bs + (int64_t)b2 * g.c_b2s + (int64_t)gi * g.c2_rs + (int64_t)gj * g.c2_cs] = (float)v;
     }
 }
 
@@ -386,6 +400,30 @@ __global__ void gmean_kernel(const double* __restrict__ gsum, const float* __res
     if (threadIdx.x == 0) gmean[c] = (float)(red[0] / (double)M);
 }
 
+// grouped forward: center[c] = mean_g mu[g][c];  bias[s][n] = beta[s % Kc][n] - sum_c (mu[g][c] - center[c]) A[s][c][n],
+// s = g*Kc + k.  One block per slot s.
+__global__ __launch_bounds__(256) void group_bias_kernel(const float* __restrict__ mu, const float* __restrict__ A,
+                                                         const float* __restrict__ beta, int G, int Kc, int C,
+                                                         float* __restrict__ center, float* __restrict__ bias)
+{
+    __shared__ double dm[1024];
+    const int s_ = blockIdx.x, g = s_ / Kc, k = s_ % Kc;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double m = 0.0;
+        for (int gg = 0; gg < G; ++gg) m += (double)mu[(int64_t)gg * C + c];
+        m /= (double)G;
+        dm[c] = (double)mu[(int64_t)g * C + c] - m;
+        if (s_ == 0) center[c] = (float)m;
+    }
+    __syncthreads();
+    const float* As = A + (int64_t)s_ * C * C;
+    for (int n = threadIdx.x; n < C; n += 256) {
+        double acc = beta ? (double)beta[(int64_t)k * C + n] : 0.0;
+        for (int c = 0; c < C; ++c) acc -= dm[c] * (double)As[(int64_t)c * C + n];
+        bias[(int64_t)s_ * C + n] = (float)acc;
+    }
+}
+
 __global__ void f64_to_f32_kernel(const double* __restrict__ src, float* __restrict__ dst, int64_t n)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -395,10 +433,11 @@ __global__ void f64_to_f32_kernel(const double* __restrict__ src, float* __restr
 }  // namespace
 
 hipError_t wc_launch_stats_finalize(const double* P, const float* colsum, const float* shift, int nslab,
-                                    int64_t M, int C, double* Sp, double* sum, double* xtx, hipStream_t st)
+                                    int64_t M, int C, int groups, double* Sp, double* sum, double* xtx, hipStream_t st)
 {
-    hipLaunchKernelGGL(stats_colsum_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, colsum, shift, nslab, M, C, Sp, sum);
-    hipLaunchKernelGGL(stats_xtx_kernel, dim3((C + 63) / 64, C), dim3(256), 0, st, P, shift, (const double*)Sp, nslab, M, C, xtx);
+    // nslab and M are PER GROUP; group g owns slabs [g*nslab, (g+1)*nslab)
+    hipLaunchKernelGGL(stats_colsum_kernel, dim3((C + 63) / 64, groups), dim3(1024), 0, st, colsum, shift, nslab, M, C, Sp, sum);
+    hipLaunchKernelGGL(stats_xtx_kernel, dim3((C + 63) / 64, C, groups), dim3(256), 0, st, P, shift, (const double*)Sp, nslab, M, C, xtx);
     return hipGetLastError();
 }
 
@@ -412,15 +451,15 @@ hipError_t wc_launch_bwd_combine(const double* P, const float* colsum, const int
 }
 
 hipError_t wc_launch_factor_prepare(const double* sum, const double* xtx, int64_t M, int C, double eps, double momentum,
-                                    int ddof, int training, float* moving_mean, float* moving_cov, float* mu,
+                                    int ddof, int training, int groups, float* moving_mean, float* moving_cov, float* mu,
                                     float* chan_scale, double* T, hipStream_t st)
 {
     hipLaunchKernelGGL(factor_prepare_kernel, dim3((C + 127) / 128, C), dim3(128), 0, st,
-                       sum, xtx, M, C, eps, momentum, ddof, training, moving_mean, moving_cov, mu, chan_scale, T);
+                       sum, xtx, M, C, eps, momentum, ddof, training, groups, moving_mean, moving_cov, mu, chan_scale, T);
     return hipGetLastError();
 }
 
-hipError_t wc_launch_cholesky(double* T, int C, hipStream_t st)
+hipError_t wc_launch_cholesky(double* T, int C, int groups, hipStream_t st)
 {
     int ldp = C - CH_NB;
     if (ldp < 4) ldp = 4;
@@ -431,13 +470,13 @@ hipError_t wc_launch_cholesky(double* T, int C, hipStream_t st)
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(cholesky_kernel, dim3(1), dim3(1024), lds, st, T, C, ldp);
+    hipLaunchKernelGGL(cholesky_kernel, dim3(groups), dim3(1024), lds, st, T, C, ldp);
     return hipGetLastError();
 }
 
 hipError_t wc_launch_gemm(const WcGemm& g, hipStream_t st)
 {
-    const dim3 grid(g.m / 32, g.n / 32, g.batch);
+    const dim3 grid(g.m / 32, g.n / 32, g.batch * (g.batch2 > 0 ? g.batch2 : 1));
     if (g.a_is_f32 && g.b_is_f32) hipLaunchKernelGGL((gemm_f64_kernel<float, float>), grid, dim3(256), 0, st, g);
     else if (g.a_is_f32) hipLaunchKernelGGL((gemm_f64_kernel<float, double>), grid, dim3(256), 0, st, g);
     else if (g.b_is_f32) hipLaunchKernelGGL((gemm_f64_kernel<double, float>), grid, dim3(256), 0, st, g);
@@ -447,11 +486,12 @@ hipError_t wc_launch_gemm(const WcGemm& g, hipStream_t st)
 
 // W = L^-1: invert the 32-wide diagonal blocks, then double the block size level by level:
 //   [L11 0; L21 L22]^-1 = [W11 0; -W22 L21 W11, W22]
-hipError_t wc_launch_tri_inverse(const double* L, double* W, double* tmp, int C, hipStream_t st)
+hipError_t wc_launch_tri_inverse(const double* L, double* W, double* tmp, int C, int groups, hipStream_t st)
 {
-    hipError_t e = hipMemsetAsync(W, 0, (size_t)C * C * sizeof(double), st);
+    const int64_t CCg = (int64_t)C * C;
+    hipError_t e = hipMemsetAsync(W, 0, (size_t)groups * C * C * sizeof(double), st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(tri_inv_diag_kernel, dim3(C / 32), dim3(64), 0, st, L, W, C);
+    hipLaunchKernelGGL(tri_inv_diag_kernel, dim3(C / 32, groups), dim3(64), 0, st, L, W, C);
     for (int b = 32; b < C; b *= 2) {
         const int nfull = C / (2 * b);
         const int rem = C - 2 * b * nfull;
@@ -466,6 +506,7 @@ hipError_t wc_launch_tri_inverse(const double* L, double* W, double* tmp, int C,
             g1.B = W + (int64_t)start * C + start;       g1.b_rs = C; g1.b_cs = 1; g1.b_bs = pair;
             g1.Cm = tmp; g1.c_rs = b; g1.c_cs = 1; g1.c_bs = (int64_t)b * b;
             g1.m = mrows; g1.n = b; g1.k = b; g1.batch = batch; g1.nred = 1; g1.alpha = 1.0; g1.epi = WC_EPI_NONE;
+            g1.batch2 = groups; g1.a_b2s = CCg; g1.b_b2s = CCg; g1.c_b2s = CCg;      // tmp is [group][C*C]
             e = wc_launch_gemm(g1, st);
             if (e != hipSuccess) return e;
             WcGemm g2 = {};
@@ -473,6 +514,7 @@ hipError_t wc_launch_tri_inverse(const double* L, double* W, double* tmp, int C,
             g2.B = tmp; g2.b_rs = b; g2.b_cs = 1; g2.b_bs = (int64_t)b * b;
             g2.Cm = W + (int64_t)(start + b) * C + start; g2.c_rs = C; g2.c_cs = 1; g2.c_bs = pair;
             g2.m = mrows; g2.n = b; g2.k = mrows; g2.batch = batch; g2.nred = 1; g2.alpha = -1.0; g2.epi = WC_EPI_NONE;
+            g2.batch2 = groups; g2.a_b2s = CCg; g2.b_b2s = CCg; g2.c_b2s = CCg;
             e = wc_launch_gemm(g2, st);
             if (e != hipSuccess) return e;
         }
@@ -495,6 +537,13 @@ hipError_t wc_launch_sym_scale_f32(const double* Q, int C, double scale, float* 
 hipError_t wc_launch_gmean(const double* gsum, const float* A, int Kc, int C, int64_t M, float* gmean, hipStream_t st)
 {
     hipLaunchKernelGGL(gmean_kernel, dim3(C), dim3(256), 0, st, gsum, A, Kc, C, M, gmean);
+    return hipGetLastError();
+}
+
+hipError_t wc_launch_group_bias(const float* mu, const float* A, const float* beta, int G, int Kc, int C,
+                                float* center, float* bias, hipStream_t st)
+{
+    hipLaunchKernelGGL(group_bias_kernel, dim3(G * Kc), dim3(256), 0, st, mu, A, beta, G, Kc, C, center, bias);
     return hipGetLastError();
 }
 

@@ -89,6 +89,32 @@ class WhitenColorFunction(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
+def whiten_color_grouped(x, groups, gamma=None, beta=None, slot=None, moving_mean=None, moving_cov=None,
+                         eps=1e-3, momentum=0.99, ddof=1):
+    """Training-mode forward of `groups` INDEPENDENT batches stacked along N (no autograd): each run of N/groups
+    samples is whitened with its own batch statistics, exactly as `groups` separate calls would be, but the
+    covariance / Cholesky / inverse problems of the groups are solved side by side in one set of launches.
+    Used for the generator passes inside the critic updates (fixed generator weights, no graph)."""
+    N, C = x.shape[0], x.shape[-1]
+    if N % groups != 0:
+        raise ValueError("N must be a multiple of groups")
+    x = x.detach().contiguous()
+    M = x.numel() // C
+    Mg = M // groups
+    dev = x.device
+    s, xtx = ops.stats(x.view(M, C), groups)
+    mm = moving_mean.view(-1) if moving_mean is not None else None
+    mu, L, W, cs = ops.factor(s, xtx, Mg, C, eps, momentum, ddof, True, mm, moving_cov, dev, want_scale=True, groups=groups)
+    g = gamma.detach().contiguous() if gamma is not None else None
+    b = beta.detach().contiguous() if beta is not None else None
+    Kc = 1 if g is None else g.shape[0]
+    A, At, plan = ops.color(W, g, cs, groups)
+    center, bias = ops.group_bias(mu.view(groups, C), A, b, groups, Kc)
+    grp = torch.arange(N, device=dev, dtype=torch.int32) // (N // groups)
+    full_slot = grp * Kc + (slot if slot is not None else 0)
+    return ops.apply(x, center, A, bias, full_slot.to(torch.int32).contiguous(), plan=plan)
+
+
 def whiten_color(x, gamma=None, beta=None, slot=None, moving_mean=None, moving_cov=None, training=True,
                  eps=1e-3, momentum=0.99, ddof=1, process_group=None):
     """y = coloring(whitening(x)).  x: (N, H, W, C) float32 on the GPU, C % 32 == 0 (see layers for padding)."""

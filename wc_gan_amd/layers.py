@@ -30,6 +30,27 @@ import torch.nn.functional as F
 from . import functional as WF
 
 
+_STAT_GROUPS = 1
+
+
+class statistic_groups:
+    """Context: WC layers treat the batch as `n` independent, equally sized batches stacked along N, each whitened
+    with its own statistics (training mode, no autograd).  Equivalent to n separate forward passes."""
+
+    def __init__(self, n):
+        self.n = int(n)
+
+    def __enter__(self):
+        global _STAT_GROUPS
+        self.prev, _STAT_GROUPS = _STAT_GROUPS, self.n
+        return self
+
+    def __exit__(self, *exc):
+        global _STAT_GROUPS
+        _STAT_GROUPS = self.prev
+        return False
+
+
 def _glorot_uniform_(t, fan_in, fan_out):
     limit = math.sqrt(6.0 / (fan_in + fan_out))
     with torch.no_grad():
@@ -100,6 +121,11 @@ class DecorelationNormalization(_Lazy):
                 raise NotImplementedError("renorm is defined for decomposition='cholesky' only")
             return WF.whiten_color_modular(x, gamma, beta, slot, self.moving_mean, self.moving_cov, self.training,
                                            self.epsilon, self.momentum, 1, 'zca')
+        if _STAT_GROUPS > 1 and self.training and not self.renorm:
+            if torch.is_grad_enabled() and (x.requires_grad or (gamma is not None and gamma.requires_grad)):
+                raise RuntimeError("statistic_groups() is a forward-only path: wrap the call in torch.no_grad()")
+            return WF.whiten_color_grouped(x, _STAT_GROUPS, gamma, beta, slot, self.moving_mean, self.moving_cov,
+                                           self.epsilon, self.momentum, 1)
         if self.renorm and self.training:
             gamma = self._renorm_gamma(x, gamma)
         return WF.whiten_color(x, gamma, beta, slot, self.moving_mean, self.moving_cov, self.training,

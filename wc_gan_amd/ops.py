@@ -38,34 +38,37 @@ def _workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
-def stats(x2d):
-    """K1: x2d (M, C) float32 -> (sum (C,) f64, xtx (C, C) f64), the raw additive moments."""
+def stats(x2d, groups=1):
+    """K1: x2d (M, C) float32 -> (sum (C,) f64, xtx (C, C) f64), the raw additive moments.
+    groups > 1: M/groups consecutive rows per statistic group -> sum (G, C), xtx (G, C, C)."""
     lib = _lib.load()
     _need(x2d, torch.float32, "x", 2)
     M, C = x2d.shape
-    s = torch.empty(C, dtype=torch.float64, device=x2d.device)
-    xtx = torch.empty(C, C, dtype=torch.float64, device=x2d.device)
-    nb = lib.wc_stats_workspace_bytes(M, C)
+    lead = (groups,) if groups > 1 else ()
+    s = torch.empty(*lead, C, dtype=torch.float64, device=x2d.device)
+    xtx = torch.empty(*lead, C, C, dtype=torch.float64, device=x2d.device)
+    nb = lib.wc_stats_workspace_bytes(M, C, groups)
     if nb == 0:
-        _lib.check(-3, "wc_stats_f32")
+        _lib.check(-3 if M % groups == 0 else -2, "wc_stats_f32")
     ws = _workspace(nb, x2d.device)
-    _lib.check(lib.wc_stats_f32(_ptr(x2d), M, C, _ptr(s), _ptr(xtx), _ptr(ws), ws.numel(), _stream()), "wc_stats_f32")
+    _lib.check(lib.wc_stats_f32(_ptr(x2d), M, C, groups, _ptr(s), _ptr(xtx), _ptr(ws), ws.numel(), _stream()), "wc_stats_f32")
     return s, xtx
 
 
-def factor(s, xtx, M, C, eps, momentum, ddof, training, moving_mean, moving_cov, device, want_scale=False):
+def factor(s, xtx, M, C, eps, momentum, ddof, training, moving_mean, moving_cov, device, want_scale=False, groups=1):
     """K2: -> (mu (C,) f32, L (C,C) f64, W (C,C) f64); updates the moving statistics in place when training.
     With want_scale=True also returns chan_scale (C,) f32, the power-of-two 1/sigma the fp16 fast path uses."""
     lib = _lib.load()
-    mu = torch.empty(C, dtype=torch.float32, device=device)
+    lead = (groups,) if groups > 1 else ()
+    mu = torch.empty(*lead, C, dtype=torch.float32, device=device)
     chan_scale = torch.empty(C, dtype=torch.float32, device=device) if want_scale else None
-    L = torch.empty(C, C, dtype=torch.float64, device=device)
-    W = torch.empty(C, C, dtype=torch.float64, device=device)
+    L = torch.empty(*lead, C, C, dtype=torch.float64, device=device)
+    W = torch.empty(*lead, C, C, dtype=torch.float64, device=device)
     if moving_mean is not None:
         _need(moving_mean, torch.float32, "moving_mean")
         _need(moving_cov, torch.float32, "moving_cov", 2)
-    ws = _workspace(lib.wc_factor_workspace_bytes(C), device)
-    _lib.check(lib.wc_factor_f64(_ptr(s), _ptr(xtx), int(M), C, float(eps), float(momentum), int(ddof), int(bool(training)),
+    ws = _workspace(lib.wc_factor_workspace_bytes(C, groups), device)
+    _lib.check(lib.wc_factor_f64(_ptr(s), _ptr(xtx), int(M), C, groups, float(eps), float(momentum), int(ddof), int(bool(training)),
                                  _ptr(moving_mean), _ptr(moving_cov), _ptr(mu), _ptr(chan_scale), _ptr(L), _ptr(W),
                                  _ptr(ws), ws.numel(), _stream()), "wc_factor_f64")
     if want_scale:
@@ -73,25 +76,36 @@ def factor(s, xtx, M, C, eps, momentum, ddof, training, moving_mean, moving_cov,
     return mu, L, W
 
 
-def color(W, gamma, chan_scale=None):
+def color(W, gamma, chan_scale=None, groups=1):
     """A_k = W^T Gamma_k and At_k = A_k^T.  gamma (Kc, C, C) float32 or None (whitening only).
     With chan_scale also returns the apply plan (opaque uint8 tensor) -> (A, At, plan)."""
     lib = _lib.load()
-    C = W.shape[0]
+    C = W.shape[-1]
     Kc = 1 if gamma is None else gamma.shape[0]
     if gamma is not None:
         _need(gamma, torch.float32, "gamma", 3)
-    A = torch.empty(Kc, C, C, dtype=torch.float32, device=W.device)
-    At = torch.empty(Kc, C, C, dtype=torch.float32, device=W.device)
+    A = torch.empty(groups * Kc, C, C, dtype=torch.float32, device=W.device)      # index g*Kc + k
+    At = torch.empty(groups * Kc, C, C, dtype=torch.float32, device=W.device)
     ws = _workspace(lib.wc_color_workspace_bytes(C, Kc), W.device)
     plan = None
     if chan_scale is not None and C in (32, 64, 128, 256):
-        plan = _workspace(lib.wc_apply_plan_bytes(C, Kc), W.device)
-    _lib.check(lib.wc_color_f32(_ptr(W), _ptr(gamma), Kc, C, _ptr(A), _ptr(At), _ptr(chan_scale), _ptr(plan),
+        plan = _workspace(lib.wc_apply_plan_bytes(C, groups * Kc), W.device)
+    _lib.check(lib.wc_color_f32(_ptr(W), _ptr(gamma), Kc, C, groups, _ptr(A), _ptr(At), _ptr(chan_scale), _ptr(plan),
                                 _ptr(ws), ws.numel(), _stream()), "wc_color_f32")
     if chan_scale is not None:
         return A, At, plan
     return A, At
+
+
+def group_bias(mu, A, beta, groups, Kc):
+    """Grouped forward glue -> (center (C,), bias (groups*Kc, C)); see wc_group_bias_f32."""
+    lib = _lib.load()
+    C = mu.shape[-1]
+    center = torch.empty(C, dtype=torch.float32, device=mu.device)
+    bias = torch.empty(groups * Kc, C, dtype=torch.float32, device=mu.device)
+    _lib.check(lib.wc_group_bias_f32(_ptr(mu), _ptr(A), _ptr(beta), groups, Kc, C, _ptr(center), _ptr(bias), _stream()),
+               "wc_group_bias_f32")
+    return center, bias
 
 
 def apply(x, mu, A, bias, slot, out=None, fast=True, plan=None):

@@ -80,10 +80,20 @@ class GanTrainer:
         out = self.D(x, cls if self.conditional else None)
         return out[0] if isinstance(out, tuple) else out
 
-    def d_step(self, real, real_cls=None):
-        z, cls = self._noise(self.batch_size)
-        with torch.no_grad():
+    def generate(self, rounds):
+        """The `rounds` generated batches of one G+D step in ONE generator pass.  The generator's weights are fixed
+        while the critic trains, so its `rounds` forward passes are independent; they run as a single batch of
+        rounds x batch_size whose WC layers keep per-round statistics (layers.statistic_groups) -- the same numbers
+        as separate passes, with the covariance / Cholesky problems of the rounds solved side by side."""
+        from .layers import statistic_groups
+        z, cls = self._noise(self.batch_size * rounds)
+        with torch.no_grad(), statistic_groups(rounds):
             fake = self.G(z, cls)                      # train-mode WC forward (batch statistics), no graph
+        return fake.split(self.batch_size), cls.split(self.batch_size)
+
+    def d_step(self, real, real_cls=None, fake=None, cls=None):
+        if fake is None:
+            (fake,), (cls,) = self.generate(1)
         self.d_bucket.zero()
         # real and generated images go through the critic as ONE batch of 128: the critic has no batch-dependent
         # layer (discriminator_norm is 'n' in every recipe), so this equals two applications with shared weights,
@@ -112,8 +122,9 @@ class GanTrainer:
 
     def step(self, real_batches):
         """One G+D step: training_ratio critic updates, then one generator update."""
+        fakes, clss = self.generate(self.training_ratio)
         for r in range(self.training_ratio):
-            d_loss = self.d_step(real_batches[r % len(real_batches)])
+            d_loss = self.d_step(real_batches[r % len(real_batches)], fake=fakes[r], cls=clss[r])
         g_loss = self.g_step()
         return d_loss, g_loss
 
