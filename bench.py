@@ -135,7 +135,8 @@ def main():
     ap.add_argument("--training-ratio", type=int, default=TRAINING_RATIO)
     ap.add_argument("--sync-wc", action="store_true", help="all-reduce WC statistics across replicas")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the whole G+D step as one hipGraph (measured equal to eager launches: the step is GPU-bound)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -169,7 +170,7 @@ def main():
     for _ in range(args.warmup):
         step()
     launch_mode = "eager"
-    if not args.no_graph:
+    if args.graph:
         try:
             step = trainer.capture(reals)        # the whole G+D step as one hipGraph: the host leaves the loop
             launch_mode = "hipgraph"
