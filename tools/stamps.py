@@ -9,11 +9,11 @@ lib = _lib.load()
 nb = lib.wc_apply_workspace_bytes(N, H * H, C, 1)
 ws = torch.zeros(nb, dtype=torch.uint8, device='cuda')
 for _ in range(5):
-    rc = lib.wc_apply_f32(x.data_ptr(), mu.data_ptr(), A.data_ptr(), b.data_ptr(), None, N, H * H, C, 1, y.data_ptr(), ws.data_ptr(), nb, torch.cuda.current_stream().cuda_stream)
+    rc = lib.wc_apply_f32(x.data_ptr(), mu.data_ptr(), A.data_ptr(), b.data_ptr(), None, N, H * H, C, 1, y.data_ptr(), None, ws.data_ptr(), nb, torch.cuda.current_stream().cuda_stream)
 torch.cuda.synchronize()
 d = ws[nb - 2048:nb - 1024].view(torch.int64).cpu().view(2, 8, 8)
-names = ['start', 'sb0 mfma done', 'sb0 stores issued', 'sb1 mfma done', 'sb1 stores issued', 'pre-barrier', 'post-barrier']
+names = ['start', 'vmcnt wait done', 'dma issued', 'mfma+convert done', 'stores issued', 'post-barrier', '-']
 for wg in range(2):
     for w in (0, 4):
         t = d[wg, w].tolist()
-        print(f'WG{wg} wave{w}:', ' '.join(f'{names[i]}=+{t[i]-t[0]}' for i in range(1, 7)))
+        print(f'WG{wg} wave{w}:', ' '.join(f'{names[i]}=+{t[i]-t[0]}' for i in range(1, 6)))

@@ -402,6 +402,262 @@ __global__ __launch_bounds__(512, 2) void affine_f16x3_kernel(FastArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Ring variant (non-accumulating calls).  Two things the register-staged kernel above cannot do:
+//  * The activation rows travel HBM -> LDS by LDS-DMA (global_load_lds, no VGPR in between) into a two-deep ring of
+//    raw fp32 tiles, two tile periods ahead of their use: the load latency is off the critical path (measured: 4 %
+//    of a tile in the vmcnt wait, against ~40 % when a register-staged load is consumed one tile after its issue).
+//  * There is NO workgroup barrier in the tile loop.  A barrier keeps all eight waves in the same phase, so the
+//    matrix pipe idles whenever they store or stage (measured: pipe saturated for 3100 of 5400 ticks per tile, idle
+//    for the rest).  Instead two monotonic LDS counters order the only true dependencies -- "tile t is converted by
+//    all waves" before anyone reads it, "tile t-1 is read by all waves" before its image buffer is rewritten -- and
+//    a wave's stores, DMA issue and waits overlap the MFMAs of the other wave on its SIMD.
+// Tiles are 32 KiB (8192/C rows): 2 fp16 image buffers + 2 raw slots + counters.  Every wave owns one 32-row
+// sub-tile per tile and converts exactly the 4 KiB of the next tile that its own DMA brought in (ds_read_b128 ->
+// centre/scale/split -> ds_write_b64), so a raw slot needs no cross-wave hand-off at all.  Hand count at the top of
+// a tile: the 4 DMAs of tile t+1 were issued one tile ago and only that tile's 16 stores are younger -> vmcnt(16).
+// An element outside the fp16 range marks the workgroup; it then recomputes all of its tiles in fp32 at the end.
+// ---------------------------------------------------------------------------------------------------------------
+template <int C, bool HAS_SLOT>
+__global__ __launch_bounds__(512, 2) void affine_ring_kernel(FastArgs a)
+{
+    constexpr int TR = 8192 / C;              // rows per tile (32 KiB of fp32)
+    constexpr int CPR = C / 8, KS = C / 16, CG = C / 32, C4 = C / 4;
+    constexpr int IMG = TR * C * 2;           // one fp16 image: 16 KiB
+    constexpr int FBUF = 2 * IMG;             // hi | lo
+    constexpr int RAW = TR * C * 4;           // 32 KiB
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // F0 | F1 | R0 | R1 | counters
+    char* const fbuf = smem;
+    char* const ring = smem + 2 * FBUF;
+    volatile int* const cnt = reinterpret_cast<volatile int*>(smem + 2 * FBUF + 2 * RAW);   // [0] converted, [1] read, [2] dirty
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cg = wave % CG, rg = wave / CG;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    int t_first, t_stride, n;
+    if (HAS_SLOT) {
+        t_first = blockIdx.x * a.tiles_per_wg; t_stride = 1;
+        n = a.ntiles - t_first; if (n > a.tiles_per_wg) n = a.tiles_per_wg;
+    } else {
+        t_first = blockIdx.x; t_stride = gridDim.x;
+        n = (a.ntiles - t_first + t_stride - 1) / t_stride;
+    }
+    if (n <= 0) return;
+    auto tile_of = [&](int i) { return t_first + i * t_stride; };
+    auto swz = [](int row) -> int {
+        if (CPR >= 16) return row & 15;
+        return (row / (16 / CPR)) & (CPR - 1);
+    };
+
+    if (tid < 3) cnt[tid] = 0;
+    __syncthreads();
+
+    // DMA: wave w moves bytes [4w KiB, 4w+4 KiB) of a tile with four 1-KiB instructions (lane = 16 B)
+    auto dma_tile = [&](int i) {
+        const char* g = reinterpret_cast<const char*>(a.in + (int64_t)tile_of(i) * (TR * C)) + wave * 4096 + lane * 16;
+        char* l = ring + (i & 1) * RAW + wave * 4096;
+        // inline asm on purpose: hipcc drains vmcnt(0) before any ds_read that may alias a pending LDS-DMA it knows of,
+        // which would wait for the DMA issued a moment ago and for every store in flight.  M0 (the LDS destination
+        // base) is set and restored inside the statement; completion is counted by hand (vmcnt(16) below).
+        const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)l);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned keep;
+            const char* gq = g + q * 1024;
+            const unsigned lq = __builtin_amdgcn_readfirstlane(lds0 + q * 1024);
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(gq), "s"(lq) : "memory");
+        }
+    };
+
+    // conversion of this wave's own 4 KiB: float4 #e = 256*wave + lane + 64*p
+    const int c4i = lane % C4;
+    const f32x4 scl = ld4f(a.scale + 4 * c4i);
+    f32x4 ncs = {0.f, 0.f, 0.f, 0.f};
+    if (a.center) ncs = -ld4f(a.center + 4 * c4i) * scl;
+    bool overflow = false;
+    auto convert_chunk = [&](int i, int p) {
+        const int e = 256 * wave + lane + 64 * p;
+        const int row = e / C4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ring + (i & 1) * RAW + e * 16);
+        const f32x4 g = v * scl + ncs;
+        overflow |= (fabsf(g[0]) > kF16Guard) | (fabsf(g[1]) > kF16Guard) | (fabsf(g[2]) > kF16Guard) | (fabsf(g[3]) > kF16Guard);
+        const unsigned hw01 = pk_rne(g[0], g[1]), hw23 = pk_rne(g[2], g[3]);
+        const f16x2 h01 = __builtin_bit_cast(f16x2, hw01), h23 = __builtin_bit_cast(f16x2, hw23);
+        const unsigned l01 = pk_rne(g[0] - (float)h01[0], g[1] - (float)h01[1]);
+        const unsigned l23 = pk_rne(g[2] - (float)h23[0], g[3] - (float)h23[1]);
+        char* dst = fbuf + (i & 1) * FBUF + row * (C * 2) + (((c4i >> 1) ^ swz(row)) * 16) + (c4i & 1) * 8;
+        *reinterpret_cast<uint2*>(dst) = make_uint2(hw01, hw23);
+        *reinterpret_cast<uint2*>(dst + IMG) = make_uint2(l01, l23);
+    };
+    // one arrival per wave on a monotonic counter, after this wave's LDS traffic has completed
+    // (asm: a C++ volatile/atomic access makes hipcc drain vmcnt(0) around it, i.e. wait for the stores in flight)
+    const unsigned cnt_lds = (unsigned)(size_t)((__attribute__((address_space(3))) char*)(smem + 2 * FBUF + 2 * RAW));
+    auto arrive = [&](int which) {
+        if (lane == 0) {
+            const unsigned one = 1u, addr = cnt_lds + 4u * which;
+            asm volatile("ds_add_u32 %0, %1" :: "v"(addr), "v"(one) : "memory");
+        }
+    };
+    auto wait_for = [&](int which, int target) {
+        const unsigned addr = cnt_lds + 4u * which;
+        for (;;) {
+            int v;
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+            if (__builtin_amdgcn_readfirstlane(v) >= target) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
+
+    f16x8 bhi[KS], blo[KS];
+    float cscale = 1.f, addv = 0.f;
+    int cur_slot = -1;
+    const int col = cg * 32 + l31;
+    auto load_b = [&](int slot) {
+        const _Float16* ph = a.Bhi + (int64_t)slot * a.slot_stride + (col * C + 8 * lh);
+        const _Float16* pl = a.Blo + (int64_t)slot * a.slot_stride + (col * C + 8 * lh);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            bhi[s] = *reinterpret_cast<const f16x8*>(ph + 16 * s);
+            blo[s] = *reinterpret_cast<const f16x8*>(pl + 16 * s);
+        }
+        const int64_t srow_ = a.slot_stride ? slot : 0;
+        cscale = a.colscale[srow_ * C + col];
+        addv = 0.f;
+        if (a.bias) addv += a.bias[(int64_t)slot * C + col];
+        if (a.sub) addv -= a.sub[col];
+        cur_slot = slot;
+    };
+
+    // prologue: two tiles in flight, this wave's share of the first one converted
+    dma_tile(0);
+    if (n > 1) dma_tile(1);
+    if (!HAS_SLOT) load_b(0);
+    // the BUILTIN wait (not asm): hipcc must see that the B' loads have completed here, or it waits for them with
+    // small vmcnt counts inside the loop -- draining the DMAs and stores the loop wants to keep in flight
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0) only
+#pragma unroll
+    for (int p = 0; p < 4; ++p) convert_chunk(0, p);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    arrive(0);
+
+    const int rbase = rg * 32;
+    const int sw = swz(rbase + l31);
+    const int rd_off = (rbase + l31) * (C * 2);
+    const int out_lane = (rbase + 4 * lh) * C + col;
+    unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool stamp_on = false;
+
+    for (int t = 0; t < n; ++t) {
+        stamp_on = WC_STAMPS && (t == 6);
+        WC_STAMP(0);
+        if (HAS_SLOT) {
+            const int slot = a.slot[((int64_t)tile_of(t) * TR) / a.HW];
+            if (slot != cur_slot) { load_b(slot); __builtin_amdgcn_s_waitcnt(0x0F70); }
+        }
+        wait_for(0, 8 * (t + 1));                  // tile t converted by all eight waves
+        wait_for(1, 8 * t);                        // tile t-1 read by all: image buffer (t+1)&1 may be rewritten
+        const bool conv = t + 1 < n;
+        if (conv) {     // this wave's DMA of tile t+1 must have landed before it converts it (see the count above)
+            if (t >= 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        WC_STAMP(1);
+        if (t + 2 < n) dma_tile(t + 2);            // raw slot t&1: this wave finished converting tile t one tile ago
+        WC_STAMP(2);
+        float* out_tile = a.out + (int64_t)tile_of(t) * (TR * C);
+        const char* hrow = fbuf + (t & 1) * FBUF + rd_off;
+        const char* lrow = hrow + IMG;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        f16x8 ah = *reinterpret_cast<const f16x8*>(hrow + ((0 + lh) ^ sw) * 16);
+        f16x8 al = *reinterpret_cast<const f16x8*>(lrow + ((0 + lh) ^ sw) * 16);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            f16x8 nh = ah, nl = al;
+            if (s + 1 < KS) {
+                const int chunk = (2 * (s + 1) + lh) ^ sw;
+                nh = *reinterpret_cast<const f16x8*>(hrow + chunk * 16);
+                nl = *reinterpret_cast<const f16x8*>(lrow + chunk * 16);
+            }
+            constexpr int STEP = (KS >= 4) ? KS / 4 : 1;
+            constexpr int PER = (KS >= 4) ? 1 : 4 / KS;
+            if (conv && (s % STEP) == 0 && (s / STEP) < 4) {
+#pragma unroll
+                for (int q = 0; q < PER; ++q) convert_chunk(t + 1, (s / STEP) * PER + q);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bhi[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, blo[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bhi[s], acc, 0, 0, 0);
+            ah = nh; al = nl;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my image reads and my conversion writes are done
+        if (conv) arrive(0);
+        arrive(1);
+        WC_STAMP(3);
+        float* po = out_tile + out_lane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) po[((r & 3) + 8 * (r >> 2)) * C] = acc[r] * cscale + addv;
+        WC_STAMP(4);
+    }
+    if (WC_STAMPS && a.dbg && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 100)) {
+        unsigned long long* d = a.dbg + ((blockIdx.x ? 1 : 0) * 8 + wave) * 8;
+        for (int i = 0; i < 8; ++i) d[i] = ts[i];
+    }
+
+    // exact redo of the whole workgroup if anything it staged was outside the fp16 range (rare)
+    if (overflow) cnt[2] = 1;
+    __syncthreads();
+    if (cnt[2]) {
+        for (int t = 0; t < n; ++t) {
+            int slot = 0;
+            if (HAS_SLOT) slot = a.slot[((int64_t)tile_of(t) * TR) / a.HW];
+            const float* xin = a.in + (int64_t)tile_of(t) * (TR * C);
+            float* out_tile = a.out + (int64_t)tile_of(t) * (TR * C);
+            const float* Bf = a.Bf + (int64_t)slot * a.bf_stride + col;
+            float add = 0.f;
+            if (a.bias) add += a.bias[(int64_t)slot * C + col];
+            if (a.sub) add -= a.sub[col];
+            for (int i = 0; i < 16; ++i) {
+                const int row = rbase + (i & 3) + 8 * (i >> 2) + 4 * lh;
+                const float* xrow = xin + row * C;
+                float accf = 0.f;
+                for (int k = 0; k < C; ++k) accf = fmaf(xrow[k] - (a.center ? a.center[k] : 0.f), Bf[(int64_t)k * C], accf);
+                out_tile[row * C + col] = accf + add;
+            }
+        }
+    }
+}
+
+template <int C>
+hipError_t launch_affine_ring(const FastArgs& a, hipStream_t st)
+{
+    constexpr int TR = 8192 / C;
+    constexpr size_t lds = 128 * 1024 + 64;       // 2 image buffers + 2 raw slots + counters
+    FastArgs b = a;
+    b.ntiles = (int)(a.M / TR);
+    int nwg = b.ntiles < 256 ? b.ntiles : 256;
+    b.tiles_per_wg = (b.ntiles + nwg - 1) / nwg;
+    nwg = (b.ntiles + b.tiles_per_wg - 1) / b.tiles_per_wg;
+#define WC_LAUNCH_RING(SLOT_)                                                                                          \
+    do {                                                                                                                \
+        static bool attr_set = false;                                                                                   \
+        if (!attr_set) {                                                                                                \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(affine_ring_kernel<C, SLOT_>),             \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
+            if (e != hipSuccess) return e;                                                                              \
+            attr_set = true;                                                                                            \
+        }                                                                                                               \
+        hipLaunchKernelGGL((affine_ring_kernel<C, SLOT_>), dim3(nwg), dim3(512), lds, st, b);                           \
+    } while (0)
+    if (b.slot != nullptr) WC_LAUNCH_RING(true); else WC_LAUNCH_RING(false);
+#undef WC_LAUNCH_RING
+    return hipGetLastError();
+}
+
 template <int C>
 hipError_t launch_affine(const FastArgs& a, hipStream_t st)
 {
@@ -492,6 +748,15 @@ hipError_t wc_launch_fast_affine_planned(const float* in, const float* center, c
     a.slot_stride = shared_table ? 0 : (int64_t)C * C;
     a.bias = bias; a.sub = sub; a.slot = shared_table ? nullptr : slot; a.M = N * HW; a.HW = HW;
     a.accumulate = accumulate; a.Bf = B; a.bf_stride = shared_table ? 0 : (int64_t)C * C; a.out = out; a.dbg = v.dbg;
+    static const bool use_ring = getenv("WC_NO_RING") == nullptr;
+    if (!accumulate && use_ring && (HW % (8192 / C)) == 0) {
+        switch (C) {
+            case 32: return launch_affine_ring<32>(a, st);
+            case 64: return launch_affine_ring<64>(a, st);
+            case 128: return launch_affine_ring<128>(a, st);
+            case 256: return launch_affine_ring<256>(a, st);
+        }
+    }
     switch (C) {
         case 32: return launch_affine<32>(a, st);
         case 64: return launch_affine<64>(a, st);
