@@ -75,7 +75,7 @@ def roofline_apply(dev):
     pmc = os.path.join(ROOT, "profiles", "r1_apply_k3_pmc.json")
     if os.path.exists(pmc):
         traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
-    return {"bound": "hbm", "kernel": "affine_f16x3_kernel<256> (wc_apply_f32 with plan, 128x32x32x256 fp32)",
+    return {"bound": "hbm", "kernel": "affine_ring_kernel<256,false> (wc_apply_f32 with plan, 128x32x32x256 fp32)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "launch_us": round(t * 1e6, 2), "algorithmic_bytes": alg_bytes,
@@ -85,21 +85,20 @@ def roofline_apply(dev):
 
 def wc_sites_gpu(dev, ratio):
     """GPU time of the WC sites of one G+D step (what cpu_baseline times on the host)."""
-    from wc_gan_amd.functional import whiten_color
+    from wc_gan_amd.functional import whiten_color, whiten_color_grouped
     g = torch.Generator(device="cpu"); g.manual_seed(1234)
     work = []
     for H, C in CIFAR_SITES:
         G = (torch.randn(1, C, C, generator=g) / C ** 0.5).to(dev).requires_grad_(True)
         B = torch.zeros(1, C, device=dev, requires_grad=True)
-        x64 = torch.randn(64, H, H, C, generator=g).to(dev)
+        xd = torch.randn(64 * ratio, H, H, C, generator=g).to(dev)      # the critic-phase passes, stacked (train.generate)
         x128 = torch.randn(128, H, H, C, generator=g).to(dev).requires_grad_(True)
-        work.append((x64, x128, G, B, torch.randn(128, H, H, C, generator=g).to(dev)))
+        work.append((xd, x128, G, B, torch.randn(128, H, H, C, generator=g).to(dev)))
 
     def one():
-        for x64, x128, G, B, gy in work:
+        for xd, x128, G, B, gy in work:
             with torch.no_grad():
-                for _ in range(ratio):
-                    whiten_color(x64, G, B)
+                whiten_color_grouped(xd, ratio, G, B)        # `ratio` forward passes with per-pass statistics
             whiten_color(x128, G, B).backward(gy)
     return time_kernel(one, iters=5, warm=2)
 
