@@ -188,3 +188,29 @@ def test_statistic_groups_equal_separate_passes(shape, Kc, G):
     for g in range(G):
         y_ref, _ = o.wc_forward(x[g * n:(g + 1) * n], Gm, B, slot[g * n:(g + 1) * n])
         assert rel(y_grouped[g * n:(g + 1) * n].cpu(), y_ref) < TOL
+
+
+def test_eval_mode_plan_is_cached_and_invalidated():
+    from wc_gan_amd.generator import create_norm
+    C, K = 64, 4
+    stack = create_norm('d', 'ucconv', number_of_classes=K)(axis=-1, name='s', channels=C).cuda()
+    for p in stack.parameters():
+        torch.nn.init.normal_(p, std=0.3)
+    rng = np.random.default_rng(41)
+    x = o.synth_activation(rng, (8, 8, 8, C), "well").astype(np.float32)
+    cls = dev(rng.integers(0, K, (8, 1)), torch.int32)
+    stack.train(); stack(dev(x), cls)             # one training call moves the statistics off their initial values
+    stack.eval()
+    with torch.no_grad():
+        y1 = stack(dev(x), cls)
+        key1 = stack.npart._eval_plan.key
+        y2 = stack(dev(x), cls)
+        assert stack.npart._eval_plan.key == key1 and torch.equal(y1, y2)
+        gamma, beta, slot = stack.coloring_table(dev(x), cls)
+        y_ref, _ = o.wc_forward(x, gamma.cpu().numpy(), beta.cpu().numpy(), slot.cpu().numpy(), training=False,
+                                moving_mean=stack.npart.moving_mean.cpu().numpy().reshape(-1),
+                                moving_cov=stack.npart.moving_cov.cpu().numpy())
+        assert rel(y1.cpu(), y_ref) < TOL
+        stack.npart.moving_cov.mul_(1.5)           # in-place change of the statistics -> the plan must be rebuilt
+        y3 = stack(dev(x), cls)
+        assert stack.npart._eval_plan.key != key1 and not torch.equal(y1, y3)

@@ -115,6 +115,39 @@ def whiten_color_grouped(x, groups, gamma=None, beta=None, slot=None, moving_mea
     return ops.apply(x, center, A, bias, full_slot.to(torch.int32).contiguous(), plan=plan)
 
 
+class EvalPlan:
+    """Eval-mode cache: the moving statistics are constants between weight updates, so
+    mu, W = chol((1-eps) moving_cov + eps I)^-1, A = W^T Gamma and the apply plan are computed once and reused --
+    the reference redoes the Cholesky on every scorer.py call.  Invalidated by any in-place change of the inputs."""
+
+    def __init__(self):
+        self.key = None
+        self.val = None
+
+    def get(self, C, gamma, moving_mean, moving_cov, eps, dev, gamma_key=None):
+        # gamma is usually rebuilt from the coloring weights on every call: key on those weights (gamma_key) when given
+        gk = gamma_key if gamma_key is not None else (None if gamma is None else (gamma.data_ptr(), gamma._version))
+        key = (C, eps, moving_mean._version, moving_cov._version, moving_mean.data_ptr(), moving_cov.data_ptr(),
+               None if gamma is None else tuple(gamma.shape), gk)
+        if key != self.key:
+            with torch.no_grad():
+                mu, L, W, cs = ops.factor(None, None, 1, C, eps, 0.0, 1, False, moving_mean.view(-1), moving_cov, dev,
+                                          want_scale=True)
+                g = gamma.detach().contiguous() if gamma is not None else None
+                A, At, plan = ops.color(W, g, cs)
+            self.key, self.val = key, (mu, A, At, plan)
+        return self.val
+
+
+def whiten_color_eval_cached(x, cache, gamma=None, beta=None, slot=None, moving_mean=None, moving_cov=None, eps=1e-3,
+                             gamma_key=None):
+    """Inference forward (no autograd) through an EvalPlan: one K3 launch per call once the plan is warm."""
+    C = x.shape[-1]
+    mu, A, At, plan = cache.get(C, gamma, moving_mean, moving_cov, eps, x.device, gamma_key)
+    b = beta.detach().contiguous() if beta is not None else None
+    return ops.apply(x.detach().contiguous(), mu, A, b, slot, plan=plan)
+
+
 def whiten_color(x, gamma=None, beta=None, slot=None, moving_mean=None, moving_cov=None, training=True,
                  eps=1e-3, momentum=0.99, ddof=1, process_group=None):
     """y = coloring(whitening(x)).  x: (N, H, W, C) float32 on the GPU, C % 32 == 0 (see layers for padding)."""

@@ -110,7 +110,7 @@ class DecorelationNormalization(_Lazy):
         self.register_buffer('moving_mean', torch.zeros(C, 1, device=device))
         self.register_buffer('moving_cov', torch.eye(C, device=device))
 
-    def transform(self, x, gamma=None, beta=None, slot=None):
+    def transform(self, x, gamma=None, beta=None, slot=None, gamma_key=None):
         """Whitening fused with an optional coloring table (gamma (Kc,C,C), beta (Kc,C), slot (N,))."""
         self._ensure(x)
         C = self.channels
@@ -126,6 +126,12 @@ class DecorelationNormalization(_Lazy):
                 raise RuntimeError("statistic_groups() is a forward-only path: wrap the call in torch.no_grad()")
             return WF.whiten_color_grouped(x, _STAT_GROUPS, gamma, beta, slot, self.moving_mean, self.moving_cov,
                                            self.epsilon, self.momentum, 1)
+        if not self.training and not torch.is_grad_enabled():
+            # inference (scorer.py:60,72): moving statistics are constants -> cached factorisation, one K3 launch
+            if not hasattr(self, '_eval_plan'):
+                self._eval_plan = WF.EvalPlan()
+            return WF.whiten_color_eval_cached(x, self._eval_plan, gamma, beta, slot, self.moving_mean, self.moving_cov,
+                                               self.epsilon, gamma_key)
         if self.renorm and self.training:
             gamma = self._renorm_gamma(x, gamma)
         return WF.whiten_color(x, gamma, beta, slot, self.moving_mean, self.moving_cov, self.training,
@@ -337,4 +343,8 @@ class WhiteningColoring(nn.Module):
             gamma = gamma.contiguous()
         if beta is not None:
             beta = beta.contiguous()
-        return self.npart.transform(x, gamma, beta, slot)
+        # identity of the coloring weights (for the eval-mode plan cache); per-sample tables depend on cls -> no key
+        per_sample = gamma is not None and slot is not None and gamma.shape[0] == x.shape[0] and \
+            any(getattr(b, 'number_of_classes', 0) > x.shape[0] for b in self.branches)
+        key = None if per_sample else tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return self.npart.transform(x, gamma, beta, slot, gamma_key=key)
