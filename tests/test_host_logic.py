@@ -124,3 +124,23 @@ def test_flat_grad_bucket_views_track_backward():
     assert all(p.grad.data_ptr() >= b.flat.data_ptr() for p in params)
     b.zero()
     assert float(lin.weight.grad.abs().sum()) == 0.0
+
+
+def test_keras_named_checkpoint_roundtrip(tmp_path):
+    from wc_gan_amd.checkpoint import keras_named_state, load_keras_named, save_keras_named
+    G = make_generator(**CIFAR10_COND['generator'])
+    st = keras_named_state(G)
+    # names follow generator.py:85-86 / 55-58 / 154
+    assert 'Generator.BN.Final_npart/moving_cov:0' in st and st['Generator.BN.Final_npart/moving_mean:0'].shape == (128, 1)
+    assert st['Generator.BN.Final_repart/kernel:0'].shape == (1, 1, 128, 128)
+    assert st['Generator.0.bn1_repart_c/kernel:0'].shape == (10, 128, 128)
+    assert st['Generator.0.bn1_repart_u/bias:0'].shape == (128,)
+    p = str(tmp_path / "g.npz")
+    save_keras_named(G, p)
+    G2 = make_generator(**CIFAR10_COND['generator'])
+    loaded = load_keras_named(G2, p)
+    assert len(loaded) == len(st)
+    for k, v in keras_named_state(G2).items():
+        assert np.array_equal(v, st[k])
+    with pytest.raises(KeyError):
+        load_keras_named(G2, {k: v for k, v in list(st.items())[:-1]})
