@@ -16,4 +16,4 @@ names = ['start', 'vmcnt wait done', 'dma issued', 'mfma+convert done', 'stores 
 for wg in range(2):
     for w in (0, 4):
         t = d[wg, w].tolist()
-        print(f'WG{wg} wave{w}:', ' '.join(f'{names[i]}=+{t[i]-t[0]}' for i in range(1, 6)))
+        print(f'WG{wg} wave{w}:', ' '.join(f'{names[i]}=+{t[i]-t[0]}' for i in range(1, 5)), f'| loop: {t[6]} shader ticks / {t[7]} x10ns -> {t[6]/max(t[7],1)*0.1:.2f} GHz')

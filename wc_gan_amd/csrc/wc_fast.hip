@@ -415,7 +415,7 @@ __global__ __launch_bounds__(512, 2) void affine_f16x3_kernel(FastArgs a)
 // Tiles are 32 KiB (8192/C rows): 2 fp16 image buffers + 2 raw slots + counters.  Every wave owns one 32-row
 // sub-tile per tile and converts exactly the 4 KiB of the next tile that its own DMA brought in (ds_read_b128 ->
 // centre/scale/split -> ds_write_b64), so a raw slot needs no cross-wave hand-off at all.  Hand count at the top of
-// a tile: the 4 DMAs of tile t+1 were issued one tile ago and only that tile's 16 stores are younger -> vmcnt(16).
+// a tile: the 4 DMAs of tile t+1 were issued one tile ago and only the 16 stores issued since are younger -> vmcnt(16).
 // An element outside the fp16 range marks the workgroup; it then recomputes all of its tiles in fp32 at the end.
 // ---------------------------------------------------------------------------------------------------------------
 template <int C, bool HAS_SLOT>
@@ -549,6 +549,12 @@ __global__ __launch_bounds__(512, 2) void affine_ring_kernel(FastArgs a)
     const int out_lane = (rbase + 4 * lh) * C + col;
     unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool stamp_on = false;
+    f32x16 pacc;                       // finished rows of the previous tile, stored during the current one
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pacc[r] = 0.f;
+    float* ppo = a.out;
+    unsigned long long clk0 = 0, rt0 = 0;
+    if (WC_STAMPS) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
 
     for (int t = 0; t < n; ++t) {
         stamp_on = WC_STAMPS && (t == 6);
@@ -561,48 +567,65 @@ __global__ __launch_bounds__(512, 2) void affine_ring_kernel(FastArgs a)
         wait_for(1, 8 * t);                        // tile t-1 read by all: image buffer (t+1)&1 may be rewritten
         const bool conv = t + 1 < n;
         if (conv) {     // this wave's DMA of tile t+1 must have landed before it converts it (see the count above)
-            if (t >= 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            // younger than those DMAs: the 16 stores (of tile t-2) that rode in tile t-1's MFMA gaps -- none before t = 2
+            if (t >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         WC_STAMP(1);
-        if (t + 2 < n) dma_tile(t + 2);            // raw slot t&1: this wave finished converting tile t one tile ago
+        if (t + 2 < n && !(WC_ABL & 8)) dma_tile(t + 2);   // raw slot t&1: this wave finished converting tile t one tile ago
         WC_STAMP(2);
-        float* out_tile = a.out + (int64_t)tile_of(t) * (TR * C);
         const char* hrow = fbuf + (t & 1) * FBUF + rd_off;
         const char* lrow = hrow + IMG;
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        f16x8 ah = *reinterpret_cast<const f16x8*>(hrow + ((0 + lh) ^ sw) * 16);
-        f16x8 al = *reinterpret_cast<const f16x8*>(lrow + ((0 + lh) ^ sw) * 16);
+        // fragments are fetched TWO k-steps ahead: with eight waves on the LDS a ds_read_b128 takes longer than the
+        // 96 cycles of one k-step's three MFMAs, and an in-order wave that waits for it issues nothing else
+        auto frag = [&](const char* base, int s) { return *reinterpret_cast<const f16x8*>(base + (((2 * s + lh) ^ sw) * 16)); };
+        f16x8 ah = frag(hrow, 0), al = frag(lrow, 0);
+        f16x8 bh_ = ah, bl_ = al;
+        if (KS > 1) { bh_ = frag(hrow, 1); bl_ = frag(lrow, 1); }
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            f16x8 nh = ah, nl = al;
-            if (s + 1 < KS) {
-                const int chunk = (2 * (s + 1) + lh) ^ sw;
-                nh = *reinterpret_cast<const f16x8*>(hrow + chunk * 16);
-                nl = *reinterpret_cast<const f16x8*>(lrow + chunk * 16);
-            }
+            f16x8 nh = bh_, nl = bl_;
+            if (s + 2 < KS) { nh = frag(hrow, s + 2); nl = frag(lrow, s + 2); }
             constexpr int STEP = (KS >= 4) ? KS / 4 : 1;
             constexpr int PER = (KS >= 4) ? 1 : 4 / KS;
             if (conv && (s % STEP) == 0 && (s / STEP) < 4) {
 #pragma unroll
-                for (int q = 0; q < PER; ++q) convert_chunk(t + 1, (s / STEP) * PER + q);
+                for (int q = 0; q < PER; ++q) if (!(WC_ABL & 4)) convert_chunk(t + 1, (s / STEP) * PER + q);
             }
+            // the PREVIOUS tile's 16 output rows leave in the gaps of this tile's MFMAs (a store phase of its own
+            // would keep the matrix pipe idle for ~20 % of the tile: all eight waves reach it together)
+            constexpr int SPS = 16 / KS > 0 ? 16 / KS : 1;      // stores per k-step
+            if (t > 0 && s * SPS < 16) {
+#pragma unroll
+                for (int q = 0; q < SPS; ++q) {
+                    const int r = s * SPS + q;
+                    if (WC_ABL & 1) asm volatile("" :: "v"(pacc[r])); else
+                    ppo[((r & 3) + 8 * (r >> 2)) * C] = pacc[r];
+                }
+            }
+            if (WC_ABL & 2) { asm volatile("" :: "v"(ah), "v"(al)); }
+            else {
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bhi[s], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, blo[s], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bhi[s], acc, 0, 0, 0);
-            ah = nh; al = nl;
+            }
+            ah = bh_; al = bl_; bh_ = nh; bl_ = nl;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my image reads and my conversion writes are done
         if (conv) arrive(0);
         arrive(1);
         WC_STAMP(3);
-        float* po = out_tile + out_lane;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) po[((r & 3) + 8 * (r >> 2)) * C] = acc[r] * cscale + addv;
+        for (int r = 0; r < 16; ++r) pacc[r] = acc[r] * cscale + addv;
+        ppo = a.out + (int64_t)tile_of(t) * (TR * C) + out_lane;
         WC_STAMP(4);
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ppo[((r & 3) + 8 * (r >> 2)) * C] = pacc[r];      // the last tile's rows
+    if (WC_STAMPS) { ts[6] = __builtin_amdgcn_s_memtime() - clk0; ts[7] = __builtin_amdgcn_s_memrealtime() - rt0; }
     if (WC_STAMPS && a.dbg && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 100)) {
         unsigned long long* d = a.dbg + ((blockIdx.x ? 1 : 0) * 8 + wave) * 8;
         for (int i = 0; i < 8; ++i) d[i] = ts[i];
