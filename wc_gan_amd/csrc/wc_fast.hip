@@ -22,8 +22,11 @@
 #define WC_STAMPS 0
 #endif
 #define WC_STAMP(i) do { if (WC_STAMPS && stamp_on) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ts[i] = t_; } } while (0)
+#ifndef WC_NO_PIPE
+#define WC_NO_PIPE 0   // development: 1 leaves the ring kernel's k-loop to hipcc's own schedule
+#endif
 #ifndef WC_ABL
-#define WC_ABL 0      // development ablation bits: 1 no stores, 2 no MFMA, 4 no staging writes, 8 no loads
+#define WC_ABL 0      // development ablation bits: 1 no stores, 2 no MFMA, 4 no staging writes, 8 no loads, 16 no counters, 32 MFMA operands from registers only
 #endif
 #include <type_traits>
 
@@ -76,8 +79,12 @@ __global__ __launch_bounds__(1024) void channel_scale_kernel(const float* __rest
 }
 
 // --------------------------------------------------------------------------------------------
-// B table split: B[slot][k][n] fp32 (row-major, as wc_color_f32 writes A / At) -> transposed fp16 hi/lo
-// images T[slot][n][k] of  B[k][n] / s_k / colscale[n]   (k contiguous: one 16-B load per MFMA fragment).
+// B table split: B[slot][k][n] fp32 (row-major, as wc_color_f32 writes A / At) -> fp16 hi/lo images of
+// B[k][n] / s_k / colscale[n], stored in the order the apply kernels load them: for column group g = n/32 and
+// k-step s = k/16 the 64 lanes' 16-byte MFMA B-fragments (lane = 32*((k/8)&1) + n%32, 8 consecutive k each) form one
+// contiguous KiB.  Every workgroup of an apply kernel pulls the whole 4*C*C-byte table into registers, so with a
+// plain [n][k] image each load instruction touched 32 cache lines for 32 bytes apiece and the prologue took ~9 us
+// at C = 256 (measured); in this order each byte crosses the L2 -> CU path once per workgroup.
 // one wave per (slot, n)
 // --------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void split_table_kernel(const float* __restrict__ B, const float* __restrict__ scale,
@@ -108,8 +115,13 @@ __global__ __launch_bounds__(64) void split_table_kernel(const float* __restrict
             const float w = v[i] * inv;
             const _Float16 h = (_Float16)w;
             const _Float16 l = (_Float16)(w - (float)h);
-            hi[row * C + k] = h;
-            lo[row * C + k] = l;
+            // "register image" order: the 16 bytes a lane loads for MFMA fragment (column group n/32, k-step k/16) sit
+            // with the other 63 lanes' in one contiguous KiB
+            const int n = (int)(row % C), KS = C / 16;
+            const int64_t idx = (row / C) * (int64_t)C * C +
+                                ((((int64_t)(n >> 5) * KS + (k >> 4)) * 64 + ((k >> 3) & 1) * 32 + (n & 31)) * 8 + (k & 7));
+            hi[idx] = h;
+            lo[idx] = l;
         }
     }
     if (lane == 0) colscale[row] = cs;
@@ -117,9 +129,10 @@ __global__ __launch_bounds__(64) void split_table_kernel(const float* __restrict
 
 struct FastArgs {
     const float* in; const float* center; const float* scale;       // [M,C], [C]|null, [C]
-    const _Float16* Bhi; const _Float16* Blo; const float* colscale; // [slots][C(n)][C(k)], [slots][C]
+    const _Float16* Bhi; const _Float16* Blo; const float* colscale; // [slots][C*C] in register-image order, [slots][C]
     int64_t slot_stride;                                             // C*C, or 0 when the table is shared
-    const float* bias; const float* sub; const int32_t* slot;
+    const float* bias; const float* sub; const int32_t* slot;          // bias/sub may be null
+    int bias_on, sub_on;                                             // ring kernel: bias/sub are then pointed at `scale` and ignored
     int64_t M, HW;
     int accumulate;
     const float* Bf; int64_t bf_stride;                             // the fp32 table [slot][k][n] for the exact path
@@ -233,12 +246,12 @@ __global__ __launch_bounds__(512, 2) void affine_f16x3_kernel(FastArgs a)
     int cur_slot = -1;
     const int col = cg * 32 + l31;
     auto load_b = [&](int slot) {
-        const _Float16* ph = a.Bhi + (int64_t)slot * a.slot_stride + (col * C + 8 * lh);
-        const _Float16* pl = a.Blo + (int64_t)slot * a.slot_stride + (col * C + 8 * lh);
+        const _Float16* ph = a.Bhi + (int64_t)slot * a.slot_stride + ((int64_t)cg * KS * 64 + lane) * 8;
+        const _Float16* pl = a.Blo + (int64_t)slot * a.slot_stride + ((int64_t)cg * KS * 64 + lane) * 8;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            bhi[s] = *reinterpret_cast<const f16x8*>(ph + 16 * s);
-            blo[s] = *reinterpret_cast<const f16x8*>(pl + 16 * s);
+            bhi[s] = *reinterpret_cast<const f16x8*>(ph + 512 * s);
+            blo[s] = *reinterpret_cast<const f16x8*>(pl + 512 * s);
         }
         const int64_t srow_ = a.slot_stride ? slot : 0;
         cscale = a.colscale[srow_ * C + col];
@@ -403,34 +416,54 @@ __global__ __launch_bounds__(512, 2) void affine_f16x3_kernel(FastArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Ring variant (non-accumulating calls).  Two things the register-staged kernel above cannot do:
-//  * The activation rows travel HBM -> LDS by LDS-DMA (global_load_lds, no VGPR in between) into a two-deep ring of
-//    raw fp32 tiles, two tile periods ahead of their use: the load latency is off the critical path (measured: 4 %
-//    of a tile in the vmcnt wait, against ~40 % when a register-staged load is consumed one tile after its issue).
-//  * There is NO workgroup barrier in the tile loop.  A barrier keeps all eight waves in the same phase, so the
-//    matrix pipe idles whenever they store or stage (measured: pipe saturated for 3100 of 5400 ticks per tile, idle
-//    for the rest).  Instead two monotonic LDS counters order the only true dependencies -- "tile t is converted by
-//    all waves" before anyone reads it, "tile t-1 is read by all waves" before its image buffer is rewritten -- and
-//    a wave's stores, DMA issue and waits overlap the MFMAs of the other wave on its SIMD.
-// Tiles are 32 KiB (8192/C rows): 2 fp16 image buffers + 2 raw slots + counters.  Every wave owns one 32-row
-// sub-tile per tile and converts exactly the 4 KiB of the next tile that its own DMA brought in (ds_read_b128 ->
-// centre/scale/split -> ds_write_b64), so a raw slot needs no cross-wave hand-off at all.  Hand count at the top of
-// a tile: the 4 DMAs of tile t+1 were issued one tile ago and only the 16 stores issued since are younger -> vmcnt(16).
-// An element outside the fp16 range marks the workgroup; it then recomputes all of its tiles in fp32 at the end.
+// Ring variant (non-accumulating calls).  What the register-staged kernel above cannot do:
+//  * The activation rows travel HBM -> LDS by LDS-DMA (global_load_lds, no VGPR in between) in 1-KiB chunks (one
+//    wave-instruction), into a ring of SEVEN chunk slots per wave: chunk i+7 is requested the moment chunk i has been
+//    read out for conversion, so every wave keeps 6-7 KiB in flight ~1.75 tiles ahead of use and a raw slot needs no
+//    cross-wave hand-off at all (each wave converts exactly what its own DMA brought in).
+//  * There is NO workgroup barrier in the tile loop and the eight waves are NOT kept in lock-step.  Measured on the
+//    two-image-buffer predecessor of this kernel: its two hand-offs ("tile t converted by all" before anyone reads it,
+//    "tile t-1 read by all" before its buffer is rewritten) amounted to a barrier per tile; the k-loop itself ran at
+//    ~3400 of the 3072 matrix-pipe cycles a SIMD needs per tile, but every tile then lost ~2000 cycles to the slowest
+//    wave, the counter polls and the DMA issue, on all SIMDs at once.  Here there are THREE fp16 image buffers, the
+//    conversion of tile t+1 rides in the FIRST half of tile t's k-loop and is published in mid-loop, so both
+//    hand-offs have half a tile of slack; waves 4-7 start half a tile late, and from then on one wave of each SIMD
+//    polls, issues DMA and converts while its partner is in the MFMA-only half of its loop.
+//  * Inside the k-loop every MFMA is followed by its share of the other work (LDS reads two k-steps ahead, one
+//    conversion stage, a store of the previous tile's rows): the order is pinned gap by gap with sched_barrier.
+// Tiles are 32 KiB (8192/C rows).  An element outside the fp16 range marks the workgroup; it then recomputes all of
+// its tiles in fp32 at the end.
+// vmcnt by hand: before chunk i (of tile t+1, read out during tile t) only its DMA has to have landed.  That DMA was
+// issued in the first half of tile t-1's loop; younger are the six DMAs of chunks i+1..i+6 (when those exist:
+// t + 3 < n) and the 16 stores at the end of tile t-1: vmcnt(22); fewer DMAs near the end (see WM_).
 // ---------------------------------------------------------------------------------------------------------------
+#ifndef WC_STAGGER
+#define WC_STAGGER 1
+#endif
+#ifndef WC_AHEAD
+#define WC_AHEAD 1      // k-steps between a fragment's ds_read and its MFMAs (2 measured no faster, costs 8 VGPRs)
+#endif
+
 template <int C, bool HAS_SLOT>
 __global__ __launch_bounds__(512, 2) void affine_ring_kernel(FastArgs a)
 {
     constexpr int TR = 8192 / C;              // rows per tile (32 KiB of fp32)
     constexpr int CPR = C / 8, KS = C / 16, CG = C / 32, C4 = C / 4;
-    constexpr int IMG = TR * C * 2;           // one fp16 image: 16 KiB
+    // fp16 image rows: C >= 128 pads every row by one 16-byte chunk (row r starts r chunks further round the 64 banks,
+    // conflict-free for the ds_read_b128 lane groups, and every fragment address is lane base + immediate); the
+    // narrower tiles have no LDS to spare for that and XOR-swizzle the chunks of a row instead
+    constexpr int PAD = C >= 128 ? 16 : 0;
+    constexpr int PITCH = C * 2 + PAD;
+    constexpr int IMG = TR * PITCH;           // one fp16 image: 16 KiB (+ padding)
     constexpr int FBUF = 2 * IMG;             // hi | lo
-    constexpr int RAW = TR * C * 4;           // 32 KiB
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // F0 | F1 | R0 | R1 | counters
+    constexpr int NSLOT = 7, RAWW = NSLOT * 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // F0 | F1 | F2 | raw[8 waves][7 KiB] | counters
     char* const fbuf = smem;
-    char* const ring = smem + 2 * FBUF;
-    volatile int* const cnt = reinterpret_cast<volatile int*>(smem + 2 * FBUF + 2 * RAW);   // [0] converted, [1] read, [2] dirty
+    char* const ring = smem + 3 * FBUF;
+    volatile int* const cnt = reinterpret_cast<volatile int*>(smem + 3 * FBUF + 8 * RAWW);   // [0] converted, [1] read, [2] dirty
 
+    unsigned long long rt_in = 0;
+    if (WC_STAMPS) rt_in = __builtin_amdgcn_s_memrealtime();
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cg = wave % CG, rg = wave / CG;
@@ -447,6 +480,7 @@ __global__ __launch_bounds__(512, 2) void affine_ring_kernel(FastArgs a)
     if (n <= 0) return;
     auto tile_of = [&](int i) { return t_first + i * t_stride; };
     auto swz = [](int row) -> int {
+        if (PAD) return 0;
         if (CPR >= 16) return row & 15;
         return (row / (16 / CPR)) & (CPR - 1);
     };
@@ -454,22 +488,17 @@ __global__ __launch_bounds__(512, 2) void affine_ring_kernel(FastArgs a)
     if (tid < 3) cnt[tid] = 0;
     __syncthreads();
 
-    // DMA: wave w moves bytes [4w KiB, 4w+4 KiB) of a tile with four 1-KiB instructions (lane = 16 B)
-    auto dma_tile = [&](int i) {
-        const char* g = reinterpret_cast<const char*>(a.in + (int64_t)tile_of(i) * (TR * C)) + wave * 4096 + lane * 16;
-        char* l = ring + (i & 1) * RAW + wave * 4096;
-        // inline asm on purpose: hipcc drains vmcnt(0) before any ds_read that may alias a pending LDS-DMA it knows of,
-        // which would wait for the DMA issued a moment ago and for every store in flight.  M0 (the LDS destination
-        // base) is set and restored inside the statement; completion is counted by hand (vmcnt(16) below).
-        const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)l);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            unsigned keep;
-            const char* gq = g + q * 1024;
-            const unsigned lq = __builtin_amdgcn_readfirstlane(lds0 + q * 1024);
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(gq), "s"(lq) : "memory");
-        }
+    // DMA of chunk p (1 KiB: lane = 16 B) of this wave's 4 KiB of tile tl into raw slot `slot`.
+    // Inline asm on purpose: hipcc drains vmcnt(0) before any ds_read that may alias a pending LDS-DMA it knows of,
+    // which would wait for the DMA issued a moment ago and for every store in flight.  M0 (the LDS destination base)
+    // is set and restored inside the statement; completion is counted by hand (see the header).
+    const unsigned ring_w = (unsigned)(size_t)((__attribute__((address_space(3))) char*)(ring + wave * RAWW));
+    auto dma_chunk = [&](int tl, int p, int slot, int lane_) {
+        const char* g = reinterpret_cast<const char*>(a.in + (int64_t)tile_of(tl) * (TR * C)) + wave * 4096 + p * 1024 + lane_ * 16;
+        const unsigned l = __builtin_amdgcn_readfirstlane(ring_w + slot * 1024);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(g), "s"(l) : "memory");
     };
 
     // conversion of this wave's own 4 KiB: float4 #e = 256*wave + lane + 64*p
@@ -477,24 +506,42 @@ __global__ __launch_bounds__(512, 2) void affine_ring_kernel(FastArgs a)
     const f32x4 scl = ld4f(a.scale + 4 * c4i);
     f32x4 ncs = {0.f, 0.f, 0.f, 0.f};
     if (a.center) ncs = -ld4f(a.center + 4 * c4i) * scl;
-    bool overflow = false;
-    auto convert_chunk = [&](int i, int p) {
-        const int e = 256 * wave + lane + 64 * p;
-        const int row = e / C4;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(ring + (i & 1) * RAW + e * 16);
-        const f32x4 g = v * scl + ncs;
-        overflow |= (fabsf(g[0]) > kF16Guard) | (fabsf(g[1]) > kF16Guard) | (fabsf(g[2]) > kF16Guard) | (fabsf(g[3]) > kF16Guard);
-        const unsigned hw01 = pk_rne(g[0], g[1]), hw23 = pk_rne(g[2], g[3]);
-        const f16x2 h01 = __builtin_bit_cast(f16x2, hw01), h23 = __builtin_bit_cast(f16x2, hw23);
-        const unsigned l01 = pk_rne(g[0] - (float)h01[0], g[1] - (float)h01[1]);
-        const unsigned l23 = pk_rne(g[2] - (float)h23[0], g[3] - (float)h23[1]);
-        char* dst = fbuf + (i & 1) * FBUF + row * (C * 2) + (((c4i >> 1) ^ swz(row)) * 16) + (c4i & 1) * 8;
-        *reinterpret_cast<uint2*>(dst) = make_uint2(hw01, hw23);
-        *reinterpret_cast<uint2*>(dst + IMG) = make_uint2(l01, l23);
+    float gmax = 0.f;                           // running max |scaled element| (fp16 range guard)
+    f32x4 craw, cg4;
+    unsigned chw01 = 0, chw23 = 0, clw01 = 0, clw23 = 0;
+    auto craw_read = [&](int slot, int lane_) {
+        craw = *reinterpret_cast<const f32x4*>(ring + wave * RAWW + slot * 1024 + lane_ * 16);
+    };
+    auto cv_scale = [&]() {
+        cg4 = craw * scl + ncs;
+        gmax = __builtin_fmaxf(__builtin_fmaxf(gmax, fabsf(cg4[0])), fabsf(cg4[1]));
+        gmax = __builtin_fmaxf(__builtin_fmaxf(gmax, fabsf(cg4[2])), fabsf(cg4[3]));
+    };
+    auto cv_hi = [&]() { chw01 = pk_rne(cg4[0], cg4[1]); chw23 = pk_rne(cg4[2], cg4[3]); };
+    auto cv_lo = [&]() {
+        const f16x2 h01 = __builtin_bit_cast(f16x2, chw01), h23 = __builtin_bit_cast(f16x2, chw23);
+        (void)h01; (void)h23;
+        // remainder = g - float(hi) in one mixed-precision FMA per element (v_fma_mix_f32 reads the fp16 half directly)
+        float r0, r1, r2, r3;
+        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(chw01), "v"(cg4[0]));
+        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(chw01), "v"(cg4[1]));
+        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r2) : "v"(chw23), "v"(cg4[2]));
+        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r3) : "v"(chw23), "v"(cg4[3]));
+        clw01 = pk_rne(r0, r1);
+        clw23 = pk_rne(r2, r3);
+    };
+    // padded rows: chunk p of a lane lands a constant (64 / C4) rows below its chunk 0 -- one lane offset + immediates
+    const int woff0 = ((256 * wave + lane) / C4) * PITCH + c4i * 8;
+    auto cv_write = [&](int fb, int p, int lane_, int c4i_, int woff0_) {
+        const int row = (int)((unsigned)(256 * wave + lane_ + 64 * p) / (unsigned)C4);
+        char* dst = PAD ? fbuf + fb * FBUF + woff0_ + p * ((64 / C4) * PITCH)
+                        : fbuf + fb * FBUF + row * PITCH + (((c4i_ >> 1) ^ swz(row)) * 16) + (c4i_ & 1) * 8;
+        *reinterpret_cast<uint2*>(dst) = make_uint2(chw01, chw23);
+        *reinterpret_cast<uint2*>(dst + IMG) = make_uint2(clw01, clw23);
     };
     // one arrival per wave on a monotonic counter, after this wave's LDS traffic has completed
     // (asm: a C++ volatile/atomic access makes hipcc drain vmcnt(0) around it, i.e. wait for the stores in flight)
-    const unsigned cnt_lds = (unsigned)(size_t)((__attribute__((address_space(3))) char*)(smem + 2 * FBUF + 2 * RAW));
+    const unsigned cnt_lds = (unsigned)(size_t)((__attribute__((address_space(3))) char*)(smem + 3 * FBUF + 8 * RAWW));
     auto arrive = [&](int which) {
         if (lane == 0) {
             const unsigned one = 1u, addr = cnt_lds + 4u * which;
@@ -512,123 +559,206 @@ __global__ __launch_bounds__(512, 2) void affine_ring_kernel(FastArgs a)
     };
 
     f16x8 bhi[KS], blo[KS];
-    float cscale = 1.f, addv = 0.f;
+    float cscale = 1.f, addv = 0.f, addv_b = 0.f, addv_s = 0.f;
     int cur_slot = -1;
     const int col = cg * 32 + l31;
     auto load_b = [&](int slot) {
-        const _Float16* ph = a.Bhi + (int64_t)slot * a.slot_stride + (col * C + 8 * lh);
-        const _Float16* pl = a.Blo + (int64_t)slot * a.slot_stride + (col * C + 8 * lh);
+        const _Float16* ph = a.Bhi + (int64_t)slot * a.slot_stride + ((int64_t)cg * KS * 64 + lane) * 8;
+        const _Float16* pl = a.Blo + (int64_t)slot * a.slot_stride + ((int64_t)cg * KS * 64 + lane) * 8;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            bhi[s] = *reinterpret_cast<const f16x8*>(ph + 16 * s);
-            blo[s] = *reinterpret_cast<const f16x8*>(pl + 16 * s);
+            bhi[s] = *reinterpret_cast<const f16x8*>(ph + 512 * s);
+            blo[s] = *reinterpret_cast<const f16x8*>(pl + 512 * s);
         }
         const int64_t srow_ = a.slot_stride ? slot : 0;
         cscale = a.colscale[srow_ * C + col];
-        addv = 0.f;
-        if (a.bias) addv += a.bias[(int64_t)slot * C + col];
-        if (a.sub) addv -= a.sub[col];
+        // loaded unconditionally from a valid address and selected afterwards: a consumed-at-once conditional load
+        // would make hipcc drain every load in flight right here
+        const float bv = a.bias[a.bias_on ? (int64_t)slot * C + col : 0];
+        const float sv = a.sub[a.sub_on ? col : 0];
+        addv_b = bv; addv_s = sv;
         cur_slot = slot;
     };
+    auto finish_b = [&]() { addv = (a.bias_on ? addv_b : 0.f) - (a.sub_on ? addv_s : 0.f); };
 
-    // prologue: two tiles in flight, this wave's share of the first one converted
-    dma_tile(0);
-    if (n > 1) dma_tile(1);
+    // prologue: chunks 0..6 requested, then the B' table (KS*2 + <= 3 loads per lane, in flight while tile 0 is
+    // converted); each read-out slot is refilled at once (chunks 7..10).  Chunk p's DMA always has six younger DMAs
+    // (chunks p+1..6 and the p refills) and the table's loads behind it; a single workgroup tile (n == 1) has fewer DMAs in flight and simply drains.
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) if (i / 4 < n) dma_chunk(i / 4, i % 4, i, lane);
     if (!HAS_SLOT) load_b(0);
+    constexpr int TBL = HAS_SLOT ? 0 : 2 * KS + 3;      // the table's vector loads per lane: fragments, colscale, bias, sub
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        if (n >= 2) {
+            if (p == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(TBL + 6) : "memory");
+            if (p == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(TBL + 6) : "memory");
+            if (p == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(TBL + 6) : "memory");
+            if (p == 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(TBL + 6) : "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        craw_read(p, lane);
+        cv_scale();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the slot has been read out
+        if ((p + NSLOT) / 4 < n) dma_chunk((p + NSLOT) / 4, (p + NSLOT) % 4, p, lane);
+        cv_hi(); cv_lo(); cv_write(0, p, lane, c4i, woff0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    arrive(0);
     // the BUILTIN wait (not asm): hipcc must see that the B' loads have completed here, or it waits for them with
     // small vmcnt counts inside the loop -- draining the DMAs and stores the loop wants to keep in flight
     __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0) only
-#pragma unroll
-    for (int p = 0; p < 4; ++p) convert_chunk(0, p);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    arrive(0);
+    if (!HAS_SLOT) finish_b();
 
     const int rbase = rg * 32;
     const int sw = swz(rbase + l31);
-    const int rd_off = (rbase + l31) * (C * 2);
+    const int rd_off = (rbase + l31) * PITCH;
     const int out_lane = (rbase + 4 * lh) * C + col;
     unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool stamp_on = false;
-    f32x16 pacc;                       // finished rows of the previous tile, stored during the current one
-#pragma unroll
-    for (int r = 0; r < 16; ++r) pacc[r] = 0.f;
-    float* ppo = a.out;
     unsigned long long clk0 = 0, rt0 = 0;
     if (WC_STAMPS) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+    if (WC_STAGGER && wave >= 4 && n >= 4) __builtin_amdgcn_s_sleep(24);      // ~half a tile behind waves 0-3
 
-    for (int t = 0; t < n; ++t) {
+    int rslot = 4;                     // raw slot of chunk 4(t+1) = chunk 0 of the tile converted during tile t
+    int fcur = 0;                      // image buffer of tile t
+    using T_ = std::integral_constant<bool, true>;
+    using F_ = std::integral_constant<bool, false>;
+    // CONV_: a next tile exists and is converted during this one (compile-time, so that no branch splits the gaps'
+    // issue groups).
+    // WM_ picks the hand-counted wait in front of each chunk read-out (header): 0 vmcnt(0); 1 tile 0 (six younger
+    // DMAs, no stores yet); 2 steady state; 3 tile n-3 (>= 4 younger DMAs); 4 tile n-2 (3-p younger DMAs for chunk p).
+    auto tile_body = [&](int t, auto conv_tag, auto wm_tag) {
+        constexpr bool CONV_ = decltype(conv_tag)::value;
+        constexpr int WM_ = decltype(wm_tag)::value;
         stamp_on = WC_STAMPS && (t == 6);
         WC_STAMP(0);
-        if (HAS_SLOT) {
-            const int slot = a.slot[((int64_t)tile_of(t) * TR) / a.HW];
-            if (slot != cur_slot) { load_b(slot); __builtin_amdgcn_s_waitcnt(0x0F70); }
-        }
-        wait_for(0, 8 * (t + 1));                  // tile t converted by all eight waves
-        wait_for(1, 8 * t);                        // tile t-1 read by all: image buffer (t+1)&1 may be rewritten
-        const bool conv = t + 1 < n;
-        if (conv) {     // this wave's DMA of tile t+1 must have landed before it converts it (see the count above)
-            // younger than those DMAs: the 16 stores (of tile t-2) that rode in tile t-1's MFMA gaps -- none before t = 2
-            if (t >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        const int fnext = fcur == 2 ? 0 : fcur + 1;
+        // per-tile opaque copies of the lane constants that feed LDS addresses: without them hipcc hoists every
+        // address of every instantiated tile body out of the loop (~60 VGPRs) and spills them
+        int sw_t = sw, c4i_t = c4i, lane_t = lane, lh_t = lh, woff_t = woff0;
+        asm volatile("" : "+v"(sw_t), "+v"(c4i_t), "+v"(lane_t), "+v"(lh_t), "+v"(woff_t));
+        wait_for(0, 8 * (t + 1));                  // tile t converted by all eight waves (published in mid-loop t-1)
+        if (CONV_) wait_for(1, 8 * (t - 1));       // tile t-2 read by all: image buffer (t+1)%3 may be rewritten
         WC_STAMP(1);
-        if (t + 2 < n && !(WC_ABL & 8)) dma_tile(t + 2);   // raw slot t&1: this wave finished converting tile t one tile ago
-        WC_STAMP(2);
-        const char* hrow = fbuf + (t & 1) * FBUF + rd_off;
+        // raw slots of the four chunks converted during this tile
+        int rs[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { const int v = rslot + p; rs[p] = v >= NSLOT ? v - NSLOT : v; }
+        auto chunk_wait = [&](int p) {
+            if (WM_ == 2) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+            else if (WM_ == 3) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+            else if (WM_ == 4 && p == 0) asm volatile("s_waitcnt vmcnt(19)" ::: "memory");
+            else if (WM_ == 4 && p == 1) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+            else if (WM_ == 4 && p == 2) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+            else if (WM_ == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (WM_ == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        const char* hrow = fbuf + fcur * FBUF + rd_off;
         const char* lrow = hrow + IMG;
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         // fragments are fetched TWO k-steps ahead: with eight waves on the LDS a ds_read_b128 takes longer than the
         // 96 cycles of one k-step's three MFMAs, and an in-order wave that waits for it issues nothing else
-        auto frag = [&](const char* base, int s) { return *reinterpret_cast<const f16x8*>(base + (((2 * s + lh) ^ sw) * 16)); };
+        auto frag = [&](const char* base, int s) {
+            if (PAD) return *reinterpret_cast<const f16x8*>(base + lh_t * 16 + 32 * s);      // lane base + immediate
+            return *reinterpret_cast<const f16x8*>(base + (((2 * s + lh) ^ sw_t) * 16));
+        };
+        constexpr int AHEAD = WC_AHEAD;
         f16x8 ah = frag(hrow, 0), al = frag(lrow, 0);
         f16x8 bh_ = ah, bl_ = al;
-        if (KS > 1) { bh_ = frag(hrow, 1); bl_ = frag(lrow, 1); }
+        if (KS > 1 && AHEAD == 2) { bh_ = frag(hrow, 1); bl_ = frag(lrow, 1); }
+        if (CONV_) { chunk_wait(0); craw_read(rs[0], lane_t); }
+        WC_STAMP(2);
+        // the conversion of tile t+1 as 20 small steps in the first half of the loop (chunk p: scale+refill, next
+        // chunk's read-out, split hi, split lo, write), then its publication
+        auto cstep = [&](int j) {
+            const int p = j / 5, st = j % 5;
+            if (st == 0) {
+                cv_scale();                           // consumes craw: slot rs[p] is free
+                const int tl = t + 1 + (p + NSLOT) / 4;
+                if (tl < n) dma_chunk(tl, (p + NSLOT) % 4, rs[p], lane_t);
+            } else if (st == 1) {
+                if (p + 1 < 4) { chunk_wait(p + 1); craw_read(rs[p + 1], lane_t); }
+            } else if (st == 2) cv_hi();
+            else if (st == 3) cv_lo();
+            else cv_write(fnext, p, lane_t, c4i_t, woff_t);
+        };
+        constexpr int G = 3 * KS;            // MFMAs = issue gaps per tile
+        constexpr int H = G / 2 > 0 ? G / 2 : 1;
+        // one issue gap = one MFMA plus whatever is listed for it; sched_barrier(0) pins the order gap by gap
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             f16x8 nh = bh_, nl = bl_;
-            if (s + 2 < KS) { nh = frag(hrow, s + 2); nl = frag(lrow, s + 2); }
-            constexpr int STEP = (KS >= 4) ? KS / 4 : 1;
-            constexpr int PER = (KS >= 4) ? 1 : 4 / KS;
-            if (conv && (s % STEP) == 0 && (s / STEP) < 4) {
 #pragma unroll
-                for (int q = 0; q < PER; ++q) if (!(WC_ABL & 4)) convert_chunk(t + 1, (s / STEP) * PER + q);
-            }
-            // the PREVIOUS tile's 16 output rows leave in the gaps of this tile's MFMAs (a store phase of its own
-            // would keep the matrix pipe idle for ~20 % of the tile: all eight waves reach it together)
-            constexpr int SPS = 16 / KS > 0 ? 16 / KS : 1;      // stores per k-step
-            if (t > 0 && s * SPS < 16) {
-#pragma unroll
-                for (int q = 0; q < SPS; ++q) {
-                    const int r = s * SPS + q;
-                    if (WC_ABL & 1) asm volatile("" :: "v"(pacc[r])); else
-                    ppo[((r & 3) + 8 * (r >> 2)) * C] = pacc[r];
+            for (int m = 0; m < 3; ++m) {
+                const int g = 3 * s + m;
+                if (m == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bhi[s], acc, 0, 0, 0);
+                if (m == 1) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, blo[s], acc, 0, 0, 0);
+                if (m == 2) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bhi[s], acc, 0, 0, 0);
+                if (s + AHEAD < KS) {
+                    if (m == 0) nh = frag(hrow, s + AHEAD);
+                    if (m == 1) nl = frag(lrow, s + AHEAD);
                 }
+                if (CONV_) {
+#pragma unroll
+                    for (int j = 0; j < 21; ++j) {
+                        if ((j * H) / 21 != g) continue;
+                        if (j < 20) cstep(j);
+                        else { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); arrive(0); }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            if (WC_ABL & 2) { asm volatile("" :: "v"(ah), "v"(al)); }
-            else {
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bhi[s], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, blo[s], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bhi[s], acc, 0, 0, 0);
-            }
-            ah = bh_; al = bl_; bh_ = nh; bl_ = nl;
+            if (AHEAD == 2) { ah = bh_; al = bl_; bh_ = nh; bl_ = nl; }
+            else { ah = nh; al = nl; }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my image reads and my conversion writes are done
-        if (conv) arrive(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my reads of image t are done
         arrive(1);
         WC_STAMP(3);
+        // this wave's 32 x 32 block leaves now: its SIMD partner is half a tile away, in the middle of its MFMAs
+        float* po = a.out + (int64_t)tile_of(t) * (TR * C) + out_lane;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) pacc[r] = acc[r] * cscale + addv;
-        ppo = a.out + (int64_t)tile_of(t) * (TR * C) + out_lane;
+        for (int r = 0; r < 16; ++r) po[((r & 3) + 8 * (r >> 2)) * C] = acc[r] * cscale + addv;
+        rslot = rs[3] + 1 >= NSLOT ? rs[3] + 1 - NSLOT : rs[3] + 1;
+        fcur = fnext;
         WC_STAMP(4);
+    };
+    using W0 = std::integral_constant<int, 0>; using W1 = std::integral_constant<int, 1>;
+    using W2 = std::integral_constant<int, 2>; using W3 = std::integral_constant<int, 3>;
+    using W4 = std::integral_constant<int, 4>;
+    auto pick_table = [&](int t) {       // conditional tables: a new slot's B' fragments (the wait is a full drain: rare)
+        if (HAS_SLOT) {
+            const int slot = a.slot[((int64_t)tile_of(t) * TR) / a.HW];
+            if (slot != cur_slot) { load_b(slot); __builtin_amdgcn_s_waitcnt(0x0F70); finish_b(); }
+        }
+    };
+    for (int t = 0; t + 1 < n; ++t) {
+        pick_table(t);
+        if (t == 0) { if (t + 3 < n) tile_body(t, T_{}, W1{}); else tile_body(t, T_{}, W0{}); }
+        else if (t + 3 < n) tile_body(t, T_{}, W2{});
+        else if (t + 3 == n) tile_body(t, T_{}, W3{});
+        else tile_body(t, T_{}, W4{});
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) ppo[((r & 3) + 8 * (r >> 2)) * C] = pacc[r];      // the last tile's rows
+    pick_table(n - 1);
+    tile_body(n - 1, F_{}, W0{});
+    const bool overflow = !(gmax <= kF16Guard);
     if (WC_STAMPS) { ts[6] = __builtin_amdgcn_s_memtime() - clk0; ts[7] = __builtin_amdgcn_s_memrealtime() - rt0; }
     if (WC_STAMPS && a.dbg && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 100)) {
         unsigned long long* d = a.dbg + ((blockIdx.x ? 1 : 0) * 8 + wave) * 8;
         for (int i = 0; i < 8; ++i) d[i] = ts[i];
+    }
+    if (WC_STAMPS && a.dbg && tid == 0) {      // whole-launch timeline in 10-ns units (s_memrealtime is global)
+        const unsigned long long rt1 = rt0 + ts[7], rt_out = __builtin_amdgcn_s_memrealtime(), big = 1ull << 62;
+        atomicMax(a.dbg + 128, big - rt_in);        // first workgroup start
+        atomicMax(a.dbg + 129, rt_in);              // last workgroup start
+        atomicMax(a.dbg + 130, rt0 - rt_in);        // longest prologue
+        atomicMax(a.dbg + 131, rt_out - rt1);       // longest epilogue
+        atomicMax(a.dbg + 132, big - rt_out);       // first workgroup end
+        atomicMax(a.dbg + 133, rt_out);             // last workgroup end
+        atomicMax(a.dbg + 134, rt1 - rt0);          // longest tile loop
+        atomicMax(a.dbg + 135, big - (rt1 - rt0));  // shortest tile loop
     }
 
     // exact redo of the whole workgroup if anything it staged was outside the fp16 range (rare)
@@ -659,8 +789,11 @@ template <int C>
 hipError_t launch_affine_ring(const FastArgs& a, hipStream_t st)
 {
     constexpr int TR = 8192 / C;
-    constexpr size_t lds = 128 * 1024 + 64;       // 2 image buffers + 2 raw slots + counters
+    constexpr size_t lds = 3 * 2 * (size_t)(TR * (C * 2 + (C >= 128 ? 16 : 0))) + 8 * 7 * 1024 + 64;   // 3 image buffers + 8 x 7 raw chunk slots + counters
     FastArgs b = a;
+    b.bias_on = a.bias != nullptr; b.sub_on = a.sub != nullptr;
+    if (!b.bias_on) b.bias = a.scale;       // any valid address: loaded and ignored
+    if (!b.sub_on) b.sub = a.scale;
     b.ntiles = (int)(a.M / TR);
     int nwg = b.ntiles < 256 ? b.ntiles : 256;
     b.tiles_per_wg = (b.ntiles + nwg - 1) / nwg;

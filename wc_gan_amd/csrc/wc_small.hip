@@ -177,16 +177,46 @@ __global__ __launch_bounds__(1024) void cholesky_kernel(double* __restrict__ T, 
 
     for (int j0 = 0; j0 < C; j0 += CH_NB) {
         const int rows = C - j0 - CH_NB;
+        const int g0 = j0 + CH_NB;
+        // (0) prefetch this thread's (at most two) 4x4 micro-tiles of the trailing matrix: their global loads fly
+        //     while wave 0 runs the serial 16x16 factorisation and the panel rows are solved
+        const int nt = rows > 0 ? rows >> 2 : 0;
+        const int count = nt * (nt + 1) / 2;
+        int ti_[2], tk_[2];
+        double tile[2][4][4];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = tid + 1024 * q;
+            ti_[q] = -1; tk_[q] = 0;
+            if (e < count) {
+                int ti = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+                while ((ti + 1) * (ti + 2) / 2 <= e) ++ti;
+                while (ti * (ti + 1) / 2 > e) --ti;
+                ti_[q] = ti; tk_[q] = e - ti * (ti + 1) / 2;
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    const double* tr = T + (int64_t)(g0 + 4 * ti + x) * C + g0 + 4 * tk_[q];
+#pragma unroll
+                    for (int y = 0; y < 4; ++y) tile[q][x][y] = tr[y];
+                }
+            }
+        }
+        // (1) wave 0 factors the 16x16 diagonal block in registers: lane = row, readlane broadcasts the pivot column;
+        //     the pivot's reciprocal square root comes from v_rsq_f64 + two Newton steps (no fp64 sqrt/divide chain)
         if (wave == 0) {
             double a[CH_NB];
             const int li = lane & 15;
+            double myrd = 1.0;
 #pragma unroll
             for (int c = 0; c < CH_NB; ++c) a[c] = T[(int64_t)(j0 + li) * C + j0 + c];
 #pragma unroll
             for (int j = 0; j < CH_NB; ++j) {
                 const double p = readlane64(a[j], j);
-                const double d = sqrt(p);
-                const double rd = 1.0 / d;
+                double rd = __builtin_amdgcn_rsq(p);
+                rd = rd * (1.5 - 0.5 * p * rd * rd);
+                rd = rd * (1.5 - 0.5 * p * rd * rd);
+                const double d = p * rd;
+                if (li == j) myrd = rd;
                 a[j] = (li == j) ? d : a[j] * rd;
 #pragma unroll
                 for (int k = j + 1; k < CH_NB; ++k) {
@@ -200,13 +230,13 @@ __global__ __launch_bounds__(1024) void cholesky_kernel(double* __restrict__ T, 
                     const double v = (c <= lane) ? a[c] : 0.0;
                     D[lane * 17 + c] = v;
                     T[(int64_t)(j0 + lane) * C + j0 + c] = v;
-                    if (c == lane) rdiag[lane] = 1.0 / v;
                 }
+                rdiag[lane] = myrd;
             }
         }
         __syncthreads();
         if (rows <= 0) break;
-        const int g0 = j0 + CH_NB;
+        // (2) one thread per panel row: forward substitution against the diagonal block
         if (tid < rows) {
             double x[CH_NB];
             double* trow = T + (int64_t)(g0 + tid) * C + j0;
@@ -223,9 +253,30 @@ __global__ __launch_bounds__(1024) void cholesky_kernel(double* __restrict__ T, 
             for (int c = 0; c < CH_NB; ++c) { trow[c] = x[c]; Pn[c * ldp + tid] = x[c]; }
         }
         __syncthreads();
-        const int nt = rows >> 2;
-        const int count = nt * (nt + 1) / 2;
-        for (int e = tid; e < count; e += 1024) {
+        // (3) rank-16 update of the prefetched micro-tiles (any beyond two per thread: loaded here)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (ti_[q] < 0) continue;
+            const int ti = ti_[q], tk = tk_[q];
+#pragma unroll 4
+            for (int c = 0; c < CH_NB; ++c) {
+                const double* pi = Pn + c * ldp + 4 * ti;
+                const double* pk = Pn + c * ldp + 4 * tk;
+                const double ai[4] = {pi[0], pi[1], pi[2], pi[3]};
+                const double ak[4] = {pk[0], pk[1], pk[2], pk[3]};
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int y = 0; y < 4; ++y) tile[q][x][y] -= ai[x] * ak[y];
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                double* tr = T + (int64_t)(g0 + 4 * ti + x) * C + g0 + 4 * tk;
+#pragma unroll
+                for (int y = 0; y < 4; ++y) tr[y] = tile[q][x][y];
+            }
+        }
+        for (int e = tid + 2048; e < count; e += 1024) {        // C > 272 only
             int ti = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
             while ((ti + 1) * (ti + 2) / 2 <= e) ++ti;
             while (ti * (ti + 1) / 2 > e) --ti;
