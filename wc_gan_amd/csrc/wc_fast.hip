@@ -619,6 +619,7 @@ __global__ __launch_bounds__(512, 2) void affine_ring_kernel(FastArgs a)
     if (WC_STAMPS) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
     if (WC_STAGGER && wave >= 4 && n >= 4) __builtin_amdgcn_s_sleep(24);      // ~half a tile behind waves 0-3
 
+    unsigned long long sum_wait = 0, sum_store = 0;      // WC_STAMPS builds
     int rslot = 4;                     // raw slot of chunk 4(t+1) = chunk 0 of the tile converted during tile t
     int fcur = 0;                      // image buffer of tile t
     using T_ = std::integral_constant<bool, true>;
@@ -637,8 +638,11 @@ __global__ __launch_bounds__(512, 2) void affine_ring_kernel(FastArgs a)
         // address of every instantiated tile body out of the loop (~60 VGPRs) and spills them
         int sw_t = sw, c4i_t = c4i, lane_t = lane, lh_t = lh, woff_t = woff0;
         asm volatile("" : "+v"(sw_t), "+v"(c4i_t), "+v"(lane_t), "+v"(lh_t), "+v"(woff_t));
+        unsigned long long w0_ = 0;
+        if (WC_STAMPS) w0_ = __builtin_amdgcn_s_memrealtime();
         wait_for(0, 8 * (t + 1));                  // tile t converted by all eight waves (published in mid-loop t-1)
         if (CONV_) wait_for(1, 8 * (t - 1));       // tile t-2 read by all: image buffer (t+1)%3 may be rewritten
+        if (WC_STAMPS) sum_wait += __builtin_amdgcn_s_memrealtime() - w0_;
         WC_STAMP(1);
         // raw slots of the four chunks converted during this tile
         int rs[4];
@@ -719,8 +723,11 @@ __global__ __launch_bounds__(512, 2) void affine_ring_kernel(FastArgs a)
         WC_STAMP(3);
         // this wave's 32 x 32 block leaves now: its SIMD partner is half a tile away, in the middle of its MFMAs
         float* po = a.out + (int64_t)tile_of(t) * (TR * C) + out_lane;
+        unsigned long long s0_ = 0;
+        if (WC_STAMPS) s0_ = __builtin_amdgcn_s_memrealtime();
 #pragma unroll
         for (int r = 0; r < 16; ++r) po[((r & 3) + 8 * (r >> 2)) * C] = acc[r] * cscale + addv;
+        if (WC_STAMPS) sum_store += __builtin_amdgcn_s_memrealtime() - s0_;
         rslot = rs[3] + 1 >= NSLOT ? rs[3] + 1 - NSLOT : rs[3] + 1;
         fcur = fnext;
         WC_STAMP(4);
@@ -749,6 +756,8 @@ __global__ __launch_bounds__(512, 2) void affine_ring_kernel(FastArgs a)
         unsigned long long* d = a.dbg + ((blockIdx.x ? 1 : 0) * 8 + wave) * 8;
         for (int i = 0; i < 8; ++i) d[i] = ts[i];
     }
+    if (WC_STAMPS && a.dbg && lane == 0 && (wave == 0 || wave == 4))
+        reinterpret_cast<unsigned*>(a.dbg + 384)[blockIdx.x * 2 + (wave >> 2)] = (unsigned)(sum_wait & 0xFFFF) | ((unsigned)(sum_store & 0xFFFF) << 16);
     if (WC_STAMPS && a.dbg && tid == 0) {      // whole-launch timeline in 10-ns units (s_memrealtime is global)
         const unsigned long long rt1 = rt0 + ts[7], rt_out = __builtin_amdgcn_s_memrealtime(), big = 1ull << 62;
         atomicMax(a.dbg + 128, big - rt_in);        // first workgroup start
@@ -759,6 +768,10 @@ __global__ __launch_bounds__(512, 2) void affine_ring_kernel(FastArgs a)
         atomicMax(a.dbg + 133, rt_out);             // last workgroup end
         atomicMax(a.dbg + 134, rt1 - rt0);          // longest tile loop
         atomicMax(a.dbg + 135, big - (rt1 - rt0));  // shortest tile loop
+        // per workgroup: loop time | XCC id << 16 | HW_ID[15:8] (cu, sh, se) << 20
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
+        const unsigned hwid = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);
+        reinterpret_cast<unsigned*>(a.dbg + 256)[blockIdx.x] = (unsigned)((rt1 - rt0) & 0xFFFF) | (xcc << 16) | (((hwid >> 8) & 0xFF) << 20);
     }
 
     // exact redo of the whole workgroup if anything it staged was outside the fp16 range (rare)
@@ -772,8 +785,8 @@ __global__ __launch_bounds__(512, 2) void affine_ring_kernel(FastArgs a)
             float* out_tile = a.out + (int64_t)tile_of(t) * (TR * C);
             const float* Bf = a.Bf + (int64_t)slot * a.bf_stride + col;
             float add = 0.f;
-            if (a.bias) add += a.bias[(int64_t)slot * C + col];
-            if (a.sub) add -= a.sub[col];
+            if (a.bias_on) add += a.bias[(int64_t)slot * C + col];
+            if (a.sub_on) add -= a.sub[col];
             for (int i = 0; i < 16; ++i) {
                 const int row = rbase + (i & 3) + 8 * (i >> 2) + 4 * lh;
                 const float* xrow = xin + row * C;
@@ -859,7 +872,7 @@ size_t wc_fast_affine_workspace(int C, int Kc)
 {
     // scale[C] | colscale[Kc*C] | hi[Kc*C*C] | lo[Kc*C*C]
     return wc_align_up((size_t)C * 4, 256) + wc_align_up((size_t)Kc * C * 4, 256) +
-           2 * wc_align_up((size_t)Kc * C * C * 2, 256) + 2048;     // + stamp area of WC_STAMPS builds
+           2 * wc_align_up((size_t)Kc * C * C * 2, 256) + 8192;     // + stamp area of WC_STAMPS builds
 }
 
 hipError_t wc_launch_channel_scale(const float* in, const float* center, int64_t M, int C, float* scale, hipStream_t st)
