@@ -4,11 +4,13 @@ from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "wc_gan_amd", "csrc"); OUT = os.path.join(CSRC, "build", "abl"); os.makedirs(OUT, exist_ok=True)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast"]
-others = [os.path.join(CSRC, "build", f) for f in ("wc_rows.o", "wc_fast_xty.o", "wc_small.o", "wc_abi.o")]
+ALL = ("wc_rows", "wc_fast", "wc_fast_xty", "wc_small", "wc_abi")
+SRC = os.environ.get("WC_VARIANT_SRC", "wc_fast")
+others = [os.path.join(CSRC, "build", f + ".o") for f in ALL if f != SRC]
 def one(v):
     tag = v.replace("=", "_").replace("-D", "").replace(" ", "_") or "base"
     obj = os.path.join(OUT, f"wc_fast_{tag}.o"); lib = os.path.join(OUT, f"lib_{tag}.so")
-    subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + v.split() + ["-c", os.path.join(CSRC, "wc_fast.hip"), "-o", obj])
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + v.split() + ["-c", os.path.join(CSRC, SRC + ".hip"), "-o", obj])
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, obj] + others)
     return lib
 with ThreadPoolExecutor(4) as ex:

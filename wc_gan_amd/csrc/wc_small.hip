@@ -9,6 +9,7 @@
 // float64 here is what keeps the path within 1e-4 of the float64 oracle on ill-conditioned batches
 // (hard part 2); the flops are negligible (O(C^3)) next to the M*C^2 kernels.
 #include "wc_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -313,6 +314,157 @@ __global__ __launch_bounds__(1024) void cholesky_kernel(double* __restrict__ T, 
     }
 }
 
+// Register-resident form for C <= 256: the lower triangle lives in the 1024 threads' registers as 4x4 tiles (two per
+// thread, tile e of the row-major triangle on thread e % 1024) for the whole factorisation.  Per 16-wide
+// panel: its tiles go to LDS, wave 0 factors the 16x16 diagonal block, one thread per row solves the panel, every
+// thread applies the rank-16 update to the tiles it owns -- four barriers and no global round trip inside the loop
+// (the form above pays three L2 round trips per panel: measured 190 us at C = 256, of which the flops are ~25).
+#ifndef CHOL_SKIP
+#define CHOL_SKIP 0      // development: 1 no diagonal factor, 2 no panel solve, 4 no update, 8 no extraction (wrong results)
+#endif
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+// Register-resident form for C <= 256: the trailing matrix lives in the 16 waves' registers as 16x16 blocks in the
+// f64-MFMA accumulator layout (register r of lane l = block[(l>>4) + 4r][l&15]) for the whole factorisation (8 waves).  Per
+// 16-wide panel: its blocks go to LDS, wave 0 factors the 16x16 diagonal block, one thread per row solves the panel,
+// every wave applies the rank-16 update to its blocks with four v_mfma_f64_16x16x4_f64 each (operands: two doubles
+// per lane and MFMA from the solved panel in LDS) -- four barriers and no global round trip inside the loop.  (The
+// form above pays three L2 round trips per panel and runs the update on 4x4 register micro-tiles fed from LDS.)
+// Blocks are ranked by block column, LAST column first, and dealt to the waves round-robin: the blocks still active
+// at any panel step are a prefix of the ranking, so the waves stay evenly loaded as the matrix shrinks.
+__global__ __launch_bounds__(512) void cholesky_reg_kernel(double* __restrict__ T, int C, int ldp)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double* Praw = sm;                  // [C][17]   the panel as its owners hold it (row-major)
+    double* D = Praw + C * 17;          // [16][17]  factored diagonal block
+    double* rdiag = D + 16 * 17;        // [16]
+    double* Pn = rdiag + 16;            // [16][ldp] solved panel, column-major: the update's operands
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: block ownership stays in SGPRs
+    const int li = lane & 15, lq = lane >> 4;
+    T += (int64_t)blockIdx.x * C * C;   // one matrix (statistic group) per workgroup
+    const int nb = C >> 4;              // block rows; block column 0 (the first panel) goes from global straight to LDS
+    const int nblk = (nb - 1) * nb / 2;
+
+    constexpr int SLOTS = 15;           // 120 blocks at C = 256 over 8 waves (512 threads: 256 VGPRs each, no spills)
+    int bi_[SLOTS], bj_[SLOTS];
+    f64x4 blk[SLOTS];
+#pragma unroll
+    for (int q = 0; q < SLOTS; ++q) {
+        const int r = wave + 8 * q;
+        bi_[q] = -1; bj_[q] = 0;
+        if (r < nblk) {
+            int m = (int)((sqrt(8.0 * (double)r + 1.0) - 1.0) * 0.5);
+            while ((m + 1) * (m + 2) / 2 <= r) ++m;
+            while (m * (m + 1) / 2 > r) --m;                    // column nb-1-m holds m+1 blocks
+            bj_[q] = nb - 1 - m; bi_[q] = bj_[q] + (r - m * (m + 1) / 2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) blk[q][e] = T[(int64_t)(16 * bi_[q] + lq + 4 * e) * C + 16 * bj_[q] + li];
+        }
+    }
+    for (int e = tid; e < C * 16; e += 512) Praw[(e >> 4) * 17 + (e & 15)] = T[(int64_t)(e >> 4) * C + (e & 15)];
+
+    for (int j = 0; j < nb; ++j) {
+        const int j0 = 16 * j;
+        const int rows = C - j0 - CH_NB;
+        const int g0 = j0 + CH_NB;
+        // (1) the panel's blocks (block column j) leave the registers
+        if (j > 0) {
+#pragma unroll
+            for (int q = 0; q < SLOTS; ++q) {
+                if (bi_[q] >= 0 && bj_[q] == j && !(CHOL_SKIP & 8)) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Praw[(16 * bi_[q] + lq + 4 * e) * 17 + li] = blk[q][e];
+                }
+            }
+        }
+        __syncthreads();
+        // (2) wave 0 factors the 16x16 diagonal block in registers: lane = row, readlane broadcasts the pivot column;
+        //     the pivot's reciprocal square root comes from v_rsq_f64 + two Newton steps
+        if (wave == 0 && !(CHOL_SKIP & 1)) {
+            double a[CH_NB];
+            double myrd = 1.0;
+#pragma unroll
+            for (int c = 0; c < CH_NB; ++c) a[c] = Praw[(j0 + li) * 17 + c];
+#pragma unroll
+            for (int jj = 0; jj < CH_NB; ++jj) {
+                const double p = readlane64(a[jj], jj);
+                double rd = __builtin_amdgcn_rsq(p);
+                rd = rd * (1.5 - 0.5 * p * rd * rd);
+                rd = rd * (1.5 - 0.5 * p * rd * rd);
+                const double d = p * rd;
+                if (li == jj) myrd = rd;
+                a[jj] = (li == jj) ? d : a[jj] * rd;
+#pragma unroll
+                for (int k = jj + 1; k < CH_NB; ++k) {
+                    const double lkj = readlane64(a[jj], k);
+                    a[k] -= a[jj] * lkj;
+                }
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int c = 0; c < CH_NB; ++c) {
+                    const double v = (c <= lane) ? a[c] : 0.0;
+                    D[lane * 17 + c] = v;
+                    T[(int64_t)(j0 + lane) * C + j0 + c] = v;
+                }
+                rdiag[lane] = myrd;
+            }
+        }
+        __syncthreads();
+        if (rows <= 0) break;
+        // (3) one thread per panel row: forward substitution against the diagonal block, column by column (once x[k]
+        //     is final, the entries behind it take their update independently)
+        if (tid < rows && !(CHOL_SKIP & 2)) {
+            double x[CH_NB];
+            const int r = g0 + tid;
+#pragma unroll
+            for (int c = 0; c < CH_NB; ++c) x[c] = Praw[r * 17 + c];
+#pragma unroll
+            for (int k = 0; k < CH_NB; ++k) {
+                x[k] *= rdiag[k];
+#pragma unroll
+                for (int c = k + 1; c < CH_NB; ++c) x[c] -= x[k] * D[c * 17 + k];
+            }
+            double* trow = T + (int64_t)r * C + j0;
+#pragma unroll
+            for (int c = 0; c < CH_NB; ++c) { trow[c] = x[c]; Pn[c * ldp + r] = x[c]; }
+        }
+        __syncthreads();
+        // (4) rank-16 update of the blocks still in registers: block(bi, bj) -= P[bi] P[bj]^T.  The active blocks are a
+        //     prefix of this wave's slots; they are taken three at a time -- all 24 operand reads first, then the three
+        //     independent MFMA chains interleaved -- and a dead block in the last group is simply updated too.
+        int nact = 0;
+#pragma unroll
+        for (int q = 0; q < SLOTS; ++q) nact += (bi_[q] >= 0 && bj_[q] > j) ? 1 : 0;
+        if (CHOL_SKIP & 4) nact = 0;
+#pragma unroll
+        for (int g3 = 0; g3 < SLOTS / 3; ++g3) {
+            if (3 * g3 >= nact) break;
+            double av[3][4], bv[3][4];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int q = 3 * g3 + u;
+                const int bi = bi_[q] >= 0 ? bi_[q] : 0, bj = bi_[q] >= 0 ? bj_[q] : 0;
+                const double* pa = Pn + lq * ldp + 16 * bi + li;
+                const double* pb = Pn + lq * ldp + 16 * bj + li;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) { av[u][kk] = -pa[4 * kk * ldp]; bv[u][kk] = pb[4 * kk * ldp]; }
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+                    blk[3 * g3 + u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][kk], bv[u][kk], blk[3 * g3 + u], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // strict upper triangle := 0
+    for (int64_t e = tid; e < (int64_t)C * C; e += 512) {
+        const int i = (int)(e / C), jx = (int)(e % C);
+        if (jx > i) T[e] = 0.0;
+    }
+}
+
 // inverse of each 32 x 32 diagonal block of L (lower): one wave per block, lane = column of the inverse
 __global__ __launch_bounds__(64) void tri_inv_diag_kernel(const double* __restrict__ L, double* __restrict__ W, int C)
 {
@@ -512,6 +664,16 @@ hipError_t wc_launch_factor_prepare(const double* sum, const double* xtx, int64_
 
 hipError_t wc_launch_cholesky(double* T, int C, int groups, hipStream_t st)
 {
+    static const bool no_reg = getenv("WC_CHOL_GLOBAL") != nullptr;      // development: the global-memory form
+    if (C <= 256 && !no_reg) {
+        const int ldr = C + 2;
+        const size_t ldsr = (size_t)(C * 17 + 16 * 17 + 16 + 16 * ldr) * sizeof(double);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cholesky_reg_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(cholesky_reg_kernel, dim3(groups), dim3(512), ldsr, st, T, C, ldr);
+        return hipGetLastError();
+    }
     int ldp = C - CH_NB;
     if (ldp < 4) ldp = 4;
     ldp = (ldp + 3) / 4 * 4;
