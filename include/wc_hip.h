@@ -141,6 +141,27 @@ int wc_bwd_apply_f32(const float* gy, const float* x, const float* mu, const flo
                      int64_t N, int64_t HW, int C, int Kc, float* dx,
                      void* ws, size_t ws_bytes, wc_stream_t stream);
 
+/* N3: spectral normalisation of a weight matrix W (rows, cols) row-major -- SNConv2D / SNDense /
+ * SNEmbeding at discriminator.py:26-33, generator.py:104-113 (a convolution kernel is passed in its memory order with
+ * rows = output channels; singular values do not depend on the order of the columns).
+ *   `iterations` steps of  v <- W^T u / max(|W^T u|, eps),  u <- W v / max(|W v|, eps)   (--spectral_iterations,
+ *   run.py:269; 0 = inference: u, v are used as they are);  sigma = u^T W v;  w_sn = W / sigma.
+ * u (rows) and v (cols) are updated in place when iterations > 0.  One launch of up to 32 co-resident workgroups that
+ * meet through the last 16 bytes of `ws`: a buffer of wc_spectral_norm_workspace_bytes() that belongs to this weight,
+ * ZEROED ONCE by the caller before its first use (every launch leaves the meeting words zero) and used by one launch at
+ * a time.  rows + cols floats must fit the LDS (WC_ERR_SHAPE otherwise). */
+size_t wc_spectral_norm_workspace_bytes(int rows, int cols);
+int wc_spectral_norm_f32(const float* W, int rows, int cols, float* u, float* v, int iterations, float eps,
+                         float* w_sn /*[rows*cols] out*/, float* sigma /*[1] out*/,
+                         void* ws, size_t ws_bytes, wc_stream_t stream);
+
+/* Gradient of the above w.r.t. W for constant u, v:  dW = (g - fully_diff * <g, w_sn> u v^T) / sigma.
+ * fully_diff == 0 treats sigma as a constant of the step (--fully_diff_spectral 0, run.py:268: dW = g / sigma).
+ * Same workspace rules (the same buffer as the forward may be passed: different words are used). */
+int wc_spectral_norm_bwd_f32(const float* g, const float* w_sn, const float* u, const float* v, const float* sigma,
+                             int rows, int cols, int fully_diff, float* dW,
+                             void* ws, size_t ws_bytes, wc_stream_t stream);
+
 /* Bandwidth yardstick used by bench.py: dst[i] = src[i] (float4 grid-stride copy), same stream rules. */
 int wc_stream_copy_f32(const float* src, float* dst, int64_t n, wc_stream_t stream);
 

@@ -269,3 +269,30 @@ def synth_coloring(rng, C, Kc=1):
     gamma = rng.standard_normal((Kc, C, C)) / np.sqrt(C)
     beta = 0.1 * rng.standard_normal((Kc, C))
     return gamma, beta
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N3: spectral normalisation of a weight matrix.
+# Call sites: discriminator.py:26-33, generator.py:104-113 (SNConv2D / SNDense / SNEmbeding of the un-vendored
+# gan.spectral_normalized_layers; knobs spectral_iterations / fully_diff_spectral, run.py:268-269).
+# [UPSTREAM-RECALL] arithmetic: the power-iteration estimate of Miyato et al. (Algorithm 1), as restated here.
+# ---------------------------------------------------------------------------------------------------------------------
+def spectral_normalize(W, u, v, iterations=1, eps=1e-12):
+    """W (R, K), u (R,), v (K,) float64.  `iterations` steps of v <- W^T u / max(|.|, eps), u <- W v / max(|.|, eps);
+    sigma = u^T W v; returns (W / sigma, sigma, u, v)."""
+    W = np.asarray(W, np.float64); u = np.asarray(u, np.float64).copy(); v = np.asarray(v, np.float64).copy()
+    for _ in range(int(iterations)):
+        t = W.T @ u
+        v = t / max(np.linalg.norm(t), eps)
+        s = W @ v
+        u = s / max(np.linalg.norm(s), eps)
+    sigma = float(u @ (W @ v))
+    return W / sigma, sigma, u, v
+
+
+def spectral_normalize_backward(g, w_sn, u, v, sigma, fully_diff):
+    """Gradient w.r.t. W of w_sn = W / sigma, sigma = u^T W v with u, v held constant:
+    dW = (g - fully_diff * <g, w_sn> u v^T) / sigma  (fully_diff False: sigma is a constant of the step)."""
+    g = np.asarray(g, np.float64)
+    c = float((g * w_sn).sum()) if fully_diff else 0.0
+    return (g - c * np.outer(u, v)) / sigma

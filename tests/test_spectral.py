@@ -1,0 +1,128 @@
+"""N3: the fused spectral-norm op.  CPU: the oracle against torch's own parametrisation and against torch autograd
+(independent implementations).  GPU: the HIP op, through the C ABI, against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import wc_oracle as O
+
+
+def _rand(shape, seed):
+    g = torch.Generator(device='cpu'); g.manual_seed(seed)
+    return torch.randn(*shape, generator=g, dtype=torch.float64)
+
+
+def test_oracle_power_iteration_properties():
+    W = _rand((20, 48), 11).numpy()
+    u0 = np.ones(20) / np.sqrt(20.0); v0 = np.ones(48) / np.sqrt(48.0)
+    top = np.linalg.svd(W, compute_uv=False)[0]
+    w1, s1, u1, v1 = O.spectral_normalize(W, u0, v0, iterations=1)
+    # one step by hand, in the order of SN-GAN's Algorithm 1 (v from the persistent u, then u)
+    v_ref = W.T @ u0; v_ref /= np.linalg.norm(v_ref); u_ref = W @ v_ref; s_ref = np.linalg.norm(u_ref); u_ref /= s_ref
+    assert np.abs(u1 - u_ref).max() < 1e-14 and np.abs(v1 - v_ref).max() < 1e-14 and abs(s1 - s_ref) < 1e-12
+    assert np.abs(w1 - W / s_ref).max() < 1e-14
+    w, s, u, v = O.spectral_normalize(W, u0, v0, iterations=200)
+    assert abs(s - top) / top < 1e-9 and abs(np.linalg.svd(w, compute_uv=False)[0] - 1.0) < 1e-9
+    # torch's parametrisation updates u first; started from its own (u, v) our order reproduces it one half-step later
+    lin = torch.nn.Linear(48, 20, bias=False).double()
+    with torch.no_grad():
+        lin.weight.copy_(torch.from_numpy(W))
+    sn = torch.nn.utils.parametrizations.spectral_norm(lin, n_power_iterations=1)
+    p = sn.parametrizations.weight[0]
+    ut = p._u.clone().numpy(); vt = p._v.clone().numpy()
+    sn.train(); w_t = sn.weight.detach().numpy()            # u <- N(W v), v <- N(W^T u), sigma = u^T W v
+    u_a = W @ vt; u_a /= np.linalg.norm(u_a)
+    w_o, s_o, _, _ = O.spectral_normalize(W, u_a, vt, iterations=0)
+    v_a = W.T @ u_a; v_a /= np.linalg.norm(v_a)
+    assert np.abs(w_t - W / float(u_a @ (W @ v_a))).max() < 1e-12 and s_o > 0 and ut.shape == (20,)
+    w0, s0, u_same, v_same = O.spectral_normalize(W, ut, vt, iterations=0)     # inference: u, v untouched
+    assert np.array_equal(u_same, ut) and np.array_equal(v_same, vt) and abs(s0 - ut @ (W @ vt)) < 1e-14
+
+
+@pytest.mark.parametrize("fully_diff", [True, False])
+def test_oracle_backward_matches_autograd(fully_diff):
+    W = _rand((12, 30), 1).requires_grad_(True); g = _rand((12, 30), 2)
+    u = torch.nn.functional.normalize(_rand((12,), 3), dim=0); v = torch.nn.functional.normalize(_rand((30,), 4), dim=0)
+    sigma = u @ (W @ v)
+    w_sn = W / (sigma if fully_diff else sigma.detach())
+    (w_sn * g).sum().backward()
+    d = O.spectral_normalize_backward(g.numpy(), w_sn.detach().numpy(), u.numpy(), v.numpy(), float(sigma), fully_diff)
+    assert np.abs(W.grad.numpy() - d).max() < 1e-12
+
+
+SHAPES = [(128, 3, 3, 128), (128, 3, 3, 3), (128, 1, 1, 128), (1, 128), (10, 128), (256, 3, 3, 256), (64, 100)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("iterations", [0, 1, 3])
+def test_hip_forward_matches_oracle(shape, iterations):
+    from wc_gan_amd import ops
+    if len(shape) == 4:      # (Cout, kh, kw, Cin) memory order of a channels_last kernel
+        co, kh, kw, ci = shape
+        w = _rand((co, ci, kh, kw), 5).float().cuda().contiguous(memory_format=torch.channels_last)
+        Wm = w.permute(0, 2, 3, 1).reshape(co, -1).double().cpu().numpy()
+    else:
+        w = _rand(shape, 5).float().cuda(); Wm = w.double().cpu().numpy()
+    R, K = Wm.shape
+    u = torch.nn.functional.normalize(_rand((R,), 6), dim=0).float().cuda()
+    v = torch.nn.functional.normalize(_rand((K,), 7), dim=0).float().cuda()
+    u0, v0 = u.double().cpu().numpy(), v.double().cpu().numpy()
+    ws = ops.spectral_norm_workspace(R, K, 'cuda')
+    for rep in range(2):      # the second launch finds the meeting words re-armed
+        if rep: u.copy_(torch.from_numpy(u0).float()); v.copy_(torch.from_numpy(v0).float())
+        w_sn, sigma = ops.spectral_norm(w, u, v, iterations, ws)
+    w_o, s_o, u_o, v_o = O.spectral_normalize(Wm, u0, v0, iterations)
+    got = (w_sn.permute(0, 2, 3, 1).reshape(R, K) if len(shape) == 4 else w_sn).double().cpu().numpy()
+    assert w_sn.stride() == w.stride()
+    assert abs(float(sigma) - s_o) / abs(s_o) < 2e-5           # fp32 sums of up to 2304 terms vs float64
+    assert np.abs(got - w_o).max() / np.abs(w_o).max() < 2e-5
+    assert np.abs(u.double().cpu().numpy() - u_o).max() < 2e-5 and np.abs(v.double().cpu().numpy() - v_o).max() < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(128, 3, 3, 128), (10, 128), (1, 128)])
+@pytest.mark.parametrize("fully_diff", [True, False])
+def test_hip_backward_matches_oracle(shape, fully_diff):
+    from wc_gan_amd.spectral import SpectralNormFunction
+    if len(shape) == 4:
+        co, kh, kw, ci = shape
+        w = _rand((co, ci, kh, kw), 8).float().cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        g = _rand((co, ci, kh, kw), 9).float().cuda().contiguous(memory_format=torch.channels_last)
+        mat = lambda t: t.permute(0, 2, 3, 1).reshape(co, -1).double().cpu().numpy()
+    else:
+        w = _rand(shape, 8).float().cuda().requires_grad_(True); g = _rand(shape, 9).float().cuda()
+        mat = lambda t: t.double().cpu().numpy()
+    R, K = mat(w.detach()).shape
+    u = torch.nn.functional.normalize(_rand((R,), 6), dim=0).float().cuda()
+    v = torch.nn.functional.normalize(_rand((K,), 7), dim=0).float().cuda()
+    from wc_gan_amd import ops
+    ws = ops.spectral_norm_workspace(R, K, 'cuda')
+    w_sn, sigma = SpectralNormFunction.apply(w, u, v, ws, 1, 1e-12, fully_diff)
+    (w_sn * g).sum().backward()
+    d = O.spectral_normalize_backward(mat(g), mat(w_sn.detach()), u.double().cpu().numpy(), v.double().cpu().numpy(), float(sigma), fully_diff)
+    assert w.grad.stride() == w.stride()
+    assert np.abs(mat(w.grad) - d).max() / np.abs(d).max() < 2e-5
+
+
+@pytest.mark.gpu
+def test_sn_layers_train_eval_and_state():
+    from wc_gan_amd.spectral import SNConv2d, SNEmbedding, SNLinear
+    conv = SNConv2d(16, 32, 3, padding=1).cuda()
+    x = torch.randn(4, 16, 8, 8, device='cuda').contiguous(memory_format=torch.channels_last)
+    u0 = conv.sn_u.clone()
+    conv.train(); y = conv(x); y.sum().backward()
+    assert conv.weight.grad is not None and not torch.equal(conv.sn_u, u0)          # one power iteration ran
+    conv.eval(); u1 = conv.sn_u.clone(); y1 = conv(x); y2 = conv(x)
+    assert torch.equal(conv.sn_u, u1) and torch.equal(y1, y2)                        # inference leaves u, v alone
+    wm = conv.weight.detach().permute(0, 2, 3, 1).reshape(32, -1)
+    top = torch.linalg.svdvals(wm.double())[0]
+    sig = (conv.sn_u.double() @ (wm.double() @ conv.sn_v.double()))
+    assert abs(float(sig / top) - 1) < 0.05                                           # 15 warm-up iterations at construction
+    lin = SNLinear(128, 1).cuda(); emb = SNEmbedding(10, 128).cuda()
+    h = torch.randn(8, 128, device='cuda')
+    out = lin(h) + (emb(torch.arange(8, device='cuda') % 10) * h).sum(1, keepdim=True)
+    out.sum().backward()
+    assert lin.weight.grad.shape == (1, 128) and emb.weight.grad.shape == (10, 128)
+    with pytest.raises(RuntimeError):
+        SNLinear(4, 4)(torch.randn(2, 4))                                             # no non-HIP path

@@ -4,7 +4,7 @@ from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "wc_gan_amd", "csrc"); OUT = os.path.join(CSRC, "build", "abl"); os.makedirs(OUT, exist_ok=True)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast"]
-ALL = ("wc_rows", "wc_fast", "wc_fast_xty", "wc_small", "wc_abi")
+ALL = ("wc_rows", "wc_fast", "wc_fast_xty", "wc_small", "wc_sn", "wc_abi")
 SRC = os.environ.get("WC_VARIANT_SRC", "wc_fast")
 others = [os.path.join(CSRC, "build", f + ".o") for f in ALL if f != SRC]
 def one(v):

@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_double, c_int, c_int64, c_size_t, c_void_p
+from ctypes import c_float, c_char_p, c_double, c_int, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwc_hip.so")
@@ -43,6 +43,11 @@ SIGNATURES = {
     "wc_bwd_apply_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wc_stream_copy_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "wc_spectral_norm_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "wc_spectral_norm_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p,
+                                     c_void_p, c_size_t, c_void_p]),
+    "wc_spectral_norm_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
+                                         c_void_p, c_size_t, c_void_p]),
 }
 
 _lib = None

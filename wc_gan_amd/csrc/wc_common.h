@@ -53,6 +53,13 @@ hipError_t wc_launch_xty(const WcXtyArgs& a, int nslab, hipStream_t st);
 
 hipError_t wc_launch_subsample_mean(const float* x, int64_t M, int C, float* shift, hipStream_t st);
 hipError_t wc_launch_stream_copy(const float* src, float* dst, int64_t n, hipStream_t st);
+// wc_sn.hip
+size_t wc_sn_lds_bytes(int R, int K);
+size_t wc_sn_workspace_bytes(int R, int K);
+hipError_t wc_launch_spectral_norm(const float* W, int R, int K, float* u, float* v, int iterations, float eps,
+                                   float* w_sn, float* sigma, void* ws, hipStream_t st);
+hipError_t wc_launch_spectral_norm_bwd(const float* g, const float* w_sn, const float* u, const float* v, const float* sigma,
+                                       int R, int K, int fully_diff, float* dW, void* ws, hipStream_t st);
 
 // ----- fast split-fp16 affine (wc_fast.hip) ---------------------------------------------------
 constexpr int64_t WC_FAST_MIN_ROWS = 16384;     // below this the launch-count overhead of the fast path is not repaid

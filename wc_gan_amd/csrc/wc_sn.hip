@@ -1,0 +1,240 @@
+// Spectral normalisation of a weight matrix as ONE kernel per direction.
+//   reference call sites: discriminator.py:26-33, generator.py:104-113 (SNConv2D / SNDense / SNEmbeding of the
+//   missing gan.spectral_normalized_layers; knobs spectral_iterations, fully_diff_spectral, run.py:265-270)
+//   forward : `iterations` power-iteration steps  v <- normalize(W^T u),  u <- normalize(W v)   (training only),
+//             sigma = u^T W v,   w_sn = W / sigma
+//   backward: dW = (g - fully_diff * <g, w_sn> u v^T) / sigma         (u, v are constants of the step)
+// W is (R, K) row-major: a convolution kernel in the memory order it is stored in (Cout rows; the singular values do
+// not depend on the order of the columns, only v is permuted with them).  A critic step evaluates this for every
+// layer before every forward pass -- as separate launches it is ~15 small kernels per layer (GEMVs, norms, divisions);
+// here up to 32 co-resident workgroups split the matrix (L2-resident) and meet twice per power-iteration step.
+#include "wc_common.h"
+
+namespace {
+
+constexpr int SN_THREADS = 256;
+constexpr int SN_MAXWG = 32;
+
+struct SnArgs {
+    const float* W; int R, K;
+    float* u; float* v;          // [R], [K]: read, and written back when iterations > 0
+    int iterations; float eps;
+    float* w_sn; float* sigma;   // [R*K], [1]
+    float* t; float* s;          // scratch [K], [R]: the two matrix-vector products, assembled from the workgroups' slices
+    unsigned* sync;              // [0] barrier arrivals, [1] workgroups done: both 0 between launches
+    int nwg;
+};
+
+__device__ __forceinline__ float block_sum(float x, float* red)       // SN_THREADS threads; every thread gets the sum
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();                       // red may still be read from the previous call
+    if (lane == 0) red[wave] = x;
+    __syncthreads();
+    float r = 0.f;
+#pragma unroll
+    for (int w = 0; w < SN_THREADS / 64; ++w) r += red[w];
+    return r;
+}
+
+// What the workgroups hand each other (slices of the two matrix-vector products, a few hundred bytes) is stored
+// write-through and loaded past the L1 (relaxed agent-scope atomics = sc1 accesses): the XCDs' L2s are not coherent
+// and an agent-scope release would first write back everything the kernels before this one left dirty in the L2.
+__device__ __forceinline__ void put(float* p, float x)
+{ __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float get(const float* p)
+{ return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+
+// all workgroups of the launch (co-resident: at most SN_MAXWG of them) meet here for the `phase`-th time
+__device__ __forceinline__ void grid_meet(unsigned* sync, int nwg, int phase)
+{
+    if (nwg == 1) { __syncthreads(); return; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave: my write-through stores have landed
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = (unsigned)(phase + 1) * (unsigned)nwg;
+        while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+}
+
+// One launch, nwg <= 32 workgroups.  Every workgroup owns a COLUMN slice of W for v = N(W^T u) and a ROW slice for
+// u = N(W v) and for the final scaling; the two products are assembled in global scratch between grid meetings and
+// each workgroup normalises them for itself (K + R floats: nothing), so all sums run in a fixed order.
+__global__ __launch_bounds__(SN_THREADS) void sn_forward_kernel(SnArgs a)
+{
+    extern __shared__ float sm[];
+    float* us = sm;                 // [R]
+    float* vs = us + a.R;           // [K]
+    float* red = vs + a.K;          // [SN_THREADS / 64]
+    float* part = red + SN_THREADS / 64;      // [SN_THREADS]: partial column sums
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int R = a.R, K = a.K, nwg = a.nwg, b = blockIdx.x;
+    const int j0 = (int)((int64_t)K * b / nwg), j1 = (int)((int64_t)K * (b + 1) / nwg);      // my columns
+    const int r0 = (int)((int64_t)R * b / nwg), r1 = (int)((int64_t)R * (b + 1) / nwg);      // my rows
+    for (int r = tid; r < R; r += SN_THREADS) us[r] = a.u[r];
+    for (int j = tid; j < K; j += SN_THREADS) vs[j] = a.v[j];
+    __syncthreads();
+    int phase = 0;
+
+    auto rows_times_v = [&]() {     // a.s[r0..r1) = W[r0..r1) vs: one wave per row, lanes along the row
+        for (int r = r0 + wave; r < r1; r += SN_THREADS / 64) {
+            const float* wr = a.W + (int64_t)r * K;
+            float p = 0.f;
+#pragma unroll 8                    // the loads of a row go out together: this loop is latency, not bandwidth
+            for (int j = lane; j < K; j += 64) p = fmaf(wr[j], vs[j], p);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) p += __shfl_xor(p, off);
+            if (lane == 0) put(a.s + r, p);
+        }
+    };
+
+    float sig_norm = 0.f;
+    for (int it = 0; it < a.iterations; ++it) {
+        // t[j0..j1) = sum_r W[r][j] u[r]: the slice's columns across the threads, the rows split over thread groups
+        const int nc = j1 - j0;
+        if (nc > 0) {
+            const int groups = SN_THREADS / nc > 0 ? (SN_THREADS / nc < R ? SN_THREADS / nc : R) : 1;
+            for (int c0 = 0; c0 < nc; c0 += SN_THREADS) {       // (nc > SN_THREADS only for very wide, few-row matrices)
+                const int c = c0 + tid % (nc < SN_THREADS ? nc : SN_THREADS), gidx = tid / (nc < SN_THREADS ? nc : SN_THREADS);
+                float tsum = 0.f;
+                if (c < nc && gidx < groups) {
+#pragma unroll 8
+                    for (int r = gidx; r < R; r += groups) tsum = fmaf(a.W[(int64_t)r * K + j0 + c], us[r], tsum);
+                }
+                part[tid] = (c < nc && gidx < groups) ? tsum : 0.f;
+                __syncthreads();
+                if (gidx == 0 && c < nc) {
+                    float tot = 0.f;
+                    const int stride = nc < SN_THREADS ? nc : SN_THREADS;
+                    for (int q = 0; q < groups; ++q) tot += part[q * stride + (c - c0)];
+                    put(a.t + j0 + c, tot);
+                }
+                __syncthreads();
+            }
+        }
+        grid_meet(a.sync, nwg, phase++);
+        float nrm = 0.f;
+        for (int j = tid; j < K; j += SN_THREADS) { const float tv = get(a.t + j); vs[j] = tv; nrm = fmaf(tv, tv, nrm); }
+        nrm = block_sum(nrm, red);
+        const float inv_v = 1.0f / fmaxf(sqrtf(nrm), a.eps);
+        for (int j = tid; j < K; j += SN_THREADS) vs[j] *= inv_v;
+        __syncthreads();
+        rows_times_v();
+        grid_meet(a.sync, nwg, phase++);
+        float n2 = 0.f;
+        for (int r = tid; r < R; r += SN_THREADS) { const float sv = get(a.s + r); us[r] = sv; n2 = fmaf(sv, sv, n2); }
+        n2 = block_sum(n2, red);
+        const float ns = sqrtf(n2), inv_u = 1.0f / fmaxf(ns, a.eps);
+        for (int r = tid; r < R; r += SN_THREADS) us[r] *= inv_u;
+        __syncthreads();
+        sig_norm = n2 * inv_u;                       // u^T (W v) with u = (W v) / max(|W v|, eps)
+        if (it + 1 < a.iterations) grid_meet(a.sync, nwg, phase++);      // a.t / a.s are rewritten by the next round
+    }
+    float sigma = sig_norm;
+    if (a.iterations == 0) {
+        rows_times_v();
+        grid_meet(a.sync, nwg, phase++);
+        float d = 0.f;
+        for (int r = tid; r < R; r += SN_THREADS) d = fmaf(us[r], get(a.s + r), d);
+        sigma = block_sum(d, red);
+    }
+    if (b == 0) {
+        if (a.iterations > 0) {
+            for (int r = tid; r < R; r += SN_THREADS) a.u[r] = us[r];
+            for (int j = tid; j < K; j += SN_THREADS) a.v[j] = vs[j];
+        }
+        if (tid == 0) a.sigma[0] = sigma;
+    }
+    const float inv = 1.0f / sigma;
+    const int64_t e0 = (int64_t)r0 * K, e1 = (int64_t)r1 * K;
+#pragma unroll 8
+    for (int64_t e = e0 + tid; e < e1; e += SN_THREADS) a.w_sn[e] = a.W[e] * inv;
+    // the last workgroup out re-arms the meeting counter for the next launch
+    if (nwg > 1 && tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(a.sync + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == (unsigned)nwg - 1) {
+            __hip_atomic_store(a.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.sync + 1, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+struct SnBwdArgs {
+    const float* g; const float* w_sn; const float* u; const float* v; const float* sigma;
+    int R, K, fully_diff; float* dW;
+    float* partial; unsigned* sync; int nwg;          // fully_diff: per-workgroup partial sums of <g, w_sn>
+};
+
+__global__ __launch_bounds__(SN_THREADS) void sn_backward_kernel(SnBwdArgs a)
+{
+    __shared__ float red[SN_THREADS / 64];
+    const int tid = threadIdx.x, b = blockIdx.x, nwg = a.nwg;
+    const int64_t n = (int64_t)a.R * a.K;
+    const int64_t e0 = n * b / nwg, e1 = n * (b + 1) / nwg;
+    float c = 0.f;
+    if (a.fully_diff) {
+        float p = 0.f;
+        for (int64_t e = e0 + tid; e < e1; e += SN_THREADS) p = fmaf(a.g[e], a.w_sn[e], p);
+        p = block_sum(p, red);
+        if (tid == 0) put(a.partial + b, p);
+        grid_meet(a.sync, nwg, 0);
+        for (int q = 0; q < nwg; ++q) c += get(a.partial + q);   // same order in every workgroup
+    }
+    const float inv = 1.0f / a.sigma[0];
+#pragma unroll 4
+    for (int64_t e = e0 + tid; e < e1; e += SN_THREADS) {
+        const int r = (int)(e / a.K), j = (int)(e % a.K);
+        a.dW[e] = (a.g[e] - c * a.u[r] * a.v[j]) * inv;
+    }
+    if (a.fully_diff && nwg > 1 && tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(a.sync + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == (unsigned)nwg - 1) {
+            __hip_atomic_store(a.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.sync + 1, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+int sn_workgroups(int R, int K)
+{
+    int nwg = (int)(((int64_t)R * K + 4095) / 4096);          // ~4096 elements per workgroup and pass
+    if (nwg > SN_MAXWG) nwg = SN_MAXWG;
+    if (nwg > R) nwg = R;                                     // at least one row each
+    return nwg < 1 ? 1 : nwg;
+}
+
+}  // namespace
+
+size_t wc_sn_lds_bytes(int R, int K) { return (size_t)(R + K + SN_THREADS / 64 + SN_THREADS) * sizeof(float); }
+// scratch: t[K] | s[R] | partial[32] | sync[4] (the sync words must be zero before the first launch; every launch leaves them zero)
+size_t wc_sn_workspace_bytes(int R, int K) { return ((size_t)(R + K + SN_MAXWG) * sizeof(float) + 15) / 16 * 16 + 16; }
+
+hipError_t wc_launch_spectral_norm(const float* W, int R, int K, float* u, float* v, int iterations, float eps,
+                                   float* w_sn, float* sigma, void* ws, hipStream_t st)
+{
+    const size_t lds = wc_sn_lds_bytes(R, K);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sn_forward_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    float* t = static_cast<float*>(ws);
+    unsigned* sync = reinterpret_cast<unsigned*>(static_cast<char*>(ws) + wc_sn_workspace_bytes(R, K) - 16);
+    SnArgs a{W, R, K, u, v, iterations, eps, w_sn, sigma, t, t + K, sync, sn_workgroups(R, K)};
+    hipLaunchKernelGGL(sn_forward_kernel, dim3(a.nwg), dim3(SN_THREADS), lds, st, a);
+    return hipGetLastError();
+}
+
+hipError_t wc_launch_spectral_norm_bwd(const float* g, const float* w_sn, const float* u, const float* v, const float* sigma,
+                                       int R, int K, int fully_diff, float* dW, void* ws, hipStream_t st)
+{
+    float* t = static_cast<float*>(ws);
+    unsigned* sync = reinterpret_cast<unsigned*>(static_cast<char*>(ws) + wc_sn_workspace_bytes(R, K) - 16);
+    SnBwdArgs a{g, w_sn, u, v, sigma, R, K, fully_diff, dW, t + K + R, sync + 2, sn_workgroups(R, K)};
+    hipLaunchKernelGGL(sn_backward_kernel, dim3(a.nwg), dim3(SN_THREADS), 0, st, a);
+    return hipGetLastError();
+}

@@ -2,7 +2,7 @@
 
 The discriminator holds NO whitening-and-coloring site in any shipped recipe (`--discriminator_norm`
 defaults to 'n', run.py:298), so it is the stock-torch part of the surrounding step: SN-ResNet blocks
-on MIOpen convolutions with torch's spectral-norm parametrisation standing in for gan.SNConv2D /
+on MIOpen convolutions with the fused spectral-norm op (wc_gan_amd/spectral.py) standing in for gan.SNConv2D /
 SNDense / SNEmbeding (discriminator.py:26-33).  Three heads as in discriminator.py:73-85.
 """
 from __future__ import annotations
@@ -91,16 +91,26 @@ def make_discriminator(input_image_shape=(32, 32, 3), input_cls_shape=(1,), bloc
                        sum_pool=True, dropout=False, arch='res', filters_emb=10):
     assert arch == 'res', "only the ResNet critic is built for the harness (dcgan critic: out of the WC path)"
     assert type in [None, 'AC_GAN', 'PROJECTIVE']
-    conv_layer = partial(Conv2D, spectral=bool(spectral))
+    sn_kw = dict(spectral_iterations=spectral_iterations, fully_diff_spectral=fully_diff_spectral)
+    conv_layer = partial(Conv2D, spectral=bool(spectral), conv_singular=conv_singular, **sn_kw)
 
-    def dense(i, o):
+    def dense(i, o):        # SNDense / Dense (discriminator.py:29-30)
+        if spectral:
+            from .spectral import SNLinear
+            lin = SNLinear(i, o, **sn_kw)
+            with torch.no_grad():
+                nn.init.xavier_uniform_(lin.weight); nn.init.zeros_(lin.bias)
+                lin._sn_init(**sn_kw)
+            return lin
         lin = nn.Linear(i, o)
         nn.init.xavier_uniform_(lin.weight); nn.init.zeros_(lin.bias)
-        return nn.utils.parametrizations.spectral_norm(lin) if spectral else lin
+        return lin
 
-    def emb(k, d):
-        e = nn.Embedding(k, d)
-        return nn.utils.parametrizations.spectral_norm(e) if spectral else e
+    def emb(k, d):          # SNEmbeding / Embedding (discriminator.py:33)
+        if spectral:
+            from .spectral import SNEmbedding
+            return SNEmbedding(k, d, **sn_kw)
+        return nn.Embedding(k, d)
 
     norm_layer = create_norm(norm, after_norm, number_of_classes=number_of_classes, filters_emb=filters_emb)
     return Discriminator(int(input_image_shape[-1]), block_sizes, resamples, norm_layer, conv_layer, dense, emb,

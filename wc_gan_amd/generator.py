@@ -43,16 +43,24 @@ def to_nhwc(x):
 class Conv2D(nn.Module):
     """Keras-style Conv2D on NHWC tensors (padding='same'); glorot-uniform kernel, zero bias."""
 
-    def __init__(self, in_channels, filters, kernel_size=(3, 3), use_bias=True, name=None, spectral=False):
+    def __init__(self, in_channels, filters, kernel_size=(3, 3), use_bias=True, name=None, spectral=False,
+                 spectral_iterations=1, fully_diff_spectral=False, conv_singular=True):
         super().__init__()
         k = kernel_size if isinstance(kernel_size, int) else kernel_size[0]
-        self.conv = nn.Conv2d(in_channels, filters, k, padding=k // 2, bias=use_bias)
-        nn.init.xavier_uniform_(self.conv.weight)
+        if spectral:        # SNConv2D (generator.py:105-106, discriminator.py:27-28): the fused HIP op
+            from .spectral import SNConv2d
+            self.conv = SNConv2d(in_channels, filters, k, padding=k // 2, bias=use_bias,
+                                 spectral_iterations=spectral_iterations, fully_diff_spectral=fully_diff_spectral,
+                                 conv_singular=conv_singular)
+            with torch.no_grad():
+                nn.init.xavier_uniform_(self.conv.weight)
+                self.conv._sn_init(spectral_iterations, fully_diff_spectral, conv_singular)     # u, v for the new kernel
+        else:
+            self.conv = nn.Conv2d(in_channels, filters, k, padding=k // 2, bias=use_bias)
+            nn.init.xavier_uniform_(self.conv.weight)
         if use_bias:
             nn.init.zeros_(self.conv.bias)
         self.conv = self.conv.to(memory_format=torch.channels_last)
-        if spectral:
-            self.conv = nn.utils.parametrizations.spectral_norm(self.conv)
         self.layer_name = name
 
     def forward(self, x):
@@ -196,8 +204,13 @@ class Generator(nn.Module):
             in_dim += self.first_block_shape[-1]
         self.dense = nn.Linear(in_dim, int(np.prod(self.first_block_shape)))
         nn.init.xavier_uniform_(self.dense.weight); nn.init.zeros_(self.dense.bias)
-        if dense_spectral:
-            self.dense = nn.utils.parametrizations.spectral_norm(self.dense)
+        if dense_spectral:      # SNDense (generator.py:107-108)
+            from .spectral import SNLinear
+            sn = SNLinear(self.dense.in_features, self.dense.out_features)
+            with torch.no_grad():
+                sn.weight.copy_(self.dense.weight); sn.bias.copy_(self.dense.bias)
+                sn._sn_init()
+            self.dense = sn
         blocks = []
         ch = self.first_block_shape[-1]
         for i, (bs, rs) in enumerate(zip(block_sizes, resamples)):

@@ -177,3 +177,49 @@ def stream_copy(src, dst):
     lib = _lib.load()
     _lib.check(lib.wc_stream_copy_f32(_ptr(src), _ptr(dst), src.numel(), _stream()), "wc_stream_copy_f32")
     return dst
+
+
+def spectral_norm_workspace(rows, cols, device):
+    """The per-weight scratch of the spectral-norm op: zeroed once here, left zero by every launch."""
+    lib = _lib.load()
+    return torch.zeros(int(lib.wc_spectral_norm_workspace_bytes(int(rows), int(cols))), dtype=torch.uint8, device=device)
+
+
+def spectral_norm(weight, u, v, iterations, ws, eps=1e-12):
+    """N3: one launch of the power iteration + normalisation.  weight: float32, dense (contiguous in its own memory
+    format; rows = shape[0]); u (rows,), v (numel/rows,) float32, updated in place when iterations > 0; ws from
+    spectral_norm_workspace (one per weight).  Returns (w_sn with the weight's shape/strides, sigma (1,))."""
+    lib = _lib.load()
+    if not weight.is_cuda:
+        raise _lib.WcHipError("weight must be a CUDA/HIP tensor (the spectral-norm op has no CPU fallback)")
+    if weight.dtype != torch.float32:
+        raise TypeError(f"weight must be float32, got {weight.dtype}")
+    if not (weight.is_contiguous() or (weight.dim() == 4 and weight.is_contiguous(memory_format=torch.channels_last))):
+        raise ValueError("weight must be dense (contiguous or channels_last)")
+    _need(u, torch.float32, "u", 1)
+    _need(v, torch.float32, "v", 1)
+    rows = weight.shape[0]
+    cols = weight.numel() // rows
+    if u.numel() != rows or v.numel() != cols:
+        raise ValueError(f"u/v sizes {u.numel()}/{v.numel()} do not match a ({rows}, {cols}) matrix")
+    w_sn = torch.empty_like(weight)            # preserve_format: same memory order as the weight
+    sigma = torch.empty(1, dtype=torch.float32, device=weight.device)
+    _lib.check(lib.wc_spectral_norm_f32(_ptr(weight), rows, cols, _ptr(u), _ptr(v), int(iterations), float(eps),
+                                        _ptr(w_sn), _ptr(sigma), _ptr(ws), ws.numel(), _stream()), "wc_spectral_norm_f32")
+    return w_sn, sigma
+
+
+def spectral_norm_bwd(g, w_sn, u, v, sigma, fully_diff, ws):
+    """dW = (g - fully_diff <g, w_sn> u v^T) / sigma, in w_sn's memory order."""
+    lib = _lib.load()
+    rows = w_sn.shape[0]
+    cols = w_sn.numel() // rows
+    if g.stride() != w_sn.stride():
+        g = g.contiguous(memory_format=torch.channels_last) if (w_sn.dim() == 4 and w_sn.is_contiguous(memory_format=torch.channels_last)) else g.contiguous()
+    if g.dtype != torch.float32 or not g.is_cuda:
+        raise TypeError("g must be a float32 CUDA/HIP tensor")
+    dW = torch.empty_like(w_sn)
+    _lib.check(lib.wc_spectral_norm_bwd_f32(_ptr(g), _ptr(w_sn), _ptr(u), _ptr(v), _ptr(sigma), rows, cols,
+                                            1 if fully_diff else 0, _ptr(dW), _ptr(ws), ws.numel(), _stream()),
+               "wc_spectral_norm_bwd_f32")
+    return dW
