@@ -168,14 +168,16 @@ class ResBlockUp(nn.Module):
 
     def forward(self, x, cls):
         h = F.relu(self.bn1(x, cls))
-        s = x
+        # the 1x1 shortcut commutes with nearest-neighbour upsampling (every output pixel is the same per-pixel affine
+        # map of its source pixel): run it at the input resolution, a quarter of the work, then upsample
+        s = self.shortcut(x)
         if self.resample == 'UP':
             h = upsample2x(h)
             s = upsample2x(s)
         h = self.conv1(h)
         h = F.relu(self.bn2(h, cls))
         h = self.conv2(h)
-        return h + self.shortcut(s)
+        return h + s
 
 
 class DCBlockUp(nn.Module):
