@@ -126,3 +126,36 @@ def test_sn_layers_train_eval_and_state():
     assert lin.weight.grad.shape == (1, 128) and emb.weight.grad.shape == (10, 128)
     with pytest.raises(RuntimeError):
         SNLinear(4, 4)(torch.randn(2, 4))                                             # no non-HIP path
+
+
+import os
+SN_GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "sn_golden.npz")
+SN_NAMES = ["conv3x3", "conv1x1", "dense_row", "embedding", "eval"]
+
+
+@pytest.mark.parametrize("name", SN_NAMES)
+def test_oracle_reproduces_sn_golden(name):
+    z = np.load(SN_GOLDEN)
+    f = lambda k: z[f"{name}/{k}"]
+    w_sn, sigma, u1, v1 = O.spectral_normalize(f("W"), f("u0"), f("v0"), int(f("iterations")))
+    assert np.abs(w_sn - f("w_sn")).max() < 1e-6 and abs(sigma - float(f("sigma"))) < 1e-6 * abs(sigma)
+    assert np.abs(u1 - f("u1")).max() < 1e-6 and np.abs(v1 - f("v1")).max() < 1e-6
+    for key, fd in (("dW_full", True), ("dW_const", False)):
+        d = O.spectral_normalize_backward(f("g"), w_sn, u1, v1, sigma, fd)
+        assert np.abs(d - f(key)).max() < 1e-5 * np.abs(f(key)).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SN_NAMES)
+def test_hip_matches_sn_golden(name):
+    from wc_gan_amd import ops
+    z = np.load(SN_GOLDEN)
+    f = lambda k: torch.from_numpy(np.ascontiguousarray(z[f"{name}/{k}"])).cuda()
+    W, u, v, g = f("W"), f("u0").clone(), f("v0").clone(), f("g")
+    ws = ops.spectral_norm_workspace(W.shape[0], W.shape[1], 'cuda')
+    w_sn, sigma = ops.spectral_norm(W, u, v, int(z[f"{name}/iterations"]), ws)
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+    assert rel(w_sn, f("w_sn")) < 2e-5 and rel(sigma, f("sigma").reshape(1)) < 2e-5
+    assert float((u - f("u1")).abs().max()) < 2e-5 and float((v - f("v1")).abs().max()) < 2e-5
+    for key, fd in (("dW_full", True), ("dW_const", False)):
+        assert rel(ops.spectral_norm_bwd(g, w_sn, u, v, sigma, fd, ws), f(key)) < 2e-5
