@@ -153,6 +153,8 @@ int wc_bwd_apply_f32(const float* gy, const float* x, const float* mu, const flo
 size_t wc_spectral_norm_workspace_bytes(int rows, int cols);
 int wc_spectral_norm_f32(const float* W, int rows, int cols, float* u, float* v, int iterations, float eps,
                          float* w_sn /*[rows*cols] out*/, float* sigma /*[1] out*/,
+                         float* u_used /*[rows] out, nullable*/, float* v_used /*[cols] out, nullable: u, v as used for sigma,
+                                                                    for the backward of THIS call (u, v move on)*/,
                          void* ws, size_t ws_bytes, wc_stream_t stream);
 
 /* Gradient of the above w.r.t. W for constant u, v:  dW = (g - fully_diff * <g, w_sn> u v^T) / sigma.

@@ -45,7 +45,7 @@ SIGNATURES = {
     "wc_stream_copy_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "wc_spectral_norm_workspace_bytes": (c_size_t, [c_int, c_int]),
     "wc_spectral_norm_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p,
-                                     c_void_p, c_size_t, c_void_p]),
+                                     c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wc_spectral_norm_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
                                          c_void_p, c_size_t, c_void_p]),
 }

@@ -391,14 +391,15 @@ size_t wc_spectral_norm_workspace_bytes(int rows, int cols)
 }
 
 int wc_spectral_norm_f32(const float* W, int rows, int cols, float* u, float* v, int iterations, float eps,
-                         float* w_sn, float* sigma, void* ws, size_t ws_bytes, wc_stream_t stream)
+                         float* w_sn, float* sigma, float* u_used, float* v_used,
+                         void* ws, size_t ws_bytes, wc_stream_t stream)
 {
     if (!W || !u || !v || !w_sn || !sigma || !ws) return WC_ERR_NULL;
     if (rows <= 0 || cols <= 0 || (int64_t)rows * cols > (int64_t)1 << 28) return WC_ERR_SHAPE;
     if (iterations < 0 || !(eps >= 0.f)) return WC_ERR_ARG;
     if (wc_sn_lds_bytes(rows, cols) > 150 * 1024) return WC_ERR_SHAPE;        // u and v live in LDS
     if (ws_bytes < wc_sn_workspace_bytes(rows, cols)) return WC_ERR_WORKSPACE;
-    WC_TRY(wc_launch_spectral_norm(W, rows, cols, u, v, iterations, eps, w_sn, sigma, ws, static_cast<hipStream_t>(stream)));
+    WC_TRY(wc_launch_spectral_norm(W, rows, cols, u, v, iterations, eps, w_sn, sigma, u_used, v_used, ws, static_cast<hipStream_t>(stream)));
     return WC_OK;
 }
 

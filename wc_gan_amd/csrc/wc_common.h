@@ -57,7 +57,7 @@ hipError_t wc_launch_stream_copy(const float* src, float* dst, int64_t n, hipStr
 size_t wc_sn_lds_bytes(int R, int K);
 size_t wc_sn_workspace_bytes(int R, int K);
 hipError_t wc_launch_spectral_norm(const float* W, int R, int K, float* u, float* v, int iterations, float eps,
-                                   float* w_sn, float* sigma, void* ws, hipStream_t st);
+                                   float* w_sn, float* sigma, float* u_used, float* v_used, void* ws, hipStream_t st);
 hipError_t wc_launch_spectral_norm_bwd(const float* g, const float* w_sn, const float* u, const float* v, const float* sigma,
                                        int R, int K, int fully_diff, float* dW, void* ws, hipStream_t st);
 

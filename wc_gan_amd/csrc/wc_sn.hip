@@ -20,6 +20,7 @@ struct SnArgs {
     float* u; float* v;          // [R], [K]: read, and written back when iterations > 0
     int iterations; float eps;
     float* w_sn; float* sigma;   // [R*K], [1]
+    float* u_used; float* v_used;   // nullable: copies of u, v as used for sigma (what the backward needs)
     float* t; float* s;          // scratch [K], [R]: the two matrix-vector products, assembled from the workgroups' slices
     unsigned* sync;              // [0] barrier arrivals, [1] workgroups done: both 0 between launches
     int nwg;
@@ -148,6 +149,8 @@ __global__ __launch_bounds__(SN_THREADS) void sn_forward_kernel(SnArgs a)
             for (int j = tid; j < K; j += SN_THREADS) a.v[j] = vs[j];
         }
         if (tid == 0) a.sigma[0] = sigma;
+        if (a.u_used) for (int r = tid; r < R; r += SN_THREADS) a.u_used[r] = us[r];
+        if (a.v_used) for (int j = tid; j < K; j += SN_THREADS) a.v_used[j] = vs[j];
     }
     const float inv = 1.0f / sigma;
     const int64_t e0 = (int64_t)r0 * K, e1 = (int64_t)r1 * K;
@@ -214,7 +217,7 @@ size_t wc_sn_lds_bytes(int R, int K) { return (size_t)(R + K + SN_THREADS / 64 +
 size_t wc_sn_workspace_bytes(int R, int K) { return ((size_t)(R + K + SN_MAXWG) * sizeof(float) + 15) / 16 * 16 + 16; }
 
 hipError_t wc_launch_spectral_norm(const float* W, int R, int K, float* u, float* v, int iterations, float eps,
-                                   float* w_sn, float* sigma, void* ws, hipStream_t st)
+                                   float* w_sn, float* sigma, float* u_used, float* v_used, void* ws, hipStream_t st)
 {
     const size_t lds = wc_sn_lds_bytes(R, K);
     if (lds > 48 * 1024) {
@@ -224,7 +227,7 @@ hipError_t wc_launch_spectral_norm(const float* W, int R, int K, float* u, float
     }
     float* t = static_cast<float*>(ws);
     unsigned* sync = reinterpret_cast<unsigned*>(static_cast<char*>(ws) + wc_sn_workspace_bytes(R, K) - 16);
-    SnArgs a{W, R, K, u, v, iterations, eps, w_sn, sigma, t, t + K, sync, sn_workgroups(R, K)};
+    SnArgs a{W, R, K, u, v, iterations, eps, w_sn, sigma, u_used, v_used, t, t + K, sync, sn_workgroups(R, K)};
     hipLaunchKernelGGL(sn_forward_kernel, dim3(a.nwg), dim3(SN_THREADS), lds, st, a);
     return hipGetLastError();
 }

@@ -185,10 +185,11 @@ def spectral_norm_workspace(rows, cols, device):
     return torch.zeros(int(lib.wc_spectral_norm_workspace_bytes(int(rows), int(cols))), dtype=torch.uint8, device=device)
 
 
-def spectral_norm(weight, u, v, iterations, ws, eps=1e-12):
+def spectral_norm(weight, u, v, iterations, ws, eps=1e-12, keep_uv=False):
     """N3: one launch of the power iteration + normalisation.  weight: float32, dense (contiguous in its own memory
     format; rows = shape[0]); u (rows,), v (numel/rows,) float32, updated in place when iterations > 0; ws from
-    spectral_norm_workspace (one per weight).  Returns (w_sn with the weight's shape/strides, sigma (1,))."""
+    spectral_norm_workspace (one per weight).  Returns (w_sn with the weight's shape/strides, sigma (1,)) and, with
+    keep_uv, fresh copies of u and v as used for sigma (written by the same launch)."""
     lib = _lib.load()
     if not weight.is_cuda:
         raise _lib.WcHipError("weight must be a CUDA/HIP tensor (the spectral-norm op has no CPU fallback)")
@@ -204,9 +205,12 @@ def spectral_norm(weight, u, v, iterations, ws, eps=1e-12):
         raise ValueError(f"u/v sizes {u.numel()}/{v.numel()} do not match a ({rows}, {cols}) matrix")
     w_sn = torch.empty_like(weight)            # preserve_format: same memory order as the weight
     sigma = torch.empty(1, dtype=torch.float32, device=weight.device)
+    uu = torch.empty_like(u) if keep_uv else None
+    vv = torch.empty_like(v) if keep_uv else None
     _lib.check(lib.wc_spectral_norm_f32(_ptr(weight), rows, cols, _ptr(u), _ptr(v), int(iterations), float(eps),
-                                        _ptr(w_sn), _ptr(sigma), _ptr(ws), ws.numel(), _stream()), "wc_spectral_norm_f32")
-    return w_sn, sigma
+                                        _ptr(w_sn), _ptr(sigma), _ptr(uu), _ptr(vv), _ptr(ws), ws.numel(), _stream()),
+               "wc_spectral_norm_f32")
+    return (w_sn, sigma, uu, vv) if keep_uv else (w_sn, sigma)
 
 
 def spectral_norm_bwd(g, w_sn, u, v, sigma, fully_diff, ws):

@@ -23,9 +23,9 @@ from . import ops
 class SpectralNormFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weight, u, v, ws, iterations, eps, fully_diff):
-        w_sn, sigma = ops.spectral_norm(weight.detach(), u, v, iterations, ws, eps)
-        # u, v as used for sigma: the kernel has just written them; later forwards overwrite the buffers, so keep copies
-        ctx.save_for_backward(w_sn, u.clone(), v.clone(), sigma)
+        # u, v as used for sigma come back as copies from the same launch: later forwards move the buffers on
+        w_sn, sigma, uu, vv = ops.spectral_norm(weight.detach(), u, v, iterations, ws, eps, keep_uv=True)
+        ctx.save_for_backward(w_sn, uu, vv, sigma)
         ctx.fully_diff = bool(fully_diff)
         ctx.ws = ws
         ctx.mark_non_differentiable(sigma)
