@@ -63,6 +63,15 @@ def test_fast_apply_out_of_range_tiles_take_the_exact_path(ops):
     ref = _ref_apply(x, mu, A, b, np.zeros(N, int))
     assert torch.isfinite(y).all()
     assert rel(y.cpu().numpy().reshape(ref.shape), ref) < 3e-6
+    # the redo path with NO bias and NO centre (null pointers at the ABI), and with both plus per-sample tables
+    y0 = ops.apply(dev(x), None, dev(A), None, None, fast=True)
+    assert rel(y0.cpu().numpy().reshape(ref.shape), ref) < 3e-6
+    A3 = (rng.standard_normal((3, C, C)) / np.sqrt(C)).astype(np.float32)
+    b3 = rng.standard_normal((3, C)).astype(np.float32); mu3 = rng.standard_normal(C).astype(np.float32)
+    slot = rng.integers(0, 3, N).astype(np.int32)
+    y3 = ops.apply(dev(x), dev(mu3), dev(A3), dev(b3), dev(slot, torch.int32), fast=True)
+    ref3 = _ref_apply(x, mu3, A3, b3, slot)
+    assert rel(y3.cpu().numpy().reshape(ref3.shape), ref3) < 3e-6
 
 
 @pytest.mark.parametrize("shape,Kc,train", [((16, 32, 32, 256), 1, True), ((16, 32, 32, 128), 3, True), ((32, 32, 32, 64), 1, False),
