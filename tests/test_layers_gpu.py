@@ -236,3 +236,26 @@ def test_subpixel_upsample_conv_equals_upsample_then_conv(spectral):
     b.backward(g); gb = conv.conv.weight.grad
     assert float((x1.grad - x2.grad).abs().max() / x1.grad.abs().max()) < 1e-5
     assert float((ga - gb).abs().max() / ga.abs().max()) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spectral", [False, True])
+def test_pooled_conv_equals_conv_then_average_pool(spectral):
+    """discriminator.py:41-54 runs Conv2D then AveragePooling2D; Conv2D.forward_pooled is the same map (values and grads)."""
+    import torch.nn.functional as F
+    from wc_gan_amd.generator import Conv2D, to_nchw_view, to_nhwc
+    torch.manual_seed(4)
+    conv = Conv2D(24, 40, (3, 3), spectral=spectral).cuda()
+    conv.eval()
+    with torch.no_grad():
+        conv.conv.bias.normal_()
+    x1 = torch.randn(5, 32, 32, 24, device='cuda', requires_grad=True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    a = to_nhwc(F.avg_pool2d(to_nchw_view(conv(x1)), 2)); b = conv.forward_pooled(x2)
+    assert a.shape == b.shape == (5, 16, 16, 40)
+    assert float((a - b).abs().max() / a.abs().max()) < 1e-5
+    g = torch.randn_like(a)
+    a.backward(g); ga = conv.conv.weight.grad.clone(); conv.conv.weight.grad = None
+    b.backward(g); gb = conv.conv.weight.grad
+    assert float((x1.grad - x2.grad).abs().max() / x1.grad.abs().max()) < 1e-5
+    assert float((ga - gb).abs().max() / ga.abs().max()) < 1e-5

@@ -91,6 +91,22 @@ class Conv2D(nn.Module):
         return to_nhwc(out)
 
 
+def _conv2d_forward_pooled(self, x):
+    """avg_pool2x2(conv(x)) for a 3x3 'same' convolution as ONE 4x4 stride-2 convolution: the average of the four
+    3x3 windows under an output pixel is a 4x4 window whose taps are quarter-sums of the 3x3 taps (zero padding carries
+    over, the bias is unchanged) -- 16 instead of 36 tap products per output and no full-resolution intermediate.
+    Same linear map as discriminator.py:41-54's Conv2D then AveragePooling2D; differs by fp32 summation order only."""
+    conv = self.conv
+    w = conv.normalized_weight() if hasattr(conv, 'normalized_weight') else conv.weight
+    if tuple(w.shape[2:]) != (3, 3):
+        return to_nhwc(F.avg_pool2d(to_nchw_view(self.forward(x)), 2))
+    k = (F.pad(w, (0, 1, 0, 1)) + F.pad(w, (1, 0, 0, 1)) + F.pad(w, (0, 1, 1, 0)) + F.pad(w, (1, 0, 1, 0))) * 0.25
+    return to_nhwc(F.conv2d(to_nchw_view(x), k.contiguous(memory_format=torch.channels_last), conv.bias, stride=2, padding=1))
+
+
+Conv2D.forward_pooled = _conv2d_forward_pooled
+
+
 def upsample2x(x):
     return to_nhwc(F.interpolate(to_nchw_view(x), scale_factor=2, mode='nearest'))
 
