@@ -218,7 +218,7 @@ def test_eval_mode_plan_is_cached_and_invalidated():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("spectral", [False, True])
-def test_subpixel_upsample_conv_equals_upsample_then_conv(spectral):
+def test_upsample_conv_as_transposed_conv_equals_upsample_then_conv(spectral):
     """generator.py:144-151 runs UpSampling2D then Conv2D; Conv2D.forward_upsampled is the same map (values and grads)."""
     from wc_gan_amd.generator import Conv2D, upsample2x
     torch.manual_seed(3)

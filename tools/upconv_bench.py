@@ -30,14 +30,28 @@ def upconv_subpixel(h, w, b):
         out[:, :, dy::2, dx::2] = y[:, :, dy:dy + H, dx:dx + W]
     return out
 
-for (N, C, H) in [(128, 256, 16), (320, 256, 16), (128, 256, 8), (128, 256, 4)]:
+def transposed_kernel(w):
+    # (Cout, Cin, 3, 3) -> (Cin, Cout, 4, 4): output row 2y-1+a receives x[y] times the taps that read an upsampled copy of y
+    rows = torch.stack([w[:, :, 2], w[:, :, 1] + w[:, :, 2], w[:, :, 0] + w[:, :, 1], w[:, :, 0]], dim=2)          # (Cout,Cin,4,3)
+    k = torch.stack([rows[..., 2], rows[..., 1] + rows[..., 2], rows[..., 0] + rows[..., 1], rows[..., 0]], dim=3)   # (Cout,Cin,4,4)
+    return k.transpose(0, 1)
+
+def upconv_transposed(h, w, b):
+    return F.conv_transpose2d(h, transposed_kernel(w).contiguous(memory_format=torch.channels_last), b, stride=2, padding=1)
+
+for (N, C, H) in [(128, 256, 16), (320, 256, 16), (128, 256, 8), (320, 256, 8), (128, 256, 4)]:
     h = torch.randn(N, C, H, H, device='cuda').contiguous(memory_format=torch.channels_last).requires_grad_(True)
     w = (torch.randn(C, C, 3, 3, device='cuda') / 48).contiguous(memory_format=torch.channels_last).requires_grad_(True)
     b = torch.zeros(C, device='cuda', requires_grad=True)
     ref = F.conv2d(F.interpolate(h, scale_factor=2, mode='nearest'), w, b, padding=1)
+    g = torch.randn_like(ref)
     got = upconv_subpixel(h, w, b)
     err = ((ref - got).abs().max() / ref.abs().max()).item()
-    g = torch.randn_like(ref)
+    got_t = upconv_transposed(h, w, b)
+    err_t = ((ref - got_t).abs().max() / ref.abs().max()).item()
+    def f_tr(): return upconv_transposed(h, w, b)
+    def fb_tr():
+        y = f_tr(); y.backward(torch.randn_like(ref) if False else g); h.grad = None; w.grad = None; b.grad = None
     def f_ref(): return F.conv2d(F.interpolate(h, scale_factor=2, mode='nearest'), w, b, padding=1)
     def f_sub(): return upconv_subpixel(h, w, b)
     def fb_ref():
@@ -45,5 +59,5 @@ for (N, C, H) in [(128, 256, 16), (320, 256, 16), (128, 256, 8), (128, 256, 4)]:
     def fb_sub():
         y = f_sub(); y.backward(g); h.grad = None; w.grad = None; b.grad = None
     with torch.no_grad():
-        a, s = t(f_ref), t(f_sub)
-    print(f"N={N} C={C} {H}->{2*H}: forward upsample+3x3 {a:.3f} ms, sub-pixel {s:.3f} ms; fwd+bwd {t(fb_ref):.3f} vs {t(fb_sub):.3f} ms; max rel diff {err:.1e}", flush=True)
+        a, s, tr = t(f_ref), t(f_sub), t(f_tr)
+    print(f"N={N} C={C} {H}->{2*H}: forward upsample+3x3 {a:.3f} ms, sub-pixel {s:.3f}, transposed 4x4/s2 {tr:.3f} ms; fwd+bwd {t(fb_ref):.3f} / {t(fb_sub):.3f} / {t(fb_tr):.3f} ms; max rel diff {err:.1e} / {err_t:.1e}", flush=True)

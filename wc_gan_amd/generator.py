@@ -68,27 +68,19 @@ class Conv2D(nn.Module):
 
     def forward_upsampled(self, x):
         """conv(upsample2x(x)) for a 3x3 'same' convolution, without the upsampled tensor: a nearest-neighbour 2x
-        upsample followed by a 3x3 convolution is, for each of the four output parities (dy, dx), a 2x2 convolution
-        of the LOW-resolution input whose taps are sums of the 3x3 taps that land on the same source pixel (output
-        row 2y reads source rows y-1, y, y; row 2y+1 reads y, y, y+1; zero padding carries over) -- 16 instead of 36
+        upsample followed by a 3x3 convolution is ONE transposed convolution with a 4x4 kernel, stride 2, padding 1 --
+        source pixel y feeds output rows 2y-1 .. 2y+2, each through the sum of the 3x3 taps that read an upsampled
+        copy of y there ([w2, w1+w2, w0+w1, w0] along each axis; the zero padding carries over).  16 instead of 36
         tap products per source pixel and no 4x intermediate.  Same linear map as generator.py:144-151
         (UpSampling2D then Conv2D); the results differ by fp32 summation order only (measured 3e-6)."""
         conv = self.conv
         w = conv.normalized_weight() if hasattr(conv, 'normalized_weight') else conv.weight
         if tuple(w.shape[2:]) != (3, 3):
             return self.forward(upsample2x(x))
-        h = to_nchw_view(x)
-        N, _, H, W = h.shape
-        out = torch.empty(N, w.shape[0], 2 * H, 2 * W, device=h.device, dtype=h.dtype).contiguous(memory_format=torch.channels_last)
-        r0 = torch.stack([w[:, :, 0], w[:, :, 1] + w[:, :, 2]], dim=2)
-        r1 = torch.stack([w[:, :, 0] + w[:, :, 1], w[:, :, 2]], dim=2)
-        for dy, r in enumerate((r0, r1)):
-            c0 = torch.stack([r[..., 0], r[..., 1] + r[..., 2]], dim=3)
-            c1 = torch.stack([r[..., 0] + r[..., 1], r[..., 2]], dim=3)
-            for dx, k in enumerate((c0, c1)):
-                y = F.conv2d(h, k.contiguous(memory_format=torch.channels_last), conv.bias, padding=1)     # (H+1, W+1)
-                out[:, :, dy::2, dx::2] = y[:, :, dy:dy + H, dx:dx + W]
-        return to_nhwc(out)
+        rows = torch.stack([w[:, :, 2], w[:, :, 1] + w[:, :, 2], w[:, :, 0] + w[:, :, 1], w[:, :, 0]], dim=2)
+        k = torch.stack([rows[..., 2], rows[..., 1] + rows[..., 2], rows[..., 0] + rows[..., 1], rows[..., 0]], dim=3)
+        k = k.transpose(0, 1).contiguous(memory_format=torch.channels_last)             # (Cin, Cout, 4, 4)
+        return to_nhwc(F.conv_transpose2d(to_nchw_view(x), k, conv.bias, stride=2, padding=1))
 
 
 def _conv2d_forward_pooled(self, x):
@@ -213,9 +205,10 @@ class ResBlockUp(nn.Module):
         s = self.shortcut(x)
         if self.resample == 'UP':
             s = upsample2x(s)
-            # from 16x16 inputs on, the sub-pixel form of upsample + 3x3 is faster than MIOpen on the 4x tensor
-            # (measured: 2.36 vs 3.36 ms at 320x16x16x256, break-even near 8x8)
-            h = self.conv1.forward_upsampled(h) if h.shape[1] * h.shape[2] >= 256 else self.conv1(upsample2x(h))
+            # from 8x8 inputs on, upsample + 3x3 as one 4x4 stride-2 transposed convolution is faster than MIOpen on
+            # the 4x tensor (measured forward+backward at N = 128: 3.91 -> 2.02 ms from 16x16, 1.06 -> 0.72 from 8x8,
+            # even at 4x4)
+            h = self.conv1.forward_upsampled(h) if h.shape[1] * h.shape[2] >= 64 else self.conv1(upsample2x(h))
         else:
             h = self.conv1(h)
         h = F.relu(self.bn2(h, cls))
