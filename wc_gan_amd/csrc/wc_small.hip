@@ -316,7 +316,7 @@ __global__ __launch_bounds__(1024) void cholesky_kernel(double* __restrict__ T, 
 
 // Register-resident form for C <= 256: the lower triangle lives in the 1024 threads' registers as 4x4 tiles (two per
 // thread, tile e of the row-major triangle on thread e % 1024) for the whole factorisation.  Per 16-wide
-// panel: its tiles go to LDS, wave 0 factors the 16x16 diagonal block, one thread per row solves the panel, every
+// panel: its tiles go to LDS, wave 0 factors AND inverts the 16x16 diagonal block, the panel solve is a product with that inverse on the MFMA, every
 // thread applies the rank-16 update to the tiles it owns -- four barriers and no global round trip inside the loop
 // (the form above pays three L2 round trips per panel: measured 190 us at C = 256, of which the flops are ~25).
 #ifndef CHOL_SKIP
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(1024) void cholesky_kernel(double* __restrict__ T, 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 // Register-resident form for C <= 256: the trailing matrix lives in the 16 waves' registers as 16x16 blocks in the
 // f64-MFMA accumulator layout (register r of lane l = block[(l>>4) + 4r][l&15]) for the whole factorisation (8 waves).  Per
-// 16-wide panel: its blocks go to LDS, wave 0 factors the 16x16 diagonal block, one thread per row solves the panel,
+// 16-wide panel: its blocks go to LDS, wave 0 factors AND inverts the 16x16 diagonal block, the panel solve is a product with that inverse on the MFMA,
 // every wave applies the rank-16 update to its blocks with four v_mfma_f64_16x16x4_f64 each (operands: two doubles
 // per lane and MFMA from the solved panel in LDS) -- four barriers and no global round trip inside the loop.  (The
 // form above pays three L2 round trips per panel and runs the update on 4x4 register micro-tiles fed from LDS.)
@@ -335,8 +335,8 @@ __global__ __launch_bounds__(512) void cholesky_reg_kernel(double* __restrict__ 
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double* Praw = sm;                  // [C][17]   the panel as its owners hold it (row-major)
-    double* D = Praw + C * 17;          // [16][17]  factored diagonal block
-    double* rdiag = D + 16 * 17;        // [16]
+    double* D = Praw + C * 17;          // [16][17]  INVERSE of the factored diagonal block
+    double* rdiag = D + 16 * 17;        // [16]  (unused)
     double* Pn = rdiag + 16;            // [16][ldp] solved panel, column-major: the update's operands
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: block ownership stays in SGPRs
@@ -400,34 +400,50 @@ __global__ __launch_bounds__(512) void cholesky_reg_kernel(double* __restrict__ 
                     a[k] -= a[jj] * lkj;
                 }
             }
+            // ... and inverts it: lane = column c of the inverse, forward substitution with the rows of L read by
+            // readlane (the panel solve below is then a product on the MFMA instead of 136 dependent steps per row)
+            double w[CH_NB];
+#pragma unroll
+            for (int i = 0; i < CH_NB; ++i) w[i] = (i == li) ? myrd : 0.0;
+#pragma unroll
+            for (int i = 1; i < CH_NB; ++i) {
+                double acc = 0.0;
+#pragma unroll
+                for (int kk = 0; kk < i; ++kk) acc += readlane64(a[kk], i) * w[kk];
+                const double wi = -acc * readlane64(myrd, i);
+                w[i] = (i > li) ? wi : w[i];
+            }
             if (lane < 16) {
 #pragma unroll
                 for (int c = 0; c < CH_NB; ++c) {
                     const double v = (c <= lane) ? a[c] : 0.0;
-                    D[lane * 17 + c] = v;
                     T[(int64_t)(j0 + lane) * C + j0 + c] = v;
                 }
-                rdiag[lane] = myrd;
+#pragma unroll
+                for (int i = 0; i < CH_NB; ++i) D[i * 17 + lane] = w[i];       // D[i][c] = (L^-1)[i][c]
             }
         }
         __syncthreads();
         if (rows <= 0) break;
-        // (3) one thread per panel row: forward substitution against the diagonal block, column by column (once x[k]
-        //     is final, the entries behind it take their update independently)
-        if (tid < rows && !(CHOL_SKIP & 2)) {
-            double x[CH_NB];
-            const int r = g0 + tid;
+        // (3) panel solve X = P L^-T as a product with the inverted diagonal block: X[r][c] = sum_k P[r][k] Linv[c][k],
+        //     one 16-row block per wave and pass, four f64 MFMAs each
+        if (!(CHOL_SKIP & 2)) {
+            for (int rb = wave; 16 * rb < rows; rb += 8) {
+                const int row0 = g0 + 16 * rb;
+                f64x4 x = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int c = 0; c < CH_NB; ++c) x[c] = Praw[r * 17 + c];
+                for (int kk = 0; kk < 4; ++kk) {
+                    const double av = Praw[(row0 + li) * 17 + 4 * kk + lq];
+                    const double bv = D[li * 17 + 4 * kk + lq];
+                    x = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, x, 0, 0, 0);
+                }
 #pragma unroll
-            for (int k = 0; k < CH_NB; ++k) {
-                x[k] *= rdiag[k];
-#pragma unroll
-                for (int c = k + 1; c < CH_NB; ++c) x[c] -= x[k] * D[c * 17 + k];
+                for (int e = 0; e < 4; ++e) {
+                    const int r = row0 + lq + 4 * e;
+                    T[(int64_t)r * C + j0 + li] = x[e];
+                    Pn[li * ldp + r] = x[e];
+                }
             }
-            double* trow = T + (int64_t)r * C + j0;
-#pragma unroll
-            for (int c = 0; c < CH_NB; ++c) { trow[c] = x[c]; Pn[c * ldp + r] = x[c]; }
         }
         __syncthreads();
         // (4) rank-16 update of the blocks still in registers: block(bi, bj) -= P[bi] P[bj]^T.  The active blocks are a
