@@ -116,6 +116,15 @@ int wc_apply_f32(const float* x, const float* mu, const float* A, const float* b
                  float* y, const void* plan /*from wc_color_f32, nullable*/,
                  void* ws, size_t ws_bytes, wc_stream_t stream);
 
+/* K3 with the activation that follows every WC site of the generator folded into the epilogue (SURVEY.md section 8f
+ * row N2; generator.py:144-151, 154: `Activation('relu')` after each norm stack): relu = 1 writes max(y, 0) (NaN stays
+ * NaN), relu = 0 is wc_apply_f32.  The gradient of the pair is the caller's mask (gy where y > 0, else 0) in front of
+ * the unchanged backward. */
+int wc_apply_act_f32(const float* x, const float* mu, const float* A, const float* bias,
+                     const int32_t* slot, int64_t N, int64_t HW, int C, int Kc, int relu,
+                     float* y, const void* plan /*from wc_color_f32, nullable*/,
+                     void* ws, size_t ws_bytes, wc_stream_t stream);
+
 /* K4: R[k] = sum_{n: slot[n]=k} (x[n]-mu)^T gy[n]  (Kc,C,C),  gsum[k] = sum_{n in k} rows of gy[n]  (Kc,C). */
 int wc_bwd_reduce_f32(const float* x, const float* mu, const float* gy, const int32_t* slot,
                       int64_t N, int64_t HW, int C, int Kc,

@@ -140,3 +140,23 @@ def test_fast_bwd_reduce_matches_float64(ops, shape, Kc):
         scale = np.sqrt(np.outer((f[sel] ** 2).sum((0, 1)), (g[sel] ** 2).sum((0, 1)))) + 1e-300   # per-entry natural scale
         assert np.abs((R[k].cpu().numpy() - R_ref) / scale).max() < 1e-7
         assert rel(gsum[k].cpu().numpy(), g[sel].sum((0, 1))) < 1e-5
+
+
+@pytest.mark.parametrize("shape,Kc", [((16, 32, 32, 256), 1), ((17, 32, 32, 256), 1), ((128, 32, 32, 128), 10), ((4, 64, 64, 32), 2),
+                                      ((8, 8, 8, 64), 3), ((33, 24, 24, 128), 1)])
+def test_apply_with_fused_relu(ops, shape, Kc):
+    """wc_apply_act_f32: max(y, 0) from every K3 path -- planned/unplanned fast, exact, slots, redo."""
+    rng = np.random.default_rng(21)
+    N, C = shape[0], shape[-1]
+    x = rng.standard_normal(shape).astype(np.float32)
+    x[1, 2, 3, 5] = 4.0e7                        # one tile takes the exact redo
+    mu = rng.standard_normal(C).astype(np.float32)
+    A = (rng.standard_normal((Kc, C, C)) / np.sqrt(C)).astype(np.float32)
+    b = rng.standard_normal((Kc, C)).astype(np.float32)
+    slot = rng.integers(0, Kc, N).astype(np.int32)
+    st = dev(slot, torch.int32) if Kc > 1 else None
+    ref = np.maximum(_ref_apply(x, mu, A, b, slot), 0.0)
+    for fast in (True, False):
+        y = ops.apply(dev(x), dev(mu), dev(A), dev(b), st, fast=fast, relu=True)
+        assert float(y.min()) >= 0.0
+        assert rel(y.cpu().numpy().reshape(ref.shape), ref) < 3e-6

@@ -35,6 +35,8 @@ SIGNATURES = {
                              c_void_p, c_size_t, c_void_p]),
     "wc_apply_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,
                              c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wc_apply_act_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int,
+                                 c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wc_bwd_reduce_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,
                                   c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wc_bwd_factor_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64,

@@ -200,20 +200,28 @@ int wc_apply_f32(const float* x, const float* mu, const float* A, const float* b
                  int64_t N, int64_t HW, int C, int Kc, float* y, const void* plan,
                  void* ws, size_t ws_bytes, wc_stream_t stream)
 {
+    return wc_apply_act_f32(x, mu, A, bias, slot, N, HW, C, Kc, 0, y, plan, ws, ws_bytes, stream);
+}
+
+int wc_apply_act_f32(const float* x, const float* mu, const float* A, const float* bias, const int32_t* slot,
+                     int64_t N, int64_t HW, int C, int Kc, int relu, float* y, const void* plan,
+                     void* ws, size_t ws_bytes, wc_stream_t stream)
+{
     if (!x || !A || !y) return WC_ERR_NULL;
+    if (relu != 0 && relu != 1) return WC_ERR_ARG;
     if (N <= 0 || HW <= 0 || Kc <= 0) return WC_ERR_SHAPE;
     if (bad_channels(C)) return WC_ERR_CHANNELS;
     hipStream_t st = static_cast<hipStream_t>(stream);
     WcRowsGemmArgs a = {};
     a.in[0] = x; a.center[0] = mu; a.B[0] = A; a.B_slot_stride[0] = (int64_t)C * C;
-    a.bias = bias; a.sub = nullptr; a.slot = slot; a.N = N; a.HW = HW; a.C = C; a.nstreams = 1; a.out = y;
+    a.bias = bias; a.sub = nullptr; a.slot = slot; a.N = N; a.HW = HW; a.C = C; a.nstreams = 1; a.out = y; a.relu = relu;
     const bool eligible = wc_fast_affine_supported(N, HW, C, slot != nullptr);
     if (eligible && plan) {                  // tables prepared by wc_color_f32: one launch
-        WC_TRY(wc_launch_fast_affine_planned(x, mu, A, Kc, false, bias, nullptr, slot, N, HW, C, 0, y, plan, st));
+        WC_TRY(wc_launch_fast_affine_planned(x, mu, A, Kc, false, bias, nullptr, slot, N, HW, C, 2 * relu, y, plan, st));
         return WC_OK;
     }
     if (eligible && ws && ws_bytes >= wc_fast_affine_workspace(C, Kc)) {
-        WC_TRY(wc_launch_fast_affine(x, mu, A, Kc, false, bias, nullptr, slot, N, HW, C, 0, y, ws, st));
+        WC_TRY(wc_launch_fast_affine(x, mu, A, Kc, false, bias, nullptr, slot, N, HW, C, 2 * relu, y, ws, st));
         return WC_OK;
     }
     WC_TRY(wc_launch_rows_gemm(a, st));

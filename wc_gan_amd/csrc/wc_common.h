@@ -31,6 +31,7 @@ struct WcRowsGemmArgs {
     int nstreams;
     float* out;
     const int* gate;            // optional device flag: when non-null and *gate == 0 the kernel does nothing
+    int relu;                   // epilogue: out = max(out, 0)
 };
 hipError_t wc_launch_rows_gemm(const WcRowsGemmArgs& a, hipStream_t st);
 

@@ -135,6 +135,7 @@ struct FastArgs {
     int bias_on, sub_on;                                             // ring kernel: bias/sub are then pointed at `scale` and ignored
     int64_t M, HW;
     int accumulate;
+    int relu;                                                        // epilogue: out = max(out, 0) (NaN stays NaN)
     const float* Bf; int64_t bf_stride;                             // the fp32 table [slot][k][n] for the exact path
     float* out;
     int ntiles, tiles_per_wg;
@@ -358,6 +359,7 @@ __global__ __launch_bounds__(512, 2) void affine_f16x3_kernel(FastArgs a)
                 const int ro = ((r & 3) + 8 * (r >> 2)) * C;
                 float v = acc[r] * cscale + addv;
                 if (ACC) v += po[ro];
+                if (a.relu) v = v > 0.f ? v : (v == v ? 0.f : v);
                 if (WC_ABL & 1) asm volatile("" :: "v"(v)); else
                 po[ro] = v;
             }
@@ -392,6 +394,7 @@ __global__ __launch_bounds__(512, 2) void affine_f16x3_kernel(FastArgs a)
                     float* po = out_tile + row * C + col;
                     float v = accf + addv;
                     if (ACC) v += *po;
+                    if (a.relu) v = v > 0.f ? v : (v == v ? 0.f : v);
                     *po = v;
                 }
             }
@@ -725,8 +728,16 @@ __global__ __launch_bounds__(512, 2) void affine_ring_kernel(FastArgs a)
         float* po = a.out + (int64_t)tile_of(t) * (TR * C) + out_lane;
         unsigned long long s0_ = 0;
         if (WC_STAMPS) s0_ = __builtin_amdgcn_s_memrealtime();
+        if (a.relu) {       // the ReLU that follows every WC site rides in the epilogue
 #pragma unroll
-        for (int r = 0; r < 16; ++r) po[((r & 3) + 8 * (r >> 2)) * C] = acc[r] * cscale + addv;
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[r] * cscale + addv;
+                po[((r & 3) + 8 * (r >> 2)) * C] = v > 0.f ? v : (v == v ? 0.f : v);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) po[((r & 3) + 8 * (r >> 2)) * C] = acc[r] * cscale + addv;
+        }
         if (WC_STAMPS) sum_store += __builtin_amdgcn_s_memrealtime() - s0_;
         rslot = rs[3] + 1 >= NSLOT ? rs[3] + 1 - NSLOT : rs[3] + 1;
         fcur = fnext;
@@ -792,7 +803,7 @@ __global__ __launch_bounds__(512, 2) void affine_ring_kernel(FastArgs a)
                 const float* xrow = xin + row * C;
                 float accf = 0.f;
                 for (int k = 0; k < C; ++k) accf = fmaf(xrow[k] - (a.center ? a.center[k] : 0.f), Bf[(int64_t)k * C], accf);
-                out_tile[row * C + col] = accf + add;
+                { const float v = accf + add; out_tile[row * C + col] = a.relu ? (v > 0.f ? v : (v == v ? 0.f : v)) : v; }
             }
         }
     }
@@ -916,9 +927,9 @@ hipError_t wc_launch_fast_affine_planned(const float* in, const float* center, c
     a.in = in; a.center = center; a.scale = v.scale; a.Bhi = v.hi; a.Blo = v.lo; a.colscale = v.colscale;
     a.slot_stride = shared_table ? 0 : (int64_t)C * C;
     a.bias = bias; a.sub = sub; a.slot = shared_table ? nullptr : slot; a.M = N * HW; a.HW = HW;
-    a.accumulate = accumulate; a.Bf = B; a.bf_stride = shared_table ? 0 : (int64_t)C * C; a.out = out; a.dbg = v.dbg;
+    a.accumulate = accumulate & 1; a.relu = (accumulate >> 1) & 1; a.Bf = B; a.bf_stride = shared_table ? 0 : (int64_t)C * C; a.out = out; a.dbg = v.dbg;
     static const bool use_ring = getenv("WC_NO_RING") == nullptr;
-    if (!accumulate && use_ring && (HW % (8192 / C)) == 0) {
+    if (!(accumulate & 1) && use_ring && (HW % (8192 / C)) == 0) {
         switch (C) {
             case 32: return launch_affine_ring<32>(a, st);
             case 64: return launch_affine_ring<64>(a, st);

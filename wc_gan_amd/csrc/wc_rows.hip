@@ -146,7 +146,11 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(WcRowsGemmArgs a, int nc
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wr * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row < rows_valid) a.out[(row0 + row) * C + col] = acc[t][u][r] + add;
+                if (row < rows_valid) {
+                    float v = acc[t][u][r] + add;
+                    if (a.relu) v = v > 0.f ? v : (v == v ? 0.f : v);        // NaN stays NaN
+                    a.out[(row0 + row) * C + col] = v;
+                }
             }
         }
     }

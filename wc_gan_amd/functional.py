@@ -27,7 +27,7 @@ def _allreduce_(tensors, group):
 
 class WhitenColorFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, slot, moving_mean, moving_cov, training, eps, momentum, ddof, process_group):
+    def forward(ctx, x, gamma, beta, slot, moving_mean, moving_cov, training, eps, momentum, ddof, process_group, relu=False):
         # x: (N, ..., C) float32 contiguous (NHWC); gamma (Kc,C,C)|None; beta (Kc,C)|None; slot int32 (N,)|None
         C = x.shape[-1]
         M_local = x.numel() // C
@@ -47,9 +47,11 @@ class WhitenColorFunction(torch.autograd.Function):
         g = gamma.contiguous() if gamma is not None else None
         b = beta.contiguous() if beta is not None else None
         A, At, plan = ops.color(W, g, chan_scale)      # plan: the apply's fp16 tables, so K3 is one launch
-        y = ops.apply(x, mu, A, b, slot, plan=plan)
+        y = ops.apply(x, mu, A, b, slot, plan=plan, relu=relu)      # relu: folded into K3's epilogue (row N2)
         ctx.save_for_backward(x, mu, L, W, A, At, g if g is not None else torch.empty(0, device=dev),
-                              slot if slot is not None else torch.empty(0, dtype=torch.int32, device=dev))
+                              slot if slot is not None else torch.empty(0, dtype=torch.int32, device=dev),
+                              y if relu else torch.empty(0, device=dev))
+        ctx.relu = bool(relu)
         ctx.has_gamma = g is not None
         ctx.has_beta = b is not None
         ctx.has_slot = slot is not None
@@ -59,10 +61,12 @@ class WhitenColorFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
-        x, mu, L, W, A, At, g, slot = ctx.saved_tensors
+        x, mu, L, W, A, At, g, slot, y = ctx.saved_tensors
         g = g if ctx.has_gamma else None
         slot = slot if ctx.has_slot else None
         gy = gy.contiguous()
+        if ctx.relu:                      # the fused activation's gradient: the mask in front of the unchanged backward
+            gy = torch.where(y > 0, gy, torch.zeros((), dtype=gy.dtype, device=gy.device))
         need_x, need_g, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         Kc = A.shape[0]
         dgamma = dbeta = dx = S = gmean = None
@@ -86,11 +90,11 @@ class WhitenColorFunction(torch.autograd.Function):
                                                     want_dgamma=False, want_dbeta=False)
         if need_x:
             dx = ops.bwd_apply(gy, x, mu, At, S, gmean, slot)
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
 def whiten_color_grouped(x, groups, gamma=None, beta=None, slot=None, moving_mean=None, moving_cov=None,
-                         eps=1e-3, momentum=0.99, ddof=1):
+                         eps=1e-3, momentum=0.99, ddof=1, relu=False):
     """Training-mode forward of `groups` INDEPENDENT batches stacked along N (no autograd): each run of N/groups
     samples is whitened with its own batch statistics, exactly as `groups` separate calls would be, but the
     covariance / Cholesky / inverse problems of the groups are solved side by side in one set of launches.
@@ -112,7 +116,7 @@ def whiten_color_grouped(x, groups, gamma=None, beta=None, slot=None, moving_mea
     center, bias = ops.group_bias(mu.view(groups, C), A, b, groups, Kc)
     grp = torch.arange(N, device=dev, dtype=torch.int32) // (N // groups)
     full_slot = grp * Kc + (slot if slot is not None else 0)
-    return ops.apply(x, center, A, bias, full_slot.to(torch.int32).contiguous(), plan=plan)
+    return ops.apply(x, center, A, bias, full_slot.to(torch.int32).contiguous(), plan=plan, relu=relu)
 
 
 class EvalPlan:
@@ -140,19 +144,20 @@ class EvalPlan:
 
 
 def whiten_color_eval_cached(x, cache, gamma=None, beta=None, slot=None, moving_mean=None, moving_cov=None, eps=1e-3,
-                             gamma_key=None):
+                             gamma_key=None, relu=False):
     """Inference forward (no autograd) through an EvalPlan: one K3 launch per call once the plan is warm."""
     C = x.shape[-1]
     mu, A, At, plan = cache.get(C, gamma, moving_mean, moving_cov, eps, x.device, gamma_key)
     b = beta.detach().contiguous() if beta is not None else None
-    return ops.apply(x.detach().contiguous(), mu, A, b, slot, plan=plan)
+    return ops.apply(x.detach().contiguous(), mu, A, b, slot, plan=plan, relu=relu)
 
 
 def whiten_color(x, gamma=None, beta=None, slot=None, moving_mean=None, moving_cov=None, training=True,
-                 eps=1e-3, momentum=0.99, ddof=1, process_group=None):
-    """y = coloring(whitening(x)).  x: (N, H, W, C) float32 on the GPU, C % 32 == 0 (see layers for padding)."""
+                 eps=1e-3, momentum=0.99, ddof=1, process_group=None, relu=False):
+    """y = coloring(whitening(x)) (relu=True: max(y, 0) from the same kernel).  x: (N, H, W, C) float32 on the GPU,
+    C % 32 == 0 (see layers for padding)."""
     return WhitenColorFunction.apply(x, gamma, beta, slot, moving_mean, moving_cov, bool(training),
-                                     float(eps), float(momentum), int(ddof), process_group)
+                                     float(eps), float(momentum), int(ddof), process_group, bool(relu))
 
 
 # ---------------------------------------------------------------------------------------------

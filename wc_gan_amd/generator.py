@@ -187,6 +187,14 @@ def create_norm(norm, after_norm, cls=None, number_of_classes=None, filters_emb=
 # ---------------------------------------------------------------------------------------------
 # generator
 # ---------------------------------------------------------------------------------------------
+def _norm_relu(norm, x, cls):
+    """relu(norm(x, cls)) (generator.py:144-151, 154); the fused WC stack takes the activation into its apply kernel."""
+    from .layers import WhiteningColoring
+    if isinstance(norm, WhiteningColoring):
+        return norm(x, cls, relu=True)
+    return F.relu(norm(x, cls))
+
+
 class ResBlockUp(nn.Module):
     def __init__(self, in_ch, nfilters, resample, name, norm, conv_layer):
         super().__init__()
@@ -199,7 +207,7 @@ class ResBlockUp(nn.Module):
         self.shortcut = conv_layer(in_ch, nfilters, (1, 1), name=name + '.shortcut')
 
     def forward(self, x, cls):
-        h = F.relu(self.bn1(x, cls))
+        h = _norm_relu(self.bn1, x, cls)
         # the 1x1 shortcut commutes with nearest-neighbour upsampling (every output pixel is the same per-pixel affine
         # map of its source pixel): run it at the input resolution, a quarter of the work, then upsample
         s = self.shortcut(x)
@@ -211,7 +219,7 @@ class ResBlockUp(nn.Module):
             h = self.conv1.forward_upsampled(h) if h.shape[1] * h.shape[2] >= 64 else self.conv1(upsample2x(h))
         else:
             h = self.conv1(h)
-        h = F.relu(self.bn2(h, cls))
+        h = _norm_relu(self.bn2, h, cls)
         h = self.conv2(h)
         return h + s
 
@@ -225,7 +233,7 @@ class DCBlockUp(nn.Module):
 
     def forward(self, x, cls):
         h = to_nhwc(self.deconv(to_nchw_view(x)))
-        return F.relu(self.bn(h, cls))
+        return _norm_relu(self.bn, h, cls)
 
 
 class Generator(nn.Module):
@@ -270,7 +278,7 @@ class Generator(nn.Module):
         y = self.dense(y).view(-1, *self.first_block_shape)
         for blk in self.blocks:
             y = blk(y, cls)
-        y = F.relu(self.final_norm(y, cls))
+        y = _norm_relu(self.final_norm, y, cls)
         return torch.tanh(self.final_conv(y))
 
 

@@ -110,32 +110,35 @@ class DecorelationNormalization(_Lazy):
         self.register_buffer('moving_mean', torch.zeros(C, 1, device=device))
         self.register_buffer('moving_cov', torch.eye(C, device=device))
 
-    def transform(self, x, gamma=None, beta=None, slot=None, gamma_key=None):
-        """Whitening fused with an optional coloring table (gamma (Kc,C,C), beta (Kc,C), slot (N,))."""
+    def transform(self, x, gamma=None, beta=None, slot=None, gamma_key=None, relu=False):
+        """Whitening fused with an optional coloring table (gamma (Kc,C,C), beta (Kc,C), slot (N,)); relu=True also
+        folds the ReLU that follows the site into the apply kernel where that path has it (else applied after)."""
         self._ensure(x)
         C = self.channels
         if C % 32 != 0:
-            return self._padded(x, gamma, beta, slot)
+            y = self._padded(x, gamma, beta, slot)
+            return F.relu(y) if relu else y
         if self.decomposition == 'zca':
             if self.renorm:
                 raise NotImplementedError("renorm is defined for decomposition='cholesky' only")
-            return WF.whiten_color_modular(x, gamma, beta, slot, self.moving_mean, self.moving_cov, self.training,
-                                           self.epsilon, self.momentum, 1, 'zca')
+            y = WF.whiten_color_modular(x, gamma, beta, slot, self.moving_mean, self.moving_cov, self.training,
+                                        self.epsilon, self.momentum, 1, 'zca')
+            return F.relu(y) if relu else y
         if _STAT_GROUPS > 1 and self.training and not self.renorm:
             if torch.is_grad_enabled() and (x.requires_grad or (gamma is not None and gamma.requires_grad)):
                 raise RuntimeError("statistic_groups() is a forward-only path: wrap the call in torch.no_grad()")
             return WF.whiten_color_grouped(x, _STAT_GROUPS, gamma, beta, slot, self.moving_mean, self.moving_cov,
-                                           self.epsilon, self.momentum, 1)
+                                           self.epsilon, self.momentum, 1, relu=relu)
         if not self.training and not torch.is_grad_enabled():
             # inference (scorer.py:60,72): moving statistics are constants -> cached factorisation, one K3 launch
             if not hasattr(self, '_eval_plan'):
                 self._eval_plan = WF.EvalPlan()
             return WF.whiten_color_eval_cached(x, self._eval_plan, gamma, beta, slot, self.moving_mean, self.moving_cov,
-                                               self.epsilon, gamma_key)
+                                               self.epsilon, gamma_key, relu=relu)
         if self.renorm and self.training:
             gamma = self._renorm_gamma(x, gamma)
         return WF.whiten_color(x, gamma, beta, slot, self.moving_mean, self.moving_cov, self.training,
-                               self.epsilon, self.momentum, 1, self.process_group)
+                               self.epsilon, self.momentum, 1, self.process_group, relu=relu)
 
     def _renorm_gamma(self, x, gamma):
         # W_eff = L_mov^-1 . stop_grad(L_batch) . L_batch^-1 (row a4): the batch factor carries the gradient,
@@ -335,7 +338,7 @@ class WhiteningColoring(nn.Module):
             beta = beta.expand(gamma.shape[0], -1)
         return gamma, beta, slot
 
-    def forward(self, x, cls=None):
+    def forward(self, x, cls=None, relu=False):
         if isinstance(x, (list, tuple)):
             x, cls = x
         gamma, beta, slot = self.coloring_table(x, cls)
@@ -347,4 +350,4 @@ class WhiteningColoring(nn.Module):
         per_sample = gamma is not None and slot is not None and gamma.shape[0] == x.shape[0] and \
             any(getattr(b, 'number_of_classes', 0) > x.shape[0] for b in self.branches)
         key = None if per_sample else tuple((p.data_ptr(), p._version) for p in self.parameters())
-        return self.npart.transform(x, gamma, beta, slot, gamma_key=key)
+        return self.npart.transform(x, gamma, beta, slot, gamma_key=key, relu=relu)

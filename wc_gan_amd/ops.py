@@ -108,8 +108,9 @@ def group_bias(mu, A, beta, groups, Kc):
     return center, bias
 
 
-def apply(x, mu, A, bias, slot, out=None, fast=True, plan=None):
-    """K3: y[n] = (x[n] - mu) A[slot[n]] + bias[slot[n]];  x is (N, ..., C) with C contiguous."""
+def apply(x, mu, A, bias, slot, out=None, fast=True, plan=None, relu=False):
+    """K3: y[n] = (x[n] - mu) A[slot[n]] + bias[slot[n]];  x is (N, ..., C) with C contiguous.
+    relu=True folds the ReLU that follows the site into the epilogue (wc_apply_act_f32)."""
     lib = _lib.load()
     _need(x, torch.float32, "x")
     N, C = x.shape[0], x.shape[-1]
@@ -121,9 +122,9 @@ def apply(x, mu, A, bias, slot, out=None, fast=True, plan=None):
         _need(slot, torch.int32, "slot", 1)
     y = torch.empty_like(x) if out is None else out
     ws = _workspace(lib.wc_apply_workspace_bytes(N, HW, C, Kc), x.device) if (fast and plan is None) else None
-    _lib.check(lib.wc_apply_f32(_ptr(x), _ptr(mu), _ptr(A), _ptr(bias), _ptr(slot), N, HW, C, Kc, _ptr(y),
-                                _ptr(plan) if fast else None, _ptr(ws), ws.numel() if ws is not None else 0, _stream()),
-               "wc_apply_f32")
+    _lib.check(lib.wc_apply_act_f32(_ptr(x), _ptr(mu), _ptr(A), _ptr(bias), _ptr(slot), N, HW, C, Kc, 1 if relu else 0,
+                                    _ptr(y), _ptr(plan) if fast else None, _ptr(ws), ws.numel() if ws is not None else 0,
+                                    _stream()), "wc_apply_act_f32")
     return y
 
 
