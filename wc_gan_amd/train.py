@@ -65,8 +65,11 @@ class GanTrainer:
         self.d_bucket = FlatGradBucket(self.D.parameters(), process_group)
         # capturable: the step counters live on the device, so a whole G+D step can be recorded into one hipGraph
         cap = self.dev.type == 'cuda'
-        self.opt_g = torch.optim.Adam(self.g_bucket.params, lr=lr, betas=(beta1, beta2), capturable=cap)
-        self.opt_d = torch.optim.Adam(self.d_bucket.params, lr=lr, betas=(beta1, beta2), capturable=cap)
+        # fused: one multi-tensor kernel per update instead of ~10 small launches per parameter (step counters on the
+        # device either way)
+        kw = dict(fused=True) if cap else dict()
+        self.opt_g = torch.optim.Adam(self.g_bucket.params, lr=lr, betas=(beta1, beta2), capturable=cap, **kw)
+        self.opt_d = torch.optim.Adam(self.d_bucket.params, lr=lr, betas=(beta1, beta2), capturable=cap, **kw)
         if cap:
             torch.cuda.manual_seed(seed)         # the default device generator: its Philox offset is graph-safe
         self._graph = None
