@@ -17,10 +17,18 @@ import torch.nn.functional as F
 
 
 class FlatGradBucket:
-    """All gradients of one network in one contiguous buffer; .grad tensors are views into it."""
+    """All gradients of one network in one contiguous buffer; .grad tensors are views into it.
+    `flat=False` (what the trainer picks for a single process): no buffer -- zero() just drops the gradients, so autograd
+    hands each parameter its gradient tensor instead of adding it into a view (one small kernel per parameter and
+    backward pass saved; nothing is all-reduced anyway)."""
 
-    def __init__(self, params, process_group=None):
+    def __init__(self, params, process_group=None, flat=True):
         self.params = [p for p in params if p.requires_grad]
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.flat = None
+        if not flat:
+            return
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -33,14 +41,16 @@ class FlatGradBucket:
             else:
                 p.grad = seg.view_as(p)
             off += p.numel()
-        self.group = process_group
-        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
 
     def zero(self):
-        self.flat.zero_()
+        if self.flat is None:
+            for p in self.params:
+                p.grad = None
+        else:
+            self.flat.zero_()
 
     def allreduce_mean(self):
-        if self.world > 1:
+        if self.world > 1 and self.flat is not None:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
             self.flat.mul_(1.0 / self.world)
 
@@ -61,8 +71,9 @@ class GanTrainer:
         self.batch_size, self.gbm, self.training_ratio = batch_size, generator_batch_multiple, training_ratio
         self.noise_dim, self.K, self.conditional = noise_dim, number_of_classes, conditional
         self.dev = next(generator.parameters()).device
-        self.g_bucket = FlatGradBucket(self.G.parameters(), process_group)
-        self.d_bucket = FlatGradBucket(self.D.parameters(), process_group)
+        world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.g_bucket = FlatGradBucket(self.G.parameters(), process_group, flat=world > 1)
+        self.d_bucket = FlatGradBucket(self.D.parameters(), process_group, flat=world > 1)
         # capturable: the step counters live on the device, so a whole G+D step can be recorded into one hipGraph
         cap = self.dev.type == 'cuda'
         # fused: one multi-tensor kernel per update instead of ~10 small launches per parameter (step counters on the
