@@ -283,3 +283,26 @@ def test_fused_relu_stack_matches_relu_after_stack(after_norm):
     for pa, pb in zip(a.parameters(), b.parameters()):
         assert float((pa.grad - pb.grad).abs().max()) <= 1e-6 * float(pb.grad.abs().max() + 1e-12)
     assert torch.equal(a.npart.moving_cov, b.npart.moving_cov)
+
+
+@pytest.mark.gpu
+def test_narrow_conv_as_gemm_equals_convolution():
+    """The generator's last layer (3x3 conv to 3 channels, generator.py:155-157) as GEMM + col2im: values and gradients."""
+    from wc_gan_amd.generator import Conv2D, to_nchw_view, to_nhwc
+    torch.manual_seed(6)
+    conv = Conv2D(64, 3, (3, 3)).cuda()
+    with torch.no_grad():
+        conv.conv.bias.normal_()
+    x1 = torch.randn(7, 12, 12, 64, device='cuda', requires_grad=True)
+    x2 = x1.detach().clone().requires_grad_(True)
+    a = conv(x1)                                              # the GEMM + col2im form
+    b = to_nhwc(conv.conv(to_nchw_view(x2)))                  # the literal convolution
+    assert a.shape == b.shape == (7, 12, 12, 3)
+    assert float((a - b).abs().max() / b.abs().max()) < 1e-5
+    g = torch.randn_like(b)
+    a.backward(g); ga, gba = conv.conv.weight.grad.clone(), conv.conv.bias.grad.clone()
+    conv.conv.weight.grad = None; conv.conv.bias.grad = None
+    b.backward(g)
+    assert float((x1.grad - x2.grad).abs().max() / x2.grad.abs().max()) < 1e-5
+    assert float((ga - conv.conv.weight.grad).abs().max() / ga.abs().max()) < 1e-5
+    assert float((gba - conv.conv.bias.grad).abs().max() / gba.abs().max()) < 1e-5
