@@ -173,6 +173,21 @@ int wc_spectral_norm_bwd_f32(const float* g, const float* w_sn, const float* u, 
                              int rows, int cols, int fully_diff, float* dW,
                              void* ws, size_t ws_bytes, wc_stream_t stream);
 
+/* The same two operations for EVERY spectrally normalised layer of a network in one launch each: the layers depend on
+ * the weights only, not on each other or on the activations, and one launch keeps up to 16 x 32 workgroups busy where
+ * per-layer launches run back to back on a mostly idle chip.  `items` is a HOST array (its contents travel in the
+ * kernel arguments); every field as in the per-layer calls, one workspace per item. */
+typedef struct {
+    const float* W; float* u; float* v; float* w_sn; float* sigma; float* u_used; float* v_used; void* ws;
+    int rows, cols;
+} wc_sn_item;
+typedef struct {
+    const float* g; const float* w_sn; const float* u; const float* v; const float* sigma; float* dW; void* ws;
+    int rows, cols;
+} wc_sn_bwd_item;
+int wc_spectral_norm_batched_f32(const wc_sn_item* items, int count, int iterations, float eps, wc_stream_t stream);
+int wc_spectral_norm_bwd_batched_f32(const wc_sn_bwd_item* items, int count, int fully_diff, wc_stream_t stream);
+
 /* Bandwidth yardstick used by bench.py: dst[i] = src[i] (float4 grid-stride copy), same stream rules. */
 int wc_stream_copy_f32(const float* src, float* dst, int64_t n, wc_stream_t stream);
 

@@ -159,3 +159,43 @@ def test_hip_matches_sn_golden(name):
     assert float((u - f("u1")).abs().max()) < 2e-5 and float((v - f("v1")).abs().max()) < 2e-5
     for key, fd in (("dW_full", True), ("dW_const", False)):
         assert rel(ops.spectral_norm_bwd(g, w_sn, u, v, sigma, fd, ws), f(key)) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fully_diff", [False, True])
+def test_batched_layers_match_layer_by_layer(fully_diff):
+    """prepare_spectral (one launch for every layer) gives bit-identical weights, gradients and u/v to per-layer calls."""
+    import copy
+    import torch.nn as nn
+    from wc_gan_amd.spectral import SNConv2d, SNLinear, prepare_spectral
+    torch.manual_seed(9)
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            kw = dict(fully_diff_spectral=fully_diff)
+            self.a = SNConv2d(8, 16, 3, padding=1, **kw); self.b = SNConv2d(16, 16, 1, **kw); self.c = SNLinear(16, 1, **kw)
+
+        def forward(self, x, batched):
+            if batched:
+                prepare_spectral(self)
+            h = torch.relu(self.a(x)); h = torch.relu(self.b(h))
+            return self.c(h.mean(dim=(2, 3)))
+
+    n1 = Net().cuda(); n2 = copy.deepcopy(n1)
+    x = torch.randn(4, 8, 10, 10, device='cuda').contiguous(memory_format=torch.channels_last)
+    for step in range(2):                          # second round: meeting words re-armed, u/v moved on identically
+        y1 = n1(x, True); y2 = n2(x, False)
+        assert torch.equal(y1, y2)
+        y1.sum().backward(); y2.sum().backward()
+        for p1, p2 in zip(n1.parameters(), n2.parameters()):      # (MIOpen's weight-gradient kernels are not bit-reproducible)
+            assert float((p1.grad - p2.grad).abs().max()) <= 1e-5 * float(p2.grad.abs().max())
+        for b1, b2 in zip(n1.buffers(), n2.buffers()):
+            assert torch.equal(b1, b2)
+        n1.zero_grad(); n2.zero_grad()
+    # a weight that changed after prepare_spectral is re-normalised by its layer, not served stale
+    n1.eval(); n2.eval()                           # inference: u, v stay put, so the extra prepare changes no state
+    prepare_spectral(n1)
+    with torch.no_grad():
+        n1.a.weight.mul_(2.0); n2.a.weight.mul_(2.0)
+    assert torch.equal(n1(x, False), n2(x, False))

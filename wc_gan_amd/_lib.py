@@ -46,11 +46,25 @@ SIGNATURES = {
                                  c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wc_stream_copy_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "wc_spectral_norm_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "wc_spectral_norm_batched_f32": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p]),
+    "wc_spectral_norm_bwd_batched_f32": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "wc_spectral_norm_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wc_spectral_norm_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
                                          c_void_p, c_size_t, c_void_p]),
 }
+
+
+
+class SnItem(ctypes.Structure):          # wc_sn_item
+    _fields_ = [("W", c_void_p), ("u", c_void_p), ("v", c_void_p), ("w_sn", c_void_p), ("sigma", c_void_p),
+                ("u_used", c_void_p), ("v_used", c_void_p), ("ws", c_void_p), ("rows", c_int), ("cols", c_int)]
+
+
+class SnBwdItem(ctypes.Structure):       # wc_sn_bwd_item
+    _fields_ = [("g", c_void_p), ("w_sn", c_void_p), ("u", c_void_p), ("v", c_void_p), ("sigma", c_void_p),
+                ("dW", c_void_p), ("ws", c_void_p), ("rows", c_int), ("cols", c_int)]
+
 
 _lib = None
 

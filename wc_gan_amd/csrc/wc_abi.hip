@@ -421,4 +421,32 @@ int wc_spectral_norm_bwd_f32(const float* g, const float* w_sn, const float* u, 
     return WC_OK;
 }
 
+int wc_spectral_norm_batched_f32(const wc_sn_item* items, int count, int iterations, float eps, wc_stream_t stream)
+{
+    if (!items) return WC_ERR_NULL;
+    if (count <= 0) return WC_ERR_SHAPE;
+    if (iterations < 0 || !(eps >= 0.f)) return WC_ERR_ARG;
+    for (int i = 0; i < count; ++i) {
+        const wc_sn_item& it = items[i];
+        if (!it.W || !it.u || !it.v || !it.w_sn || !it.sigma || !it.ws) return WC_ERR_NULL;
+        if (it.rows <= 0 || it.cols <= 0 || (int64_t)it.rows * it.cols > (int64_t)1 << 28) return WC_ERR_SHAPE;
+        if (wc_sn_lds_bytes(it.rows, it.cols) > 150 * 1024) return WC_ERR_SHAPE;
+    }
+    WC_TRY(wc_launch_spectral_norm_batched(items, count, iterations, eps, static_cast<hipStream_t>(stream)));
+    return WC_OK;
+}
+
+int wc_spectral_norm_bwd_batched_f32(const wc_sn_bwd_item* items, int count, int fully_diff, wc_stream_t stream)
+{
+    if (!items) return WC_ERR_NULL;
+    if (count <= 0) return WC_ERR_SHAPE;
+    for (int i = 0; i < count; ++i) {
+        const wc_sn_bwd_item& it = items[i];
+        if (!it.g || !it.w_sn || !it.u || !it.v || !it.sigma || !it.dW || !it.ws) return WC_ERR_NULL;
+        if (it.rows <= 0 || it.cols <= 0 || (int64_t)it.rows * it.cols > (int64_t)1 << 28) return WC_ERR_SHAPE;
+    }
+    WC_TRY(wc_launch_spectral_norm_bwd_batched(items, count, fully_diff, static_cast<hipStream_t>(stream)));
+    return WC_OK;
+}
+
 }  // extern "C"

@@ -55,6 +55,11 @@ hipError_t wc_launch_xty(const WcXtyArgs& a, int nslab, hipStream_t st);
 hipError_t wc_launch_subsample_mean(const float* x, int64_t M, int C, float* shift, hipStream_t st);
 hipError_t wc_launch_stream_copy(const float* src, float* dst, int64_t n, hipStream_t st);
 // wc_sn.hip
+#include "../../include/wc_hip.h"
+typedef wc_sn_item WcSnItem;
+typedef wc_sn_bwd_item WcSnBwdItem;
+hipError_t wc_launch_spectral_norm_batched(const WcSnItem* items, int count, int iterations, float eps, hipStream_t st);
+hipError_t wc_launch_spectral_norm_bwd_batched(const WcSnBwdItem* items, int count, int fully_diff, hipStream_t st);
 size_t wc_sn_lds_bytes(int R, int K);
 size_t wc_sn_workspace_bytes(int R, int K);
 hipError_t wc_launch_spectral_norm(const float* W, int R, int K, float* u, float* v, int iterations, float eps,

@@ -65,7 +65,7 @@ __device__ __forceinline__ void grid_meet(unsigned* sync, int nwg, int phase)
 // One launch, nwg <= 32 workgroups.  Every workgroup owns a COLUMN slice of W for v = N(W^T u) and a ROW slice for
 // u = N(W v) and for the final scaling; the two products are assembled in global scratch between grid meetings and
 // each workgroup normalises them for itself (K + R floats: nothing), so all sums run in a fixed order.
-__global__ __launch_bounds__(SN_THREADS) void sn_forward_kernel(SnArgs a)
+__device__ __forceinline__ void sn_forward_body(const SnArgs& a, const int b)
 {
     extern __shared__ float sm[];
     float* us = sm;                 // [R]
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(SN_THREADS) void sn_forward_kernel(SnArgs a)
     float* red = vs + a.K;          // [SN_THREADS / 64]
     float* part = red + SN_THREADS / 64;      // [SN_THREADS]: partial column sums
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int R = a.R, K = a.K, nwg = a.nwg, b = blockIdx.x;
+    const int R = a.R, K = a.K, nwg = a.nwg;
     const int j0 = (int)((int64_t)K * b / nwg), j1 = (int)((int64_t)K * (b + 1) / nwg);      // my columns
     const int r0 = (int)((int64_t)R * b / nwg), r1 = (int)((int64_t)R * (b + 1) / nwg);      // my rows
     for (int r = tid; r < R; r += SN_THREADS) us[r] = a.u[r];
@@ -172,10 +172,10 @@ struct SnBwdArgs {
     float* partial; unsigned* sync; int nwg;          // fully_diff: per-workgroup partial sums of <g, w_sn>
 };
 
-__global__ __launch_bounds__(SN_THREADS) void sn_backward_kernel(SnBwdArgs a)
+__device__ __forceinline__ void sn_backward_body(const SnBwdArgs& a, const int b)
 {
     __shared__ float red[SN_THREADS / 64];
-    const int tid = threadIdx.x, b = blockIdx.x, nwg = a.nwg;
+    const int tid = threadIdx.x, nwg = a.nwg;
     const int64_t n = (int64_t)a.R * a.K;
     const int64_t e0 = n * b / nwg, e1 = n * (b + 1) / nwg;
     float c = 0.f;
@@ -200,6 +200,29 @@ __global__ __launch_bounds__(SN_THREADS) void sn_backward_kernel(SnBwdArgs a)
             __hip_atomic_store(a.sync + 1, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+}
+
+__global__ __launch_bounds__(SN_THREADS) void sn_forward_kernel(SnArgs a) { sn_forward_body(a, blockIdx.x); }
+__global__ __launch_bounds__(SN_THREADS) void sn_backward_kernel(SnBwdArgs a) { sn_backward_body(a, blockIdx.x); }
+
+// Every spectrally normalised layer of a network in ONE launch: the layers are independent of each other and of the
+// activations (they depend on the weights only), but as separate launches of <= 32 workgroups each they run one
+// after the other on a mostly idle chip.  Items ride in the kernel arguments; first[i] is the first block of item i.
+constexpr int SN_MAXITEMS = 16;
+struct SnBatch { SnArgs item[SN_MAXITEMS]; int first[SN_MAXITEMS + 1]; int count; };
+struct SnBwdBatch { SnBwdArgs item[SN_MAXITEMS]; int first[SN_MAXITEMS + 1]; int count; };
+
+__global__ __launch_bounds__(SN_THREADS) void sn_forward_batched_kernel(SnBatch q)
+{
+    int i = 0;
+    while (i + 1 < q.count && (int)blockIdx.x >= q.first[i + 1]) ++i;
+    sn_forward_body(q.item[i], (int)blockIdx.x - q.first[i]);
+}
+__global__ __launch_bounds__(SN_THREADS) void sn_backward_batched_kernel(SnBwdBatch q)
+{
+    int i = 0;
+    while (i + 1 < q.count && (int)blockIdx.x >= q.first[i + 1]) ++i;
+    sn_backward_body(q.item[i], (int)blockIdx.x - q.first[i]);
 }
 
 int sn_workgroups(int R, int K)
@@ -239,5 +262,55 @@ hipError_t wc_launch_spectral_norm_bwd(const float* g, const float* w_sn, const 
     unsigned* sync = reinterpret_cast<unsigned*>(static_cast<char*>(ws) + wc_sn_workspace_bytes(R, K) - 16);
     SnBwdArgs a{g, w_sn, u, v, sigma, R, K, fully_diff, dW, t + K + R, sync + 2, sn_workgroups(R, K)};
     hipLaunchKernelGGL(sn_backward_kernel, dim3(a.nwg), dim3(SN_THREADS), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t wc_launch_spectral_norm_batched(const WcSnItem* items, int count, int iterations, float eps, hipStream_t st)
+{
+    for (int c0 = 0; c0 < count; c0 += SN_MAXITEMS) {
+        SnBatch q = {};
+        q.count = count - c0 < SN_MAXITEMS ? count - c0 : SN_MAXITEMS;
+        size_t lds = 0;
+        int blocks = 0;
+        for (int i = 0; i < q.count; ++i) {
+            const WcSnItem& it = items[c0 + i];
+            float* t = static_cast<float*>(it.ws);
+            unsigned* sync = reinterpret_cast<unsigned*>(static_cast<char*>(it.ws) + wc_sn_workspace_bytes(it.rows, it.cols) - 16);
+            q.item[i] = SnArgs{it.W, it.rows, it.cols, it.u, it.v, iterations, eps, it.w_sn, it.sigma, it.u_used, it.v_used,
+                               t, t + it.cols, sync, sn_workgroups(it.rows, it.cols)};
+            q.first[i] = blocks;
+            blocks += q.item[i].nwg;
+            const size_t l = wc_sn_lds_bytes(it.rows, it.cols);
+            if (l > lds) lds = l;
+        }
+        q.first[q.count] = blocks;
+        if (lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sn_forward_batched_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(sn_forward_batched_kernel, dim3(blocks), dim3(SN_THREADS), lds, st, q);
+    }
+    return hipGetLastError();
+}
+
+hipError_t wc_launch_spectral_norm_bwd_batched(const WcSnBwdItem* items, int count, int fully_diff, hipStream_t st)
+{
+    for (int c0 = 0; c0 < count; c0 += SN_MAXITEMS) {
+        SnBwdBatch q = {};
+        q.count = count - c0 < SN_MAXITEMS ? count - c0 : SN_MAXITEMS;
+        int blocks = 0;
+        for (int i = 0; i < q.count; ++i) {
+            const WcSnBwdItem& it = items[c0 + i];
+            float* t = static_cast<float*>(it.ws);
+            unsigned* sync = reinterpret_cast<unsigned*>(static_cast<char*>(it.ws) + wc_sn_workspace_bytes(it.rows, it.cols) - 16);
+            q.item[i] = SnBwdArgs{it.g, it.w_sn, it.u, it.v, it.sigma, it.rows, it.cols, fully_diff, it.dW,
+                                  t + it.cols + it.rows, sync + 2, sn_workgroups(it.rows, it.cols)};
+            q.first[i] = blocks;
+            blocks += q.item[i].nwg;
+        }
+        q.first[q.count] = blocks;
+        hipLaunchKernelGGL(sn_backward_batched_kernel, dim3(blocks), dim3(SN_THREADS), 0, st, q);
+    }
     return hipGetLastError();
 }

@@ -72,6 +72,8 @@ class Discriminator(nn.Module):
             self.emb = emb(number_of_classes, ch)
 
     def forward(self, x, cls=None):
+        from .spectral import prepare_spectral
+        prepare_spectral(self)              # all spectral-norm layers' weights in one launch (no-op without any)
         y = x
         for blk in self.blocks:
             y = blk(y, cls)

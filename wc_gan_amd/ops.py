@@ -10,6 +10,8 @@ enqueues the HIP stage on torch's current stream.  The six stages mirror the ref
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 
 from . import _lib
@@ -228,3 +230,44 @@ def spectral_norm_bwd(g, w_sn, u, v, sigma, fully_diff, ws):
                                             1 if fully_diff else 0, _ptr(dW), _ptr(ws), ws.numel(), _stream()),
                "wc_spectral_norm_bwd_f32")
     return dW
+
+
+def spectral_norm_batched(weights, us, vs, wss, iterations, eps=1e-12):
+    """All layers in one launch: lists of weights / u / v / workspaces -> lists (w_sn, sigma, u_used, v_used)."""
+    lib = _lib.load()
+    n = len(weights)
+    items = (_lib.SnItem * n)()
+    outs = []
+    for i, (w, u, v, ws) in enumerate(zip(weights, us, vs, wss)):
+        if not w.is_cuda or w.dtype != torch.float32:
+            raise _lib.WcHipError("spectral_norm_batched needs float32 CUDA/HIP weights")
+        if not (w.is_contiguous() or (w.dim() == 4 and w.is_contiguous(memory_format=torch.channels_last))):
+            raise ValueError("weight must be dense (contiguous or channels_last)")
+        rows = w.shape[0]; cols = w.numel() // rows
+        w_sn = torch.empty_like(w); sigma = torch.empty(1, dtype=torch.float32, device=w.device)
+        uu = torch.empty_like(u); vv = torch.empty_like(v)
+        items[i] = _lib.SnItem(_ptr(w), _ptr(u), _ptr(v), _ptr(w_sn), _ptr(sigma), _ptr(uu), _ptr(vv), _ptr(ws), rows, cols)
+        outs.append((w_sn, sigma, uu, vv))
+    _lib.check(lib.wc_spectral_norm_batched_f32(ctypes.addressof(items), n, int(iterations), float(eps), _stream()),
+               "wc_spectral_norm_batched_f32")
+    return outs
+
+
+def spectral_norm_bwd_batched(gs, w_sns, us, vs, sigmas, wss, fully_diff):
+    lib = _lib.load()
+    n = len(gs)
+    items = (_lib.SnBwdItem * n)()
+    dWs = []
+    keep = []
+    for i in range(n):
+        g, w_sn = gs[i], w_sns[i]
+        if g.stride() != w_sn.stride():
+            g = g.contiguous(memory_format=torch.channels_last) if (w_sn.dim() == 4 and w_sn.is_contiguous(memory_format=torch.channels_last)) else g.contiguous()
+        keep.append(g)
+        rows = w_sn.shape[0]; cols = w_sn.numel() // rows
+        dW = torch.empty_like(w_sn)
+        items[i] = _lib.SnBwdItem(_ptr(g), _ptr(w_sn), _ptr(us[i]), _ptr(vs[i]), _ptr(sigmas[i]), _ptr(dW), _ptr(wss[i]), rows, cols)
+        dWs.append(dW)
+    _lib.check(lib.wc_spectral_norm_bwd_batched_f32(ctypes.addressof(items), n, 1 if fully_diff else 0, _stream()),
+               "wc_spectral_norm_bwd_batched_f32")
+    return dWs

@@ -39,6 +39,54 @@ class SpectralNormFunction(torch.autograd.Function):
         return ops.spectral_norm_bwd(g, w_sn, u, v, sigma, ctx.fully_diff, ctx.ws), None, None, None, None, None, None
 
 
+class SpectralNormBatchFunction(torch.autograd.Function):
+    """Every spectrally normalised weight of a network in one launch (forward) and one launch (backward)."""
+
+    @staticmethod
+    def forward(ctx, mods, iterations, eps, fully_diff, *weights):
+        wss = [m._sn_workspace() for m in mods]
+        outs = ops.spectral_norm_batched([w.detach() for w in weights], [m.sn_u for m in mods], [m.sn_v for m in mods],
+                                         wss, iterations, eps)
+        saved = []
+        for w_sn, sigma, uu, vv in outs:
+            saved += [w_sn, uu, vv, sigma]
+        ctx.save_for_backward(*saved)
+        ctx.wss, ctx.fully_diff, ctx.n = wss, bool(fully_diff), len(mods)
+        return tuple(o[0] for o in outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        sv = ctx.saved_tensors
+        idx = [i for i in range(ctx.n) if grads[i] is not None and ctx.needs_input_grad[4 + i]]
+        out = [None] * ctx.n
+        if idx:
+            dWs = ops.spectral_norm_bwd_batched([grads[i] for i in idx], [sv[4 * i] for i in idx], [sv[4 * i + 1] for i in idx],
+                                                [sv[4 * i + 2] for i in idx], [sv[4 * i + 3] for i in idx],
+                                                [ctx.wss[i] for i in idx], ctx.fully_diff)
+            for i, d in zip(idx, dWs):
+                out[i] = d
+        return (None, None, None, None, *out)
+
+
+def prepare_spectral(root):
+    """Call at the top of a network's forward: normalises the weights of ALL its spectral-norm layers in one launch;
+    each layer's forward then picks its weight up (if that weight has not changed since).  No-op with fewer than two
+    such layers, on the CPU, or when their settings differ."""
+    mods = getattr(root, '_sn_modules', None)
+    if mods is None:
+        mods = root._sn_modules = [m for m in root.modules() if isinstance(m, _SNMixin)]
+    if len(mods) < 2 or not all(m.weight.is_cuda for m in mods):
+        return
+    m0 = mods[0]
+    it = m0.spectral_iterations if root.training else 0
+    if any((m.spectral_iterations if m.training else 0) != it or m.fully_diff_spectral != m0.fully_diff_spectral
+           or m.sn_eps != m0.sn_eps for m in mods):
+        return
+    ws = SpectralNormBatchFunction.apply(mods, it, m0.sn_eps, m0.fully_diff_spectral, *[m.weight for m in mods])
+    for m, w in zip(mods, ws):
+        m._w_ready = (w, m.weight._version, m.training)
+
+
 class _SNMixin:
     """Adds the persistent power-iteration state to a module that owns `self.weight`."""
 
@@ -66,13 +114,22 @@ class _SNMixin:
             return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
         return w.reshape(w.shape[0], -1)
 
-    def normalized_weight(self):
-        if not self.weight.is_cuda:
-            raise RuntimeError("spectral normalisation runs on the HIP op only: move the module to the GPU")
-        it = self.spectral_iterations if self.training else 0
+    def _sn_workspace(self):
         ws = getattr(self, '_sn_ws', None)
         if ws is None or ws.device != self.weight.device:      # per-weight scratch of the op (zeroed once)
             ws = self._sn_ws = ops.spectral_norm_workspace(self.sn_u.numel(), self.sn_v.numel(), self.weight.device)
+        return ws
+
+    def normalized_weight(self):
+        if not self.weight.is_cuda:
+            raise RuntimeError("spectral normalisation runs on the HIP op only: move the module to the GPU")
+        ready = getattr(self, '_w_ready', None)
+        if ready is not None:                                   # normalised by prepare_spectral() for this pass
+            self._w_ready = None
+            if ready[1] == self.weight._version and ready[2] == self.training:
+                return ready[0]
+        it = self.spectral_iterations if self.training else 0
+        ws = self._sn_workspace()
         w_sn, _sigma = SpectralNormFunction.apply(self.weight, self.sn_u, self.sn_v, ws, it, self.sn_eps, self.fully_diff_spectral)
         return w_sn
 
