@@ -306,3 +306,29 @@ def test_narrow_conv_as_gemm_equals_convolution():
     assert float((x1.grad - x2.grad).abs().max() / x2.grad.abs().max()) < 1e-5
     assert float((ga - conv.conv.weight.grad).abs().max() / ga.abs().max()) < 1e-5
     assert float((gba - conv.conv.bias.grad).abs().max() / gba.abs().max()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_overlapped_generator_forward_gives_the_same_step():
+    """GanTrainer.step with the generator update's forward pass on a second stream == the sequential order.
+    MIOpen's gradient kernels are not bit-reproducible run to run, and Adam with beta1 = 0 moves every weight by
+    ~lr * sign(gradient), so two SEQUENTIAL runs already differ (a fifth of the weights by > 2e-5 after two steps,
+    none by more than 2 steps x 2 x lr); the overlapped run has to sit inside that same spread."""
+    from wc_gan_amd.train import CIFAR10_UNCOND, build_trainer
+    reals = [torch.rand(8, 32, 32, 3, device='cuda') * 2 - 1 for _ in range(2)]
+
+    def run(overlap):
+        torch.manual_seed(11)
+        tr = build_trainer(CIFAR10_UNCOND, 'cuda', batch_size=8, training_ratio=2, seed=77)
+        tr.overlap_g_forward = overlap
+        for _ in range(2):
+            d_loss, g_loss = tr.step(reals)
+        torch.cuda.synchronize()
+        return float(d_loss), float(g_loss), torch.cat([p.detach().reshape(-1) for p in tr.G.parameters()])
+
+    ovl, seq1, seq2 = run(True), run(False), run(False)
+    spread = lambda x, y: (float((x[2] - y[2]).abs().max()), float(((x[2] - y[2]).abs() > 2e-5).float().mean()))
+    (m_o, f_o), (m_s, f_s) = spread(ovl, seq1), spread(seq1, seq2)
+    assert m_o < 1.2e-3 and m_s < 1.2e-3
+    assert f_o < 1.5 * f_s + 0.02
+    assert abs(ovl[0] - seq1[0]) < 5e-3 and abs(ovl[1] - seq1[1]) < 5e-3

@@ -84,6 +84,8 @@ class GanTrainer:
         if cap:
             torch.cuda.manual_seed(seed)         # the default device generator: its Philox offset is graph-safe
         self._graph = None
+        self._side = None
+        self.overlap_g_forward = True
 
     def _noise(self, n):
         z = torch.randn(n, self.noise_dim, device=self.dev)
@@ -121,12 +123,16 @@ class GanTrainer:
         self.opt_d.step()
         return loss.detach()
 
-    def g_step(self):
-        z, cls = self._noise(self.batch_size * self.gbm)
+    def g_step(self, generated=None):
         self.g_bucket.zero()
+        if generated is None:
+            z, cls = self._noise(self.batch_size * self.gbm)
+            fake = self.G(z, cls)
+        else:
+            fake, cls = generated
         for p in self.d_bucket.params:
             p.requires_grad_(False)
-        loss = -self._d(self.G(z, cls), cls).mean()
+        loss = -self._d(fake, cls).mean()
         loss.backward()
         for p in self.d_bucket.params:
             p.requires_grad_(True)
@@ -137,9 +143,25 @@ class GanTrainer:
     def step(self, real_batches):
         """One G+D step: training_ratio critic updates, then one generator update."""
         fakes, clss = self.generate(self.training_ratio)
+        generated = None
+        if self.overlap_g_forward and self.dev.type == 'cuda':
+            # The generator update's forward pass needs the generator's weights only, and those do not move while the
+            # critic trains: it runs on a second stream next to the critic updates and fills the chip while their
+            # narrow kernels (Cholesky, small GEMMs, spectral norm) run -- and the other way round.  Same numbers.
+            main = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                z, cls = self._noise(self.batch_size * self.gbm)
+                generated = (self.G(z, cls), cls)
         for r in range(self.training_ratio):
             d_loss = self.d_step(real_batches[r % len(real_batches)], fake=fakes[r], cls=clss[r])
-        g_loss = self.g_step()
+        if generated is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+            generated[0].record_stream(torch.cuda.current_stream())
+            generated[1].record_stream(torch.cuda.current_stream())
+        g_loss = self.g_step(generated)
         return d_loss, g_loss
 
     def capture(self, real_batches, warmup=3):
