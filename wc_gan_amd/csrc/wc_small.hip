@@ -537,8 +537,27 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(WcGemm g)
         const TA* A1 = A0 + 16 * g.a_rs;
         const TB* B0 = B + (int64_t)(bn * 32 + li) * g.b_cs;
         const TB* B1 = B0 + 16 * g.b_cs;
-#pragma unroll 4
-        for (int kk = wave * kper; kk < (wave + 1) * kper; kk += 4) {
+        // the loop is load latency, not flops: 16 k at a time, every load of the group ahead of its MFMAs
+        // (the trip count is a run-time value, so the unrolling is spelled out: hipcc declines it otherwise)
+        const int kend = (wave + 1) * kper;
+        int kk = wave * kper;
+        for (; kk + 16 <= kend; kk += 16) {
+            double a0[4], a1[4], b0[4], b1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t ka = kk + 4 * u + lq;
+                a0[u] = (double)A0[ka * g.a_cs]; a1[u] = (double)A1[ka * g.a_cs];
+                b0[u] = (double)B0[ka * g.b_rs]; b1[u] = (double)B1[ka * g.b_rs];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b1[u], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b0[u], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], acc[1][1], 0, 0, 0);
+            }
+        }
+        for (; kk < kend; kk += 4) {
             const int64_t ka = kk + lq;
             const double a0 = (double)A0[ka * g.a_cs], a1 = (double)A1[ka * g.a_cs];
             const double b0 = (double)B0[ka * g.b_rs], b1 = (double)B1[ka * g.b_rs];
