@@ -83,13 +83,12 @@ int wc_stats_f32(const float* x, int64_t M, int C, int groups, double* sum, doub
     float* colsum = cv.take<float>((size_t)p.nslab * C);
     double* P = cv.take<double>((size_t)p.nslab * C * C);
 
-    WC_TRY(wc_launch_subsample_mean(x, M, C, shift, st));
+    if (p.fast) WC_TRY(wc_launch_subsample_mean_scale(x, M, C, shift, scale, gate, st));    // shift, scale, gate := 0
+    else WC_TRY(wc_launch_subsample_mean(x, M, C, shift, st));
     WcXtyArgs a = {};
     a.X = x; a.Y = x; a.cx = shift; a.cy = shift; a.N = Ns; a.HW = HWs; a.per_sample = per_seg; a.nsplit = p.nsplit;
     a.rows_per_slab = p.rps; a.C = C; a.sym = 1; a.P = P; a.colsum = colsum;
     if (p.fast) {
-        WC_TRY(hipMemsetAsync(gate, 0, 256, st));
-        WC_TRY(wc_launch_channel_scale(x, shift, M, C, scale, st));
         WC_TRY(wc_launch_fast_xty(x, x, shift, shift, scale, scale, Ns, HWs, C, per_seg, p.nsplit, p.rps, p.nslab, p.ntypes,
                                   P, colsum, gate, st));
         a.gate = gate;                       // exact redo, a no-op unless the fp16 range was exceeded
@@ -259,9 +258,7 @@ int wc_bwd_reduce_f32(const float* x, const float* mu, const float* gy, const in
     a.X = x; a.Y = gy; a.cx = mu; a.cy = nullptr; a.N = Ns; a.HW = HWs;
     a.per_sample = per_sample; a.nsplit = p.nsplit; a.rows_per_slab = p.rps; a.C = C; a.sym = 0; a.P = P; a.colsum = colsum;
     if (p.fast) {
-        WC_TRY(hipMemsetAsync(gate, 0, 256, st));
-        WC_TRY(wc_launch_channel_scale(x, mu, N * HW, C, sx, st));
-        WC_TRY(wc_launch_channel_scale(gy, nullptr, N * HW, C, sy, st));
+        WC_TRY(wc_launch_channel_scale2(x, mu, sx, gy, nullptr, sy, N * HW, C, gate, st));      // both scales, gate := 0
         WC_TRY(wc_launch_fast_xty(x, gy, mu, nullptr, sx, sy, Ns, HWs, C, per_sample, p.nsplit, p.rps, p.nslab, p.ntypes,
                                   P, colsum, gate, st));
         a.gate = gate;

@@ -54,6 +54,7 @@ hipError_t wc_launch_xty(const WcXtyArgs& a, int nslab, hipStream_t st);
 
 hipError_t wc_launch_subsample_mean(const float* x, int64_t M, int C, float* shift, hipStream_t st);
 hipError_t wc_launch_stream_copy(const float* src, float* dst, int64_t n, hipStream_t st);
+hipError_t wc_launch_subsample_mean_scale(const float* x, int64_t M, int C, float* shift, float* scale, int* gate, hipStream_t st);
 // wc_sn.hip
 #include "../../include/wc_hip.h"
 typedef wc_sn_item WcSnItem;
@@ -89,6 +90,8 @@ hipError_t wc_launch_fast_affine_planned(const float* in, const float* center, c
                                          int64_t N, int64_t HW, int C, int accumulate, float* out,
                                          const void* plan, hipStream_t st);
 hipError_t wc_launch_channel_scale(const float* in, const float* center, int64_t M, int C, float* scale, hipStream_t st);
+hipError_t wc_launch_channel_scale2(const float* in, const float* center, float* scale, const float* in2, const float* center2,
+                                    float* scale2, int64_t M, int C, int* gate, hipStream_t st);
 
 // ----- small-matrix stage (wc_small.hip) -----------------------------------------------------
 

@@ -50,9 +50,13 @@ __device__ __forceinline__ f32x4 ld4f(const float* p) { return *reinterpret_cast
 // per-input-channel power-of-two scale from <= 256 sampled rows: s_k = 2^(4 - ceil(log2(max|in - c|)))
 // --------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void channel_scale_kernel(const float* __restrict__ in, const float* __restrict__ center,
-                                                             int64_t M, int C, float* __restrict__ scale)
+                                                             int64_t M, int C, float* __restrict__ scale,
+                                                             const float* __restrict__ in2, const float* __restrict__ center2,
+                                                             float* __restrict__ scale2, int* __restrict__ gate)
 {
     __shared__ float red[16][64];
+    if (gate && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) gate[threadIdx.x] = 0;     // the overflow gate of the call
+    if (blockIdx.y == 1) { in = in2; center = center2; scale = scale2; }                           // second operand (K4: gy)
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int part = threadIdx.x >> 6;
     const int64_t nsamp = M < 256 ? M : 256;
@@ -888,7 +892,16 @@ size_t wc_fast_affine_workspace(int C, int Kc)
 
 hipError_t wc_launch_channel_scale(const float* in, const float* center, int64_t M, int C, float* scale, hipStream_t st)
 {
-    hipLaunchKernelGGL(channel_scale_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, in, center, M, C, scale);
+    hipLaunchKernelGGL(channel_scale_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, in, center, M, C, scale,
+                       (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (int*)nullptr);
+    return hipGetLastError();
+}
+
+// two operands of equal shape and the gate's clearing in one launch (K4)
+hipError_t wc_launch_channel_scale2(const float* in, const float* center, float* scale, const float* in2, const float* center2,
+                                    float* scale2, int64_t M, int C, int* gate, hipStream_t st)
+{
+    hipLaunchKernelGGL(channel_scale_kernel, dim3((C + 63) / 64, 2), dim3(1024), 0, st, in, center, M, C, scale, in2, center2, scale2, gate);
     return hipGetLastError();
 }
 
@@ -952,7 +965,7 @@ hipError_t wc_launch_fast_affine(const float* in, const float* center, const flo
                                  int64_t N, int64_t HW, int C, int accumulate, float* out,
                                  void* ws, hipStream_t st)
 {
-    hipLaunchKernelGGL(channel_scale_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, in, center, N * HW, C, wc_fast_plan_scale(ws));
+    { hipError_t e0 = wc_launch_channel_scale(in, center, N * HW, C, wc_fast_plan_scale(ws), st); if (e0 != hipSuccess) return e0; }
     hipError_t e = wc_launch_fast_plan_tables(B, Kc, C, ws, st);
     if (e != hipSuccess) return e;
     return wc_launch_fast_affine_planned(in, center, B, Kc, shared_table, bias, sub, slot, N, HW, C, accumulate, out, ws, st);

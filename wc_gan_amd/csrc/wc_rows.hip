@@ -443,6 +443,56 @@ __global__ __launch_bounds__(1024) void subsample_mean_kernel(const float* __res
     }
 }
 
+// The same sample once more for the fast path's per-channel power-of-two scale (2^(4 - ceil(log2 max|x - shift|)), as
+// wc_fast.hip's channel_scale_kernel computes it) and the clearing of the overflow gate: one launch instead of three.
+__global__ __launch_bounds__(1024) void subsample_mean_scale_kernel(const float* __restrict__ x, int64_t M, int C,
+                                                                    float* __restrict__ shift, float* __restrict__ scale,
+                                                                    int* __restrict__ gate)
+{
+    __shared__ float red[16][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int part = threadIdx.x >> 6;
+    const int64_t nsamp = M < 256 ? M : 256;
+    const int64_t stride = M / nsamp;
+    if (blockIdx.x == 0 && threadIdx.x < 64) gate[threadIdx.x] = 0;
+    float v[16];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int64_t r = part + 16 * i;
+        v[i] = (c < C && r < nsamp) ? x[r * stride * C + c] : 0.f;
+        s += v[i];
+    }
+    red[part][threadIdx.x & 63] = s;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) t += red[p][threadIdx.x & 63];
+    const float mean = t / (float)nsamp;
+    __syncthreads();
+    float mx = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int64_t r = part + 16 * i;
+        if (c < C && r < nsamp) mx = fmaxf(mx, fabsf(v[i] - mean));
+    }
+    red[part][threadIdx.x & 63] = mx;
+    __syncthreads();
+    if (threadIdx.x < 64 && c < C) {
+        float m = 0.f;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) m = fmaxf(m, red[p][threadIdx.x]);
+        float sc = 1.0f;
+        if (m > 0.f && m < 3.0e38f) {
+            int e;
+            frexpf(m, &e);
+            sc = ldexpf(1.0f, 4 - e);
+        }
+        shift[c] = mean;
+        scale[c] = sc;
+    }
+}
+
 __global__ __launch_bounds__(256) void stream_copy_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, int64_t n4)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -506,6 +556,12 @@ hipError_t wc_launch_xty(const WcXtyArgs& a, int nslab, hipStream_t st)
 hipError_t wc_launch_subsample_mean(const float* x, int64_t M, int C, float* shift, hipStream_t st)
 {
     hipLaunchKernelGGL(subsample_mean_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, x, M, C, shift);
+    return hipGetLastError();
+}
+
+hipError_t wc_launch_subsample_mean_scale(const float* x, int64_t M, int C, float* shift, float* scale, int* gate, hipStream_t st)
+{
+    hipLaunchKernelGGL(subsample_mean_scale_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, x, M, C, shift, scale, gate);
     return hipGetLastError();
 }
 
