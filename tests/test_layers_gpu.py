@@ -332,3 +332,26 @@ def test_overlapped_generator_forward_gives_the_same_step():
     assert m_o < 1.2e-3 and m_s < 1.2e-3
     assert f_o < 1.5 * f_s + 0.02
     assert abs(ovl[0] - seq1[0]) < 5e-3 and abs(ovl[1] - seq1[1]) < 5e-3
+
+
+@pytest.mark.gpu
+def test_up_block_equals_the_literal_op_order():
+    """ResBlockUp (shortcut before the upsample, transposed-conv conv1, fused ReLU, per-patch add) against the reference's
+    literal composition generator.py:142-151: WC -> ReLU -> UpSampling2D -> Conv2D ... + Conv2D1x1(UpSampling2D(x))."""
+    import torch.nn.functional as F
+    from functools import partial
+    from wc_gan_amd.generator import Conv2D, ResBlockUp, create_norm, upsample2x
+    torch.manual_seed(8)
+    norm = create_norm('d', 'uconv', number_of_classes=10)
+    blk = ResBlockUp(64, 64, 'UP', 'G.0', partial(norm), partial(Conv2D)).cuda()
+    x = torch.randn(16, 8, 8, 64, device='cuda')
+    cls = torch.zeros(16, 1, dtype=torch.int32, device='cuda')
+    with torch.no_grad():
+        blk(x, cls)                       # builds the lazy layers, moves the moving statistics off their initial values
+        blk.eval()
+        got = blk(x, cls)
+        h = F.relu(blk.bn1(x, cls)); h = upsample2x(h); s = upsample2x(x)
+        h = blk.conv1(h); h = F.relu(blk.bn2(h, cls)); h = blk.conv2(h)
+        ref = h + blk.shortcut(s)
+    assert got.shape == ref.shape == (16, 16, 16, 64)
+    assert float((got - ref).abs().max() / ref.abs().max()) < 2e-5
