@@ -355,3 +355,22 @@ def test_up_block_equals_the_literal_op_order():
         ref = h + blk.shortcut(s)
     assert got.shape == ref.shape == (16, 16, 16, 64)
     assert float((got - ref).abs().max() / ref.abs().max()) < 2e-5
+
+
+@pytest.mark.gpu
+def test_step_with_the_data_parallel_gradient_layout():
+    """The world > 1 configuration on one GPU: flat gradient buckets (channels_last views) + fused Adam + both streams."""
+    from wc_gan_amd.train import CIFAR10_UNCOND, build_trainer
+    reals = [torch.rand(8, 32, 32, 3, device='cuda') * 2 - 1 for _ in range(2)]
+    torch.manual_seed(12)
+    tr = build_trainer(CIFAR10_UNCOND, 'cuda', batch_size=8, training_ratio=2, seed=5, flat_buckets=True)
+    assert tr.g_bucket.flat is not None and tr.d_bucket.flat is not None
+    before = torch.cat([p.detach().reshape(-1).clone() for p in tr.G.parameters()])
+    for _ in range(2):
+        d_loss, g_loss = tr.step(reals)
+    torch.cuda.synchronize()
+    after = torch.cat([p.detach().reshape(-1) for p in tr.G.parameters()])
+    assert torch.isfinite(d_loss) and torch.isfinite(g_loss) and torch.isfinite(after).all()
+    assert float((after - before).abs().max()) > 1e-5                      # the generator moved
+    assert all(p.grad.data_ptr() >= tr.g_bucket.flat.data_ptr() for p in tr.g_bucket.params)     # grads are still the views
+    assert float(tr.g_bucket.flat.abs().sum()) > 0

@@ -66,14 +66,15 @@ def broadcast_state(module, src=0, group=None):
 class GanTrainer:
     def __init__(self, generator, discriminator, batch_size=64, generator_batch_multiple=2, training_ratio=5,
                  lr=2e-4, beta1=0.0, beta2=0.9, noise_dim=128, number_of_classes=10, conditional=False,
-                 process_group=None, seed=1234):
+                 process_group=None, seed=1234, flat_buckets=None):
         self.G, self.D = generator, discriminator
         self.batch_size, self.gbm, self.training_ratio = batch_size, generator_batch_multiple, training_ratio
         self.noise_dim, self.K, self.conditional = noise_dim, number_of_classes, conditional
         self.dev = next(generator.parameters()).device
         world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
-        self.g_bucket = FlatGradBucket(self.G.parameters(), process_group, flat=world > 1)
-        self.d_bucket = FlatGradBucket(self.D.parameters(), process_group, flat=world > 1)
+        flat = (world > 1) if flat_buckets is None else bool(flat_buckets)     # (True at world 1: the DP layout, for tests)
+        self.g_bucket = FlatGradBucket(self.G.parameters(), process_group, flat=flat)
+        self.d_bucket = FlatGradBucket(self.D.parameters(), process_group, flat=flat)
         # capturable: the step counters live on the device, so a whole G+D step can be recorded into one hipGraph
         cap = self.dev.type == 'cuda'
         # fused: one multi-tensor kernel per update instead of ~10 small launches per parameter (step counters on the
