@@ -188,6 +188,56 @@ typedef struct {
 int wc_spectral_norm_batched_f32(const wc_sn_item* items, int count, int iterations, float eps, wc_stream_t stream);
 int wc_spectral_norm_bwd_batched_f32(const wc_sn_bwd_item* items, int count, int fully_diff, wc_stream_t stream);
 
+/* ---- Convolutions around the WC sites (the callers either side of the path) ------------------
+ * Replaces, for the generator/critic residual blocks, Keras `Conv2D(3x3, padding='same')` (generator.py:142-158,
+ * discriminator.py:41-54), its `UpSampling2D -> Conv2D` and `Conv2D -> AveragePooling2D` pairs (as ONE 4x4 stride-2
+ * transposed / strided convolution: exact rewrites) and the data gradient of each, fp32-accurate
+ * on the fp16 MFMA pipe with split operands (3 products, the scheme of wc_apply_f32's fast path).
+ *
+ * One geometry describes all of them as an implicit GEMM over a "virtual grid" (N, H, W): point (y, x) of phase p
+ * reads input pixel (y*in_stride + dy[p][t], x*in_stride + dx[p][t]) for tap t (zero outside the Hin x Win plane) and
+ * writes output pixel (y*out_stride + off_y[p], x*out_stride + off_x[p]) of the Hout x Wout plane; tap t of phase p
+ * multiplies by the source weight slice (wr[p][t], ws[p][t]).  Tensors are NHWC fp32, dense.
+ *   3x3 same:              H=Hin=Hout, strides 1, 9 taps dy=r-1;  1 phase
+ *   4x4 stride-2 conv:     H=Hout=Hin/2, in_stride 2, 16 taps dy=r-1; 1 phase
+ *   4x4 stride-2 transposed conv: H=Hin, out_stride 2, 4 phases (py,px) of 2x2 taps, r = py+1-2*dy
+ * Data gradients are the same three with the channel roles swapped in the weight image (stride_k <-> stride_n). */
+typedef struct {
+    int N, H, W;                    /* virtual grid */
+    int Hin, Win, Cin;              /* input plane, reduction channels (multiple of 32) */
+    int Hout, Wout, Cout;           /* output plane, output channels (multiple of 128) */
+    int in_stride, out_stride;
+    int ntaps, nphase;              /* <= 16 taps, <= 4 phases */
+    signed char dy[4][16], dx[4][16];
+    signed char wr[4][16], ws[4][16];
+    signed char off_y[4], off_x[4];
+} wc_conv_geom;
+
+#define WC_CONV_SCRATCH_BYTES 2048
+
+/* 1 when wc_conv_f16x3 takes the geometry (N*H*W a multiple of 128, channel multiples as above). */
+int wc_conv_supported(const wc_conv_geom* g);
+
+/* hi = fp16(s*x), lo = fp16(s*x - hi) over n floats (n % 4 == 0), s = the power of two that puts max|x| into
+ * [2^13, 2^14) (written to *scale on the device); relu != 0 clamps at zero first.  `amax_scratch`: WC_CONV_SCRATCH_BYTES
+ * device bytes (per-workgroup maxima; no atomics, nothing to clear). */
+int wc_conv_split_f32(const float* x, int64_t n, int relu, void* hi, void* lo, float* scale, void* amax_scratch,
+                      wc_stream_t stream);
+
+/* Weight fragment images for a geometry: element (k, n, r, s) of the source is w[k*stride_k + n*stride_n + r*stride_r +
+ * s*stride_s] (k = reduction channel, n = output channel of the product), `n_elems` = extent of the source storage (for
+ * the tensor scale).  `image`: wc_conv_weights_bytes(g) device bytes. */
+size_t wc_conv_weights_bytes(const wc_conv_geom* g);
+int wc_conv_weights_f32(const float* w, int64_t stride_k, int64_t stride_n, int64_t stride_r, int64_t stride_s,
+                        int64_t n_elems, const wc_conv_geom* g, void* image, float* scale, void* amax_scratch,
+                        wc_stream_t stream);
+
+/* y = conv(x, w) (+ bias[Cout]) (then max(., 0) when relu != 0) for the geometry; x as split planes, `zero_line` = 64
+ * device bytes of zeros (the padding). */
+int wc_conv_f16x3(const void* xhi, const void* xlo, const float* xscale, const void* wimage, const float* wscale,
+                  const float* bias, const void* zero_line, const wc_conv_geom* g, int relu, float* y,
+                  wc_stream_t stream);
+
 /* Bandwidth yardstick used by bench.py: dst[i] = src[i] (float4 grid-stride copy), same stream rules. */
 int wc_stream_copy_f32(const float* src, float* dst, int64_t n, wc_stream_t stream);
 

@@ -1,0 +1,157 @@
+"""The block convolutions on the split-fp16 MFMA kernel (wc_gan_amd/conv.py, csrc/wc_conv.hip) against torch's
+float64 convolutions of the same map (Keras Conv2D 'same', generator.py:142-158; its UpSampling2D / AveragePooling2D
+forms as 4x4 stride-2 transposed / strided convolutions).  Tolerance: 1e-5 of the result's max (fp32 convolution level;
+north_star asks for 1e-4 relative)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+TOL = 1e-5
+
+
+def _ref(x, w, b, kind):
+    xn = x.permute(0, 3, 1, 2).double()
+    bb = None if b is None else b.double()
+    if kind == 'same':
+        y = F.conv2d(xn, w.double(), bb, padding=w.shape[2] // 2)
+    elif kind == 'down':
+        y = F.conv2d(xn, w.double(), bb, stride=2, padding=1)
+    else:
+        y = F.conv_transpose2d(xn, w.double(), bb, stride=2, padding=1)
+    return y.permute(0, 2, 3, 1)
+
+
+def _weights(kind, ci, co, k, channels_last=True):
+    shape = (ci, co, 4, 4) if kind == 'up' else (co, ci, 4, 4) if kind == 'down' else (co, ci, k, k)
+    w = torch.randn(*shape, device='cuda') / (ci * shape[2] * shape[3]) ** 0.5
+    return w.contiguous(memory_format=torch.channels_last) if channels_last else w
+
+
+def _rel(a, r):
+    return float(((a.detach().double() - r.detach()).abs().max() / r.detach().abs().max()).item())
+
+
+CASES = [
+    # kind, N, H, W, Cin, Cout, k, taken
+    ('same', 2, 8, 8, 128, 128, 3, True),
+    ('same', 8, 12, 12, 128, 256, 3, True),          # sizes that are no powers of two (STL-10's 12 x 12)
+    ('same', 4, 8, 8, 256, 128, 1, True),
+    ('same', 16, 8, 8, 256, 256, 3, True),
+    ('same', 1, 16, 16, 128, 384, 3, True),          # three n-tiles of 128
+    ('down', 2, 16, 16, 128, 128, 0, True),
+    ('down', 32, 12, 12, 128, 256, 0, True),
+    ('up', 2, 8, 8, 128, 128, 0, True),
+    ('up', 32, 4, 4, 256, 256, 0, True),
+    ('same', 128, 16, 16, 256, 256, 3, True),        # the 256-point tile
+    ('up', 8, 6, 6, 256, 256, 0, False),             # 288 points: not a multiple of the 128-point tile
+    ('same', 2, 8, 8, 32, 128, 3, False),            # the data gradient would produce 32 channels
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,N,H,W,ci,co,k,taken", CASES)
+def test_forward_and_gradients_match_float64(kind, N, H, W, ci, co, k, taken):
+    from wc_gan_amd import conv as C
+    torch.manual_seed(N + H + ci)
+    x = (torch.randn(N, H, W, ci, device='cuda') * 1.7 + 0.3).requires_grad_(True)
+    w = _weights(kind, ci, co, k).requires_grad_(True)
+    b = (torch.randn(co, device='cuda') * 0.1).requires_grad_(True)
+    assert C.supported(x, w, kind) == taken
+    if not taken:
+        with pytest.raises(RuntimeError):
+            C.fast_conv(x, w, b, kind)
+        return
+    y = C.fast_conv(x, w, b, kind)
+    gy = torch.randn_like(y)
+    dx, dw, db = torch.autograd.grad(y, (x, w, b), gy)
+    y64 = _ref(x, w, b, kind)
+    dx64, dw64, db64 = torch.autograd.grad(y64, (x, w, b), gy.double())
+    assert _rel(y, y64) < TOL
+    assert _rel(dx, dx64) < TOL
+    assert _rel(dw, dw64) < 2e-5          # MIOpen's fp32 weight gradient
+    assert _rel(db, db64) < TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ci", [32, 96])
+def test_forward_with_reduction_channels_in_multiples_of_32(ci):
+    """the kernel itself takes any multiple of 32 reduction channels (the layer entry also wants the data gradient)"""
+    from wc_gan_amd import conv as C
+    torch.manual_seed(ci)
+    x = torch.randn(2, 8, 8, ci, device='cuda')
+    w = _weights('same', ci, 128, 3)
+    (gf, kf, nf), _ = C._geoms('same', 2, 8, 8, w)
+    y = C.run(C.split_planes(x), C.weight_image(w, gf, kf, nf), gf)
+    assert _rel(y, _ref(x, w, None, 'same')) < TOL
+    y = C.run(C.split_planes(x, relu=True), C.weight_image(w, gf, kf, nf), gf, relu=True)      # ReLU before and after
+    assert _rel(y, _ref(x.clamp_min(0), w, None, 'same').clamp_min(0)) < TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scale", [1e-6, 1.0, 3e4])
+def test_tensor_scales_keep_small_and_large_magnitudes_accurate(scale):
+    """gradients of 1e-6 and activations of 3e4 both go through fp16 planes: the power-of-two tensor scale keeps the
+    relative accuracy"""
+    from wc_gan_amd import conv as C
+    torch.manual_seed(3)
+    x = torch.randn(2, 8, 8, 128, device='cuda') * scale
+    w = _weights('same', 128, 128, 3) * (1.0 / scale if scale < 1 else 1.0) * 1e-3
+    y = C.fast_conv(x, w, None, 'same')
+    assert torch.isfinite(y).all()
+    assert _rel(y, _ref(x, w, None, 'same')) < TOL
+
+
+@pytest.mark.gpu
+def test_zero_input_and_wide_dynamic_range():
+    from wc_gan_amd import conv as C
+    w = _weights('same', 128, 128, 3)
+    x = torch.zeros(2, 8, 8, 128, device='cuda')
+    b = torch.randn(128, device='cuda')
+    y = C.fast_conv(x, w, b, 'same')
+    assert torch.equal(y, b.expand_as(y))
+    torch.manual_seed(5)
+    x = torch.randn(2, 8, 8, 128, device='cuda') * torch.logspace(-6, 2, 128, device='cuda')      # channels 8 decades apart
+    assert _rel(C.fast_conv(x, w, None, 'same'), _ref(x, w, None, 'same')) < TOL
+
+
+@pytest.mark.gpu
+def test_weight_image_cache_follows_the_weight_version():
+    from wc_gan_amd import conv as C
+    torch.manual_seed(7)
+    x = torch.randn(2, 8, 8, 128, device='cuda')
+    w = _weights('same', 128, 128, 3)
+    y1 = C.fast_conv(x, w, None, 'same')
+    assert len(w._wc_conv_images[1]) == 1
+    y2 = C.fast_conv(x, w, None, 'same')
+    assert torch.equal(y1, y2) and len(w._wc_conv_images[1]) == 1
+    with torch.no_grad():
+        w.mul_(2.0)                                                     # in-place update (the optimizer's): new image
+    y3 = C.fast_conv(x, w, None, 'same')
+    assert _rel(y3, 2.0 * y1.double()) < 1e-6
+
+
+@pytest.mark.gpu
+def test_generator_and_critic_blocks_agree_with_miopen_path(monkeypatch):
+    """the same networks with the kernel switched off (MIOpen fp32) give the same images and critic outputs"""
+    import wc_gan_amd.generator as G
+    from wc_gan_amd.train import CIFAR10_UNCOND, build_trainer
+    tr = build_trainer(CIFAR10_UNCOND, 'cuda', batch_size=8, seed=3)
+    torch.manual_seed(0)
+    z = torch.randn(16, 128, device='cuda'); cls = torch.zeros(16, 1, dtype=torch.int32, device='cuda')
+    tr.G.eval(); tr.D.eval()
+    with torch.no_grad():
+        monkeypatch.setattr(G, 'FAST_CONV', True)
+        img_fast = tr.G(z, cls); out_fast = tr._d(img_fast, None)
+        monkeypatch.setattr(G, 'FAST_CONV', False)
+        img_ref = tr.G(z, cls); out_ref = tr._d(img_fast, None)
+    assert float((img_fast - img_ref).abs().max()) < 2e-5            # tanh outputs in [-1, 1]
+    assert float((out_fast - out_ref).abs().max()) < 1e-4 * float(out_ref.abs().max()) + 1e-5
+
+
+def test_no_cpu_path():
+    from wc_gan_amd import conv as C
+    x = torch.randn(2, 8, 8, 32)
+    w = torch.randn(128, 32, 3, 3)
+    assert not C.supported(x, w, 'same')
+    with pytest.raises(RuntimeError):
+        C.fast_conv(x, w, None, 'same')

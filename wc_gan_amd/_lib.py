@@ -52,6 +52,13 @@ SIGNATURES = {
                                      c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wc_spectral_norm_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
                                          c_void_p, c_size_t, c_void_p]),
+    "wc_conv_supported": (c_int, [c_void_p]),
+    "wc_conv_split_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wc_conv_weights_bytes": (c_size_t, [c_void_p]),
+    "wc_conv_weights_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p]),
+    "wc_conv_f16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                              c_void_p, c_void_p]),
 }
 
 
@@ -64,6 +71,15 @@ class SnItem(ctypes.Structure):          # wc_sn_item
 class SnBwdItem(ctypes.Structure):       # wc_sn_bwd_item
     _fields_ = [("g", c_void_p), ("w_sn", c_void_p), ("u", c_void_p), ("v", c_void_p), ("sigma", c_void_p),
                 ("dW", c_void_p), ("ws", c_void_p), ("rows", c_int), ("cols", c_int)]
+
+
+class ConvGeom(ctypes.Structure):        # wc_conv_geom
+    _fields_ = [("N", c_int), ("H", c_int), ("W", c_int), ("Hin", c_int), ("Win", c_int), ("Cin", c_int),
+                ("Hout", c_int), ("Wout", c_int), ("Cout", c_int), ("in_stride", c_int), ("out_stride", c_int),
+                ("ntaps", c_int), ("nphase", c_int),
+                ("dy", (ctypes.c_byte * 16) * 4), ("dx", (ctypes.c_byte * 16) * 4),
+                ("wr", (ctypes.c_byte * 16) * 4), ("ws", (ctypes.c_byte * 16) * 4),
+                ("off_y", ctypes.c_byte * 4), ("off_x", ctypes.c_byte * 4)]
 
 
 _lib = None

@@ -1,0 +1,196 @@
+"""Convolutions of the residual blocks either side of the WC sites on the split-fp16 MFMA path (csrc/wc_conv.hip).
+
+`fast_conv(x, w, bias, kind)` on NHWC tensors:
+
+    kind 'same'  Keras `Conv2D(k x k, padding='same')`, w (Cout, Cin, k, k)          generator.py:142-158
+    kind 'down'  4x4 stride-2 padding-1 convolution, w (Cout, Cin, 4, 4)              (= Conv2D 3x3 -> AveragePooling2D, discriminator.py:41-54)
+    kind 'up'    4x4 stride-2 padding-1 TRANSPOSED convolution, w (Cin, Cout, 4, 4)   (= UpSampling2D -> Conv2D 3x3, generator.py:144-151)
+
+Forward and the data gradient run on the HIP kernel (the data gradient of 'same' is a 'same', of 'down' an 'up' and of
+'up' a 'down', with the channel roles swapped in the weight image); the weight gradient stays with MIOpen
+(`aten.convolution_backward`).  No fallback inside: `supported(...)` tells the caller whether the kernel takes a shape.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+from .ops import _ptr, _stream
+
+_zero_lines = {}
+
+
+def _zero_line(device):
+    z = _zero_lines.get(device)
+    if z is None:
+        z = _zero_lines[device] = torch.zeros(64, dtype=torch.uint8, device=device)
+    return z
+
+
+def _dense_geom(N, Hin, Win, Cin, Cout, k, stride):
+    """taps (r, s) read input (y*stride + r - pad, x*stride + s - pad); pad = k//2 for 'same', 1 for the 4x4 stride-2 form"""
+    pad = k // 2 if stride == 1 else 1
+    g = _lib.ConvGeom()
+    g.N, g.Hin, g.Win, g.Cin, g.Cout = N, Hin, Win, Cin, Cout
+    g.H, g.W = Hin // stride, Win // stride
+    g.Hout, g.Wout = g.H, g.W
+    g.in_stride, g.out_stride, g.ntaps, g.nphase = stride, 1, k * k, 1
+    for r in range(k):
+        for s in range(k):
+            t = r * k + s
+            g.dy[0][t], g.dx[0][t], g.wr[0][t], g.ws[0][t] = r - pad, s - pad, r, s
+    return g
+
+
+def _phase_geom(N, Hin, Win, Cin, Cout, flip=False):
+    """4x4 stride-2 padding-1 transposed convolution as four 2x2 sub-pixel convolutions: output (2y+py, 2x+px) reads
+    input (y+dy, x+dx) through weight tap r = py + 1 - 2 dy"""
+    g = _lib.ConvGeom()
+    g.N, g.Hin, g.Win, g.Cin, g.Cout = N, Hin, Win, Cin, Cout
+    g.H, g.W, g.Hout, g.Wout = Hin, Win, 2 * Hin, 2 * Win
+    g.in_stride, g.out_stride, g.ntaps, g.nphase = 1, 2, 4, 4
+    for py in range(2):
+        for px in range(2):
+            p = py * 2 + px
+            g.off_y[p], g.off_x[p] = py, px
+            t = 0
+            for dy in ((-1, 0) if py == 0 else (0, 1)):
+                for dx in ((-1, 0) if px == 0 else (0, 1)):
+                    g.dy[p][t], g.dx[p][t] = dy, dx
+                    g.wr[p][t], g.ws[p][t] = py + 1 - 2 * dy, px + 1 - 2 * dx
+                    t += 1
+    return g
+
+
+def _supported(g):
+    return bool(_lib.load().wc_conv_supported(ctypes.addressof(g)))
+
+
+def supported(x, w, kind):
+    """Does the kernel take this call?  (channels multiples of 32 / 128, N*H*W of the virtual grid a multiple of 128)"""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous() and w.dtype == torch.float32):
+        return False
+    N, H, W, C = x.shape
+    if kind == 'same':
+        if w.shape[1] != C or w.shape[2] != w.shape[3] or w.shape[2] % 2 == 0 or w.shape[2] > 3:
+            return False
+        fwd, bwd = _dense_geom(N, H, W, C, w.shape[0], w.shape[2], 1), _dense_geom(N, H, W, w.shape[0], C, w.shape[2], 1)
+    elif kind == 'down':
+        if w.shape[1] != C or tuple(w.shape[2:]) != (4, 4) or H % 2 or W % 2:
+            return False
+        fwd, bwd = _dense_geom(N, H, W, C, w.shape[0], 4, 2), _phase_geom(N, H // 2, W // 2, w.shape[0], C)
+    elif kind == 'up':
+        if w.shape[0] != C or tuple(w.shape[2:]) != (4, 4):
+            return False
+        fwd, bwd = _phase_geom(N, H, W, C, w.shape[1]), _dense_geom(N, 2 * H, 2 * W, w.shape[1], C, 4, 2)
+    else:
+        raise ValueError(kind)
+    return _supported(fwd) and _supported(bwd)
+
+
+def split_planes(x, relu=False):
+    """fp32 tensor -> (hi, lo, scale): fp16 planes of s*x and the device scalar s"""
+    lib = _lib.load()
+    hi = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    lo = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    scale = torch.empty(1 + 512, dtype=torch.float32, device=x.device)    # [scale | per-workgroup maxima scratch]
+    _lib.check(lib.wc_conv_split_f32(_ptr(x), x.numel(), 1 if relu else 0, _ptr(hi), _ptr(lo), _ptr(scale),
+                                     scale.data_ptr() + 4, _stream()), "wc_conv_split_f32")
+    return hi, lo, scale
+
+
+def _storage_extent(w):
+    return 1 + sum((n - 1) * s for n, s in zip(w.shape, w.stride()))
+
+
+def weight_image(w, geom, k_axis, n_axis):
+    """Fragment image of a (dense) 4-d weight for a geometry; k_axis / n_axis = which axis is reduced / produced."""
+    lib = _lib.load()
+    nbytes = lib.wc_conv_weights_bytes(ctypes.addressof(geom))
+    img = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    scale = torch.empty(1 + 512, dtype=torch.float32, device=w.device)
+    ext = _storage_extent(w)
+    if ext != w.numel():
+        raise ValueError("weight must be dense")
+    _lib.check(lib.wc_conv_weights_f32(_ptr(w), w.stride(k_axis), w.stride(n_axis), w.stride(2), w.stride(3), ext,
+                                       ctypes.addressof(geom), _ptr(img), _ptr(scale), scale.data_ptr() + 4, _stream()),
+               "wc_conv_weights_f32")
+    return img, scale
+
+
+def _cached_image(w, key, geom, k_axis, n_axis):
+    """Images are kept on the weight tensor itself, valid for one version of it (one image serves every batch size:
+    the image depends on the taps and channel counts only)."""
+    cache = getattr(w, '_wc_conv_images', None)
+    if cache is None or cache[0] != w._version:
+        cache = (w._version, {})
+        w._wc_conv_images = cache
+    hit = cache[1].get(key)
+    if hit is None:
+        hit = cache[1][key] = weight_image(w, geom, k_axis, n_axis)
+    return hit
+
+
+def run(planes, image, geom, bias=None, relu=False):
+    hi, lo, xs = planes
+    img, ws = image
+    lib = _lib.load()
+    y = torch.empty((geom.N, geom.Hout, geom.Wout, geom.Cout), dtype=torch.float32, device=hi.device)
+    _lib.check(lib.wc_conv_f16x3(_ptr(hi), _ptr(lo), _ptr(xs), _ptr(img), _ptr(ws), _ptr(bias) if bias is not None else None,
+                                 _ptr(_zero_line(hi.device)), ctypes.addressof(geom), 1 if relu else 0, _ptr(y), _stream()),
+               "wc_conv_f16x3")
+    return y
+
+
+def _geoms(kind, N, H, W, w):
+    """(forward geometry, weight axes (k, n)), (data-gradient geometry, axes) for x of shape (N, H, W, Cin)"""
+    if kind == 'same':
+        co, ci, k = w.shape[0], w.shape[1], w.shape[2]
+        fwd = _dense_geom(N, H, W, ci, co, k, 1)
+        bwd = _dense_geom(N, H, W, co, ci, k, 1)
+        for t in range(k * k):                       # dx[y] = sum_r g[y + pad - r] w[r]
+            bwd.dy[0][t], bwd.dx[0][t] = -bwd.dy[0][t], -bwd.dx[0][t]
+        return (fwd, 1, 0), (bwd, 0, 1)
+    if kind == 'down':
+        co, ci = w.shape[0], w.shape[1]
+        return (_dense_geom(N, H, W, ci, co, 4, 2), 1, 0), (_phase_geom(N, H // 2, W // 2, co, ci), 0, 1)
+    ci, co = w.shape[0], w.shape[1]                  # 'up'
+    return (_phase_geom(N, H, W, ci, co), 0, 1), (_dense_geom(N, 2 * H, 2 * W, co, ci, 4, 2), 1, 0)
+
+
+class _FastConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, kind):
+        N, H, W, _ = x.shape
+        (gf, kf, nf), _ = _geoms(kind, N, H, W, w)
+        y = run(split_planes(x), _cached_image(w, (kind, 'fwd'), gf, kf, nf), gf, bias)
+        ctx.save_for_backward(x, w)
+        ctx.kind, ctx.has_bias = kind, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        kind = ctx.kind
+        N, H, W, _ = x.shape
+        gy = gy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            _, (gb, kb, nb) = _geoms(kind, N, H, W, w)
+            dx = run(split_planes(gy), _cached_image(w, (kind, 'bwd'), gb, kb, nb), gb)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            stride = [1, 1] if kind == 'same' else [2, 2]
+            pad = [w.shape[2] // 2] * 2 if kind == 'same' else [1, 1]
+            _, dw, db = torch.ops.aten.convolution_backward(
+                gy.permute(0, 3, 1, 2), x.permute(0, 3, 1, 2), w, [w.shape[1] if kind == 'up' else w.shape[0]] if ctx.has_bias else None,
+                stride, pad, [1, 1], kind == 'up', [0, 0], 1, [False, bool(ctx.needs_input_grad[1]), ctx.has_bias and bool(ctx.needs_input_grad[2])])
+        return dx, dw, db, None
+
+
+def fast_conv(x, w, bias=None, kind='same'):
+    """NHWC convolution (see the module docstring) -- raises if the shape is not one the kernel takes."""
+    if not supported(x, w, kind):
+        raise _lib.WcHipError(f"fast_conv: unsupported call {tuple(x.shape)} x {tuple(w.shape)} ({kind})")
+    return _FastConv.apply(x, w, bias, kind)

@@ -22,8 +22,14 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import os
+
+from . import conv as fast_conv_mod
 from .layers import (CenterScale, ConditionalCenterScale, ConditionalConv11, Conv11, DecorelationNormalization,
                      FactorizedConv11, WhiteningColoring)
+
+# the block convolutions on the split-fp16 MFMA kernel where it takes the shape (WC_FAST_CONV=0: MIOpen everywhere)
+FAST_CONV = os.environ.get('WC_FAST_CONV', '1') != '0'
 
 NORMS = ['n', 'b', 'd', 'dr']
 AFTER_NORMS = ['ucs', 'ccs', 'uccs', 'uconv', 'fconv', 'ufconv', 'cconv', 'ucconv', 'ccsuconv', 'n']
@@ -92,11 +98,19 @@ class Conv2D(nn.Module):
         self.conv = self.conv.to(memory_format=torch.channels_last)
         self.layer_name = name
 
+    def _weight(self):
+        conv = self.conv
+        return conv.normalized_weight() if hasattr(conv, 'normalized_weight') else conv.weight
+
     def forward(self, x):
         c = self.conv
         if (c.out_channels <= 4 and tuple(c.kernel_size) == (3, 3) and not hasattr(c, 'normalized_weight')
                 and x.is_cuda and x.is_contiguous()):
             return _NarrowConv3x3.apply(x, c.weight, c.bias)
+        if FAST_CONV and x.is_cuda:
+            w = self._weight()
+            if fast_conv_mod.supported(x, w, 'same'):       # split-fp16 MFMA implicit GEMM (csrc/wc_conv.hip)
+                return fast_conv_mod.fast_conv(x, w, c.bias, 'same')
         return to_nhwc(self.conv(to_nchw_view(x)))
 
     def forward_upsampled(self, x):
@@ -113,6 +127,8 @@ class Conv2D(nn.Module):
         rows = torch.stack([w[:, :, 2], w[:, :, 1] + w[:, :, 2], w[:, :, 0] + w[:, :, 1], w[:, :, 0]], dim=2)
         k = torch.stack([rows[..., 2], rows[..., 1] + rows[..., 2], rows[..., 0] + rows[..., 1], rows[..., 0]], dim=3)
         k = k.transpose(0, 1).contiguous(memory_format=torch.channels_last)             # (Cin, Cout, 4, 4)
+        if FAST_CONV and x.is_cuda and fast_conv_mod.supported(x, k, 'up'):
+            return fast_conv_mod.fast_conv(x, k, conv.bias, 'up')
         return to_nhwc(F.conv_transpose2d(to_nchw_view(x), k, conv.bias, stride=2, padding=1))
 
 
@@ -126,6 +142,10 @@ def _conv2d_forward_pooled(self, x):
     if tuple(w.shape[2:]) != (3, 3):
         return to_nhwc(F.avg_pool2d(to_nchw_view(self.forward(x)), 2))
     k = (F.pad(w, (0, 1, 0, 1)) + F.pad(w, (1, 0, 0, 1)) + F.pad(w, (0, 1, 1, 0)) + F.pad(w, (1, 0, 1, 0))) * 0.25
+    if FAST_CONV and x.is_cuda:
+        k = k.contiguous(memory_format=torch.channels_last)
+        if fast_conv_mod.supported(x, k, 'down'):
+            return fast_conv_mod.fast_conv(x, k, conv.bias, 'down')
     return to_nhwc(F.conv2d(to_nchw_view(x), k.contiguous(memory_format=torch.channels_last), conv.bias, stride=2, padding=1))
 
 
