@@ -238,6 +238,16 @@ int wc_conv_f16x3(const void* xhi, const void* xlo, const float* xscale, const v
                   const float* bias, const void* zero_line, const wc_conv_geom* g, int relu, float* y,
                   wc_stream_t stream);
 
+/* Weight gradient of the same convolution: dW(k, n, r, s) = sum over the grid of x[input pixel][k] * gy[output pixel][n]
+ * for the FORWARD geometry `g` (x and gy as split planes; Cin and Cout multiples of 128), written to
+ * dw[k*stride_k + n*stride_n + r*stride_r + s*stride_s] (every element of the taps the geometry names; fixed summation
+ * order).  `ws`: wc_conv_wrw_workspace_bytes(g) device bytes. */
+size_t wc_conv_wrw_workspace_bytes(const wc_conv_geom* g);
+int wc_conv_wrw_f16x3(const void* xhi, const void* xlo, const float* xscale, const void* ghi, const void* glo,
+                      const float* gscale, const void* zero_line, const wc_conv_geom* g, float* dw, int64_t stride_k,
+                      int64_t stride_n, int64_t stride_r, int64_t stride_s, void* ws, size_t ws_bytes,
+                      wc_stream_t stream);
+
 /* Bandwidth yardstick used by bench.py: dst[i] = src[i] (float4 grid-stride copy), same stream rules. */
 int wc_stream_copy_f32(const float* src, float* dst, int64_t n, wc_stream_t stream);
 

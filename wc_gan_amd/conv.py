@@ -7,8 +7,8 @@
     kind 'up'    4x4 stride-2 padding-1 TRANSPOSED convolution, w (Cin, Cout, 4, 4)   (= UpSampling2D -> Conv2D 3x3, generator.py:144-151)
 
 Forward and the data gradient run on the HIP kernel (the data gradient of 'same' is a 'same', of 'down' an 'up' and of
-'up' a 'down', with the channel roles swapped in the weight image); the weight gradient stays with MIOpen
-(`aten.convolution_backward`).  No fallback inside: `supported(...)` tells the caller whether the kernel takes a shape.
+'up' a 'down', with the channel roles swapped in the weight image), and so does the weight gradient (pixel-major tiles
+read back through gfx950's transposing LDS read).  No fallback inside: `supported(...)` tells the caller whether the kernel takes a shape.
 """
 from __future__ import annotations
 
@@ -160,32 +160,48 @@ def _geoms(kind, N, H, W, w):
     return (_phase_geom(N, H, W, ci, co), 0, 1), (_dense_geom(N, 2 * H, 2 * W, co, ci, 4, 2), 1, 0)
 
 
+def weight_gradient(x_planes, g_planes, geom, w, k_axis, n_axis):
+    """dW (in w's own layout) from the split planes of the layer input and of the output gradient; `geom` = the forward
+    geometry."""
+    lib = _lib.load()
+    xh, xl, xs = x_planes
+    gh, gl, gs = g_planes
+    dw = torch.empty_like(w)
+    if dw.stride() != w.stride():
+        raise ValueError("weight must be dense")
+    nbytes = lib.wc_conv_wrw_workspace_bytes(ctypes.addressof(geom))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    _lib.check(lib.wc_conv_wrw_f16x3(_ptr(xh), _ptr(xl), _ptr(xs), _ptr(gh), _ptr(gl), _ptr(gs), _ptr(_zero_line(w.device)),
+                                     ctypes.addressof(geom), _ptr(dw), w.stride(k_axis), w.stride(n_axis), w.stride(2),
+                                     w.stride(3), _ptr(ws), nbytes, _stream()), "wc_conv_wrw_f16x3")
+    return dw
+
+
 class _FastConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, kind):
         N, H, W, _ = x.shape
         (gf, kf, nf), _ = _geoms(kind, N, H, W, w)
-        y = run(split_planes(x), _cached_image(w, (kind, 'fwd'), gf, kf, nf), gf, bias)
-        ctx.save_for_backward(x, w)
-        ctx.kind, ctx.has_bias = kind, bias is not None
+        planes = split_planes(x)
+        y = run(planes, _cached_image(w, (kind, 'fwd'), gf, kf, nf), gf, bias)
+        ctx.save_for_backward(w, *planes)           # the planes stand in for x (same bytes) in the weight gradient
+        ctx.kind, ctx.has_bias, ctx.xshape = kind, bias is not None, (N, H, W)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, w = ctx.saved_tensors
+        w, xh, xl, xs = ctx.saved_tensors
         kind = ctx.kind
-        N, H, W, _ = x.shape
-        gy = gy.contiguous()
+        N, H, W = ctx.xshape
+        g_planes = split_planes(gy.contiguous())
+        (gf, kf, nf), (gb, kb, nb) = _geoms(kind, N, H, W, w)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            _, (gb, kb, nb) = _geoms(kind, N, H, W, w)
-            dx = run(split_planes(gy), _cached_image(w, (kind, 'bwd'), gb, kb, nb), gb)
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            stride = [1, 1] if kind == 'same' else [2, 2]
-            pad = [w.shape[2] // 2] * 2 if kind == 'same' else [1, 1]
-            _, dw, db = torch.ops.aten.convolution_backward(
-                gy.permute(0, 3, 1, 2), x.permute(0, 3, 1, 2), w, [w.shape[1] if kind == 'up' else w.shape[0]] if ctx.has_bias else None,
-                stride, pad, [1, 1], kind == 'up', [0, 0], 1, [False, bool(ctx.needs_input_grad[1]), ctx.has_bias and bool(ctx.needs_input_grad[2])])
+            dx = run(g_planes, _cached_image(w, (kind, 'bwd'), gb, kb, nb), gb)
+        if ctx.needs_input_grad[1]:
+            dw = weight_gradient((xh, xl, xs), g_planes, gf, w, kf, nf)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = gy.sum((0, 1, 2))
         return dx, dw, db, None
 
 

@@ -262,6 +262,182 @@ __global__ __launch_bounds__(256) void conv_weights_kernel(WeightArgs a)
     }
 }
 
+// ---- weight gradient: dW[slice][ci][co] = sum over grid points of x[in pixel][ci] * gy[out pixel][co] -------------------
+// The reduction runs over PIXELS, which are the slow axis of both NHWC operands: the tiles are staged pixel-major
+// (LDS-DMA: one 1-KiB chunk = 16 pixels x 32 channels, 64 B per pixel from 4 lanes) and the MFMA fragments -- 8
+// consecutive pixels of one channel per lane -- come out of two ds_read_b64_tr_b16 each (gfx950's transposing read: a
+// 16-lane group reads 4 pixels x 16 channels and gets them channel-major; the 4 x 64 B of a 32-lane half cover all 64
+// banks once).  A workgroup owns one (slice, 64 MB input channels, 64 NB output channels) tile and a range of 32-point
+// chunks of the grid; the per-range partial sums go to a workspace and conv_wrw_reduce_kernel adds them in a fixed order
+// (deterministic) and writes dW in the weight's own layout.
+struct WrwArgs {
+    const _Float16* xhi; const _Float16* xlo; const _Float16* ghi; const _Float16* glo; const _Float16* zero;
+    float* partial;                                 // [splits][slices][Cin][Cout]
+    int N, H, W, Hin, Win, Cin, Hout, Wout, Cout, in_stride, out_stride, ntaps, nphase;
+    unsigned magHW, shHW, magW, shW;                // m / (H*W) and rem / W by multiply-shift (m < 2^31)
+    int nchunks, cps;                               // 32-point chunks in the grid, chunks per split
+    signed char dy[kMaxPhase][kMaxTaps], dx[kMaxPhase][kMaxTaps];
+    signed char offy[kMaxPhase], offx[kMaxPhase];
+};
+
+typedef short s16x4v __attribute__((__vector_size__(4 * sizeof(short))));
+
+__device__ __forceinline__ f16x8 tr_read8(const char* block, int lane_off)
+{
+    // rows q..q+3 and q+4..q+7 of this lane's channel: two transposing reads 256 B (4 pixels) apart
+    auto p = (__attribute__((address_space(3))) s16x4v*)((__attribute__((address_space(3))) char*)(block + lane_off));
+    auto q = (__attribute__((address_space(3))) s16x4v*)((__attribute__((address_space(3))) char*)(block + lane_off + 256));
+    const s16x4v a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(p);
+    const s16x4v b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(q);
+    typedef short s16x8v __attribute__((__vector_size__(8 * sizeof(short))));
+    const s16x8v ab = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(f16x8, ab);
+}
+
+template <int MB, int NB>
+__global__ __launch_bounds__(256) void conv_wrw_kernel(WrwArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TA = 64 * MB, TB = 64 * NB;
+    constexpr int A_BYTES = 2 * MB * 4 * 1024, B_BYTES = 2 * NB * 4 * 1024, STAGE = A_BYTES + B_BYTES;
+    constexpr int AQ = (2 * MB) / 4, BQ = (2 * NB) / 4;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nta = a.Cin / TA, ntb = a.Cout / TB;
+    int idx = blockIdx.y;
+    const int tb = idx % ntb; idx /= ntb;
+    const int ta = idx % nta; idx /= nta;
+    const int tap = idx % a.ntaps, phase = idx / a.ntaps;
+    const int c0 = blockIdx.x * a.cps, c1 = min(c0 + a.cps, a.nchunks);
+    const int dy = a.dy[phase][tap], dx = a.dx[phase][tap], oy0 = a.offy[phase], ox0 = a.offx[phase];
+    const unsigned HW = a.H * a.W;
+    const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
+    const int c8 = (lane & 3) * 8;                  // this lane's 8 channels inside a 32-channel block
+
+    auto issue = [&](int c, int stage) {
+        const unsigned sbase = __builtin_amdgcn_readfirstlane(lds0 + stage * STAGE);
+        #pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const unsigned m = c * 32 + s * 16 + (lane >> 2);
+            const unsigned n = __umulhi(m, a.magHW) >> a.shHW, rem = m - n * HW;
+            const unsigned yy = __umulhi(rem, a.magW) >> a.shW, xx = rem - yy * a.W;
+            const int iy = yy * a.in_stride + dy, ix = xx * a.in_stride + dx;
+            const bool ok = (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+            const int64_t ea = ((int64_t)((n * a.Hin + iy) * a.Win + ix)) * a.Cin + ta * TA + c8;
+            const int64_t eb = ((int64_t)((n * a.Hout + yy * a.out_stride + oy0) * a.Wout + xx * a.out_stride + ox0)) * a.Cout + tb * TB + c8;
+            #pragma unroll
+            for (int q = 0; q < AQ; ++q) {
+                const int b = wave * AQ + q;
+                const _Float16* ph = ok ? a.xhi + ea + b * 32 : a.zero + c8;
+                const _Float16* pl = ok ? a.xlo + ea + b * 32 : a.zero + c8;
+                const unsigned l = sbase + ((b * 2 + s) * 2) * 1024;
+                lds_dma16(ph, l);
+                lds_dma16(pl, l + 1024);
+            }
+            #pragma unroll
+            for (int q = 0; q < BQ; ++q) {
+                const int b = wave * BQ + q;
+                const unsigned l = sbase + A_BYTES + ((b * 2 + s) * 2) * 1024;
+                lds_dma16(a.ghi + eb + b * 32, l);
+                lds_dma16(a.glo + eb + b * 32, l + 1024);
+            }
+        }
+    };
+
+    f32x16 acc[MB][NB];
+    #pragma unroll
+    for (int i = 0; i < MB; ++i)
+        #pragma unroll
+        for (int j = 0; j < NB; ++j)
+            #pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // transposing-read address of this lane inside a 1-KiB (16 pixels x 64 B) block
+    const int tr_off = ((lane >> 5) * 8 + ((lane & 15) >> 2)) * 64 + (((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2;
+
+    if (c0 < c1) issue(c0, 0);
+    for (int c = c0; c < c1; ++c) {
+        const int stage = (c - c0) & 1;
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+        if (c + 1 < c1) issue(c + 1, stage ^ 1);
+        const char* sa = smem + stage * STAGE;
+        const char* sb = sa + A_BYTES;
+        #pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f16x8 ah[MB], al[MB], bh[NB], bl[NB];
+            #pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                const char* p = sa + (((wm * MB + i) * 2 + s) * 2) * 1024;
+                ah[i] = tr_read8(p, tr_off);
+                al[i] = tr_read8(p + 1024, tr_off);
+            }
+            #pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const char* p = sb + (((wn * NB + j) * 2 + s) * 2) * 1024;
+                bh[j] = tr_read8(p, tr_off);
+                bl[j] = tr_read8(p + 1024, tr_off);
+            }
+            #pragma unroll
+            for (int i = 0; i < MB; ++i)
+                #pragma unroll
+                for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            #pragma unroll
+            for (int i = 0; i < MB; ++i)
+                #pragma unroll
+                for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            #pragma unroll
+            for (int i = 0; i < MB; ++i)
+                #pragma unroll
+                for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    const int slice = phase * a.ntaps + tap, nslice = a.nphase * a.ntaps;
+    float* out = a.partial + ((int64_t)blockIdx.x * nslice + slice) * a.Cin * a.Cout;
+    #pragma unroll
+    for (int i = 0; i < MB; ++i)
+        #pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ta * TA + (wm * MB + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            float* o = out + (int64_t)ci * a.Cout + tb * TB + wn * NB * 32 + (lane & 31);
+            #pragma unroll
+            for (int j = 0; j < NB; ++j) o[j * 32] = acc[i][j][r];
+        }
+}
+
+struct WrwReduceArgs {
+    const float* partial; int splits, nslice, Cin, Cout;
+    const float* xscale; const float* gscale;
+    float* dw; int64_t sk, sn, sr, ss;
+    signed char r[kMaxPhase * kMaxTaps], s[kMaxPhase * kMaxTaps];
+};
+
+__global__ __launch_bounds__(256) void conv_wrw_reduce_kernel(WrwReduceArgs a)
+{
+    const int64_t per = (int64_t)a.nslice * a.Cin * a.Cout;
+    const float inv = 1.0f / (a.xscale[0] * a.gscale[0]);
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < per; e += (int64_t)gridDim.x * 256) {
+        float v = 0.f;
+        for (int sp = 0; sp < a.splits; ++sp) v += a.partial[sp * per + e];
+        const int co = e % a.Cout; int64_t t = e / a.Cout;
+        const int ci = t % a.Cin; const int sl = t / a.Cin;
+        a.dw[ci * a.sk + co * a.sn + a.r[sl] * a.sr + a.s[sl] * a.ss] = v * inv;
+    }
+}
+
+void magic_u31(unsigned d, unsigned* mag, unsigned* sh)
+{
+    // q = umulhi(m, mag) >> sh == m / d for m < 2^31, d >= 2
+    unsigned s = 0;
+    while ((1u << s) < d) ++s;
+    const unsigned long long num = 1ull << (31 + s);
+    *mag = (unsigned)((num + d - 1) / d);
+    *sh = s - 1;
+}
+
 int grid_for(int64_t work_items)
 {
     int64_t g = (work_items + 255) / 256;
@@ -359,6 +535,71 @@ int wc_conv_f16x3(const void* xhi, const void* xlo, const float* xscale, const v
     if ((M % 256) == 0 && wgs_big >= 256) e = wide ? launch_conv<4, 4>(a, st) : launch_conv<4, 2>(a, st);
     else                                  e = wide ? launch_conv<2, 4>(a, st) : launch_conv<2, 2>(a, st);
     return (int)e;
+}
+
+size_t wc_conv_wrw_workspace_bytes(const wc_conv_geom* g)
+{
+    if (!g) return 0;
+    const int64_t M = (int64_t)g->N * g->H * g->W;
+    const int tiles = g->nphase * g->ntaps * ((g->Cin % 256 == 0 && g->Cout % 256 == 0) ? (g->Cin / 256) * (g->Cout / 256) : (g->Cin / 128) * (g->Cout / 128));
+    int splits = (int)((504 + tiles - 1) / tiles);
+    const int64_t nchunks = M / 32;
+    if (splits > nchunks) splits = (int)nchunks;
+    if (splits < 1) splits = 1;
+    return (size_t)splits * g->nphase * g->ntaps * g->Cin * g->Cout * 4;
+}
+
+int wc_conv_wrw_f16x3(const void* xhi, const void* xlo, const float* xscale, const void* ghi, const void* glo, const float* gscale,
+                      const void* zero_line, const wc_conv_geom* g, float* dw, int64_t stride_k, int64_t stride_n,
+                      int64_t stride_r, int64_t stride_s, void* ws, size_t ws_bytes, wc_stream_t stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (!xhi || !xlo || !xscale || !ghi || !glo || !gscale || !zero_line || !g || !dw || !ws) return WC_ERR_NULL;
+    if (!wc_conv_supported(g) || (g->Cin & 127) || g->W < 2 || g->H * g->W < 2) return WC_ERR_SHAPE;
+    if (ws_bytes < wc_conv_wrw_workspace_bytes(g)) return WC_ERR_WORKSPACE;
+    const int64_t M = (int64_t)g->N * g->H * g->W;
+    const bool wide = (g->Cin % 256 == 0) && (g->Cout % 256 == 0);
+    const int T = wide ? 256 : 128;
+    const int nslice = g->nphase * g->ntaps;
+    const int tiles = nslice * (g->Cin / T) * (g->Cout / T);
+    const int nchunks = (int)(M / 32);
+    int splits = (504 + tiles - 1) / tiles;
+    if (splits > nchunks) splits = nchunks;
+    if (splits < 1) splits = 1;
+    WrwArgs a;
+    a.xhi = (const _Float16*)xhi; a.xlo = (const _Float16*)xlo; a.ghi = (const _Float16*)ghi; a.glo = (const _Float16*)glo;
+    a.zero = (const _Float16*)zero_line; a.partial = (float*)ws;
+    a.N = g->N; a.H = g->H; a.W = g->W; a.Hin = g->Hin; a.Win = g->Win; a.Cin = g->Cin; a.Hout = g->Hout; a.Wout = g->Wout;
+    a.Cout = g->Cout; a.in_stride = g->in_stride; a.out_stride = g->out_stride; a.ntaps = g->ntaps; a.nphase = g->nphase;
+    magic_u31((unsigned)(g->H * g->W), &a.magHW, &a.shHW);
+    magic_u31((unsigned)g->W, &a.magW, &a.shW);
+    a.nchunks = nchunks; a.cps = (nchunks + splits - 1) / splits;
+    splits = (nchunks + a.cps - 1) / a.cps;         // no empty ranges
+    WrwReduceArgs r;
+    for (int p = 0; p < kMaxPhase; ++p) {
+        a.offy[p] = g->off_y[p]; a.offx[p] = g->off_x[p];
+        for (int t = 0; t < kMaxTaps; ++t) {
+            a.dy[p][t] = g->dy[p][t]; a.dx[p][t] = g->dx[p][t];
+            if (p < g->nphase && t < g->ntaps) { r.r[p * g->ntaps + t] = g->wr[p][t]; r.s[p * g->ntaps + t] = g->ws[p][t]; }
+        }
+    }
+    dim3 grid((unsigned)splits, (unsigned)tiles);
+    hipError_t e = hipSuccess;
+    if (wide) {
+        constexpr int LDS = 2 * (2 * 4 * 4 * 1024 + 2 * 4 * 4 * 1024);
+        static bool set = false;
+        if (!set) { e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wrw_kernel<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); if (e != hipSuccess) return (int)e; set = true; }
+        hipLaunchKernelGGL((conv_wrw_kernel<4, 4>), grid, dim3(256), LDS, st, a);
+    } else {
+        constexpr int LDS = 2 * (2 * 2 * 4 * 1024 + 2 * 2 * 4 * 1024);
+        static bool set = false;
+        if (!set) { e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wrw_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); if (e != hipSuccess) return (int)e; set = true; }
+        hipLaunchKernelGGL((conv_wrw_kernel<2, 2>), grid, dim3(256), LDS, st, a);
+    }
+    r.partial = (const float*)ws; r.splits = splits; r.nslice = nslice; r.Cin = g->Cin; r.Cout = g->Cout;
+    r.xscale = xscale; r.gscale = gscale; r.dw = dw; r.sk = stride_k; r.sn = stride_n; r.sr = stride_r; r.ss = stride_s;
+    hipLaunchKernelGGL(conv_wrw_reduce_kernel, dim3(grid_for((int64_t)nslice * g->Cin * g->Cout)), dim3(256), 0, st, r);
+    return (int)hipGetLastError();
 }
 
 }  // extern "C"
