@@ -62,9 +62,13 @@ def case(N, H, W, Ci, Co, kind, k=3, bench=True):
         xn, gn = xd.permute(0, 3, 1, 2), gy.permute(0, 3, 1, 2)
         stride = [1, 1] if kind == 'same' else [2, 2]; pad = [w.shape[2] // 2] * 2 if kind == 'same' else [1, 1]
         t_mb = timeit(lambda: torch.ops.aten.convolution_backward(gn, xn, wd, None, stride, pad, [1, 1], kind == 'up', [0, 0], 1, [True, False, False]))
+        xpl = C.split_planes(xd)
+        kf_, nf_ = kf, nf
+        t_wk = timeit(lambda: C.weight_gradient(xpl, gpl, gf, wd, kf_, nf_))
+        t_mw = timeit(lambda: torch.ops.aten.convolution_backward(gn, xn, wd, None, stride, pad, [1, 1], kind == 'up', [0, 0], 1, [False, True, False]))
         flop = 2.0 * gf.N * gf.H * gf.W * gf.nphase * gf.ntaps * gf.Cin * gf.Cout
         msg += (f"\n      fwd {t_kernel:7.1f} us ({flop / t_kernel / 1e6:5.0f} TF) + split {t_split:5.1f} + image {t_img:5.1f} | miopen {t_mi:7.1f} us ({flop / t_mi / 1e6:4.0f} TF)"
-                f" | bwd-data {t_bk:7.1f} us vs miopen {t_mb:7.1f}")
+                f" | bwd-data {t_bk:7.1f} us vs miopen {t_mb:7.1f} | wrw {t_wk:7.1f} vs miopen {t_mw:7.1f}")
     print(msg, flush=True)
 
 

@@ -21,6 +21,7 @@
 // MFMA-bound by design: 3 * 2*M*Cout*K flop on the fp16 pipe against 2*M*Cout*K on the fp32 pipe (157 TFLOP/s peak).
 #include "wc_common.h"
 #include "../../include/wc_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -231,12 +232,30 @@ struct WeightArgs {
     const float* w; int64_t sk, sn, sr, ss;        // element (k, n, r, s) of the source = w[k*sk + n*sn + r*sr + s*ss]
     const float* amax; float* scale_out; char* img;
     int K, Nn, ntaps, nphase;                      // K = reduction channels, Nn = output channels of the product
+    int64_t n4;                                    // amax == nullptr: float4s of the whole tensor
     signed char r[kMaxPhase][kMaxTaps], s[kMaxPhase][kMaxTaps];
 };
 
 __global__ __launch_bounds__(256) void conv_weights_kernel(WeightArgs a)
 {
-    const float sc = scale_of(a.amax);
+    float sc;
+    if (a.amax) sc = scale_of(a.amax);
+    else {
+        // small tensors: every workgroup takes the maximum of the whole (L2-resident) tensor itself -- no separate pass
+        __shared__ float red[4];
+        float m = 0.f;
+        for (int64_t i = threadIdx.x; i < a.n4; i += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(a.w + 4 * i);
+            m = fmaxf(fmaxf(m, fabsf(v[0])), fmaxf(fabsf(v[1]), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        }
+        #pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        sc = 1.0f;
+        if (m > 0.f && m < 3.0e38f) { int e; (void)frexpf(m, &e); sc = ldexpf(1.0f, 14 - e); }
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) a.scale_out[0] = sc;
     const int nchunk = a.K >> 5, nblk = a.Nn >> 5;
     const int64_t groups = (int64_t)a.nphase * a.ntaps * nchunk * nblk * 2 * 64;       // one (hi, lo) pair of 16-B lane chunks each
@@ -270,14 +289,19 @@ __global__ __launch_bounds__(256) void conv_weights_kernel(WeightArgs a)
 // banks once).  A workgroup owns one (slice, 64 MB input channels, 64 NB output channels) tile and a range of 32-point
 // chunks of the grid; the per-range partial sums go to a workspace and conv_wrw_reduce_kernel adds them in a fixed order
 // (deterministic) and writes dW in the weight's own layout.
+struct WrwOperand {                                 // one side of the product: split planes [N][Hp][Wp][C], pixel = grid * stride + offset
+    const _Float16* hi; const _Float16* lo;
+    int Hp, Wp, C, stride;
+    signed char dy[kMaxPhase][kMaxTaps], dx[kMaxPhase][kMaxTaps];
+};
+
 struct WrwArgs {
-    const _Float16* xhi; const _Float16* xlo; const _Float16* ghi; const _Float16* glo; const _Float16* zero;
-    float* partial;                                 // [splits][slices][Cin][Cout]
-    int N, H, W, Hin, Win, Cin, Hout, Wout, Cout, in_stride, out_stride, ntaps, nphase;
+    WrwOperand A, B;                                // rows / columns of the result tile
+    const _Float16* zero;
+    float* partial;                                 // [splits][slices][A.C][B.C]
+    int N, H, W, ntaps, nphase;
     unsigned magHW, shHW, magW, shW;                // m / (H*W) and rem / W by multiply-shift (m < 2^31)
     int nchunks, cps;                               // 32-point chunks in the grid, chunks per split
-    signed char dy[kMaxPhase][kMaxTaps], dx[kMaxPhase][kMaxTaps];
-    signed char offy[kMaxPhase], offx[kMaxPhase];
 };
 
 typedef short s16x4v __attribute__((__vector_size__(4 * sizeof(short))));
@@ -305,13 +329,13 @@ __global__ __launch_bounds__(256) void conv_wrw_kernel(WrwArgs a)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int nta = a.Cin / TA, ntb = a.Cout / TB;
+    const int nta = a.A.C / TA, ntb = a.B.C / TB;
     int idx = blockIdx.y;
     const int tb = idx % ntb; idx /= ntb;
     const int ta = idx % nta; idx /= nta;
     const int tap = idx % a.ntaps, phase = idx / a.ntaps;
     const int c0 = blockIdx.x * a.cps, c1 = min(c0 + a.cps, a.nchunks);
-    const int dy = a.dy[phase][tap], dx = a.dx[phase][tap], oy0 = a.offy[phase], ox0 = a.offx[phase];
+    const int dya = a.A.dy[phase][tap], dxa = a.A.dx[phase][tap], dyb = a.B.dy[phase][tap], dxb = a.B.dx[phase][tap];
     const unsigned HW = a.H * a.W;
     const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
     const int c8 = (lane & 3) * 8;                  // this lane's 8 channels inside a 32-channel block
@@ -323,15 +347,17 @@ __global__ __launch_bounds__(256) void conv_wrw_kernel(WrwArgs a)
             const unsigned m = c * 32 + s * 16 + (lane >> 2);
             const unsigned n = __umulhi(m, a.magHW) >> a.shHW, rem = m - n * HW;
             const unsigned yy = __umulhi(rem, a.magW) >> a.shW, xx = rem - yy * a.W;
-            const int iy = yy * a.in_stride + dy, ix = xx * a.in_stride + dx;
-            const bool ok = (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
-            const int64_t ea = ((int64_t)((n * a.Hin + iy) * a.Win + ix)) * a.Cin + ta * TA + c8;
-            const int64_t eb = ((int64_t)((n * a.Hout + yy * a.out_stride + oy0) * a.Wout + xx * a.out_stride + ox0)) * a.Cout + tb * TB + c8;
+            const int ay = yy * a.A.stride + dya, ax = xx * a.A.stride + dxa;
+            const int by = yy * a.B.stride + dyb, bx = xx * a.B.stride + dxb;
+            const bool oka = (unsigned)ay < (unsigned)a.A.Hp && (unsigned)ax < (unsigned)a.A.Wp;
+            const bool okb = (unsigned)by < (unsigned)a.B.Hp && (unsigned)bx < (unsigned)a.B.Wp;
+            const int64_t ea = ((int64_t)((n * a.A.Hp + ay) * a.A.Wp + ax)) * a.A.C + ta * TA + c8;
+            const int64_t eb = ((int64_t)((n * a.B.Hp + by) * a.B.Wp + bx)) * a.B.C + tb * TB + c8;
             #pragma unroll
             for (int q = 0; q < AQ; ++q) {
                 const int b = wave * AQ + q;
-                const _Float16* ph = ok ? a.xhi + ea + b * 32 : a.zero + c8;
-                const _Float16* pl = ok ? a.xlo + ea + b * 32 : a.zero + c8;
+                const _Float16* ph = oka ? a.A.hi + ea + b * 32 : a.zero + c8;
+                const _Float16* pl = oka ? a.A.lo + ea + b * 32 : a.zero + c8;
                 const unsigned l = sbase + ((b * 2 + s) * 2) * 1024;
                 lds_dma16(ph, l);
                 lds_dma16(pl, l + 1024);
@@ -339,9 +365,11 @@ __global__ __launch_bounds__(256) void conv_wrw_kernel(WrwArgs a)
             #pragma unroll
             for (int q = 0; q < BQ; ++q) {
                 const int b = wave * BQ + q;
+                const _Float16* ph = okb ? a.B.hi + eb + b * 32 : a.zero + c8;
+                const _Float16* pl = okb ? a.B.lo + eb + b * 32 : a.zero + c8;
                 const unsigned l = sbase + A_BYTES + ((b * 2 + s) * 2) * 1024;
-                lds_dma16(a.ghi + eb + b * 32, l);
-                lds_dma16(a.glo + eb + b * 32, l + 1024);
+                lds_dma16(ph, l);
+                lds_dma16(pl, l + 1024);
             }
         }
     };
@@ -396,35 +424,39 @@ __global__ __launch_bounds__(256) void conv_wrw_kernel(WrwArgs a)
     }
 
     const int slice = phase * a.ntaps + tap, nslice = a.nphase * a.ntaps;
-    float* out = a.partial + ((int64_t)blockIdx.x * nslice + slice) * a.Cin * a.Cout;
+    float* out = a.partial + ((int64_t)blockIdx.x * nslice + slice) * a.A.C * a.B.C;
     #pragma unroll
     for (int i = 0; i < MB; ++i)
         #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ci = ta * TA + (wm * MB + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            float* o = out + (int64_t)ci * a.Cout + tb * TB + wn * NB * 32 + (lane & 31);
+            float* o = out + (int64_t)ci * a.B.C + tb * TB + wn * NB * 32 + (lane & 31);
             #pragma unroll
             for (int j = 0; j < NB; ++j) o[j * 32] = acc[i][j][r];
         }
 }
 
 struct WrwReduceArgs {
-    const float* partial; int splits, nslice, Cin, Cout;
+    const float* partial; int splits, nslice, Ca, Cb;    // partial [splits][slices][Ca][Cb]
     const float* xscale; const float* gscale;
-    float* dw; int64_t sk, sn, sr, ss;
+    float* dw; int64_t sa, sb, sr, ss;                   // element (a, b, r, s) -> dw[a*sa + b*sb + r*sr + s*ss]
     signed char r[kMaxPhase * kMaxTaps], s[kMaxPhase * kMaxTaps];
 };
 
 __global__ __launch_bounds__(256) void conv_wrw_reduce_kernel(WrwReduceArgs a)
 {
-    const int64_t per = (int64_t)a.nslice * a.Cin * a.Cout;
+    const int64_t per = (int64_t)a.nslice * a.Ca * a.Cb, per4 = per >> 2;
     const float inv = 1.0f / (a.xscale[0] * a.gscale[0]);
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < per; e += (int64_t)gridDim.x * 256) {
-        float v = 0.f;
-        for (int sp = 0; sp < a.splits; ++sp) v += a.partial[sp * per + e];
-        const int co = e % a.Cout; int64_t t = e / a.Cout;
-        const int ci = t % a.Cin; const int sl = t / a.Cin;
-        a.dw[ci * a.sk + co * a.sn + a.r[sl] * a.sr + a.s[sl] * a.ss] = v * inv;
+    for (int64_t e4 = (int64_t)blockIdx.x * 256 + threadIdx.x; e4 < per4; e4 += (int64_t)gridDim.x * 256) {
+        const int64_t e = e4 * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int sp = 0; sp < a.splits; ++sp) v += *reinterpret_cast<const f32x4*>(a.partial + sp * per + e);
+        v = v * inv;
+        const int cb = e % a.Cb; int64_t t = e / a.Cb;
+        const int ca = t % a.Ca; const int sl = t / a.Ca;
+        float* o = a.dw + ca * a.sa + cb * a.sb + a.r[sl] * a.sr + a.s[sl] * a.ss;
+        if (a.sb == 1 && ((uintptr_t)o & 15) == 0) *reinterpret_cast<f32x4*>(o) = v;
+        else { o[0] = v[0]; o[a.sb] = v[1]; o[2 * a.sb] = v[2]; o[3 * a.sb] = v[3]; }
     }
 }
 
@@ -488,10 +520,12 @@ int wc_conv_weights_f32(const float* w, int64_t stride_k, int64_t stride_n, int6
     if (!w || !g || !image || !scale || !amax_scratch || n_elems <= 0) return WC_ERR_ARG;
     if (g->ntaps < 1 || g->ntaps > kMaxTaps || g->nphase < 1 || g->nphase > kMaxPhase || (g->Cin & 31) || (g->Cout & 31)) return WC_ERR_ARG;
     // the scale comes from the whole source tensor (n_elems covers its storage extent)
-    hipLaunchKernelGGL(conv_absmax_kernel, dim3(kAmaxBlocks), dim3(256), 0, st, w, n_elems / 4, n_elems, (float*)amax_scratch);
+    const bool inline_max = n_elems <= 32768 && (n_elems & 3) == 0 && ((uintptr_t)w & 15) == 0;   // (a 128 x 128 x 1 x 1 shortcut)
+    if (!inline_max) hipLaunchKernelGGL(conv_absmax_kernel, dim3(kAmaxBlocks), dim3(256), 0, st, w, n_elems / 4, n_elems, (float*)amax_scratch);
     WeightArgs a;
+    a.n4 = n_elems / 4;
     a.w = w; a.sk = stride_k; a.sn = stride_n; a.sr = stride_r; a.ss = stride_s;
-    a.amax = (const float*)amax_scratch; a.scale_out = scale; a.img = (char*)image;
+    a.amax = inline_max ? nullptr : (const float*)amax_scratch; a.scale_out = scale; a.img = (char*)image;
     a.K = g->Cin; a.Nn = g->Cout; a.ntaps = g->ntaps; a.nphase = g->nphase;
     for (int p = 0; p < kMaxPhase; ++p)
         for (int t = 0; t < kMaxTaps; ++t) { a.r[p][t] = g->wr[p][t]; a.s[p][t] = g->ws[p][t]; }
@@ -537,16 +571,29 @@ int wc_conv_f16x3(const void* xhi, const void* xlo, const float* xscale, const v
     return (int)e;
 }
 
+static int wrw_splits(const wc_conv_geom* g, int* tile)
+{
+    // 256 x 256 tiles when there are enough of them (a 1x1 convolution has one slice: 128 x 128 tiles then)
+    const bool wide = (g->Cin % 256 == 0) && (g->Cout % 256 == 0) && g->nphase * g->ntaps * (g->Cin / 256) * (g->Cout / 256) >= 4;
+    *tile = wide ? 256 : 128;
+    const int tiles = g->nphase * g->ntaps * (g->Cin / *tile) * (g->Cout / *tile);
+    const int64_t nchunks = (int64_t)g->N * g->H * g->W / 32;
+    // The workgroups of one pixel range (one per slice and tile) read the same activations: a split count that is a
+    // multiple of 8 puts them on one XCD (workgroup id mod 8), i.e. behind one L2 -- measured 650 against 790 us at
+    // 128 x 32 x 32 x 256 x 256 for 56 against 28 ranges.  About two workgroups per CU in all.
+    static const int target = getenv("WC_WRW_TARGET") ? atoi(getenv("WC_WRW_TARGET")) : 512;      // development knob
+    int splits = target / tiles / 8 * 8;
+    if (splits < 8) splits = 8;
+    if (splits > 64) splits = 64;                   // (the partial sums are splits x the weight size)
+    if (splits > nchunks) splits = (int)nchunks;
+    return splits < 1 ? 1 : splits;
+}
+
 size_t wc_conv_wrw_workspace_bytes(const wc_conv_geom* g)
 {
     if (!g) return 0;
-    const int64_t M = (int64_t)g->N * g->H * g->W;
-    const int tiles = g->nphase * g->ntaps * ((g->Cin % 256 == 0 && g->Cout % 256 == 0) ? (g->Cin / 256) * (g->Cout / 256) : (g->Cin / 128) * (g->Cout / 128));
-    int splits = (int)((504 + tiles - 1) / tiles);
-    const int64_t nchunks = M / 32;
-    if (splits > nchunks) splits = (int)nchunks;
-    if (splits < 1) splits = 1;
-    return (size_t)splits * g->nphase * g->ntaps * g->Cin * g->Cout * 4;
+    int tile;
+    return (size_t)wrw_splits(g, &tile) * g->nphase * g->ntaps * g->Cin * g->Cout * 4;
 }
 
 int wc_conv_wrw_f16x3(const void* xhi, const void* xlo, const float* xscale, const void* ghi, const void* glo, const float* gscale,
@@ -557,35 +604,36 @@ int wc_conv_wrw_f16x3(const void* xhi, const void* xlo, const float* xscale, con
     if (!xhi || !xlo || !xscale || !ghi || !glo || !gscale || !zero_line || !g || !dw || !ws) return WC_ERR_NULL;
     if (!wc_conv_supported(g) || (g->Cin & 127) || g->W < 2 || g->H * g->W < 2) return WC_ERR_SHAPE;
     if (ws_bytes < wc_conv_wrw_workspace_bytes(g)) return WC_ERR_WORKSPACE;
+    int T;
+    int splits = wrw_splits(g, &T);
     const int64_t M = (int64_t)g->N * g->H * g->W;
-    const bool wide = (g->Cin % 256 == 0) && (g->Cout % 256 == 0);
-    const int T = wide ? 256 : 128;
     const int nslice = g->nphase * g->ntaps;
     const int tiles = nslice * (g->Cin / T) * (g->Cout / T);
     const int nchunks = (int)(M / 32);
-    int splits = (504 + tiles - 1) / tiles;
-    if (splits > nchunks) splits = nchunks;
-    if (splits < 1) splits = 1;
+    WrwOperand X, G;
+    X.hi = (const _Float16*)xhi; X.lo = (const _Float16*)xlo; X.Hp = g->Hin; X.Wp = g->Win; X.C = g->Cin; X.stride = g->in_stride;
+    G.hi = (const _Float16*)ghi; G.lo = (const _Float16*)glo; G.Hp = g->Hout; G.Wp = g->Wout; G.C = g->Cout; G.stride = g->out_stride;
+    WrwReduceArgs r;
+    for (int p = 0; p < kMaxPhase; ++p)
+        for (int t = 0; t < kMaxTaps; ++t) {
+            X.dy[p][t] = g->dy[p][t]; X.dx[p][t] = g->dx[p][t];
+            G.dy[p][t] = g->off_y[p]; G.dx[p][t] = g->off_x[p];
+            if (p < g->nphase && t < g->ntaps) { r.r[p * g->ntaps + t] = g->wr[p][t]; r.s[p * g->ntaps + t] = g->ws[p][t]; }
+        }
+    // the lanes of a result tile run along its columns: put the weight's contiguous channel axis there
+    static const bool noswap = getenv("WC_WRW_NOSWAP") != nullptr;                              // development knob
+    const bool x_cols = stride_k == 1 && !noswap;
     WrwArgs a;
-    a.xhi = (const _Float16*)xhi; a.xlo = (const _Float16*)xlo; a.ghi = (const _Float16*)ghi; a.glo = (const _Float16*)glo;
+    a.A = x_cols ? G : X; a.B = x_cols ? X : G;
     a.zero = (const _Float16*)zero_line; a.partial = (float*)ws;
-    a.N = g->N; a.H = g->H; a.W = g->W; a.Hin = g->Hin; a.Win = g->Win; a.Cin = g->Cin; a.Hout = g->Hout; a.Wout = g->Wout;
-    a.Cout = g->Cout; a.in_stride = g->in_stride; a.out_stride = g->out_stride; a.ntaps = g->ntaps; a.nphase = g->nphase;
+    a.N = g->N; a.H = g->H; a.W = g->W; a.ntaps = g->ntaps; a.nphase = g->nphase;
     magic_u31((unsigned)(g->H * g->W), &a.magHW, &a.shHW);
     magic_u31((unsigned)g->W, &a.magW, &a.shW);
     a.nchunks = nchunks; a.cps = (nchunks + splits - 1) / splits;
     splits = (nchunks + a.cps - 1) / a.cps;         // no empty ranges
-    WrwReduceArgs r;
-    for (int p = 0; p < kMaxPhase; ++p) {
-        a.offy[p] = g->off_y[p]; a.offx[p] = g->off_x[p];
-        for (int t = 0; t < kMaxTaps; ++t) {
-            a.dy[p][t] = g->dy[p][t]; a.dx[p][t] = g->dx[p][t];
-            if (p < g->nphase && t < g->ntaps) { r.r[p * g->ntaps + t] = g->wr[p][t]; r.s[p * g->ntaps + t] = g->ws[p][t]; }
-        }
-    }
     dim3 grid((unsigned)splits, (unsigned)tiles);
     hipError_t e = hipSuccess;
-    if (wide) {
+    if (T == 256) {
         constexpr int LDS = 2 * (2 * 4 * 4 * 1024 + 2 * 4 * 4 * 1024);
         static bool set = false;
         if (!set) { e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wrw_kernel<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); if (e != hipSuccess) return (int)e; set = true; }
@@ -596,9 +644,10 @@ int wc_conv_wrw_f16x3(const void* xhi, const void* xlo, const float* xscale, con
         if (!set) { e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wrw_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); if (e != hipSuccess) return (int)e; set = true; }
         hipLaunchKernelGGL((conv_wrw_kernel<2, 2>), grid, dim3(256), LDS, st, a);
     }
-    r.partial = (const float*)ws; r.splits = splits; r.nslice = nslice; r.Cin = g->Cin; r.Cout = g->Cout;
-    r.xscale = xscale; r.gscale = gscale; r.dw = dw; r.sk = stride_k; r.sn = stride_n; r.sr = stride_r; r.ss = stride_s;
-    hipLaunchKernelGGL(conv_wrw_reduce_kernel, dim3(grid_for((int64_t)nslice * g->Cin * g->Cout)), dim3(256), 0, st, r);
+    r.partial = (const float*)ws; r.splits = splits; r.nslice = nslice; r.Ca = a.A.C; r.Cb = a.B.C;
+    r.xscale = xscale; r.gscale = gscale; r.dw = dw;
+    r.sa = x_cols ? stride_n : stride_k; r.sb = x_cols ? stride_k : stride_n; r.sr = stride_r; r.ss = stride_s;
+    hipLaunchKernelGGL(conv_wrw_reduce_kernel, dim3(grid_for((int64_t)nslice * g->Cin * g->Cout / 4)), dim3(256), 0, st, r);
     return (int)hipGetLastError();
 }
 
