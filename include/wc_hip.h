@@ -234,9 +234,10 @@ int wc_conv_weights_f32(const float* w, int64_t stride_k, int64_t stride_n, int6
 
 /* y = conv(x, w) (+ bias[Cout]) (then max(., 0) when relu != 0) for the geometry; x as split planes, `zero_line` = 64
  * device bytes of zeros (the padding). */
+size_t wc_conv_workspace_bytes(const wc_conv_geom* g);     /* 0 unless the grid is small (the tap loop is then shared) */
 int wc_conv_f16x3(const void* xhi, const void* xlo, const float* xscale, const void* wimage, const float* wscale,
                   const float* bias, const void* zero_line, const wc_conv_geom* g, int relu, float* y,
-                  wc_stream_t stream);
+                  void* ws, size_t ws_bytes, wc_stream_t stream);
 
 /* Weight gradient of the same convolution: dW(k, n, r, s) = sum over the grid of x[input pixel][k] * gy[output pixel][n]
  * for the FORWARD geometry `g` (x and gy as split planes; Cin and Cout multiples of 128), written to

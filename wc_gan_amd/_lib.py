@@ -60,8 +60,9 @@ SIGNATURES = {
     "wc_conv_wrw_workspace_bytes": (c_size_t, [c_void_p]),
     "wc_conv_wrw_f16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_int64, c_int64, c_int64, c_int64, c_void_p, c_size_t, c_void_p]),
+    "wc_conv_workspace_bytes": (c_size_t, [c_void_p]),
     "wc_conv_f16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                              c_void_p, c_void_p]),
+                              c_void_p, c_void_p, c_size_t, c_void_p]),
 }
 
 

@@ -69,32 +69,53 @@ def _supported(g):
 
 
 def supported(x, w, kind):
-    """Does the kernel take this call?  (channels multiples of 32 / 128, N*H*W of the virtual grid a multiple of 128)"""
+    """Does the kernel take this call?  (channels multiples of 128, N*H*W of the virtual grid a multiple of 128)"""
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous() and w.dtype == torch.float32):
         return False
-    N, H, W, C = x.shape
-    if kind == 'same':
-        if w.shape[1] != C or w.shape[2] != w.shape[3] or w.shape[2] % 2 == 0 or w.shape[2] > 3:
-            return False
-        fwd, bwd = _dense_geom(N, H, W, C, w.shape[0], w.shape[2], 1), _dense_geom(N, H, W, w.shape[0], C, w.shape[2], 1)
-    elif kind == 'down':
-        if w.shape[1] != C or tuple(w.shape[2:]) != (4, 4) or H % 2 or W % 2:
-            return False
-        fwd, bwd = _dense_geom(N, H, W, C, w.shape[0], 4, 2), _phase_geom(N, H // 2, W // 2, w.shape[0], C)
-    elif kind == 'up':
-        if w.shape[0] != C or tuple(w.shape[2:]) != (4, 4):
-            return False
-        fwd, bwd = _phase_geom(N, H, W, C, w.shape[1]), _dense_geom(N, 2 * H, 2 * W, w.shape[1], C, 4, 2)
-    else:
-        raise ValueError(kind)
-    return _supported(fwd) and _supported(bwd)
+    p = _plan(kind, x, w)
+    return bool(p) and p.ok
+
+
+class _Plan:
+    """Everything about a call that depends on the shapes only, built once: the two geometries, the weight axes, the
+    support verdict and the workspace sizes (the per-call host work is what is left: a few allocations and launches)."""
+    __slots__ = ('ok', 'fwd', 'bwd', 'fwd_ws', 'bwd_ws', 'wrw_ws', 'fwd_ptr', 'bwd_ptr')
+
+    def __init__(self, kind, N, H, W, wshape):
+        class _W:                                   # shape-only stand-in for the weight
+            shape = wshape
+        lib = _lib.load()
+        (gf, kf, nf), (gb, kb, nb) = _geoms(kind, N, H, W, _W)
+        self.fwd, self.bwd = (gf, kf, nf), (gb, kb, nb)
+        self.fwd_ptr, self.bwd_ptr = ctypes.addressof(gf), ctypes.addressof(gb)
+        self.ok = bool(lib.wc_conv_supported(self.fwd_ptr)) and bool(lib.wc_conv_supported(self.bwd_ptr))
+        self.fwd_ws = lib.wc_conv_workspace_bytes(self.fwd_ptr) if self.ok else 0
+        self.bwd_ws = lib.wc_conv_workspace_bytes(self.bwd_ptr) if self.ok else 0
+        self.wrw_ws = lib.wc_conv_wrw_workspace_bytes(self.fwd_ptr) if self.ok else 0
+
+
+_plans = {}
+
+
+def _plan(kind, x, w):
+    key = (kind, tuple(x.shape), tuple(w.shape))
+    p = _plans.get(key)
+    if p is None:
+        N, H, W, C = x.shape
+        good = (kind == 'same' and w.shape[1] == C and w.shape[2] == w.shape[3] and w.shape[2] in (1, 3)) or \
+               (kind == 'down' and w.shape[1] == C and tuple(w.shape[2:]) == (4, 4) and H % 2 == 0 and W % 2 == 0) or \
+               (kind == 'up' and w.shape[0] == C and tuple(w.shape[2:]) == (4, 4))
+        if kind not in ('same', 'down', 'up'):
+            raise ValueError(kind)
+        p = _plans[key] = _Plan(kind, N, H, W, tuple(w.shape)) if good else False
+    return p
 
 
 def split_planes(x, relu=False):
     """fp32 tensor -> (hi, lo, scale): fp16 planes of s*x and the device scalar s"""
     lib = _lib.load()
-    hi = torch.empty(x.shape, dtype=torch.float16, device=x.device)
-    lo = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    both = torch.empty((2,) + tuple(x.shape), dtype=torch.float16, device=x.device)
+    hi, lo = both[0], both[1]
     scale = torch.empty(1 + 512, dtype=torch.float32, device=x.device)    # [scale | per-workgroup maxima scratch]
     _lib.check(lib.wc_conv_split_f32(_ptr(x), x.numel(), 1 if relu else 0, _ptr(hi), _ptr(lo), _ptr(scale),
                                      scale.data_ptr() + 4, _stream()), "wc_conv_split_f32")
@@ -133,14 +154,17 @@ def _cached_image(w, key, geom, k_axis, n_axis):
     return hit
 
 
-def run(planes, image, geom, bias=None, relu=False):
+def run(planes, image, geom, bias=None, relu=False, nbytes=None):
     hi, lo, xs = planes
     img, ws = image
     lib = _lib.load()
     y = torch.empty((geom.N, geom.Hout, geom.Wout, geom.Cout), dtype=torch.float32, device=hi.device)
+    if nbytes is None:
+        nbytes = lib.wc_conv_workspace_bytes(ctypes.addressof(geom))
+    work = torch.empty(nbytes, dtype=torch.uint8, device=hi.device) if nbytes else None
     _lib.check(lib.wc_conv_f16x3(_ptr(hi), _ptr(lo), _ptr(xs), _ptr(img), _ptr(ws), _ptr(bias) if bias is not None else None,
-                                 _ptr(_zero_line(hi.device)), ctypes.addressof(geom), 1 if relu else 0, _ptr(y), _stream()),
-               "wc_conv_f16x3")
+                                 _ptr(_zero_line(hi.device)), ctypes.addressof(geom), 1 if relu else 0, _ptr(y),
+                                 _ptr(work), nbytes, _stream()), "wc_conv_f16x3")
     return y
 
 
@@ -160,7 +184,7 @@ def _geoms(kind, N, H, W, w):
     return (_phase_geom(N, H, W, ci, co), 0, 1), (_dense_geom(N, 2 * H, 2 * W, co, ci, 4, 2), 1, 0)
 
 
-def weight_gradient(x_planes, g_planes, geom, w, k_axis, n_axis):
+def weight_gradient(x_planes, g_planes, geom, w, k_axis, n_axis, nbytes=None):
     """dW (in w's own layout) from the split planes of the layer input and of the output gradient; `geom` = the forward
     geometry."""
     lib = _lib.load()
@@ -169,7 +193,8 @@ def weight_gradient(x_planes, g_planes, geom, w, k_axis, n_axis):
     dw = torch.empty_like(w)
     if dw.stride() != w.stride():
         raise ValueError("weight must be dense")
-    nbytes = lib.wc_conv_wrw_workspace_bytes(ctypes.addressof(geom))
+    if nbytes is None:
+        nbytes = lib.wc_conv_wrw_workspace_bytes(ctypes.addressof(geom))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
     _lib.check(lib.wc_conv_wrw_f16x3(_ptr(xh), _ptr(xl), _ptr(xs), _ptr(gh), _ptr(gl), _ptr(gs), _ptr(_zero_line(w.device)),
                                      ctypes.addressof(geom), _ptr(dw), w.stride(k_axis), w.stride(n_axis), w.stride(2),
@@ -179,34 +204,40 @@ def weight_gradient(x_planes, g_planes, geom, w, k_axis, n_axis):
 
 class _FastConv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, kind):
-        N, H, W, _ = x.shape
-        (gf, kf, nf), _ = _geoms(kind, N, H, W, w)
+    def forward(ctx, x, w, bias, kind, plan):
+        gf, kf, nf = plan.fwd
         planes = split_planes(x)
-        y = run(planes, _cached_image(w, (kind, 'fwd'), gf, kf, nf), gf, bias)
+        y = run(planes, _cached_image(w, (kind, 'fwd'), gf, kf, nf), gf, bias, nbytes=plan.fwd_ws)
         ctx.save_for_backward(w, *planes)           # the planes stand in for x (same bytes) in the weight gradient
-        ctx.kind, ctx.has_bias, ctx.xshape = kind, bias is not None, (N, H, W)
+        ctx.kind, ctx.has_bias, ctx.plan = kind, bias is not None, plan
         return y
 
     @staticmethod
     def backward(ctx, gy):
         w, xh, xl, xs = ctx.saved_tensors
-        kind = ctx.kind
-        N, H, W = ctx.xshape
+        kind, plan = ctx.kind, ctx.plan
         g_planes = split_planes(gy.contiguous())
-        (gf, kf, nf), (gb, kb, nb) = _geoms(kind, N, H, W, w)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = run(g_planes, _cached_image(w, (kind, 'bwd'), gb, kb, nb), gb)
+            gb, kb, nb = plan.bwd
+            dx = run(g_planes, _cached_image(w, (kind, 'bwd'), gb, kb, nb), gb, nbytes=plan.bwd_ws)
         if ctx.needs_input_grad[1]:
-            dw = weight_gradient((xh, xl, xs), g_planes, gf, w, kf, nf)
+            gf, kf, nf = plan.fwd
+            dw = weight_gradient((xh, xl, xs), g_planes, gf, w, kf, nf, nbytes=plan.wrw_ws)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = gy.sum((0, 1, 2))
-        return dx, dw, db, None
+        return dx, dw, db, None, None
+
+
+def fast_conv_or_none(x, w, bias=None, kind='same'):
+    """fast_conv when the kernel takes the call, else None (the caller's other path)."""
+    if not supported(x, w, kind):
+        return None
+    return _FastConv.apply(x, w, bias, kind, _plan(kind, x, w))
 
 
 def fast_conv(x, w, bias=None, kind='same'):
     """NHWC convolution (see the module docstring) -- raises if the shape is not one the kernel takes."""
     if not supported(x, w, kind):
         raise _lib.WcHipError(f"fast_conv: unsupported call {tuple(x.shape)} x {tuple(w.shape)} ({kind})")
-    return _FastConv.apply(x, w, bias, kind)
+    return _FastConv.apply(x, w, bias, kind, _plan(kind, x, w))

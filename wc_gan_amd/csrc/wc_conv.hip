@@ -23,6 +23,10 @@
 #include "../../include/wc_hip.h"
 #include <stdlib.h>
 
+#ifndef WC_CONV_PIPE
+#define WC_CONV_PIPE 1   // 0: the compiler-scheduled k-loop (development)
+#endif
+
 namespace {
 
 constexpr int kMaxTaps = 16, kMaxPhase = 4;
@@ -35,6 +39,7 @@ struct ConvArgs {
     const float* bias;                              // [Cout] or nullptr
     float* y;                                       // [N][Hout][Wout][Cout]
     int N, H, W, Hin, Win, Cin, Cout, in_stride, ntaps, nphase, Hout, Wout, out_stride, relu;
+    int ksplit; float* partial;                     // ksplit > 1: blockIdx.z takes a share of the (tap, chunk) loop, raw sums -> partial[z][output]
     signed char dy[kMaxPhase][kMaxTaps], dx[kMaxPhase][kMaxTaps];
     signed char offy[kMaxPhase], offx[kMaxPhase];
 };
@@ -46,7 +51,7 @@ __device__ __forceinline__ void lds_dma16(const void* g, unsigned lds)
                  : "=&s"(keep) : "v"(g), "s"(lds) : "memory");
 }
 
-template <int MB, int NB>
+template <int MB, int NB, bool KS>
 __global__ __launch_bounds__(256) void conv_f16x3_kernel(ConvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -112,12 +117,98 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(ConvArgs a)
             #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    issue(0, 0);
-    for (int it = 0; it < iters; ++it) {
-        const int stage = it & 1;
+    const int it0 = KS ? (int)blockIdx.z * iters / a.ksplit : 0, it1 = KS ? ((int)blockIdx.z + 1) * iters / a.ksplit : iters;
+#if WC_CONV_PIPE
+    // Hand-placed iteration: the fragments of k-step 0 right behind the barrier, then the MFMAs of both k-steps with the
+    // next iteration's DMAs (one every GAP MFMAs) and the fragment reads of k-step 1 in their shadow -- the wave issues
+    // in order, so whatever stands between the barrier and the first MFMA is time the MFMA pipe idles.
+    constexpr int NA = AQ * 4, ND = NA + 2 * NB, HALF = ND / 2, PER = 3 * MB * NB, GAP = PER / HALF;
+    static_assert(PER % HALF == 0, "DMAs spread evenly");
+    int tabv = 0;                                   // lane t: packed (dy, dx) of tap t of this phase
+    if (lane < a.ntaps) tabv = (a.dy[phase][lane] & 0xff) | ((a.dx[phase][lane] & 0xff) << 8);
+    const char* pa[AQ][2];                          // next iteration: hi / lo source of this lane's A rows (k-step 0)
+    int pstep[AQ];                                  // bytes to k-step 1 (0 on the zero line)
+    const char* pw;                                 // next iteration: this lane's first weight chunk
+    unsigned sb_next = 0;
+    auto prep = [&](int it, int stage) {
+        const int tap = it / nchunk, ch = it - tap * nchunk;
+        const int p = __builtin_amdgcn_readlane(tabv, tap);
+        const int dy = (signed char)(p & 0xff), dx = (signed char)((p >> 8) & 0xff);
+        #pragma unroll
+        for (int q = 0; q < AQ; ++q) {
+            const int iy = gy[q] + dy, ix = gx[q] + dx;
+            const bool ok = (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+            const int64_t e = ((int64_t)(gpix[q] + iy * a.Win + ix)) * a.Cin + ch * 32 + koff;
+            pa[q][0] = reinterpret_cast<const char*>(ok ? a.xhi + e : a.zero + koff);
+            pa[q][1] = reinterpret_cast<const char*>(ok ? a.xlo + e : a.zero + koff);
+            pstep[q] = ok ? 32 : 0;
+        }
+        pw = a.wimg + ((((int64_t)(phase * a.ntaps + tap) * nchunk + ch) * nblk_all + nt * 2 * NB) << 12) + wave * (2 * NB * 1024) + lane * 16;
+        sb_next = __builtin_amdgcn_readfirstlane(lds0 + stage * STAGE);
+    };
+    auto dma = [&](int d) {
+        if (d < NA) {
+            const int q = d >> 2, ks = (d >> 1) & 1, pl = d & 1;
+            lds_dma16(pa[q][pl] + ks * pstep[q], sb_next + (((wave * AQ + q) * 2 + ks) * 2 + pl) * 1024);
+        } else {
+            const int c = d - NA;
+            lds_dma16(pw + c * 1024, sb_next + A_BYTES + (wave * 2 * NB + c) * 1024);
+        }
+    };
+    f16x8 fa[2][MB][2], fb[2][NB][2];               // [k-step][block][hi | lo]
+    auto frags = [&](int stage, int ks) {
+        const char* sa = smem + stage * STAGE;
+        const char* sb = sa + A_BYTES;
+        #pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            const char* p = sa + (((wm * MB + i) * 2 + ks) * 2) * 1024 + lane * 16;
+            fa[ks][i][0] = *reinterpret_cast<const f16x8*>(p);
+            fa[ks][i][1] = *reinterpret_cast<const f16x8*>(p + 1024);
+        }
+        #pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const char* p = sb + (((wn * NB + j) * 2 + ks) * 2) * 1024 + lane * 16;
+            fb[ks][j][0] = *reinterpret_cast<const f16x8*>(p);
+            fb[ks][j][1] = *reinterpret_cast<const f16x8*>(p + 1024);
+        }
+    };
+    prep(it0, 0);
+    #pragma unroll
+    for (int d = 0; d < ND; ++d) dma(d);
+    for (int it = it0; it < it1; ++it) {
+        const int stage = (it - it0) & 1;
         __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): this wave's chunks of the stage have landed
         __syncthreads();                           // ... and everybody's; the other stage is free (its readers are done)
-        if (it + 1 < iters) issue(it + 1, stage ^ 1);
+        frags(stage, 0);
+        // the last iteration re-fetches its own data into the idle stage: no branch in the loop, nobody reads it
+        prep(it + 1 < it1 ? it + 1 : it, stage ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        #pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            #pragma unroll
+            for (int g = 0; g < PER; ++g) {
+                const int prod = g / (MB * NB), i = (g / NB) % MB, j = g % NB;
+                // lo*hi, hi*lo, hi*hi
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks][i][prod == 0 ? 1 : 0], fb[ks][j][prod == 1 ? 1 : 0], acc[i][j], 0, 0, 0);
+                if ((g + 1) % GAP == 0) {
+                    dma(ks * HALF + g / GAP);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (ks == 0 && g == PER / 2) {
+                    frags(stage, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);            // the idle stage's last DMAs
+#else
+    issue(it0, 0);
+    for (int it = it0; it < it1; ++it) {
+        const int stage = (it - it0) & 1;
+        __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): this wave's chunks of the stage have landed
+        __syncthreads();                           // ... and everybody's; the other stage is free (its readers are done)
+        if (it + 1 < it1) issue(it + 1, stage ^ 1);
         const char* sa = smem + stage * STAGE;
         const char* sb = sa + A_BYTES;
         #pragma unroll
@@ -150,6 +241,7 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(ConvArgs a)
         }
     }
 
+#endif
     // epilogue: unscale, bias, scatter rows to their output pixels
     const float inv = 1.0f / (a.xscale[0] * a.wscale[0]);
     const int oy0 = a.offy[phase], ox0 = a.offx[phase];
@@ -165,14 +257,37 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(ConvArgs a)
             const unsigned n = m / HW, rem = m - n * HW;
             const unsigned yy = rem / a.W, xx = rem - yy * a.W;
             const int64_t opix = ((int64_t)n * a.Hout + (yy * a.out_stride + oy0)) * a.Wout + (xx * a.out_stride + ox0);
-            float* o = a.y + opix * a.Cout + nt * TN + wn * NB * 32 + (lane & 31);
-            #pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                float v = acc[i][j][r] * inv + bj[j];
-                if (a.relu) v = fmaxf(v, 0.f);
-                o[j * 32] = v;
+            const int64_t oe = opix * a.Cout + nt * TN + wn * NB * 32 + (lane & 31);
+            if (KS) {                               // raw partial sums; conv_ksplit_reduce_kernel finishes
+                float* o = a.partial + (int64_t)blockIdx.z * ((int64_t)a.N * a.Hout * a.Wout * a.Cout) + oe;
+                #pragma unroll
+                for (int j = 0; j < NB; ++j) o[j * 32] = acc[i][j][r];
+            } else {
+                float* o = a.y + oe;
+                #pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    float v = acc[i][j][r] * inv + bj[j];
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    o[j * 32] = v;
+                }
             }
         }
+    }
+}
+
+// ---- small grids: the (tap, chunk) loop split over blockIdx.z; y = (sum of the partial sums) / (sx*sw) + bias ---------
+__global__ __launch_bounds__(256) void conv_ksplit_reduce_kernel(const float* __restrict__ partial, int ksplit, int64_t n4, int cout,
+                                                                 const float* __restrict__ xscale, const float* __restrict__ wscale,
+                                                                 const float* __restrict__ bias, int relu, float* __restrict__ y)
+{
+    const float inv = 1.0f / (xscale[0] * wscale[0]);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(partial + 4 * i);
+        for (int z = 1; z < ksplit; ++z) v += *reinterpret_cast<const f32x4*>(partial + 4 * (z * n4 + i));
+        v = v * inv;
+        if (bias) v += *reinterpret_cast<const f32x4*>(bias + (4 * i) % cout);
+        if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        *reinterpret_cast<f32x4*>(y + 4 * i) = v;
     }
 }
 
@@ -476,20 +591,20 @@ int grid_for(int64_t work_items)
     return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
 }
 
-template <int MB, int NB>
+template <int MB, int NB, bool KS = false>
 hipError_t launch_conv(const ConvArgs& a, hipStream_t st)
 {
     constexpr int LDS = 2 * (2 * MB * 4 * 1024 + 2 * NB * 4 * 1024);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_f16x3_kernel<MB, NB>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_f16x3_kernel<MB, NB, KS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const int64_t M = (int64_t)a.N * a.H * a.W;
-    dim3 grid((unsigned)(M / (64 * MB)), (unsigned)(a.nphase * (a.Cout / (64 * NB))));
-    hipLaunchKernelGGL((conv_f16x3_kernel<MB, NB>), grid, dim3(256), LDS, st, a);
+    dim3 grid((unsigned)(M / (64 * MB)), (unsigned)(a.nphase * (a.Cout / (64 * NB))), (unsigned)a.ksplit);
+    hipLaunchKernelGGL((conv_f16x3_kernel<MB, NB, KS>), grid, dim3(256), LDS, st, a);
     return hipGetLastError();
 }
 
@@ -545,8 +660,29 @@ int wc_conv_supported(const wc_conv_geom* g)
     return 1;
 }
 
+static int conv_ksplit(const wc_conv_geom* g)
+{
+    // small grids leave most CUs idle with 128-point x (128|256)-output tiles: share the (tap, chunk) loop
+    const int64_t M = (int64_t)g->N * g->H * g->W;
+    const bool wide = (g->Cout % 256) == 0;
+    const int64_t wgs = (M / 128) * g->nphase * (g->Cout / (wide ? 256 : 128));
+    const int iters = g->ntaps * (g->Cin / 32);
+    if (wgs > 96 || iters < 8) return 1;
+    int k = (int)((256 + wgs - 1) / wgs);
+    if (k > iters / 4) k = iters / 4;               // at least 4 iterations each
+    return k < 1 ? 1 : (k > 8 ? 8 : k);
+}
+
+size_t wc_conv_workspace_bytes(const wc_conv_geom* g)
+{
+    if (!g) return 0;
+    const int k = conv_ksplit(g);
+    return k > 1 ? (size_t)k * g->N * g->Hout * g->Wout * g->Cout * 4 : 0;
+}
+
 int wc_conv_f16x3(const void* xhi, const void* xlo, const float* xscale, const void* wimage, const float* wscale,
-                  const float* bias, const void* zero_line, const wc_conv_geom* g, int relu, float* y, wc_stream_t stream)
+                  const float* bias, const void* zero_line, const wc_conv_geom* g, int relu, float* y,
+                  void* ws, size_t ws_bytes, wc_stream_t stream)
 {
     hipStream_t st = (hipStream_t)stream;
     if (!xhi || !xlo || !xscale || !wimage || !wscale || !zero_line || !g || !y) return WC_ERR_ARG;
@@ -557,6 +693,8 @@ int wc_conv_f16x3(const void* xhi, const void* xlo, const float* xscale, const v
     a.N = g->N; a.H = g->H; a.W = g->W; a.Hin = g->Hin; a.Win = g->Win; a.Cin = g->Cin; a.Cout = g->Cout;
     a.in_stride = g->in_stride; a.ntaps = g->ntaps; a.nphase = g->nphase; a.Hout = g->Hout; a.Wout = g->Wout;
     a.out_stride = g->out_stride; a.relu = relu;
+    a.ksplit = conv_ksplit(g); a.partial = (float*)ws;
+    if (a.ksplit > 1 && (!ws || ws_bytes < wc_conv_workspace_bytes(g))) return WC_ERR_WORKSPACE;
     for (int p = 0; p < kMaxPhase; ++p) {
         a.offy[p] = g->off_y[p]; a.offx[p] = g->off_x[p];
         for (int t = 0; t < kMaxTaps; ++t) { a.dy[p][t] = g->dy[p][t]; a.dx[p][t] = g->dx[p][t]; }
@@ -566,9 +704,16 @@ int wc_conv_f16x3(const void* xhi, const void* xlo, const float* xscale, const v
     // the larger pixel tile when it still gives every CU a workgroup
     const int64_t wgs_big = (M / 256) * g->nphase * (g->Cout / (wide ? 256 : 128));
     hipError_t e;
-    if ((M % 256) == 0 && wgs_big >= 256) e = wide ? launch_conv<4, 4>(a, st) : launch_conv<4, 2>(a, st);
-    else                                  e = wide ? launch_conv<2, 4>(a, st) : launch_conv<2, 2>(a, st);
-    return (int)e;
+    if (a.ksplit == 1 && (M % 256) == 0 && wgs_big >= 256) e = wide ? launch_conv<4, 4>(a, st) : launch_conv<4, 2>(a, st);
+    else if (a.ksplit > 1)                                  e = wide ? launch_conv<2, 4, true>(a, st) : launch_conv<2, 2, true>(a, st);
+    else                                                    e = wide ? launch_conv<2, 4>(a, st) : launch_conv<2, 2>(a, st);
+    if (e != hipSuccess) return (int)e;
+    if (a.ksplit > 1) {
+        const int64_t n4 = (int64_t)g->N * g->Hout * g->Wout * g->Cout / 4;
+        hipLaunchKernelGGL(conv_ksplit_reduce_kernel, dim3(grid_for(n4)), dim3(256), 0, st, (const float*)ws, a.ksplit, n4, g->Cout,
+                           xscale, wscale, bias, relu, y);
+    }
+    return (int)hipGetLastError();
 }
 
 static int wrw_splits(const wc_conv_geom* g, int* tile)

@@ -108,9 +108,9 @@ class Conv2D(nn.Module):
                 and x.is_cuda and x.is_contiguous()):
             return _NarrowConv3x3.apply(x, c.weight, c.bias)
         if FAST_CONV and x.is_cuda:
-            w = self._weight()
-            if fast_conv_mod.supported(x, w, 'same'):       # split-fp16 MFMA implicit GEMM (csrc/wc_conv.hip)
-                return fast_conv_mod.fast_conv(x, w, c.bias, 'same')
+            y = fast_conv_mod.fast_conv_or_none(x, self._weight(), c.bias, 'same')      # split-fp16 MFMA implicit GEMM (csrc/wc_conv.hip)
+            if y is not None:
+                return y
         return to_nhwc(self.conv(to_nchw_view(x)))
 
     def forward_upsampled(self, x):
@@ -127,8 +127,10 @@ class Conv2D(nn.Module):
         rows = torch.stack([w[:, :, 2], w[:, :, 1] + w[:, :, 2], w[:, :, 0] + w[:, :, 1], w[:, :, 0]], dim=2)
         k = torch.stack([rows[..., 2], rows[..., 1] + rows[..., 2], rows[..., 0] + rows[..., 1], rows[..., 0]], dim=3)
         k = k.transpose(0, 1).contiguous(memory_format=torch.channels_last)             # (Cin, Cout, 4, 4)
-        if FAST_CONV and x.is_cuda and fast_conv_mod.supported(x, k, 'up'):
-            return fast_conv_mod.fast_conv(x, k, conv.bias, 'up')
+        if FAST_CONV and x.is_cuda:
+            y = fast_conv_mod.fast_conv_or_none(x, k, conv.bias, 'up')
+            if y is not None:
+                return y
         return to_nhwc(F.conv_transpose2d(to_nchw_view(x), k, conv.bias, stride=2, padding=1))
 
 
@@ -144,8 +146,9 @@ def _conv2d_forward_pooled(self, x):
     k = (F.pad(w, (0, 1, 0, 1)) + F.pad(w, (1, 0, 0, 1)) + F.pad(w, (0, 1, 1, 0)) + F.pad(w, (1, 0, 1, 0))) * 0.25
     if FAST_CONV and x.is_cuda:
         k = k.contiguous(memory_format=torch.channels_last)
-        if fast_conv_mod.supported(x, k, 'down'):
-            return fast_conv_mod.fast_conv(x, k, conv.bias, 'down')
+        y = fast_conv_mod.fast_conv_or_none(x, k, conv.bias, 'down')
+        if y is not None:
+            return y
     return to_nhwc(F.conv2d(to_nchw_view(x), k.contiguous(memory_format=torch.channels_last), conv.bias, stride=2, padding=1))
 
 
