@@ -135,8 +135,11 @@ def main():
     ap.add_argument("--sync-wc", action="store_true", help="all-reduce WC statistics across replicas")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true",
-                    help="replay the whole G+D step as one hipGraph (measured equal to eager launches, which is the default: "
-                         "~2000 launches per step, still GPU-bound; the eager step is reported next to it)")
+                    help="replay the whole G+D step as one hipGraph.  The default on one GPU: with ~2000 launches per step the "
+                         "eager loop is at the edge of host-bound (26-32 ms per step depending on the box's CPU, against "
+                         "26.5 ms of GPU work); the eager step is reported next to it")
+    ap.add_argument("--eager", action="store_true", help="launch kernel by kernel from Python (the default with several GPUs: "
+                    "capturing the RCCL all-reduces could not be tried on the one-GPU development box)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -171,7 +174,7 @@ def main():
         step()
     launch_mode = "eager"
     eager_step = step
-    if args.graph:
+    if args.graph or (world == 1 and not args.eager):
         try:
             step = trainer.capture(reals)        # the whole G+D step as one hipGraph: the host leaves the loop
             launch_mode = "hipgraph"

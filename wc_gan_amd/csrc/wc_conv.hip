@@ -500,6 +500,92 @@ __global__ __launch_bounds__(256) void conv_wrw_kernel(WrwArgs a)
     // transposing-read address of this lane inside a 1-KiB (16 pixels x 64 B) block
     const int tr_off = ((lane >> 5) * 8 + ((lane & 15) >> 2)) * 64 + (((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2;
 
+#if WC_CONV_PIPE
+    // the hand-placed iteration of conv_f16x3_kernel: fragments of k-step 0 behind the barrier, the next chunk's
+    // addresses and DMAs and the transposing reads of k-step 1 in the shadow of the MFMAs
+    constexpr int NA = AQ * 4, ND = NA + BQ * 4, HALF = ND / 2, PER = 3 * MB * NB, GAP = PER / HALF;
+    static_assert(PER % HALF == 0, "DMAs spread evenly");
+    const char* pA[2][2]; const char* pB[2][2];     // [k-step][hi | lo] sources of this lane's first block
+    int stA[2], stB[2];                             // bytes to the next 32-channel block (0 on the zero line)
+    unsigned sb_next = 0;
+    auto prep = [&](int c, int stage) {
+        #pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const unsigned m = c * 32 + s * 16 + (lane >> 2);
+            const unsigned n = __umulhi(m, a.magHW) >> a.shHW, rem = m - n * HW;
+            const unsigned yy = __umulhi(rem, a.magW) >> a.shW, xx = rem - yy * a.W;
+            const int ay = yy * a.A.stride + dya, ax = xx * a.A.stride + dxa;
+            const int by = yy * a.B.stride + dyb, bx = xx * a.B.stride + dxb;
+            const bool oka = (unsigned)ay < (unsigned)a.A.Hp && (unsigned)ax < (unsigned)a.A.Wp;
+            const bool okb = (unsigned)by < (unsigned)a.B.Hp && (unsigned)bx < (unsigned)a.B.Wp;
+            const int64_t ea = ((int64_t)((n * a.A.Hp + ay) * a.A.Wp + ax)) * a.A.C + ta * TA + wave * (AQ * 32) + c8;
+            const int64_t eb = ((int64_t)((n * a.B.Hp + by) * a.B.Wp + bx)) * a.B.C + tb * TB + wave * (BQ * 32) + c8;
+            pA[s][0] = reinterpret_cast<const char*>(oka ? a.A.hi + ea : a.zero + c8);
+            pA[s][1] = reinterpret_cast<const char*>(oka ? a.A.lo + ea : a.zero + c8);
+            pB[s][0] = reinterpret_cast<const char*>(okb ? a.B.hi + eb : a.zero + c8);
+            pB[s][1] = reinterpret_cast<const char*>(okb ? a.B.lo + eb : a.zero + c8);
+            stA[s] = oka ? 64 : 0; stB[s] = okb ? 64 : 0;
+        }
+        sb_next = __builtin_amdgcn_readfirstlane(lds0 + stage * STAGE);
+    };
+    auto dma = [&](int d) {
+        if (d < NA) {
+            const int s = d / (AQ * 2), q = (d >> 1) % AQ, pl = d & 1;
+            lds_dma16(pA[s][pl] + q * stA[s], sb_next + (((wave * AQ + q) * 2 + s) * 2 + pl) * 1024);
+        } else {
+            const int e = d - NA;
+            const int s = e / (BQ * 2), q = (e >> 1) % BQ, pl = e & 1;
+            lds_dma16(pB[s][pl] + q * stB[s], sb_next + A_BYTES + (((wave * BQ + q) * 2 + s) * 2 + pl) * 1024);
+        }
+    };
+    f16x8 fa[2][MB][2], fb[2][NB][2];               // [k-step][block][hi | lo]
+    auto frags = [&](int stage, int ks) {
+        const char* sa = smem + stage * STAGE;
+        const char* sb = sa + A_BYTES;
+        #pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            const char* p = sa + (((wm * MB + i) * 2 + ks) * 2) * 1024;
+            fa[ks][i][0] = tr_read8(p, tr_off);
+            fa[ks][i][1] = tr_read8(p + 1024, tr_off);
+        }
+        #pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const char* p = sb + (((wn * NB + j) * 2 + ks) * 2) * 1024;
+            fb[ks][j][0] = tr_read8(p, tr_off);
+            fb[ks][j][1] = tr_read8(p + 1024, tr_off);
+        }
+    };
+    if (c0 < c1) {
+        prep(c0, 0);
+        #pragma unroll
+        for (int d = 0; d < ND; ++d) dma(d);
+    }
+    for (int c = c0; c < c1; ++c) {
+        const int stage = (c - c0) & 1;
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+        frags(stage, 0);
+        prep(c + 1 < c1 ? c + 1 : c, stage ^ 1);    // the last chunk re-fetches itself into the idle stage: no branch
+        __builtin_amdgcn_sched_barrier(0);
+        #pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            #pragma unroll
+            for (int g = 0; g < PER; ++g) {
+                const int prod = g / (MB * NB), i = (g / NB) % MB, j = g % NB;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks][i][prod == 0 ? 1 : 0], fb[ks][j][prod == 1 ? 1 : 0], acc[i][j], 0, 0, 0);
+                if ((g + 1) % GAP == 0) {
+                    dma(ks * HALF + g / GAP);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (ks == 0 && g == PER / 2) {
+                    frags(stage, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+#else
     if (c0 < c1) issue(c0, 0);
     for (int c = c0; c < c1; ++c) {
         const int stage = (c - c0) & 1;
@@ -537,6 +623,8 @@ __global__ __launch_bounds__(256) void conv_wrw_kernel(WrwArgs a)
                 for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
+
+#endif
 
     const int slice = phase * a.ntaps + tap, nslice = a.nphase * a.ntaps;
     float* out = a.partial + ((int64_t)blockIdx.x * nslice + slice) * a.A.C * a.B.C;
