@@ -138,6 +138,9 @@ def main():
                     help="replay the whole G+D step as one hipGraph.  The default on one GPU: with ~2000 launches per step the "
                          "eager loop is at the edge of host-bound (26-32 ms per step depending on the box's CPU, against "
                          "26.5 ms of GPU work); the eager step is reported next to it")
+    ap.add_argument("--segments", action="store_true",
+                    help="replay the step as a chain of hipGraphs cut at the gradient all-reduces, which stay plain RCCL calls "
+                         "(the default with several GPUs, unless --sync-wc puts collectives inside the WC layers)")
     ap.add_argument("--eager", action="store_true", help="launch kernel by kernel from Python (the default with several GPUs: "
                     "capturing the RCCL all-reduces could not be tried on the one-GPU development box)")
     args = ap.parse_args()
@@ -174,7 +177,16 @@ def main():
         step()
     launch_mode = "eager"
     eager_step = step
-    if args.graph or (world == 1 and not args.eager):
+    if args.segments or (world > 1 and not args.eager and not args.graph and not args.sync_wc):
+        try:
+            step = trainer.capture_segments(reals)
+            launch_mode = "hipgraph-segments"
+            step()
+        except Exception as exc:
+            print(f"[bench] segment capture failed ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
+            torch.cuda.synchronize()
+            step = lambda: trainer.step(reals)
+    elif args.graph or (world == 1 and not args.eager):
         try:
             step = trainer.capture(reals)        # the whole G+D step as one hipGraph: the host leaves the loop
             launch_mode = "hipgraph"
@@ -214,7 +226,7 @@ def main():
         trainer.training_ratio = args.training_ratio
 
     dt_eager = None
-    if launch_mode == "hipgraph":                # the same step launched kernel by kernel, for the record
+    if launch_mode != "eager":                   # the same step launched kernel by kernel, for the record
         ne = max(3, args.steps // 2)
         eager_step(); barrier()
         te = time.perf_counter()

@@ -87,6 +87,16 @@ class GanTrainer:
         self._graph = None
         self._side = None
         self.overlap_g_forward = True
+        self._boundary = None            # set while capture_segments() records: called where a gradient all-reduce goes
+        self._side_pending = False
+
+    def _sync_grads(self, bucket):
+        """The gradient all-reduce of one network (a no-op for a single process) -- or, while capture_segments() records,
+        the end of one graph segment and the start of the next."""
+        if self._boundary is not None:
+            self._boundary(bucket)
+        else:
+            bucket.allreduce_mean()
 
     def _noise(self, n):
         z = torch.randn(n, self.noise_dim, device=self.dev)
@@ -120,7 +130,7 @@ class GanTrainer:
         out = self._d(torch.cat([real, fake], dim=0), both_cls)
         loss = F.relu(1.0 - out[:n]).mean() + F.relu(1.0 + out[n:]).mean()
         loss.backward()
-        self.d_bucket.allreduce_mean()
+        self._sync_grads(self.d_bucket)
         self.opt_d.step()
         return loss.detach()
 
@@ -137,7 +147,7 @@ class GanTrainer:
         loss.backward()
         for p in self.d_bucket.params:
             p.requires_grad_(True)
-        self.g_bucket.allreduce_mean()
+        self._sync_grads(self.g_bucket)
         self.opt_g.step()
         return loss.detach()
 
@@ -156,10 +166,12 @@ class GanTrainer:
             with torch.cuda.stream(self._side):
                 z, cls = self._noise(self.batch_size * self.gbm)
                 generated = (self.G(z, cls), cls)
+            self._side_pending = True
         for r in range(self.training_ratio):
             d_loss = self.d_step(real_batches[r % len(real_batches)], fake=fakes[r], cls=clss[r])
         if generated is not None:
             torch.cuda.current_stream().wait_stream(self._side)
+            self._side_pending = False
             generated[0].record_stream(torch.cuda.current_stream())
             generated[1].record_stream(torch.cuda.current_stream())
         g_loss = self.g_step(generated)
@@ -186,6 +198,60 @@ class GanTrainer:
         def replay():
             graph.replay()
             return self._static_losses
+        return replay
+
+
+    def capture_segments(self, real_batches, warmup=3):
+        """The step as a CHAIN of hipGraphs cut at the gradient all-reduces, which stay ordinary RCCL calls between the
+        replays: no collective is ever captured (that could not be tried on the one-GPU development box), yet the
+        ~2000 kernel launches of a step leave the host loop -- the eager loop is at the edge of host-bound.  Segments:
+        [generated batches + first critic pass] | [critic update + next pass] x (training_ratio - 1) |
+        [critic update + generator pass] | [generator update]; the generator forward of the update still forks onto the
+        second stream, but joins at the first cut (a captured graph must end with its branches joined).  The graphs share
+        one memory pool and are replayed in capture order; autograd state crosses the cuts as ordinary tensors of that
+        pool.  Returns a callable that replays the chain."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.step(real_batches)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        pool = torch.cuda.graph_pool_handle()
+        segments, cur = [], {}
+
+        def begin():
+            g = torch.cuda.CUDAGraph()
+            ctx = torch.cuda.graph(g, pool=pool)
+            ctx.__enter__()
+            cur['g'], cur['ctx'] = g, ctx
+
+        def end(bucket):
+            if self._side_pending:                   # join the forked generator forward before the graph ends
+                torch.cuda.current_stream().wait_stream(self._side)
+            cur['ctx'].__exit__(None, None, None)
+            segments.append((cur['g'], bucket))
+
+        def boundary(bucket):
+            end(bucket)
+            bucket.allreduce_mean()                  # (on buffers the recording never filled: only its place matters)
+            begin()
+
+        self._boundary = boundary
+        try:
+            begin()
+            losses = self.step(real_batches)
+            end(None)
+        finally:
+            self._boundary = None
+        self._segments = segments
+
+        def replay():
+            for g, bucket in segments:
+                g.replay()
+                if bucket is not None:
+                    bucket.allreduce_mean()
+            return losses
         return replay
 
 
