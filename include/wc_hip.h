@@ -197,7 +197,7 @@ int wc_spectral_norm_bwd_batched_f32(const wc_sn_bwd_item* items, int count, int
  * One geometry describes all of them as an implicit GEMM over a "virtual grid" (N, H, W): point (y, x) of phase p
  * reads input pixel (y*in_stride + dy[p][t], x*in_stride + dx[p][t]) for tap t (zero outside the Hin x Win plane) and
  * writes output pixel (y*out_stride + off_y[p], x*out_stride + off_x[p]) of the Hout x Wout plane; tap t of phase p
- * multiplies by the source weight slice (wr[p][t], ws[p][t]).  Tensors are NHWC fp32, dense.
+ * multiplies by a weight slice built from the source slices (wr, ws) below.  Tensors are NHWC fp32, dense.
  *   3x3 same:              H=Hin=Hout, strides 1, 9 taps dy=r-1;  1 phase
  *   4x4 stride-2 conv:     H=Hout=Hin/2, in_stride 2, 16 taps dy=r-1; 1 phase
  *   4x4 stride-2 transposed conv: H=Hin, out_stride 2, 4 phases (py,px) of 2x2 taps, r = py+1-2*dy
@@ -209,8 +209,13 @@ typedef struct {
     int in_stride, out_stride;
     int ntaps, nphase;              /* <= 16 taps, <= 4 phases */
     signed char dy[4][16], dx[4][16];
-    signed char wr[4][16], ws[4][16];
     signed char off_y[4], off_x[4];
+    /* the weight slice of tap t of phase p = wcoef * the sum of nsrc[p][t] (1..4) source slices (wr[p][t][m], ws[p][t][m]):
+     * one slice for a plain convolution; the 4x4 kernels of the pooled / upsampled 3x3 convolutions are sums of 3x3 taps
+     *  and are formed here, from the 3x3 weight -- and the weight gradient is folded back the same way */
+    signed char nsrc[4][16];
+    signed char wr[4][16][4], ws[4][16][4];
+    float wcoef;
 } wc_conv_geom;
 
 #define WC_CONV_SCRATCH_BYTES 2048

@@ -73,6 +73,31 @@ def test_forward_and_gradients_match_float64(kind, N, H, W, ci, co, k, taken):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind,N,H,ci,co", [('down3', 8, 16, 128, 128), ('down3', 32, 12, 128, 256), ('up3', 8, 8, 128, 128),
+                                            ('up3', 32, 4, 256, 256), ('up3', 128, 16, 256, 256)])
+def test_pooled_and_upsampled_3x3_layers_from_the_3x3_weight(kind, N, H, ci, co):
+    """Conv2D 3x3 -> AveragePooling2D and UpSampling2D -> Conv2D 3x3 (generator.py:144-151, discriminator.py:41-54) given
+    the 3x3 weight: the 4x4 stride-2 kernels are formed inside the weight image, the weight gradient is folded back."""
+    from wc_gan_amd import conv as C
+    torch.manual_seed(N + H)
+    x = (torch.randn(N, H, H, ci, device='cuda') * 1.3 - 0.2).requires_grad_(True)
+    w = _weights('same', ci, co, 3).requires_grad_(True)
+    b = (torch.randn(co, device='cuda') * 0.1).requires_grad_(True)
+    assert C.supported(x, w, kind)
+    y = C.fast_conv(x, w, b, kind)
+    xn = x.permute(0, 3, 1, 2).double()
+    if kind == 'down3':
+        y64 = F.avg_pool2d(F.conv2d(xn, w.double(), b.double(), padding=1), 2).permute(0, 2, 3, 1)
+    else:
+        y64 = F.conv2d(F.interpolate(xn, scale_factor=2, mode='nearest'), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
+    assert y.shape == y64.shape
+    gy = torch.randn_like(y)
+    dx, dw, db = torch.autograd.grad(y, (x, w, b), gy)
+    dx64, dw64, db64 = torch.autograd.grad(y64, (x, w, b), gy.double())
+    assert _rel(y, y64) < TOL and _rel(dx, dx64) < TOL and _rel(dw, dw64) < TOL and _rel(db, db64) < TOL
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("ci", [32, 96])
 def test_forward_with_reduction_channels_in_multiples_of_32(ci):
     """the kernel itself takes any multiple of 32 reduction channels (the layer entry also wants the data gradient)"""

@@ -82,8 +82,10 @@ class ConvGeom(ctypes.Structure):        # wc_conv_geom
                 ("Hout", c_int), ("Wout", c_int), ("Cout", c_int), ("in_stride", c_int), ("out_stride", c_int),
                 ("ntaps", c_int), ("nphase", c_int),
                 ("dy", (ctypes.c_byte * 16) * 4), ("dx", (ctypes.c_byte * 16) * 4),
-                ("wr", (ctypes.c_byte * 16) * 4), ("ws", (ctypes.c_byte * 16) * 4),
-                ("off_y", ctypes.c_byte * 4), ("off_x", ctypes.c_byte * 4)]
+                ("off_y", ctypes.c_byte * 4), ("off_x", ctypes.c_byte * 4),
+                ("nsrc", (ctypes.c_byte * 16) * 4),
+                ("wr", ((ctypes.c_byte * 4) * 16) * 4), ("ws", ((ctypes.c_byte * 4) * 16) * 4),
+                ("wcoef", c_float)]
 
 
 _lib = None

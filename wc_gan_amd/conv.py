@@ -5,6 +5,8 @@
     kind 'same'  Keras `Conv2D(k x k, padding='same')`, w (Cout, Cin, k, k)          generator.py:142-158
     kind 'down'  4x4 stride-2 padding-1 convolution, w (Cout, Cin, 4, 4)              (= Conv2D 3x3 -> AveragePooling2D, discriminator.py:41-54)
     kind 'up'    4x4 stride-2 padding-1 TRANSPOSED convolution, w (Cin, Cout, 4, 4)   (= UpSampling2D -> Conv2D 3x3, generator.py:144-151)
+    kind 'down3' / 'up3'  the same two layers given the 3x3 weight (Cout, Cin, 3, 3) itself: the 4x4 kernels are sums of 3x3
+                 taps, formed while the weight image is built and folded back in the weight gradient
 
 Forward and the data gradient run on the HIP kernel (the data gradient of 'same' is a 'same', of 'down' an 'up' and of
 'up' a 'down', with the channel roles swapped in the weight image), and so does the weight gradient (pixel-major tiles
@@ -29,7 +31,32 @@ def _zero_line(device):
     return z
 
 
-def _dense_geom(N, Hin, Win, Cin, Cout, k, stride):
+def _plain(r, s):
+    return [(r, s)], 1.0
+
+
+def _pooled3(r, s):
+    """4x4 stride-2 kernel of Conv2D 3x3 -> AveragePooling2D: tap (r, s) = 1/4 of the 3x3 taps (r - a, s - b), a, b in {0, 1}"""
+    return [(r - a, s - b) for a in (0, 1) for b in (0, 1) if 0 <= r - a <= 2 and 0 <= s - b <= 2], 0.25
+
+
+_UP_ROWS = ((2,), (1, 2), (0, 1), (0,))
+
+
+def _upsampled3(r, s):
+    """4x4 stride-2 transposed kernel of UpSampling2D -> Conv2D 3x3: rows [w2, w1 + w2, w0 + w1, w0] along each axis"""
+    return [(r3, s3) for r3 in _UP_ROWS[r] for s3 in _UP_ROWS[s]], 1.0
+
+
+def _set_sources(g, p, t, r, s, source):
+    taps, coef = source(r, s)
+    g.nsrc[p][t] = len(taps)
+    for m, (r3, s3) in enumerate(taps):
+        g.wr[p][t][m], g.ws[p][t][m] = r3, s3
+    g.wcoef = coef
+
+
+def _dense_geom(N, Hin, Win, Cin, Cout, k, stride, source=_plain):
     """taps (r, s) read input (y*stride + r - pad, x*stride + s - pad); pad = k//2 for 'same', 1 for the 4x4 stride-2 form"""
     pad = k // 2 if stride == 1 else 1
     g = _lib.ConvGeom()
@@ -40,11 +67,12 @@ def _dense_geom(N, Hin, Win, Cin, Cout, k, stride):
     for r in range(k):
         for s in range(k):
             t = r * k + s
-            g.dy[0][t], g.dx[0][t], g.wr[0][t], g.ws[0][t] = r - pad, s - pad, r, s
+            g.dy[0][t], g.dx[0][t] = r - pad, s - pad
+            _set_sources(g, 0, t, r, s, source)
     return g
 
 
-def _phase_geom(N, Hin, Win, Cin, Cout, flip=False):
+def _phase_geom(N, Hin, Win, Cin, Cout, source=_plain):
     """4x4 stride-2 padding-1 transposed convolution as four 2x2 sub-pixel convolutions: output (2y+py, 2x+px) reads
     input (y+dy, x+dx) through weight tap r = py + 1 - 2 dy"""
     g = _lib.ConvGeom()
@@ -59,7 +87,7 @@ def _phase_geom(N, Hin, Win, Cin, Cout, flip=False):
             for dy in ((-1, 0) if py == 0 else (0, 1)):
                 for dx in ((-1, 0) if px == 0 else (0, 1)):
                     g.dy[p][t], g.dx[p][t] = dy, dx
-                    g.wr[p][t], g.ws[p][t] = py + 1 - 2 * dy, px + 1 - 2 * dx
+                    _set_sources(g, p, t, py + 1 - 2 * dy, px + 1 - 2 * dx, source)
                     t += 1
     return g
 
@@ -104,8 +132,10 @@ def _plan(kind, x, w):
         N, H, W, C = x.shape
         good = (kind == 'same' and w.shape[1] == C and w.shape[2] == w.shape[3] and w.shape[2] in (1, 3)) or \
                (kind == 'down' and w.shape[1] == C and tuple(w.shape[2:]) == (4, 4) and H % 2 == 0 and W % 2 == 0) or \
+               (kind == 'down3' and w.shape[1] == C and tuple(w.shape[2:]) == (3, 3) and H % 2 == 0 and W % 2 == 0) or \
+               (kind == 'up3' and w.shape[1] == C and tuple(w.shape[2:]) == (3, 3)) or \
                (kind == 'up' and w.shape[0] == C and tuple(w.shape[2:]) == (4, 4))
-        if kind not in ('same', 'down', 'up'):
+        if kind not in ('same', 'down', 'up', 'down3', 'up3'):
             raise ValueError(kind)
         p = _plans[key] = _Plan(kind, N, H, W, tuple(w.shape)) if good else False
     return p
@@ -177,9 +207,13 @@ def _geoms(kind, N, H, W, w):
         for t in range(k * k):                       # dx[y] = sum_r g[y + pad - r] w[r]
             bwd.dy[0][t], bwd.dx[0][t] = -bwd.dy[0][t], -bwd.dx[0][t]
         return (fwd, 1, 0), (bwd, 0, 1)
-    if kind == 'down':
+    if kind in ('down', 'down3'):                    # 'down3': the 3x3 weight itself, the pooled 4x4 kernel is formed in the image
         co, ci = w.shape[0], w.shape[1]
-        return (_dense_geom(N, H, W, ci, co, 4, 2), 1, 0), (_phase_geom(N, H // 2, W // 2, co, ci), 0, 1)
+        src = _pooled3 if kind == 'down3' else _plain
+        return (_dense_geom(N, H, W, ci, co, 4, 2, src), 1, 0), (_phase_geom(N, H // 2, W // 2, co, ci, src), 0, 1)
+    if kind == 'up3':                                # the 3x3 weight (Cout, Cin, 3, 3) of UpSampling2D -> Conv2D
+        co, ci = w.shape[0], w.shape[1]
+        return (_phase_geom(N, H, W, ci, co, _upsampled3), 1, 0), (_dense_geom(N, 2 * H, 2 * W, co, ci, 4, 2, _upsampled3), 0, 1)
     ci, co = w.shape[0], w.shape[1]                  # 'up'
     return (_phase_geom(N, H, W, ci, co), 0, 1), (_dense_geom(N, 2 * H, 2 * W, co, ci, 4, 2), 1, 0)
 

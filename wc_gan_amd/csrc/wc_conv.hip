@@ -311,12 +311,13 @@ __global__ __launch_bounds__(256) void conv_absmax_kernel(const float* __restric
 }
 
 // power-of-two scale that puts max|x| into [2^13, 2^14); every thread of a workgroup folds the partials (L2 hits)
-__device__ __forceinline__ float scale_of(const float* __restrict__ partial)
+__device__ __forceinline__ float scale_of(const float* __restrict__ partial, float mul = 1.0f)
 {
     float amax = 0.f;
     for (int i = threadIdx.x & 63; i < kAmaxBlocks; i += 64) amax = fmaxf(amax, partial[i]);
     #pragma unroll
     for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    amax *= mul;
     if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.0f;
     int e;
     (void)frexpf(amax, &e);                        // amax = f * 2^e, f in [0.5, 1)
@@ -348,13 +349,15 @@ struct WeightArgs {
     const float* amax; float* scale_out; char* img;
     int K, Nn, ntaps, nphase;                      // K = reduction channels, Nn = output channels of the product
     int64_t n4;                                    // amax == nullptr: float4s of the whole tensor
-    signed char r[kMaxPhase][kMaxTaps], s[kMaxPhase][kMaxTaps];
+    float coef, bound_mul;                         // slice = coef * sum of its sources; max|slice| <= bound_mul * max|w|
+    signed char nsrc[kMaxPhase][kMaxTaps];
+    signed char r[kMaxPhase][kMaxTaps][4], s[kMaxPhase][kMaxTaps][4];
 };
 
 __global__ __launch_bounds__(256) void conv_weights_kernel(WeightArgs a)
 {
     float sc;
-    if (a.amax) sc = scale_of(a.amax);
+    if (a.amax) sc = scale_of(a.amax, a.bound_mul);
     else {
         // small tensors: every workgroup takes the maximum of the whole (L2-resident) tensor itself -- no separate pass
         __shared__ float red[4];
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(256) void conv_weights_kernel(WeightArgs a)
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
         __syncthreads();
-        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * a.bound_mul;
         sc = 1.0f;
         if (m > 0.f && m < 3.0e38f) { int e; (void)frexpf(m, &e); sc = ldexpf(1.0f, 14 - e); }
     }
@@ -383,11 +386,19 @@ __global__ __launch_bounds__(256) void conv_weights_kernel(WeightArgs a)
         const int tap = t % a.ntaps; const int ph = t / a.ntaps;
         const int n = nb * 32 + (lane & 31);
         const int k0 = ch * 32 + ks * 16 + (lane >> 5) * 8;
-        const float* src = a.w + n * a.sn + a.r[ph][tap] * a.sr + a.s[ph][tap] * a.ss;
+        const float* base = a.w + n * a.sn;
+        const int ns = a.nsrc[ph][tap];
+        float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < ns; ++m) {
+            const float* src = base + a.r[ph][tap][m] * a.sr + a.s[ph][tap][m] * a.ss;
+            #pragma unroll
+            for (int j = 0; j < 8; ++j) acc8[j] += src[(k0 + j) * a.sk];
+        }
+        const float cs = a.coef * sc;
         f16x8 h, l;
         #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float v = src[(k0 + j) * a.sk] * sc;
+            const float v = acc8[j] * cs;
             h[j] = (_Float16)v; l[j] = (_Float16)(v - (float)h[j]);
         }
         char* dst = a.img + (((((int64_t)(ph * a.ntaps + tap) * nchunk + ch) * nblk + nb) * 2 + ks) * 2) * 1024 + lane * 16;
@@ -643,23 +654,28 @@ struct WrwReduceArgs {
     const float* partial; int splits, nslice, Ca, Cb;    // partial [splits][slices][Ca][Cb]
     const float* xscale; const float* gscale;
     float* dw; int64_t sa, sb, sr, ss;                   // element (a, b, r, s) -> dw[a*sa + b*sb + r*sr + s*ss]
-    signed char r[kMaxPhase * kMaxTaps], s[kMaxPhase * kMaxTaps];
+    float coef;
+    int nout;                                            // source taps of the weight; each collects the slices built from it
+    signed char r[kMaxTaps], s[kMaxTaps], cnt[kMaxTaps], slice[kMaxTaps][4];
 };
 
 __global__ __launch_bounds__(256) void conv_wrw_reduce_kernel(WrwReduceArgs a)
 {
-    const int64_t per = (int64_t)a.nslice * a.Ca * a.Cb, per4 = per >> 2;
-    const float inv = 1.0f / (a.xscale[0] * a.gscale[0]);
-    for (int64_t e4 = (int64_t)blockIdx.x * 256 + threadIdx.x; e4 < per4; e4 += (int64_t)gridDim.x * 256) {
+    const int64_t plane = (int64_t)a.Ca * a.Cb, per = (int64_t)a.nslice * plane, total4 = (int64_t)a.nout * plane >> 2;
+    const float inv = a.coef / (a.xscale[0] * a.gscale[0]);
+    for (int64_t e4 = (int64_t)blockIdx.x * 256 + threadIdx.x; e4 < total4; e4 += (int64_t)gridDim.x * 256) {
         const int64_t e = e4 * 4;
+        const int o = e / plane; const int64_t w = e - o * plane;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        for (int sp = 0; sp < a.splits; ++sp) v += *reinterpret_cast<const f32x4*>(a.partial + sp * per + e);
+        for (int i = 0; i < a.cnt[o]; ++i) {
+            const float* src = a.partial + a.slice[o][i] * plane + w;
+            for (int sp = 0; sp < a.splits; ++sp) v += *reinterpret_cast<const f32x4*>(src + sp * per);
+        }
         v = v * inv;
-        const int cb = e % a.Cb; int64_t t = e / a.Cb;
-        const int ca = t % a.Ca; const int sl = t / a.Ca;
-        float* o = a.dw + ca * a.sa + cb * a.sb + a.r[sl] * a.sr + a.s[sl] * a.ss;
-        if (a.sb == 1 && ((uintptr_t)o & 15) == 0) *reinterpret_cast<f32x4*>(o) = v;
-        else { o[0] = v[0]; o[a.sb] = v[1]; o[2 * a.sb] = v[2]; o[3 * a.sb] = v[3]; }
+        const int cb = w % a.Cb, ca = w / a.Cb;
+        float* out = a.dw + ca * a.sa + cb * a.sb + a.r[o] * a.sr + a.s[o] * a.ss;
+        if (a.sb == 1 && ((uintptr_t)out & 15) == 0) *reinterpret_cast<f32x4*>(out) = v;
+        else { out[0] = v[0]; out[a.sb] = v[1]; out[2 * a.sb] = v[2]; out[3 * a.sb] = v[3]; }
     }
 }
 
@@ -730,8 +746,17 @@ int wc_conv_weights_f32(const float* w, int64_t stride_k, int64_t stride_n, int6
     a.w = w; a.sk = stride_k; a.sn = stride_n; a.sr = stride_r; a.ss = stride_s;
     a.amax = inline_max ? nullptr : (const float*)amax_scratch; a.scale_out = scale; a.img = (char*)image;
     a.K = g->Cin; a.Nn = g->Cout; a.ntaps = g->ntaps; a.nphase = g->nphase;
+    int most = 1;
     for (int p = 0; p < kMaxPhase; ++p)
-        for (int t = 0; t < kMaxTaps; ++t) { a.r[p][t] = g->wr[p][t]; a.s[p][t] = g->ws[p][t]; }
+        for (int t = 0; t < kMaxTaps; ++t) {
+            a.nsrc[p][t] = g->nsrc[p][t];
+            if (p < g->nphase && t < g->ntaps) {
+                if (g->nsrc[p][t] < 1 || g->nsrc[p][t] > 4) return WC_ERR_ARG;
+                if (g->nsrc[p][t] > most) most = g->nsrc[p][t];
+            }
+            for (int m = 0; m < 4; ++m) { a.r[p][t][m] = g->wr[p][t][m]; a.s[p][t][m] = g->ws[p][t][m]; }
+        }
+    a.coef = g->wcoef; a.bound_mul = fabsf(g->wcoef) * most;
     const int64_t groups = (int64_t)g->nphase * g->ntaps * (g->Cin >> 5) * (g->Cout >> 5) * 128;
     hipLaunchKernelGGL(conv_weights_kernel, dim3(grid_for(groups)), dim3(256), 0, st, a);
     return (int)hipGetLastError();
@@ -847,11 +872,23 @@ int wc_conv_wrw_f16x3(const void* xhi, const void* xlo, const float* xscale, con
     X.hi = (const _Float16*)xhi; X.lo = (const _Float16*)xlo; X.Hp = g->Hin; X.Wp = g->Win; X.C = g->Cin; X.stride = g->in_stride;
     G.hi = (const _Float16*)ghi; G.lo = (const _Float16*)glo; G.Hp = g->Hout; G.Wp = g->Wout; G.C = g->Cout; G.stride = g->out_stride;
     WrwReduceArgs r;
+    r.nout = 0; r.coef = g->wcoef;
     for (int p = 0; p < kMaxPhase; ++p)
         for (int t = 0; t < kMaxTaps; ++t) {
             X.dy[p][t] = g->dy[p][t]; X.dx[p][t] = g->dx[p][t];
             G.dy[p][t] = g->off_y[p]; G.dx[p][t] = g->off_x[p];
-            if (p < g->nphase && t < g->ntaps) { r.r[p * g->ntaps + t] = g->wr[p][t]; r.s[p * g->ntaps + t] = g->ws[p][t]; }
+            if (p >= g->nphase || t >= g->ntaps) continue;
+            if (g->nsrc[p][t] < 1 || g->nsrc[p][t] > 4) return WC_ERR_ARG;
+            for (int m = 0; m < g->nsrc[p][t]; ++m) {           // source tap -> the slices built from it
+                int o = 0;
+                while (o < r.nout && (r.r[o] != g->wr[p][t][m] || r.s[o] != g->ws[p][t][m])) ++o;
+                if (o == r.nout) {
+                    if (r.nout == kMaxTaps) return WC_ERR_ARG;
+                    r.r[o] = g->wr[p][t][m]; r.s[o] = g->ws[p][t][m]; r.cnt[o] = 0; ++r.nout;
+                }
+                if (r.cnt[o] == 4) return WC_ERR_ARG;
+                r.slice[o][r.cnt[o]++] = (signed char)(p * g->ntaps + t);
+            }
         }
     // the lanes of a result tile run along its columns: put the weight's contiguous channel axis there
     static const bool noswap = getenv("WC_WRW_NOSWAP") != nullptr;                              // development knob
@@ -880,7 +917,7 @@ int wc_conv_wrw_f16x3(const void* xhi, const void* xlo, const float* xscale, con
     r.partial = (const float*)ws; r.splits = splits; r.nslice = nslice; r.Ca = a.A.C; r.Cb = a.B.C;
     r.xscale = xscale; r.gscale = gscale; r.dw = dw;
     r.sa = x_cols ? stride_n : stride_k; r.sb = x_cols ? stride_k : stride_n; r.sr = stride_r; r.ss = stride_s;
-    hipLaunchKernelGGL(conv_wrw_reduce_kernel, dim3(grid_for((int64_t)nslice * g->Cin * g->Cout / 4)), dim3(256), 0, st, r);
+    hipLaunchKernelGGL(conv_wrw_reduce_kernel, dim3(grid_for((int64_t)r.nout * g->Cin * g->Cout / 4)), dim3(256), 0, st, r);
     return (int)hipGetLastError();
 }
 

@@ -124,13 +124,13 @@ class Conv2D(nn.Module):
         w = conv.normalized_weight() if hasattr(conv, 'normalized_weight') else conv.weight
         if tuple(w.shape[2:]) != (3, 3):
             return self.forward(upsample2x(x))
+        if FAST_CONV and x.is_cuda:                 # the 4x4 kernel is formed inside the weight image (csrc/wc_conv.hip)
+            y = fast_conv_mod.fast_conv_or_none(x, w, conv.bias, 'up3')
+            if y is not None:
+                return y
         rows = torch.stack([w[:, :, 2], w[:, :, 1] + w[:, :, 2], w[:, :, 0] + w[:, :, 1], w[:, :, 0]], dim=2)
         k = torch.stack([rows[..., 2], rows[..., 1] + rows[..., 2], rows[..., 0] + rows[..., 1], rows[..., 0]], dim=3)
         k = k.transpose(0, 1).contiguous(memory_format=torch.channels_last)             # (Cin, Cout, 4, 4)
-        if FAST_CONV and x.is_cuda:
-            y = fast_conv_mod.fast_conv_or_none(x, k, conv.bias, 'up')
-            if y is not None:
-                return y
         return to_nhwc(F.conv_transpose2d(to_nchw_view(x), k, conv.bias, stride=2, padding=1))
 
 
@@ -143,12 +143,11 @@ def _conv2d_forward_pooled(self, x):
     w = conv.normalized_weight() if hasattr(conv, 'normalized_weight') else conv.weight
     if tuple(w.shape[2:]) != (3, 3):
         return to_nhwc(F.avg_pool2d(to_nchw_view(self.forward(x)), 2))
-    k = (F.pad(w, (0, 1, 0, 1)) + F.pad(w, (1, 0, 0, 1)) + F.pad(w, (0, 1, 1, 0)) + F.pad(w, (1, 0, 1, 0))) * 0.25
     if FAST_CONV and x.is_cuda:
-        k = k.contiguous(memory_format=torch.channels_last)
-        y = fast_conv_mod.fast_conv_or_none(x, k, conv.bias, 'down')
+        y = fast_conv_mod.fast_conv_or_none(x, w, conv.bias, 'down3')
         if y is not None:
             return y
+    k = (F.pad(w, (0, 1, 0, 1)) + F.pad(w, (1, 0, 0, 1)) + F.pad(w, (0, 1, 1, 0)) + F.pad(w, (1, 0, 1, 0))) * 0.25
     return to_nhwc(F.conv2d(to_nchw_view(x), k.contiguous(memory_format=torch.channels_last), conv.bias, stride=2, padding=1))
 
 
