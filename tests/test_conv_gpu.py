@@ -98,6 +98,25 @@ def test_pooled_and_upsampled_3x3_layers_from_the_3x3_weight(kind, N, H, ci, co)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ['same', 'down3'])
+def test_relu_in_the_split_equals_relu_then_layer(kind):
+    """conv(relu(x)) with the ReLU done while x is split; the mask comes back in the data gradient"""
+    from wc_gan_amd import conv as C
+    torch.manual_seed(11)
+    x = torch.randn(8, 16, 16, 128, device='cuda').requires_grad_(True)
+    w = _weights('same', 128, 128, 3).requires_grad_(True)
+    b = (torch.randn(128, device='cuda') * 0.1).requires_grad_(True)
+    y = C.fast_conv_or_none(x, w, b, kind, relu_input=True)
+    z = F.conv2d(F.relu(x.permute(0, 3, 1, 2).double()), w.double(), b.double(), padding=1)
+    y64 = (F.avg_pool2d(z, 2) if kind == 'down3' else z).permute(0, 2, 3, 1)
+    gy = torch.randn_like(y)
+    dx, dw, db = torch.autograd.grad(y, (x, w, b), gy)
+    dx64, dw64, db64 = torch.autograd.grad(y64, (x, w, b), gy.double())
+    assert _rel(y, y64) < TOL and _rel(dx, dx64) < TOL and _rel(dw, dw64) < TOL and _rel(db, db64) < TOL
+    assert bool(((dx == 0) | (x > 0)).all())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("ci", [32, 96])
 def test_forward_with_reduction_channels_in_multiples_of_32(ci):
     """the kernel itself takes any multiple of 32 reduction channels (the layer entry also wants the data gradient)"""

@@ -238,36 +238,39 @@ def weight_gradient(x_planes, g_planes, geom, w, k_axis, n_axis, nbytes=None):
 
 class _FastConv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, kind, plan):
+    def forward(ctx, x, w, bias, kind, plan, relu_input=False):
         gf, kf, nf = plan.fwd
-        planes = split_planes(x)
+        planes = split_planes(x, relu=relu_input)   # relu_input: the layer is conv(relu(x)); the ReLU happens in the split
         y = run(planes, _cached_image(w, (kind, 'fwd'), gf, kf, nf), gf, bias, nbytes=plan.fwd_ws)
-        ctx.save_for_backward(w, *planes)           # the planes stand in for x (same bytes) in the weight gradient
-        ctx.kind, ctx.has_bias, ctx.plan = kind, bias is not None, plan
+        # the planes stand in for (relu of) x (same bytes) in the weight gradient; x itself only for the ReLU mask
+        ctx.save_for_backward(w, *planes, *((x,) if relu_input else ()))
+        ctx.kind, ctx.has_bias, ctx.plan, ctx.relu_input = kind, bias is not None, plan, relu_input
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        w, xh, xl, xs = ctx.saved_tensors
+        w, xh, xl, xs = ctx.saved_tensors[:4]
         kind, plan = ctx.kind, ctx.plan
         g_planes = split_planes(gy.contiguous())
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             gb, kb, nb = plan.bwd
             dx = run(g_planes, _cached_image(w, (kind, 'bwd'), gb, kb, nb), gb, nbytes=plan.bwd_ws)
+            if ctx.relu_input:
+                dx = torch.ops.aten.threshold_backward(dx, ctx.saved_tensors[4], 0)
         if ctx.needs_input_grad[1]:
             gf, kf, nf = plan.fwd
             dw = weight_gradient((xh, xl, xs), g_planes, gf, w, kf, nf, nbytes=plan.wrw_ws)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = gy.sum((0, 1, 2))
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
-def fast_conv_or_none(x, w, bias=None, kind='same'):
-    """fast_conv when the kernel takes the call, else None (the caller's other path)."""
+def fast_conv_or_none(x, w, bias=None, kind='same', relu_input=False):
+    """fast_conv when the kernel takes the call, else None (the caller's other path).  relu_input: conv(relu(x))."""
     if not supported(x, w, kind):
         return None
-    return _FastConv.apply(x, w, bias, kind, _plan(kind, x, w))
+    return _FastConv.apply(x, w, bias, kind, _plan(kind, x, w), relu_input)
 
 
 def fast_conv(x, w, bias=None, kind='same'):

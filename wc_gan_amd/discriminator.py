@@ -34,19 +34,21 @@ class ResBlockDown(nn.Module):
             self.shortcut = conv_layer(in_ch, nfilters, (1, 1), name=name + '.shortcut')
 
     def forward(self, x, cls):
-        h = x
-        if not self.is_first:
-            h = F.relu(self.bn1(h, cls))
-        h = self.conv1(h)
-        h = F.relu(self.bn2(h, cls))
+        # relu -> conv as one layer call: on the fast path the ReLU happens while the activation is split
+        h = self.conv1(x) if self.is_first else self.conv1.forward_relu(self.bn1(x, cls))
+        h = self.bn2(h, cls)
         s = x
         if self.resample == 'DOWN':
-            # from 32x32 on, conv2 + average pooling run as one 4x4 stride-2 convolution (same map; measured
-            # 1.23 -> 0.71 ms forward+backward at 128x32x32x128, slower than the two ops at 16x16)
-            h = self.conv2.forward_pooled(h) if h.shape[1] * h.shape[2] >= 1024 else downsample2x(self.conv2(h))
+            # conv2 + average pooling as one 4x4 stride-2 convolution (same map): always on the fast kernel; with MIOpen
+            # only from 32x32 on (measured 1.23 -> 0.71 ms forward+backward at 128x32x32x128, slower than the two ops at 16x16)
+            from . import generator as _g
+            if h.shape[1] * h.shape[2] >= 1024 or (_g.FAST_CONV and h.is_cuda):
+                h = self.conv2.forward_pooled(h, relu_input=True)
+            else:
+                h = downsample2x(self.conv2.forward_relu(h))
             s = downsample2x(s)
         else:
-            h = self.conv2(h)
+            h = self.conv2.forward_relu(h)
         if self.has_shortcut:
             s = self.shortcut(s)
         return h + s

@@ -102,6 +102,14 @@ class Conv2D(nn.Module):
         conv = self.conv
         return conv.normalized_weight() if hasattr(conv, 'normalized_weight') else conv.weight
 
+    def forward_relu(self, x):
+        """conv(relu(x)): on the fast path the ReLU happens while the activation is split (one kernel and one pass less)"""
+        if FAST_CONV and x.is_cuda:
+            y = fast_conv_mod.fast_conv_or_none(x, self._weight(), self.conv.bias, 'same', relu_input=True)
+            if y is not None:
+                return y
+        return self.forward(F.relu(x))
+
     def forward(self, x):
         c = self.conv
         if (c.out_channels <= 4 and tuple(c.kernel_size) == (3, 3) and not hasattr(c, 'normalized_weight')
@@ -134,19 +142,21 @@ class Conv2D(nn.Module):
         return to_nhwc(F.conv_transpose2d(to_nchw_view(x), k, conv.bias, stride=2, padding=1))
 
 
-def _conv2d_forward_pooled(self, x):
+def _conv2d_forward_pooled(self, x, relu_input=False):
     """avg_pool2x2(conv(x)) for a 3x3 'same' convolution as ONE 4x4 stride-2 convolution: the average of the four
     3x3 windows under an output pixel is a 4x4 window whose taps are quarter-sums of the 3x3 taps (zero padding carries
     over, the bias is unchanged) -- 16 instead of 36 tap products per output and no full-resolution intermediate.
     Same linear map as discriminator.py:41-54's Conv2D then AveragePooling2D; differs by fp32 summation order only."""
     conv = self.conv
     w = conv.normalized_weight() if hasattr(conv, 'normalized_weight') else conv.weight
-    if tuple(w.shape[2:]) != (3, 3):
-        return to_nhwc(F.avg_pool2d(to_nchw_view(self.forward(x)), 2))
-    if FAST_CONV and x.is_cuda:
-        y = fast_conv_mod.fast_conv_or_none(x, w, conv.bias, 'down3')
+    if FAST_CONV and x.is_cuda and tuple(w.shape[2:]) == (3, 3):
+        y = fast_conv_mod.fast_conv_or_none(x, w, conv.bias, 'down3', relu_input=relu_input)
         if y is not None:
             return y
+    if relu_input:
+        x = F.relu(x)
+    if tuple(w.shape[2:]) != (3, 3):
+        return to_nhwc(F.avg_pool2d(to_nchw_view(self.forward(x)), 2))
     k = (F.pad(w, (0, 1, 0, 1)) + F.pad(w, (1, 0, 0, 1)) + F.pad(w, (0, 1, 1, 0)) + F.pad(w, (1, 0, 1, 0))) * 0.25
     return to_nhwc(F.conv2d(to_nchw_view(x), k.contiguous(memory_format=torch.channels_last), conv.bias, stride=2, padding=1))
 
