@@ -160,6 +160,9 @@ int wc_bwd_apply_f32(const float* gy, const float* x, const float* mu, const flo
  * ZEROED ONCE by the caller before its first use (every launch leaves the meeting words zero) and used by one launch at
  * a time.  rows + cols floats must fit the LDS (WC_ERR_SHAPE otherwise). */
 size_t wc_spectral_norm_workspace_bytes(int rows, int cols);
+/* After a forward call the 32 floats at this byte offset of `ws` hold per-workgroup maxima of |w_sn| (unused entries keep
+ * the caller's zeros): wc_conv_weights_f32 takes them as `known_amax` and skips its own sweep over the weight. */
+size_t wc_spectral_norm_amax_offset(int rows, int cols);
 int wc_spectral_norm_f32(const float* W, int rows, int cols, float* u, float* v, int iterations, float eps,
                          float* w_sn /*[rows*cols] out*/, float* sigma /*[1] out*/,
                          float* u_used /*[rows] out, nullable*/, float* v_used /*[cols] out, nullable: u, v as used for sigma,
@@ -231,11 +234,12 @@ int wc_conv_split_f32(const float* x, int64_t n, int relu, void* hi, void* lo, f
 
 /* Weight fragment images for a geometry: element (k, n, r, s) of the source is w[k*stride_k + n*stride_n + r*stride_r +
  * s*stride_s] (k = reduction channel, n = output channel of the product), `n_elems` = extent of the source storage (for
- * the tensor scale).  `image`: wc_conv_weights_bytes(g) device bytes. */
+ * the tensor scale).  `image`: wc_conv_weights_bytes(g) device bytes.  `known_amax` (nullable): `known_count` device
+ * floats whose maximum is max|w| (e.g. the ones wc_spectral_norm_f32 leaves) -- then the weight is not swept again. */
 size_t wc_conv_weights_bytes(const wc_conv_geom* g);
 int wc_conv_weights_f32(const float* w, int64_t stride_k, int64_t stride_n, int64_t stride_r, int64_t stride_s,
                         int64_t n_elems, const wc_conv_geom* g, void* image, float* scale, void* amax_scratch,
-                        wc_stream_t stream);
+                        const float* known_amax, int known_count, wc_stream_t stream);
 
 /* y = conv(x, w) (+ bias[Cout]) (then max(., 0) when relu != 0) for the geometry; x as split planes, `zero_line` = 64
  * device bytes of zeros (the padding). */

@@ -199,3 +199,21 @@ def test_batched_layers_match_layer_by_layer(fully_diff):
     with torch.no_grad():
         n1.a.weight.mul_(2.0); n2.a.weight.mul_(2.0)
     assert torch.equal(n1(x, False), n2(x, False))
+
+
+@pytest.mark.gpu
+def test_forward_leaves_the_maximum_of_the_normalised_weight():
+    """the 32 floats behind wc_spectral_norm_amax_offset: their maximum is max|w_sn| (the convolution's weight split reads
+    them instead of sweeping the weight again)"""
+    from wc_gan_amd.spectral import SNConv2d
+    torch.manual_seed(4)
+    for cin, cout in ((128, 128), (3, 128), (256, 64)):
+        m = SNConv2d(cin, cout, 3, padding=1)
+        m._sn_init(1, False, True)
+        m = m.cuda()
+        m.train()
+        w = m.normalized_weight()
+        assert float(w._wc_amax.max()) == float(w.detach().abs().max())
+        m.eval()
+        w = m.normalized_weight()
+        assert float(w._wc_amax.max()) == float(w.detach().abs().max())

@@ -165,8 +165,10 @@ def weight_image(w, geom, k_axis, n_axis):
     ext = _storage_extent(w)
     if ext != w.numel():
         raise ValueError("weight must be dense")
+    known = getattr(w, '_wc_amax', None)        # floats whose maximum is max|w| (left by the spectral-norm op): no sweep here
     _lib.check(lib.wc_conv_weights_f32(_ptr(w), w.stride(k_axis), w.stride(n_axis), w.stride(2), w.stride(3), ext,
-                                       ctypes.addressof(geom), _ptr(img), _ptr(scale), scale.data_ptr() + 4, _stream()),
+                                       ctypes.addressof(geom), _ptr(img), _ptr(scale), scale.data_ptr() + 4,
+                                       _ptr(known), 0 if known is None else known.numel(), _stream()),
                "wc_conv_weights_f32")
     return img, scale
 

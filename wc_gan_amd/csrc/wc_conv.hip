@@ -311,10 +311,10 @@ __global__ __launch_bounds__(256) void conv_absmax_kernel(const float* __restric
 }
 
 // power-of-two scale that puts max|x| into [2^13, 2^14); every thread of a workgroup folds the partials (L2 hits)
-__device__ __forceinline__ float scale_of(const float* __restrict__ partial, float mul = 1.0f)
+__device__ __forceinline__ float scale_of(const float* __restrict__ partial, float mul = 1.0f, int count = kAmaxBlocks)
 {
     float amax = 0.f;
-    for (int i = threadIdx.x & 63; i < kAmaxBlocks; i += 64) amax = fmaxf(amax, partial[i]);
+    for (int i = threadIdx.x & 63; i < count; i += 64) amax = fmaxf(amax, partial[i]);
     #pragma unroll
     for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
     amax *= mul;
@@ -350,6 +350,7 @@ struct WeightArgs {
     int K, Nn, ntaps, nphase;                      // K = reduction channels, Nn = output channels of the product
     int64_t n4;                                    // amax == nullptr: float4s of the whole tensor
     float coef, bound_mul;                         // slice = coef * sum of its sources; max|slice| <= bound_mul * max|w|
+    int amax_count;                                // floats behind amax
     signed char nsrc[kMaxPhase][kMaxTaps];
     signed char r[kMaxPhase][kMaxTaps][4], s[kMaxPhase][kMaxTaps][4];
 };
@@ -357,7 +358,7 @@ struct WeightArgs {
 __global__ __launch_bounds__(256) void conv_weights_kernel(WeightArgs a)
 {
     float sc;
-    if (a.amax) sc = scale_of(a.amax, a.bound_mul);
+    if (a.amax) sc = scale_of(a.amax, a.bound_mul, a.amax_count);
     else {
         // small tensors: every workgroup takes the maximum of the whole (L2-resident) tensor itself -- no separate pass
         __shared__ float red[4];
@@ -733,18 +734,20 @@ size_t wc_conv_weights_bytes(const wc_conv_geom* g)
 }
 
 int wc_conv_weights_f32(const float* w, int64_t stride_k, int64_t stride_n, int64_t stride_r, int64_t stride_s, int64_t n_elems,
-                        const wc_conv_geom* g, void* image, float* scale, void* amax_scratch, wc_stream_t stream)
+                        const wc_conv_geom* g, void* image, float* scale, void* amax_scratch,
+                        const float* known_amax, int known_count, wc_stream_t stream)
 {
     hipStream_t st = (hipStream_t)stream;
-    if (!w || !g || !image || !scale || !amax_scratch || n_elems <= 0) return WC_ERR_ARG;
+    if (!w || !g || !image || !scale || (!amax_scratch && !known_amax) || n_elems <= 0) return WC_ERR_ARG;
+    if (known_amax && (known_count < 1 || known_count > 4096)) return WC_ERR_ARG;
     if (g->ntaps < 1 || g->ntaps > kMaxTaps || g->nphase < 1 || g->nphase > kMaxPhase || (g->Cin & 31) || (g->Cout & 31)) return WC_ERR_ARG;
     // the scale comes from the whole source tensor (n_elems covers its storage extent)
-    const bool inline_max = n_elems <= 32768 && (n_elems & 3) == 0 && ((uintptr_t)w & 15) == 0;   // (a 128 x 128 x 1 x 1 shortcut)
-    if (!inline_max) hipLaunchKernelGGL(conv_absmax_kernel, dim3(kAmaxBlocks), dim3(256), 0, st, w, n_elems / 4, n_elems, (float*)amax_scratch);
+    const bool inline_max = !known_amax && n_elems <= 32768 && (n_elems & 3) == 0 && ((uintptr_t)w & 15) == 0;   // (a 128 x 128 x 1 x 1 shortcut)
+    if (!inline_max && !known_amax) hipLaunchKernelGGL(conv_absmax_kernel, dim3(kAmaxBlocks), dim3(256), 0, st, w, n_elems / 4, n_elems, (float*)amax_scratch);
     WeightArgs a;
     a.n4 = n_elems / 4;
     a.w = w; a.sk = stride_k; a.sn = stride_n; a.sr = stride_r; a.ss = stride_s;
-    a.amax = inline_max ? nullptr : (const float*)amax_scratch; a.scale_out = scale; a.img = (char*)image;
+    a.amax = inline_max ? nullptr : (known_amax ? known_amax : (const float*)amax_scratch); a.amax_count = known_amax ? known_count : kAmaxBlocks; a.scale_out = scale; a.img = (char*)image;
     a.K = g->Cin; a.Nn = g->Cout; a.ntaps = g->ntaps; a.nphase = g->nphase;
     int most = 1;
     for (int p = 0; p < kMaxPhase; ++p)

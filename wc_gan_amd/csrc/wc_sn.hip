@@ -24,6 +24,7 @@ struct SnArgs {
     float* t; float* s;          // scratch [K], [R]: the two matrix-vector products, assembled from the workgroups' slices
     unsigned* sync;              // [0] barrier arrivals, [1] workgroups done: both 0 between launches
     int nwg;
+    float* amax;                 // [SN_MAXWG]: max |w_sn| of each workgroup's rows (entries >= nwg stay as the caller zeroed them)
 };
 
 __device__ __forceinline__ float block_sum(float x, float* red)       // SN_THREADS threads; every thread gets the sum
@@ -154,8 +155,21 @@ __device__ __forceinline__ void sn_forward_body(const SnArgs& a, const int b)
     }
     const float inv = 1.0f / sigma;
     const int64_t e0 = (int64_t)r0 * K, e1 = (int64_t)r1 * K;
+    float wmax = 0.f;
 #pragma unroll 8
-    for (int64_t e = e0 + tid; e < e1; e += SN_THREADS) a.w_sn[e] = a.W[e] * inv;
+    for (int64_t e = e0 + tid; e < e1; e += SN_THREADS) { const float w = a.W[e] * inv; a.w_sn[e] = w; wmax = fmaxf(wmax, fabsf(w)); }
+    // max |w_sn| of this slice, for the consumer that splits w_sn into fp16 pairs (wc_conv_weights_f32): one sweep less there
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, off));
+    __syncthreads();
+    if (lane == 0) red[wave] = wmax;
+    __syncthreads();
+    if (tid == 0) {
+        float m = red[0];
+#pragma unroll
+        for (int w = 1; w < SN_THREADS / 64; ++w) m = fmaxf(m, red[w]);
+        a.amax[b] = m;
+    }
     // the last workgroup out re-arms the meeting counter for the next launch
     if (nwg > 1 && tid == 0) {
         const unsigned old = __hip_atomic_fetch_add(a.sync + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
@@ -236,8 +250,9 @@ int sn_workgroups(int R, int K)
 }  // namespace
 
 size_t wc_sn_lds_bytes(int R, int K) { return (size_t)(R + K + SN_THREADS / 64 + SN_THREADS) * sizeof(float); }
-// scratch: t[K] | s[R] | partial[32] | sync[4] (the sync words must be zero before the first launch; every launch leaves them zero)
-size_t wc_sn_workspace_bytes(int R, int K) { return ((size_t)(R + K + SN_MAXWG) * sizeof(float) + 15) / 16 * 16 + 16; }
+// scratch: t[K] | s[R] | partial[32] | amax[32] | sync[4] (the sync words must be zero before the first launch; every launch leaves them zero)
+size_t wc_sn_workspace_bytes(int R, int K) { return ((size_t)(R + K + 2 * SN_MAXWG) * sizeof(float) + 15) / 16 * 16 + 16; }
+size_t wc_sn_amax_offset(int R, int K) { return (size_t)(R + K + SN_MAXWG) * sizeof(float); }
 
 hipError_t wc_launch_spectral_norm(const float* W, int R, int K, float* u, float* v, int iterations, float eps,
                                    float* w_sn, float* sigma, float* u_used, float* v_used, void* ws, hipStream_t st)
@@ -250,7 +265,7 @@ hipError_t wc_launch_spectral_norm(const float* W, int R, int K, float* u, float
     }
     float* t = static_cast<float*>(ws);
     unsigned* sync = reinterpret_cast<unsigned*>(static_cast<char*>(ws) + wc_sn_workspace_bytes(R, K) - 16);
-    SnArgs a{W, R, K, u, v, iterations, eps, w_sn, sigma, u_used, v_used, t, t + K, sync, sn_workgroups(R, K)};
+    SnArgs a{W, R, K, u, v, iterations, eps, w_sn, sigma, u_used, v_used, t, t + K, sync, sn_workgroups(R, K), t + K + R + SN_MAXWG};
     hipLaunchKernelGGL(sn_forward_kernel, dim3(a.nwg), dim3(SN_THREADS), lds, st, a);
     return hipGetLastError();
 }
@@ -277,7 +292,7 @@ hipError_t wc_launch_spectral_norm_batched(const WcSnItem* items, int count, int
             float* t = static_cast<float*>(it.ws);
             unsigned* sync = reinterpret_cast<unsigned*>(static_cast<char*>(it.ws) + wc_sn_workspace_bytes(it.rows, it.cols) - 16);
             q.item[i] = SnArgs{it.W, it.rows, it.cols, it.u, it.v, iterations, eps, it.w_sn, it.sigma, it.u_used, it.v_used,
-                               t, t + it.cols, sync, sn_workgroups(it.rows, it.cols)};
+                               t, t + it.cols, sync, sn_workgroups(it.rows, it.cols), t + it.cols + it.rows + SN_MAXWG};
             q.first[i] = blocks;
             blocks += q.item[i].nwg;
             const size_t l = wc_sn_lds_bytes(it.rows, it.cols);

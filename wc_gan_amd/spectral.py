@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import _lib, ops
 
 
 class SpectralNormFunction(torch.autograd.Function):
@@ -84,6 +84,7 @@ def prepare_spectral(root):
         return
     ws = SpectralNormBatchFunction.apply(mods, it, m0.sn_eps, m0.fully_diff_spectral, *[m.weight for m in mods])
     for m, w in zip(mods, ws):
+        w._wc_amax = m._sn_amax()                    # max|w_sn| as the op left it: the convolution's weight split needs no sweep
         m._w_ready = (w, m.weight._version, m.training)
 
 
@@ -120,6 +121,15 @@ class _SNMixin:
             ws = self._sn_ws = ops.spectral_norm_workspace(self.sn_u.numel(), self.sn_v.numel(), self.weight.device)
         return ws
 
+    def _sn_amax(self):
+        """The 32 floats of the workspace where the forward op leaves per-workgroup maxima of |w_sn|."""
+        a = getattr(self, '_sn_amax_view', None)
+        ws = self._sn_workspace()
+        if a is None or a.untyped_storage().data_ptr() != ws.untyped_storage().data_ptr():
+            off = _lib.load().wc_spectral_norm_amax_offset(self.sn_u.numel(), self.sn_v.numel())
+            a = self._sn_amax_view = ws[off:off + 128].view(torch.float32)
+        return a
+
     def normalized_weight(self):
         if not self.weight.is_cuda:
             raise RuntimeError("spectral normalisation runs on the HIP op only: move the module to the GPU")
@@ -131,6 +141,7 @@ class _SNMixin:
         it = self.spectral_iterations if self.training else 0
         ws = self._sn_workspace()
         w_sn, _sigma = SpectralNormFunction.apply(self.weight, self.sn_u, self.sn_v, ws, it, self.sn_eps, self.fully_diff_spectral)
+        w_sn._wc_amax = self._sn_amax()
         return w_sn
 
 
