@@ -18,7 +18,7 @@ import ctypes
 
 import torch
 
-from . import _lib
+from . import _lib, _state
 from .ops import _ptr, _stream
 
 _zero_lines = {}
@@ -174,16 +174,11 @@ def weight_image(w, geom, k_axis, n_axis):
 
 
 def _cached_image(w, key, geom, k_axis, n_axis):
-    """Images are kept on the weight tensor itself, valid for one version of it (one image serves every batch size:
-    the image depends on the taps and channel counts only)."""
-    cache = getattr(w, '_wc_conv_images', None)
-    if cache is None or cache[0] != w._version:
-        cache = (w._version, {})
-        w._wc_conv_images = cache
-    hit = cache[1].get(key)
-    if hit is None:
-        hit = cache[1][key] = weight_image(w, geom, k_axis, n_axis)
-    return hit
+    """The image is rebuilt on every call (two small launches).  It used to be cached on the weight tensor per
+    `w._version` -- but fused optimizers (torch's fused Adam) and replayed hipGraphs update weights WITHOUT moving that
+    counter, and a stale image is a silently wrong convolution; the reuse it bought (the generator's 7 weights, twice per
+    step) was ~0.1 ms."""
+    return weight_image(w, geom, k_axis, n_axis)
 
 
 def run(planes, image, geom, bias=None, relu=False, nbytes=None):

@@ -12,7 +12,7 @@ from __future__ import annotations
 import torch
 import torch.distributed as dist
 
-from . import ops
+from . import _state, ops
 
 
 def _allreduce_(tensors, group):
@@ -131,7 +131,7 @@ class EvalPlan:
     def get(self, C, gamma, moving_mean, moving_cov, eps, dev, gamma_key=None):
         # gamma is usually rebuilt from the coloring weights on every call: key on those weights (gamma_key) when given
         gk = gamma_key if gamma_key is not None else (None if gamma is None else (gamma.data_ptr(), gamma._version))
-        key = (C, eps, moving_mean._version, moving_cov._version, moving_mean.data_ptr(), moving_cov.data_ptr(),
+        key = (_state.replays, C, eps, moving_mean._version, moving_cov._version, moving_mean.data_ptr(), moving_cov.data_ptr(),
                None if gamma is None else tuple(gamma.shape), gk)
         if key != self.key:
             with torch.no_grad():

@@ -27,6 +27,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _state
 from . import functional as WF
 
 
@@ -349,5 +350,5 @@ class WhiteningColoring(nn.Module):
         # identity of the coloring weights (for the eval-mode plan cache); per-sample tables depend on cls -> no key
         per_sample = gamma is not None and slot is not None and gamma.shape[0] == x.shape[0] and \
             any(getattr(b, 'number_of_classes', 0) > x.shape[0] for b in self.branches)
-        key = None if per_sample else tuple((p.data_ptr(), p._version) for p in self.parameters())
+        key = None if per_sample else (_state.replays,) + tuple((p.data_ptr(), p._version) for p in self.parameters())
         return self.npart.transform(x, gamma, beta, slot, gamma_key=key, relu=relu)

@@ -15,6 +15,8 @@ import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
+from . import _state
+
 
 class FlatGradBucket:
     """All gradients of one network in one contiguous buffer; .grad tensors are views into it.
@@ -61,6 +63,15 @@ def broadcast_state(module, src=0, group=None):
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src=src, group=group)
+
+
+def _bump_versions(params):
+    """torch's fused Adam updates the weights without moving their version counters; everything that caches per
+    `tensor._version` (the eval-mode WC plan keys on the coloring weights) must still see the update."""
+    inc = getattr(torch.autograd.graph, 'increment_version', None)
+    if inc is not None:
+        for p in params:
+            inc(p)
 
 
 class GanTrainer:
@@ -132,6 +143,7 @@ class GanTrainer:
         loss.backward()
         self._sync_grads(self.d_bucket)
         self.opt_d.step()
+        _bump_versions(self.d_bucket.params)
         return loss.detach()
 
     def g_step(self, generated=None):
@@ -149,6 +161,7 @@ class GanTrainer:
             p.requires_grad_(True)
         self._sync_grads(self.g_bucket)
         self.opt_g.step()
+        _bump_versions(self.g_bucket.params)
         return loss.detach()
 
     def step(self, real_batches):
@@ -197,6 +210,7 @@ class GanTrainer:
 
         def replay():
             graph.replay()
+            _state.replays += 1                      # caches keyed by tensor versions: see _state.py
             return self._static_losses
         return replay
 
@@ -251,6 +265,7 @@ class GanTrainer:
                 g.replay()
                 if bucket is not None:
                     bucket.allreduce_mean()
+            _state.replays += 1                      # caches keyed by tensor versions: see _state.py
             return losses
         return replay
 
