@@ -445,3 +445,25 @@ def test_version_keyed_caches_are_rebuilt_after_graph_replays():
     tr.G.train()
     assert float((y1 - y0).abs().max()) > 1e-4     # the generator moved
     assert torch.equal(y1, y2)
+
+
+@pytest.mark.gpu
+def test_eval_plan_follows_training_updates_of_the_moving_statistics():
+    """the HIP stages move moving_mean / moving_cov through raw pointers: an eval-mode plan cached before a training call
+    must not be served after it"""
+    from wc_gan_amd.generator import create_norm
+    C = 64
+    stack = create_norm('d', 'uconv')(axis=-1, name='s', channels=C).cuda()
+    rng = np.random.default_rng(5)
+    x = dev(o.synth_activation(rng, (8, 8, 8, C), "well").astype(np.float32))
+    stack.train(); stack(x, None)
+    stack.eval()
+    with torch.no_grad():
+        y1 = stack(x, None).clone()
+    stack.train(); stack(x * 3.0 + 1.0, None)      # moves the statistics
+    stack.eval()
+    with torch.no_grad():
+        y2 = stack(x, None).clone()
+        stack.npart._eval_plan.key = None          # force a rebuild: the reference
+        y3 = stack(x, None).clone()
+    assert torch.equal(y2, y3) and not torch.equal(y1, y2)

@@ -44,6 +44,8 @@ class WhitenColorFunction(torch.autograd.Function):
             s = xtx = None
         mm = moving_mean.view(-1) if moving_mean is not None else None
         mu, L, W, chan_scale = ops.factor(s, xtx, M, C, eps, momentum, ddof, training, mm, moving_cov, dev, want_scale=True)
+        if training:
+            _touched(moving_mean, moving_cov)
         g = gamma.contiguous() if gamma is not None else None
         b = beta.contiguous() if beta is not None else None
         A, At, plan = ops.color(W, g, chan_scale)      # plan: the apply's fp16 tables, so K3 is one launch
@@ -109,6 +111,7 @@ def whiten_color_grouped(x, groups, gamma=None, beta=None, slot=None, moving_mea
     s, xtx = ops.stats(x.view(M, C), groups)
     mm = moving_mean.view(-1) if moving_mean is not None else None
     mu, L, W, cs = ops.factor(s, xtx, Mg, C, eps, momentum, ddof, True, mm, moving_cov, dev, want_scale=True, groups=groups)
+    _touched(moving_mean, moving_cov)
     g = gamma.detach().contiguous() if gamma is not None else None
     b = beta.detach().contiguous() if beta is not None else None
     Kc = 1 if g is None else g.shape[0]
@@ -117,6 +120,16 @@ def whiten_color_grouped(x, groups, gamma=None, beta=None, slot=None, moving_mea
     grp = torch.arange(N, device=dev, dtype=torch.int32) // (N // groups)
     full_slot = grp * Kc + (slot if slot is not None else 0)
     return ops.apply(x, center, A, bias, full_slot.to(torch.int32).contiguous(), plan=plan, relu=relu)
+
+
+def _touched(*tensors):
+    """The HIP stages update the moving statistics through raw pointers: tell torch (version counters), so that whatever is
+    cached per version -- the eval-mode plan below -- sees the update."""
+    inc = getattr(torch.autograd.graph, 'increment_version', None)
+    if inc is not None:
+        for t in tensors:
+            if t is not None:
+                inc(t)
 
 
 class EvalPlan:
