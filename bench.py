@@ -83,6 +83,27 @@ def roofline_apply(dev):
             "frac_of_stream_copy": round(achieved / (2 * M * C * 4 / t_copy / 1e9), 4)}
 
 
+MFMA_F16_PEAK_TFLOPS = 2500.0      # dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md); the power-limited sustained rate measured here is 1430
+
+
+def conv_roofline(dev):
+    """The kernel the step spends most time in after the WC path: the 3x3 256->256 block convolution at 128x32x32
+    (conv_f16x3_kernel<4,4>), MFMA-bound: 3 fp16 MFMA products per fp32 product."""
+    from wc_gan_amd import conv as C
+    N, H, Cc = 128, 32, 256
+    g = torch.Generator(device="cpu"); g.manual_seed(1234)
+    x = torch.randn(N, H, H, Cc, generator=g).to(dev)
+    w = (torch.randn(Cc, Cc, 3, 3, generator=g) / (9 * Cc) ** 0.5).to(dev).contiguous(memory_format=torch.channels_last)
+    (gf, kf, nf), _ = C._geoms('same', N, H, H, w)
+    planes, img = C.split_planes(x), C.weight_image(w, gf, kf, nf)
+    t = time_kernel(lambda: C.run(planes, img, gf))
+    flop32 = 2.0 * N * H * H * 9 * Cc * Cc
+    return {"bound": "mfma", "kernel": "conv_f16x3_kernel<4,4> (3x3 'same' 256->256 at 128x32x32, split-fp16 operands)",
+            "achieved": round(3 * flop32 / t / 1e12, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s (fp16 MFMA flops issued)",
+            "frac": round(3 * flop32 / t / 1e12 / MFMA_F16_PEAK_TFLOPS, 4), "launch_us": round(t * 1e6, 1),
+            "fp32_equivalent_TFLOPs": round(flop32 / t / 1e12, 1), "frac_of_sustained_1430": round(3 * flop32 / t / 1e12 / 1430.0, 4)}
+
+
 def wc_sites_gpu(dev, ratio):
     """GPU time of the WC sites of one G+D step (what cpu_baseline times on the host)."""
     from wc_gan_amd.functional import whiten_color, whiten_color_grouped
@@ -242,6 +263,7 @@ def main():
         if dt1 is not None:
             extra["training_ratio_1"] = {"value": round(64.0 * world / dt1, 2), "unit": "images/sec", "ms_per_step": round(dt1 * 1e3, 3)}
         roof = roofline_apply(dev)
+        extra["roofline_conv"] = conv_roofline(dev)
         wc_gpu = wc_sites_gpu(dev, args.training_ratio)
         extra["wc_sites_gpu"] = {"value": round(64.0 / wc_gpu, 1), "unit": "images/sec (WC sites of one G+D step only)",
                                  "ms": round(wc_gpu * 1e3, 3)}

@@ -2,7 +2,7 @@
 import sys, time
 import torch
 import torch.nn.functional as F
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from wc_gan_amd import conv as C
 
 
