@@ -488,6 +488,12 @@ __global__ __launch_bounds__(64) void tri_inv_diag_kernel(const double* __restri
     const int b0 = blockIdx.x * 32;
     const int lane = threadIdx.x;
     L += (int64_t)blockIdx.y * C * C; W += (int64_t)blockIdx.y * C * C;      // group
+    // this block row of W outside its diagonal block starts as zero (the upper triangle stays so; the block doubling
+    // fills the lower part): no separate memset launch
+    for (int e = lane; e < 32 * C; e += 64) {
+        const int i = e / C, k = e - i * C;
+        if (k < b0 || k >= b0 + 32) W[(int64_t)(b0 + i) * C + k] = 0.0;
+    }
     for (int e = lane; e < 32 * 32; e += 64) {
         const int i = e >> 5, k = e & 31;
         Lb[i * 33 + k] = L[(int64_t)(b0 + i) * C + b0 + k];
@@ -737,8 +743,7 @@ hipError_t wc_launch_gemm(const WcGemm& g, hipStream_t st)
 hipError_t wc_launch_tri_inverse(const double* L, double* W, double* tmp, int C, int groups, hipStream_t st)
 {
     const int64_t CCg = (int64_t)C * C;
-    hipError_t e = hipMemsetAsync(W, 0, (size_t)groups * C * C * sizeof(double), st);
-    if (e != hipSuccess) return e;
+    hipError_t e = hipSuccess;
     hipLaunchKernelGGL(tri_inv_diag_kernel, dim3(C / 32, groups), dim3(64), 0, st, L, W, C);
     for (int b = 32; b < C; b *= 2) {
         const int nfull = C / (2 * b);
