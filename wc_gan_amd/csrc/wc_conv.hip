@@ -16,8 +16,12 @@
 //   * B operand: the weights are pre-arranged (conv_weights_kernel) as the same kind of 1-KiB fragment images in
 //     (phase, tap, 32-channel chunk, n-block, k-step, hi|lo) order: a plain linear LDS-DMA copy.
 //   * a workgroup = 4 waves as 2x2, each wave (32 MB) pixels x (32 NB) outputs with 16 MB NB accumulator registers; one
-//     iteration = (tap, 32 input channels) = 2 k-steps; two LDS stages (the DMA of iteration i+1 runs under the MFMAs
-//     of iteration i; one barrier per iteration).
+//     iteration = (tap, 32 input channels) = 2 k-steps; two LDS stages, one barrier per iteration, hand-placed: fragments
+//     of k-step 0 right behind the barrier, then the MFMAs with the next iteration's addresses, DMAs and the fragment
+//     reads of k-step 1 in their shadow (WC_CONV_PIPE).
+//   * small grids (< ~100 workgroups) share the (tap, chunk) loop over blockIdx.z (conv_ksplit_reduce_kernel finishes).
+//   * weight gradient: conv_wrw_kernel (pixel-major tiles, ds_read_b64_tr_b16 fragments, split over pixel ranges) +
+//     conv_wrw_reduce_kernel (fixed-order sum into the weight's layout, 4x4 slices folded back onto 3x3 taps).
 // MFMA-bound by design: 3 * 2*M*Cout*K flop on the fp16 pipe against 2*M*Cout*K on the fp32 pipe (157 TFLOP/s peak).
 #include "wc_common.h"
 #include "../../include/wc_hip.h"
