@@ -787,8 +787,10 @@ static int conv_ksplit(const wc_conv_geom* g)
     const bool wide = (g->Cout % 256) == 0;
     const int64_t wgs = (M / 128) * g->nphase * (g->Cout / (wide ? 256 : 128));
     const int iters = g->ntaps * (g->Cin / 32);
-    if (wgs > 96 || iters < 8) return 1;
-    int k = (int)((256 + wgs - 1) / wgs);
+    static const int thr = getenv("WC_KSPLIT_WGS") ? atoi(getenv("WC_KSPLIT_WGS")) : 96;         // development knobs
+    static const int tgt = getenv("WC_KSPLIT_TARGET") ? atoi(getenv("WC_KSPLIT_TARGET")) : 256;
+    if (wgs > thr || iters < 8) return 1;
+    int k = (int)((tgt + wgs - 1) / wgs);
     if (k > iters / 4) k = iters / 4;               // at least 4 iterations each
     return k < 1 ? 1 : (k > 8 ? 8 : k);
 }
