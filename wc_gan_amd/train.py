@@ -183,8 +183,9 @@ class GanTrainer:
         for r in range(self.training_ratio):
             d_loss = self.d_step(real_batches[r % len(real_batches)], fake=fakes[r], cls=clss[r])
         if generated is not None:
-            torch.cuda.current_stream().wait_stream(self._side)
-            self._side_pending = False
+            if self._side_pending:                   # (a graph segment that ended in between has joined it already)
+                torch.cuda.current_stream().wait_stream(self._side)
+                self._side_pending = False
             generated[0].record_stream(torch.cuda.current_stream())
             generated[1].record_stream(torch.cuda.current_stream())
         g_loss = self.g_step(generated)
@@ -236,13 +237,16 @@ class GanTrainer:
 
         def begin():
             g = torch.cuda.CUDAGraph()
-            ctx = torch.cuda.graph(g, pool=pool)
+            # thread_local: calls of OTHER threads (the process group's watchdog polls its events) must not invalidate
+            # a capture that contains none of their work
+            ctx = torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local")
             ctx.__enter__()
             cur['g'], cur['ctx'] = g, ctx
 
         def end(bucket):
             if self._side_pending:                   # join the forked generator forward before the graph ends
                 torch.cuda.current_stream().wait_stream(self._side)
+                self._side_pending = False
             cur['ctx'].__exit__(None, None, None)
             segments.append((cur['g'], bucket))
 
