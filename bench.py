@@ -174,8 +174,9 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     group = None
-    if world > 1:
+    if world > 1 or os.environ.get("WC_FORCE_COLLECTIVES") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         group = dist.group.WORLD
 
@@ -183,7 +184,8 @@ def main():
     from wc_gan_amd.train import CIFAR10_UNCOND, build_trainer
     _lib.load()
     torch.manual_seed(1234)
-    trainer = build_trainer(CIFAR10_UNCOND, dev, process_group=group, sync_wc=args.sync_wc,
+    kw = dict(flat_buckets=True) if os.environ.get("WC_FORCE_COLLECTIVES") == "1" else {}      # development: the N > 1 layout on one GPU
+    trainer = build_trainer(CIFAR10_UNCOND, dev, process_group=group, sync_wc=args.sync_wc, **kw,
                             training_ratio=args.training_ratio, seed=1234 + rank)
     g = torch.Generator(device="cpu"); g.manual_seed(1234 + rank)
     reals = [(torch.rand(64, 32, 32, 3, generator=g) * 2 - 1).to(dev) for _ in range(args.training_ratio)]
@@ -198,7 +200,13 @@ def main():
         step()
     launch_mode = "eager"
     eager_step = step
-    if args.segments or (world > 1 and not args.eager and not args.graph and not args.sync_wc):
+    in_group = dist.is_available() and dist.is_initialized()
+    if args.graph and in_group:
+        # tried on one GPU with a one-rank group: capturing the RCCL all-reduce aborts the process (SIGABRT inside the
+        # capture) -- the chain of graphs with the collectives between them is the supported form
+        print("[bench] --graph with a process group: using --segments (collectives cannot be captured)", file=sys.stderr)
+        args.graph, args.segments = False, True
+    if args.segments or (world > 1 and not args.eager and not args.sync_wc):
         try:
             step = trainer.capture_segments(reals)
             launch_mode = "hipgraph-segments"
@@ -284,7 +292,7 @@ def main():
         }
         out.update(extra)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

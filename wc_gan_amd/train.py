@@ -18,6 +18,10 @@ import torch.nn.functional as F
 from . import _state
 
 
+# development: run the gradient collectives even in a one-rank process group (exercises RCCL between graph segments on one GPU)
+_FORCE_COLLECTIVES = __import__('os').environ.get('WC_FORCE_COLLECTIVES', '0') == '1'
+
+
 class FlatGradBucket:
     """All gradients of one network in one contiguous buffer; .grad tensors are views into it.
     `flat=False` (what the trainer picks for a single process): no buffer -- zero() just drops the gradients, so autograd
@@ -52,7 +56,7 @@ class FlatGradBucket:
             self.flat.zero_()
 
     def allreduce_mean(self):
-        if self.world > 1 and self.flat is not None:
+        if (self.world > 1 or _FORCE_COLLECTIVES) and self.flat is not None:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
             self.flat.mul_(1.0 / self.world)
 
