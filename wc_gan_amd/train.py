@@ -196,11 +196,14 @@ class GanTrainer:
         return d_loss, g_loss
 
     def capture(self, real_batches, warmup=3):
-        """Record one whole G+D step (~5000 kernel launches, the collectives included) into a hipGraph.
+        """Record one whole G+D step (~1700 kernel launches) into ONE hipGraph -- single process only: capturing an RCCL
+        all-reduce aborts the process (tried with a one-rank group), so with gradient collectives use capture_segments().
 
         The C-ABI stages never synchronise or allocate and the gate of the fast path is a device flag, so the
         step is capturable as is; `real_batches` become the graph's static inputs (copy new data into them).
         Returns a callable that replays the step.  Every replay draws fresh noise and updates the weights."""
+        if (self.g_bucket.world > 1 or _FORCE_COLLECTIVES) and self.g_bucket.flat is not None:
+            raise RuntimeError("capture(): gradient all-reduces cannot be captured; use capture_segments()")
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
