@@ -43,6 +43,7 @@ struct ConvArgs {
     const float* bias;                              // [Cout] or nullptr
     float* y;                                       // [N][Hout][Wout][Cout]
     int N, H, W, Hin, Win, Cin, Cout, in_stride, ntaps, nphase, Hout, Wout, out_stride, relu;
+    unsigned magHW, shHW, magW, shW;                // m / (H*W) and rem / W by multiply-shift (m < 2^31)
     int ksplit; float* partial;                     // ksplit > 1: blockIdx.z takes a share of the (tap, chunk) loop, raw sums -> partial[z][output]
     signed char dy[kMaxPhase][kMaxTaps], dx[kMaxPhase][kMaxTaps];
     signed char offy[kMaxPhase], offx[kMaxPhase];
@@ -78,8 +79,8 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(ConvArgs a)
     #pragma unroll
     for (int q = 0; q < AQ; ++q) {
         const unsigned m = m0 + (wave * AQ + q) * 32 + (lane & 31);
-        const unsigned n = m / HW, rem = m - n * HW;
-        const unsigned yy = rem / a.W, xx = rem - yy * a.W;
+        const unsigned n = __umulhi(m, a.magHW) >> a.shHW, rem = m - n * HW;
+        const unsigned yy = __umulhi(rem, a.magW) >> a.shW, xx = rem - yy * a.W;
         gy[q] = yy * a.in_stride; gx[q] = xx * a.in_stride; gpix[q] = n * (a.Hin * a.Win);
     }
     const unsigned lds0 = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
@@ -258,8 +259,8 @@ __global__ __launch_bounds__(256) void conv_f16x3_kernel(ConvArgs a)
         for (int r = 0; r < 16; ++r) {
             const unsigned row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             const unsigned m = m0 + (wm * MB + i) * 32 + row;
-            const unsigned n = m / HW, rem = m - n * HW;
-            const unsigned yy = rem / a.W, xx = rem - yy * a.W;
+            const unsigned n = __umulhi(m, a.magHW) >> a.shHW, rem = m - n * HW;
+            const unsigned yy = __umulhi(rem, a.magW) >> a.shW, xx = rem - yy * a.W;
             const int64_t opix = ((int64_t)n * a.Hout + (yy * a.out_stride + oy0)) * a.Wout + (xx * a.out_stride + ox0);
             const int64_t oe = opix * a.Cout + nt * TN + wn * NB * 32 + (lane & 31);
             if (KS) {                               // raw partial sums; conv_ksplit_reduce_kernel finishes
@@ -777,6 +778,7 @@ int wc_conv_supported(const wc_conv_geom* g)
     const int64_t M = (int64_t)g->N * g->H * g->W;
     if (M <= 0 || (M & 127) || M > (int64_t)1 << 31) return 0;
     if ((int64_t)g->N * g->Hin * g->Win > (int64_t)1 << 31) return 0;
+    if (g->W < 2 || g->H < 1) return 0;             // (the multiply-shift division wants divisors >= 2)
     return 1;
 }
 
@@ -816,6 +818,8 @@ int wc_conv_f16x3(const void* xhi, const void* xlo, const float* xscale, const v
     a.in_stride = g->in_stride; a.ntaps = g->ntaps; a.nphase = g->nphase; a.Hout = g->Hout; a.Wout = g->Wout;
     a.out_stride = g->out_stride; a.relu = relu;
     a.ksplit = conv_ksplit(g); a.partial = (float*)ws;
+    magic_u31((unsigned)(g->H * g->W), &a.magHW, &a.shHW);
+    magic_u31((unsigned)g->W, &a.magW, &a.shW);
     if (a.ksplit > 1 && (!ws || ws_bytes < wc_conv_workspace_bytes(g))) return WC_ERR_WORKSPACE;
     for (int p = 0; p < kMaxPhase; ++p) {
         a.offy[p] = g->off_y[p]; a.offx[p] = g->off_x[p];
