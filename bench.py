@@ -150,8 +150,8 @@ def cpu_baseline(ratio):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--training-ratio", type=int, default=TRAINING_RATIO)
     ap.add_argument("--sync-wc", action="store_true", help="all-reduce WC statistics across replicas")
     ap.add_argument("--no-cpu-baseline", action="store_true")
