@@ -9,8 +9,11 @@
 //    XOR-swizzled [C][R] image.  No transposed LDS read, no shuffles.
 //  * Accuracy of the covariance decides parity on ill-conditioned batches, so the fp32 MFMA
 //    accumulators are flushed into FLOAT64 registers after every stage (64 rows: a 12-step fp32 chain).  That
-//    costs 48 VGPRs per block, so a wave owns only 2 of the C/32 x C/32 blocks and the blocks of one slab are
-//    spread over `ntypes` workgroups that stream the same rows (co-scheduled on one XCD: L2 serves the re-reads).
+//    costs 48 VGPRs per block, so a wave owns only 3 of the C/32 x C/32 blocks (the LDS images allow one 512-thread
+//    workgroup per CU anyway, i.e. 256 VGPRs per thread: 3 blocks fit without spills, 4 do not) and the blocks of one
+//    slab are spread over `ntypes` workgroups that stream the same rows (co-scheduled on one XCD: L2 serves the
+//    re-reads).  3 instead of 2 blocks: 2 instead of 3 (covariance) / 3 instead of 4 (two operands) workgroups convert
+//    every row -- K1 113.6 -> 83.5 us, K4 174.7 -> 146.4 us at 128x32x32x256.
 //  * fp16 range: per-channel power-of-two scales from a row subsample, undone exactly in the float64 flush; an
 //    out-of-range element raises the same device gate as in wc_fast.hip and the exact kernel redoes the call.
 #include "wc_common.h"
@@ -28,7 +31,7 @@ __device__ __forceinline__ unsigned pk_rne(float a, float b)
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
 }
 constexpr float kGuard = 60000.0f;
-constexpr int BW = 2;                      // 32x32 blocks per wave
+constexpr int BW = 3;                      // 32x32 blocks per wave
 
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
@@ -46,7 +49,7 @@ struct FastXtyArgs {
 };
 
 template <int C, bool TWO>
-__global__ __launch_bounds__(512, 2) void xty_f16x3_kernel(FastXtyArgs a)
+__global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
 {
     constexpr int C4 = C / 4;
     constexpr int RGRP = 512 / C4;                    // 8-row groups covered by the 512 threads
