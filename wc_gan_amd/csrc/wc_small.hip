@@ -482,23 +482,25 @@ __global__ __launch_bounds__(512) void cholesky_reg_kernel(double* __restrict__ 
 }
 
 // inverse of each 32 x 32 diagonal block of L (lower): one wave per block, lane = column of the inverse
-__global__ __launch_bounds__(64) void tri_inv_diag_kernel(const double* __restrict__ L, double* __restrict__ W, int C)
+__global__ __launch_bounds__(256) void tri_inv_diag_kernel(const double* __restrict__ L, double* __restrict__ W, int C)
 {
     __shared__ double Lb[32 * 33];
     const int b0 = blockIdx.x * 32;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     L += (int64_t)blockIdx.y * C * C; W += (int64_t)blockIdx.y * C * C;      // group
     // this block row of W outside its diagonal block starts as zero (the upper triangle stays so; the block doubling
-    // fills the lower part): no separate memset launch
-    for (int e = lane; e < 32 * C; e += 64) {
-        const int i = e / C, k = e - i * C;
-        if (k < b0 || k >= b0 + 32) W[(int64_t)(b0 + i) * C + k] = 0.0;
+    // fills the lower part): no separate memset launch.  All 256 threads, 16 B each.
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    for (int e = tid; e < 16 * C; e += 256) {       // pairs of doubles: 32 rows x C/2 pairs
+        const int i = e / (C >> 1), k = 2 * (e - i * (C >> 1));
+        if (k < b0 || k >= b0 + 32) *reinterpret_cast<f64x2*>(W + (int64_t)(b0 + i) * C + k) = f64x2{0.0, 0.0};
     }
-    for (int e = lane; e < 32 * 32; e += 64) {
+    for (int e = tid; e < 32 * 32; e += 256) {
         const int i = e >> 5, k = e & 31;
         Lb[i * 33 + k] = L[(int64_t)(b0 + i) * C + b0 + k];
     }
     __syncthreads();
+    if (tid >= 64) return;                          // one wave inverts
     const int c = lane & 31;
     double w[32];
 #pragma unroll
@@ -744,7 +746,7 @@ hipError_t wc_launch_tri_inverse(const double* L, double* W, double* tmp, int C,
 {
     const int64_t CCg = (int64_t)C * C;
     hipError_t e = hipSuccess;
-    hipLaunchKernelGGL(tri_inv_diag_kernel, dim3(C / 32, groups), dim3(64), 0, st, L, W, C);
+    hipLaunchKernelGGL(tri_inv_diag_kernel, dim3(C / 32, groups), dim3(256), 0, st, L, W, C);
     for (int b = 32; b < C; b *= 2) {
         const int nfull = C / (2 * b);
         const int rem = C - 2 * b * nfull;
