@@ -452,7 +452,7 @@ __global__ __launch_bounds__(512, 2) void affine_f16x3_kernel(FastArgs a)
 #endif
 
 template <int C, bool HAS_SLOT>
-__global__ __launch_bounds__(512, 2) void affine_ring_kernel(FastArgs a)
+__global__ __launch_bounds__(512, 1) void affine_ring_kernel(FastArgs a)
 {
     constexpr int TR = 8192 / C;              // rows per tile (32 KiB of fp32)
     constexpr int CPR = C / 8, KS = C / 16, CG = C / 32, C4 = C / 4;
