@@ -217,3 +217,23 @@ def test_forward_leaves_the_maximum_of_the_normalised_weight():
         m.eval()
         w = m.normalized_weight()
         assert float(w._wc_amax.max()) == float(w.detach().abs().max())
+
+
+@pytest.mark.gpu
+def test_one_power_iteration_per_forward_on_every_layer_path():
+    """a spectrally normalised layer advances u, v ONCE per training forward, also when the fast convolution kernel does
+    not take the shape and the layer falls back to MIOpen (the critic's 3 -> 128 first layer)"""
+    from wc_gan_amd.generator import Conv2D
+    torch.manual_seed(3)
+    for cin, cout, k in ((3, 128, 3), (3, 128, 1), (128, 128, 3)):
+        layer = Conv2D(cin, cout, (k, k), spectral=True).cuda().train()
+        ref = Conv2D(cin, cout, (k, k), spectral=True).cuda().train()
+        ref.load_state_dict(layer.state_dict())
+        x = torch.randn(8, 8, 8, cin, device='cuda')
+        layer(x)                                       # whatever path the shape takes
+        ref.conv.normalized_weight()                   # exactly one iteration
+        torch.cuda.synchronize()
+        assert torch.equal(layer.conv.sn_u, ref.conv.sn_u) and torch.equal(layer.conv.sn_v, ref.conv.sn_v)
+        layer.forward_relu(x)
+        ref.conv.normalized_weight()
+        assert torch.equal(layer.conv.sn_u, ref.conv.sn_u)

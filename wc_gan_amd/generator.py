@@ -104,22 +104,25 @@ class Conv2D(nn.Module):
 
     def forward_relu(self, x):
         """conv(relu(x)): on the fast path the ReLU happens while the activation is split (one kernel and one pass less)"""
+        w = self._weight()
         if FAST_CONV and x.is_cuda:
-            y = fast_conv_mod.fast_conv_or_none(x, self._weight(), self.conv.bias, 'same', relu_input=True)
+            y = fast_conv_mod.fast_conv_or_none(x, w, self.conv.bias, 'same', relu_input=True)
             if y is not None:
                 return y
-        return self.forward(F.relu(x))
+        return self.forward(F.relu(x), _w=w)
 
-    def forward(self, x):
+    def forward(self, x, _w=None):
         c = self.conv
         if (c.out_channels <= 4 and tuple(c.kernel_size) == (3, 3) and not hasattr(c, 'normalized_weight')
                 and x.is_cuda and x.is_contiguous()):
             return _NarrowConv3x3.apply(x, c.weight, c.bias)
+        # the weight ONCE per forward: a spectrally normalised layer advances its power iteration in normalized_weight()
+        w = self._weight() if _w is None else _w
         if FAST_CONV and x.is_cuda:
-            y = fast_conv_mod.fast_conv_or_none(x, self._weight(), c.bias, 'same')      # split-fp16 MFMA implicit GEMM (csrc/wc_conv.hip)
+            y = fast_conv_mod.fast_conv_or_none(x, w, c.bias, 'same')      # split-fp16 MFMA implicit GEMM (csrc/wc_conv.hip)
             if y is not None:
                 return y
-        return to_nhwc(self.conv(to_nchw_view(x)))
+        return to_nhwc(c._conv_forward(to_nchw_view(x), w, c.bias))
 
     def forward_upsampled(self, x):
         """conv(upsample2x(x)) for a 3x3 'same' convolution, without the upsampled tensor: a nearest-neighbour 2x
@@ -131,7 +134,7 @@ class Conv2D(nn.Module):
         conv = self.conv
         w = conv.normalized_weight() if hasattr(conv, 'normalized_weight') else conv.weight
         if tuple(w.shape[2:]) != (3, 3):
-            return self.forward(upsample2x(x))
+            return self.forward(upsample2x(x), _w=w)
         if FAST_CONV and x.is_cuda:                 # the 4x4 kernel is formed inside the weight image (csrc/wc_conv.hip)
             y = fast_conv_mod.fast_conv_or_none(x, w, conv.bias, 'up3')
             if y is not None:
@@ -156,7 +159,7 @@ def _conv2d_forward_pooled(self, x, relu_input=False):
     if relu_input:
         x = F.relu(x)
     if tuple(w.shape[2:]) != (3, 3):
-        return to_nhwc(F.avg_pool2d(to_nchw_view(self.forward(x)), 2))
+        return to_nhwc(F.avg_pool2d(to_nchw_view(self.forward(x, _w=w)), 2))
     k = (F.pad(w, (0, 1, 0, 1)) + F.pad(w, (1, 0, 0, 1)) + F.pad(w, (0, 1, 1, 0)) + F.pad(w, (1, 0, 1, 0))) * 0.25
     return to_nhwc(F.conv2d(to_nchw_view(x), k.contiguous(memory_format=torch.channels_last), conv.bias, stride=2, padding=1))
 
