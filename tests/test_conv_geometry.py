@@ -79,3 +79,37 @@ def test_every_source_tap_is_named_by_the_forward_geometry():
         taps = {(gf.wr[p][t][m], gf.ws[p][t][m]) for p in range(gf.nphase) for t in range(gf.ntaps) for m in range(gf.nsrc[p][t])}
         assert taps == {(r, s) for r in range(3) for s in range(3)}
         assert all(1 <= gf.nsrc[p][t] <= 4 for p in range(gf.nphase) for t in range(gf.ntaps))
+
+
+def interpret_wrw(g, x, gy, wshape, k_axis, n_axis):
+    """dW per the FORWARD geometry: every slice's product sum, folded (x wcoef) onto each source tap it was formed from"""
+    dw = np.zeros(np.moveaxis(np.zeros(wshape), (k_axis, n_axis), (0, 1)).shape)      # (k, n, r, s)
+    for p in range(g.nphase):
+        for t in range(g.ntaps):
+            P = np.zeros((g.Cin, g.Cout))
+            for yy in range(g.H):
+                iy = yy * g.in_stride + g.dy[p][t]
+                if not 0 <= iy < g.Hin:
+                    continue
+                for xx in range(g.W):
+                    ix = xx * g.in_stride + g.dx[p][t]
+                    if not 0 <= ix < g.Win:
+                        continue
+                    P += x[:, iy, ix, :].T @ gy[:, yy * g.out_stride + g.off_y[p], xx * g.out_stride + g.off_x[p], :]
+            for m in range(g.nsrc[p][t]):
+                dw[:, :, g.wr[p][t][m], g.ws[p][t][m]] += g.wcoef * P
+    return np.moveaxis(dw, (0, 1), (k_axis, n_axis))
+
+
+@pytest.mark.parametrize("kind,k,wshape", CASES)
+def test_geometry_reproduces_the_weight_gradient(kind, k, wshape):
+    torch.manual_seed(k)
+    N, H, W, ci = 2, 4, 6, 4
+    x = torch.randn(N, H, W, ci, dtype=torch.float64)
+    w = torch.randn(*wshape, dtype=torch.float64, requires_grad=True)
+    (gf, kf, nf), _ = C._geoms(kind, N, H, W, w)
+    y_ref = reference(kind, x, w)
+    gy = torch.randn_like(y_ref)
+    dw_ref, = torch.autograd.grad(y_ref, w, gy)
+    dw = interpret_wrw(gf, x.numpy(), gy.numpy(), wshape, kf, nf)
+    assert np.abs(dw - dw_ref.numpy()).max() < 1e-11
