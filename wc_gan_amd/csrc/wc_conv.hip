@@ -667,16 +667,22 @@ struct WrwReduceArgs {
 
 __global__ __launch_bounds__(256) void conv_wrw_reduce_kernel(WrwReduceArgs a)
 {
+    // four lanes per output float4: each takes every fourth range, a fixed two-step butterfly joins them (the order of the
+    // additions is the same in every run) -- four times the loads in flight of one thread walking all the ranges
     const int64_t plane = (int64_t)a.Ca * a.Cb, per = (int64_t)a.nslice * plane, total4 = (int64_t)a.nout * plane >> 2;
     const float inv = a.coef / (a.xscale[0] * a.gscale[0]);
-    for (int64_t e4 = (int64_t)blockIdx.x * 256 + threadIdx.x; e4 < total4; e4 += (int64_t)gridDim.x * 256) {
+    const int part = threadIdx.x & 3;
+    for (int64_t e4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 2; e4 < total4; e4 += (int64_t)gridDim.x * 64) {
         const int64_t e = e4 * 4;
         const int o = e / plane; const int64_t w = e - o * plane;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         for (int i = 0; i < a.cnt[o]; ++i) {
             const float* src = a.partial + a.slice[o][i] * plane + w;
-            for (int sp = 0; sp < a.splits; ++sp) v += *reinterpret_cast<const f32x4*>(src + sp * per);
+            for (int sp = part; sp < a.splits; sp += 4) v += *reinterpret_cast<const f32x4*>(src + sp * per);
         }
+        #pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] += __shfl_xor(v[j], 1); v[j] += __shfl_xor(v[j], 2); }
+        if (part != 0) continue;
         v = v * inv;
         const int cb = w % a.Cb, ca = w / a.Cb;
         float* out = a.dw + ca * a.sa + cb * a.sb + a.r[o] * a.sr + a.s[o] * a.ss;
@@ -930,7 +936,7 @@ int wc_conv_wrw_f16x3(const void* xhi, const void* xlo, const float* xscale, con
     r.partial = (const float*)ws; r.splits = splits; r.nslice = nslice; r.Ca = a.A.C; r.Cb = a.B.C;
     r.xscale = xscale; r.gscale = gscale; r.dw = dw;
     r.sa = x_cols ? stride_n : stride_k; r.sb = x_cols ? stride_k : stride_n; r.sr = stride_r; r.ss = stride_s;
-    hipLaunchKernelGGL(conv_wrw_reduce_kernel, dim3(grid_for((int64_t)r.nout * g->Cin * g->Cout / 4)), dim3(256), 0, st, r);
+    hipLaunchKernelGGL(conv_wrw_reduce_kernel, dim3(grid_for((int64_t)r.nout * g->Cin * g->Cout)), dim3(256), 0, st, r);
     return (int)hipGetLastError();
 }
 
