@@ -241,6 +241,14 @@ int wc_conv_weights_f32(const float* w, int64_t stride_k, int64_t stride_n, int6
                         int64_t n_elems, const wc_conv_geom* g, void* image, float* scale, void* amax_scratch,
                         const float* known_amax, int known_count, wc_stream_t stream);
 
+/* The images of one weight for two geometries (the layer's forward and its data gradient) in one launch: as two calls of
+ * wc_conv_weights_f32 with the same source; `scale`: TWO floats (one per image, equal). */
+int wc_conv_weights_pair_f32(const float* w, int64_t stride_r, int64_t stride_s, int64_t n_elems,
+                             int64_t a_stride_k, int64_t a_stride_n, const wc_conv_geom* ga, void* image_a,
+                             int64_t b_stride_k, int64_t b_stride_n, const wc_conv_geom* gb, void* image_b,
+                             float* scale, void* amax_scratch, const float* known_amax, int known_count,
+                             wc_stream_t stream);
+
 /* y = conv(x, w) (+ bias[Cout]) (then max(., 0) when relu != 0) for the geometry; x as split planes, `zero_line` = 64
  * device bytes of zeros (the padding). */
 size_t wc_conv_workspace_bytes(const wc_conv_geom* g);     /* 0 unless the grid is small (the tap loop is then shared) */

@@ -173,6 +173,25 @@ def weight_image(w, geom, k_axis, n_axis):
     return img, scale
 
 
+def weight_image_pair(w, fwd, bwd):
+    """The forward and the data-gradient image of one weight in one launch; fwd / bwd = (geometry, k_axis, n_axis)."""
+    lib = _lib.load()
+    (ga, ka, na), (gb, kb, nb) = fwd, bwd
+    img_a = torch.empty(lib.wc_conv_weights_bytes(ctypes.addressof(ga)), dtype=torch.uint8, device=w.device)
+    img_b = torch.empty(lib.wc_conv_weights_bytes(ctypes.addressof(gb)), dtype=torch.uint8, device=w.device)
+    scale = torch.empty(2 + 512, dtype=torch.float32, device=w.device)
+    ext = _storage_extent(w)
+    if ext != w.numel():
+        raise ValueError("weight must be dense")
+    known = getattr(w, '_wc_amax', None)
+    _lib.check(lib.wc_conv_weights_pair_f32(_ptr(w), w.stride(2), w.stride(3), ext,
+                                            w.stride(ka), w.stride(na), ctypes.addressof(ga), _ptr(img_a),
+                                            w.stride(kb), w.stride(nb), ctypes.addressof(gb), _ptr(img_b),
+                                            _ptr(scale), scale.data_ptr() + 8, _ptr(known), 0 if known is None else known.numel(),
+                                            _stream()), "wc_conv_weights_pair_f32")
+    return (img_a, scale[0:1]), (img_b, scale[1:2])
+
+
 def _cached_image(w, key, geom, k_axis, n_axis):
     """The image is rebuilt on every call (two small launches).  It used to be cached on the weight tensor per
     `w._version` -- but fused optimizers (torch's fused Adam) and replayed hipGraphs update weights WITHOUT moving that
@@ -238,7 +257,11 @@ class _FastConv(torch.autograd.Function):
     def forward(ctx, x, w, bias, kind, plan, relu_input=False):
         gf, kf, nf = plan.fwd
         planes = split_planes(x, relu=relu_input)   # relu_input: the layer is conv(relu(x)); the ReLU happens in the split
-        y = run(planes, _cached_image(w, (kind, 'fwd'), gf, kf, nf), gf, bias, nbytes=plan.fwd_ws)
+        if ctx.needs_input_grad[0]:                 # the data gradient will want its image too: both in one launch
+            img, ctx.bwd_image = weight_image_pair(w, plan.fwd, plan.bwd)
+        else:
+            img, ctx.bwd_image = weight_image(w, gf, kf, nf), None
+        y = run(planes, img, gf, bias, nbytes=plan.fwd_ws)
         # the planes stand in for (relu of) x (same bytes) in the weight gradient; x itself only for the ReLU mask
         ctx.save_for_backward(w, *planes, *((x,) if relu_input else ()))
         ctx.kind, ctx.has_bias, ctx.plan, ctx.relu_input = kind, bias is not None, plan, relu_input
@@ -252,7 +275,8 @@ class _FastConv(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             gb, kb, nb = plan.bwd
-            dx = run(g_planes, _cached_image(w, (kind, 'bwd'), gb, kb, nb), gb, nbytes=plan.bwd_ws)
+            image = ctx.bwd_image if ctx.bwd_image is not None else weight_image(w, gb, kb, nb)
+            dx = run(g_planes, image, gb, nbytes=plan.bwd_ws)
             if ctx.relu_input:
                 dx = torch.ops.aten.threshold_backward(dx, ctx.saved_tensors[4], 0)
         if ctx.needs_input_grad[1]:

@@ -360,7 +360,7 @@ struct WeightArgs {
     signed char r[kMaxPhase][kMaxTaps][4], s[kMaxPhase][kMaxTaps][4];
 };
 
-__global__ __launch_bounds__(256) void conv_weights_kernel(WeightArgs a)
+__device__ __forceinline__ void conv_weights_body(const WeightArgs& a, const int bid, const int nblocks)
 {
     float sc;
     if (a.amax) sc = scale_of(a.amax, a.bound_mul, a.amax_count);
@@ -380,10 +380,10 @@ __global__ __launch_bounds__(256) void conv_weights_kernel(WeightArgs a)
         sc = 1.0f;
         if (m > 0.f && m < 3.0e38f) { int e; (void)frexpf(m, &e); sc = ldexpf(1.0f, 14 - e); }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) a.scale_out[0] = sc;
+    if (bid == 0 && threadIdx.x == 0) a.scale_out[0] = sc;
     const int nchunk = a.K >> 5, nblk = a.Nn >> 5;
     const int64_t groups = (int64_t)a.nphase * a.ntaps * nchunk * nblk * 2 * 64;       // one (hi, lo) pair of 16-B lane chunks each
-    for (int64_t g = blockIdx.x * 256 + threadIdx.x; g < groups; g += (int64_t)gridDim.x * 256) {
+    for (int64_t g = (int64_t)bid * 256 + threadIdx.x; g < groups; g += (int64_t)nblocks * 256) {
         const int lane = g & 63;
         int64_t t = g >> 6;
         const int ks = t & 1; t >>= 1;
@@ -411,6 +411,15 @@ __global__ __launch_bounds__(256) void conv_weights_kernel(WeightArgs a)
         *reinterpret_cast<f16x8*>(dst) = h;
         *reinterpret_cast<f16x8*>(dst + 1024) = l;
     }
+}
+
+__global__ __launch_bounds__(256) void conv_weights_kernel(WeightArgs a) { conv_weights_body(a, blockIdx.x, gridDim.x); }
+
+// the forward image and the data-gradient image of one weight in ONE launch (same source, same scale, other geometry)
+__global__ __launch_bounds__(256) void conv_weights_pair_kernel(WeightArgs a, WeightArgs b, int blocks_a)
+{
+    if ((int)blockIdx.x < blocks_a) conv_weights_body(a, blockIdx.x, blocks_a);
+    else conv_weights_body(b, blockIdx.x - blocks_a, gridDim.x - blocks_a);
 }
 
 // ---- weight gradient: dW[slice][ci][co] = sum over grid points of x[in pixel][ci] * gy[out pixel][co] -------------------
@@ -744,21 +753,13 @@ size_t wc_conv_weights_bytes(const wc_conv_geom* g)
     return (size_t)g->nphase * g->ntaps * g->Cin * g->Cout * 4;      // hi + lo halves
 }
 
-int wc_conv_weights_f32(const float* w, int64_t stride_k, int64_t stride_n, int64_t stride_r, int64_t stride_s, int64_t n_elems,
-                        const wc_conv_geom* g, void* image, float* scale, void* amax_scratch,
-                        const float* known_amax, int known_count, wc_stream_t stream)
+static int fill_weight_args(WeightArgs& a, const float* w, int64_t stride_k, int64_t stride_n, int64_t stride_r, int64_t stride_s,
+                            int64_t n_elems, const wc_conv_geom* g, void* image, float* scale, const float* amax, int amax_count)
 {
-    hipStream_t st = (hipStream_t)stream;
-    if (!w || !g || !image || !scale || (!amax_scratch && !known_amax) || n_elems <= 0) return WC_ERR_ARG;
-    if (known_amax && (known_count < 1 || known_count > 4096)) return WC_ERR_ARG;
     if (g->ntaps < 1 || g->ntaps > kMaxTaps || g->nphase < 1 || g->nphase > kMaxPhase || (g->Cin & 31) || (g->Cout & 31)) return WC_ERR_ARG;
-    // the scale comes from the whole source tensor (n_elems covers its storage extent)
-    const bool inline_max = !known_amax && n_elems <= 32768 && (n_elems & 3) == 0 && ((uintptr_t)w & 15) == 0;   // (a 128 x 128 x 1 x 1 shortcut)
-    if (!inline_max && !known_amax) hipLaunchKernelGGL(conv_absmax_kernel, dim3(kAmaxBlocks), dim3(256), 0, st, w, n_elems / 4, n_elems, (float*)amax_scratch);
-    WeightArgs a;
-    a.n4 = n_elems / 4;
     a.w = w; a.sk = stride_k; a.sn = stride_n; a.sr = stride_r; a.ss = stride_s;
-    a.amax = inline_max ? nullptr : (known_amax ? known_amax : (const float*)amax_scratch); a.amax_count = known_amax ? known_count : kAmaxBlocks; a.scale_out = scale; a.img = (char*)image;
+    a.amax = amax; a.amax_count = amax_count; a.scale_out = scale; a.img = (char*)image;
+    a.n4 = n_elems / 4;
     a.K = g->Cin; a.Nn = g->Cout; a.ntaps = g->ntaps; a.nphase = g->nphase;
     int most = 1;
     for (int p = 0; p < kMaxPhase; ++p)
@@ -771,8 +772,48 @@ int wc_conv_weights_f32(const float* w, int64_t stride_k, int64_t stride_n, int6
             for (int m = 0; m < 4; ++m) { a.r[p][t][m] = g->wr[p][t][m]; a.s[p][t][m] = g->ws[p][t][m]; }
         }
     a.coef = g->wcoef; a.bound_mul = fabsf(g->wcoef) * most;
+    return WC_OK;
+}
+
+int wc_conv_weights_f32(const float* w, int64_t stride_k, int64_t stride_n, int64_t stride_r, int64_t stride_s, int64_t n_elems,
+                        const wc_conv_geom* g, void* image, float* scale, void* amax_scratch,
+                        const float* known_amax, int known_count, wc_stream_t stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (!w || !g || !image || !scale || (!amax_scratch && !known_amax) || n_elems <= 0) return WC_ERR_ARG;
+    if (known_amax && (known_count < 1 || known_count > 4096)) return WC_ERR_ARG;
+    // the scale comes from the whole source tensor (n_elems covers its storage extent)
+    const bool inline_max = !known_amax && n_elems <= 32768 && (n_elems & 3) == 0 && ((uintptr_t)w & 15) == 0;   // (a 128 x 128 x 1 x 1 shortcut)
+    if (!inline_max && !known_amax) hipLaunchKernelGGL(conv_absmax_kernel, dim3(kAmaxBlocks), dim3(256), 0, st, w, n_elems / 4, n_elems, (float*)amax_scratch);
+    WeightArgs a;
+    const int rc = fill_weight_args(a, w, stride_k, stride_n, stride_r, stride_s, n_elems, g, image, scale,
+                                    inline_max ? nullptr : (known_amax ? known_amax : (const float*)amax_scratch), known_amax ? known_count : kAmaxBlocks);
+    if (rc != WC_OK) return rc;
     const int64_t groups = (int64_t)g->nphase * g->ntaps * (g->Cin >> 5) * (g->Cout >> 5) * 128;
     hipLaunchKernelGGL(conv_weights_kernel, dim3(grid_for(groups)), dim3(256), 0, st, a);
+    return (int)hipGetLastError();
+}
+
+int wc_conv_weights_pair_f32(const float* w, int64_t stride_r, int64_t stride_s, int64_t n_elems,
+                             int64_t a_stride_k, int64_t a_stride_n, const wc_conv_geom* ga, void* image_a,
+                             int64_t b_stride_k, int64_t b_stride_n, const wc_conv_geom* gb, void* image_b,
+                             float* scale, void* amax_scratch, const float* known_amax, int known_count, wc_stream_t stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (!w || !ga || !gb || !image_a || !image_b || !scale || (!amax_scratch && !known_amax) || n_elems <= 0) return WC_ERR_ARG;
+    if (known_amax && (known_count < 1 || known_count > 4096)) return WC_ERR_ARG;
+    if (!known_amax) hipLaunchKernelGGL(conv_absmax_kernel, dim3(kAmaxBlocks), dim3(256), 0, st, w, n_elems / 4, n_elems, (float*)amax_scratch);
+    const float* amax = known_amax ? known_amax : (const float*)amax_scratch;
+    const int cnt = known_amax ? known_count : kAmaxBlocks;
+    WeightArgs a, b;
+    int rc = fill_weight_args(a, w, a_stride_k, a_stride_n, stride_r, stride_s, n_elems, ga, image_a, scale, amax, cnt);
+    if (rc != WC_OK) return rc;
+    rc = fill_weight_args(b, w, b_stride_k, b_stride_n, stride_r, stride_s, n_elems, gb, image_b, scale + 1, amax, cnt);
+    if (rc != WC_OK) return rc;
+    if (a.bound_mul != b.bound_mul) return WC_ERR_ARG;             // (one weight, one kind: the same scale both ways)
+    const int blocks_a = grid_for((int64_t)ga->nphase * ga->ntaps * (ga->Cin >> 5) * (ga->Cout >> 5) * 128);
+    const int blocks_b = grid_for((int64_t)gb->nphase * gb->ntaps * (gb->Cin >> 5) * (gb->Cout >> 5) * 128);
+    hipLaunchKernelGGL(conv_weights_pair_kernel, dim3(blocks_a + blocks_b), dim3(256), 0, st, a, b, blocks_a);
     return (int)hipGetLastError();
 }
 
