@@ -330,7 +330,9 @@ def test_overlapped_generator_forward_gives_the_same_step():
     spread = lambda x, y: (float((x[2] - y[2]).abs().max()), float(((x[2] - y[2]).abs() > 2e-5).float().mean()))
     (m_o, f_o), (m_s, f_s) = spread(ovl, seq1), spread(seq1, seq2)
     assert m_o < 1.2e-3 and m_s < 1.2e-3
-    assert f_o < 1.5 * f_s + 0.02
+    # two sequential runs differ in 0.2-0.4 of the weights (measured over many runs); a step that is really different
+    # (e.g. stale convolution weights) differs in 0.85
+    assert f_o < max(1.5 * f_s + 0.02, 0.55)
     assert abs(ovl[0] - seq1[0]) < 5e-3 and abs(ovl[1] - seq1[1]) < 5e-3
 
 
@@ -416,7 +418,9 @@ def test_segment_graphs_cut_at_the_gradient_all_reduces():
     spread = lambda x, y: (float((x - y).abs().max()), float(((x - y).abs() > 2e-5).float().mean()))
     (m_s, f_s), (m_e, f_e) = spread(w_seg, w_e1), spread(w_e1, w_e2)
     assert m_s < 2e-3 and m_e < 2e-3                           # nobody further than 3 steps x ~2 x lr
-    assert f_s < 1.5 * f_e + 0.03
+    # two eager runs differ in 0.2-0.4 of the weights (measured over many runs); a chain that really computes something else
+    # (the stale weight images it once had) differs in 0.85
+    assert f_s < max(1.5 * f_e + 0.03, 0.55)
     assert abs(float(d_loss) - float(dl)) < 2e-2 and abs(float(g_loss) - float(gl)) < 2e-2
 
 
