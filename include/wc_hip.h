@@ -232,6 +232,13 @@ int wc_conv_supported(const wc_conv_geom* g);
 int wc_conv_split_f32(const float* x, int64_t n, int relu, void* hi, void* lo, float* scale, void* amax_scratch,
                       wc_stream_t stream);
 
+/* The same, and -- when `colsum_partials` (WC_CONV_COLSUM_ROWS x C floats) is given -- partial column sums of x seen as
+ * rows of C channels (C a multiple of 4 with 256 % (C/4) == 0), collected while the maximum is taken: the bias gradient of
+ * a layer whose output gradient is being split; wc_conv_wrw_bias_f16x3 adds the rows up. */
+#define WC_CONV_COLSUM_ROWS 512
+int wc_conv_split_colsum_f32(const float* x, int64_t n, int relu, void* hi, void* lo, float* scale, void* amax_scratch,
+                             float* colsum_partials, int C, wc_stream_t stream);
+
 /* Weight fragment images for a geometry: element (k, n, r, s) of the source is w[k*stride_k + n*stride_n + r*stride_r +
  * s*stride_s] (k = reduction channel, n = output channel of the product), `n_elems` = extent of the source storage (for
  * the tensor scale).  `image`: wc_conv_weights_bytes(g) device bytes.  `known_amax` (nullable): `known_count` device
@@ -265,6 +272,13 @@ int wc_conv_wrw_f16x3(const void* xhi, const void* xlo, const float* xscale, con
                       const float* gscale, const void* zero_line, const wc_conv_geom* g, float* dw, int64_t stride_k,
                       int64_t stride_n, int64_t stride_r, int64_t stride_s, void* ws, size_t ws_bytes,
                       wc_stream_t stream);
+
+/* wc_conv_wrw_f16x3 plus the bias gradient db[Cout] = column sums of gy, from the partial rows wc_conv_split_colsum_f32
+ * left while gy was split (fixed summation order, no extra launch). */
+int wc_conv_wrw_bias_f16x3(const void* xhi, const void* xlo, const float* xscale, const void* ghi, const void* glo,
+                           const float* gscale, const void* zero_line, const wc_conv_geom* g, float* dw, int64_t stride_k,
+                           int64_t stride_n, int64_t stride_r, int64_t stride_s, const float* colsum_partials, float* db,
+                           void* ws, size_t ws_bytes, wc_stream_t stream);
 
 /* Bandwidth yardstick used by bench.py: dst[i] = src[i] (float4 grid-stride copy), same stream rules. */
 int wc_stream_copy_f32(const float* src, float* dst, int64_t n, wc_stream_t stream);

@@ -141,15 +141,26 @@ def _plan(kind, x, w):
     return p
 
 
-def split_planes(x, relu=False):
-    """fp32 tensor -> (hi, lo, scale): fp16 planes of s*x and the device scalar s"""
+def _colsum_ok(C):
+    return C % 4 == 0 and 256 % (C // 4) == 0
+
+
+def split_planes(x, relu=False, colsum=False):
+    """fp32 tensor -> (hi, lo, scale): fp16 planes of s*x and the device scalar s.  colsum: also the 512 partial rows of the
+    column sums over the last axis (-> the bias gradient, finished by weight_gradient), returned as a 4th element."""
     lib = _lib.load()
     both = torch.empty((2,) + tuple(x.shape), dtype=torch.float16, device=x.device)
     hi, lo = both[0], both[1]
     scale = torch.empty(1 + 512, dtype=torch.float32, device=x.device)    # [scale | per-workgroup maxima scratch]
-    _lib.check(lib.wc_conv_split_f32(_ptr(x), x.numel(), 1 if relu else 0, _ptr(hi), _ptr(lo), _ptr(scale),
-                                     scale.data_ptr() + 4, _stream()), "wc_conv_split_f32")
-    return hi, lo, scale
+    if not colsum:
+        _lib.check(lib.wc_conv_split_f32(_ptr(x), x.numel(), 1 if relu else 0, _ptr(hi), _ptr(lo), _ptr(scale),
+                                         scale.data_ptr() + 4, _stream()), "wc_conv_split_f32")
+        return hi, lo, scale
+    C = x.shape[-1]
+    part = torch.empty((512, C), dtype=torch.float32, device=x.device)
+    _lib.check(lib.wc_conv_split_colsum_f32(_ptr(x), x.numel(), 1 if relu else 0, _ptr(hi), _ptr(lo), _ptr(scale),
+                                            scale.data_ptr() + 4, _ptr(part), C, _stream()), "wc_conv_split_colsum_f32")
+    return hi, lo, scale, part
 
 
 def _storage_extent(w):
@@ -234,18 +245,25 @@ def _geoms(kind, N, H, W, w):
     return (_phase_geom(N, H, W, ci, co), 0, 1), (_dense_geom(N, 2 * H, 2 * W, co, ci, 4, 2), 1, 0)
 
 
-def weight_gradient(x_planes, g_planes, geom, w, k_axis, n_axis, nbytes=None):
+def weight_gradient(x_planes, g_planes, geom, w, k_axis, n_axis, nbytes=None, colsum=None):
     """dW (in w's own layout) from the split planes of the layer input and of the output gradient; `geom` = the forward
-    geometry."""
+    geometry.  colsum: the partial rows split_planes(gy, colsum=True) left -> returns (dW, db)."""
     lib = _lib.load()
     xh, xl, xs = x_planes
-    gh, gl, gs = g_planes
+    gh, gl, gs = g_planes[:3]
     dw = torch.empty_like(w)
     if dw.stride() != w.stride():
         raise ValueError("weight must be dense")
     if nbytes is None:
         nbytes = lib.wc_conv_wrw_workspace_bytes(ctypes.addressof(geom))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    if colsum is not None:
+        db = torch.empty(geom.Cout, dtype=torch.float32, device=w.device)
+        _lib.check(lib.wc_conv_wrw_bias_f16x3(_ptr(xh), _ptr(xl), _ptr(xs), _ptr(gh), _ptr(gl), _ptr(gs), _ptr(_zero_line(w.device)),
+                                              ctypes.addressof(geom), _ptr(dw), w.stride(k_axis), w.stride(n_axis), w.stride(2),
+                                              w.stride(3), _ptr(colsum), _ptr(db), _ptr(ws), nbytes, _stream()),
+                   "wc_conv_wrw_bias_f16x3")
+        return dw, db
     _lib.check(lib.wc_conv_wrw_f16x3(_ptr(xh), _ptr(xl), _ptr(xs), _ptr(gh), _ptr(gl), _ptr(gs), _ptr(_zero_line(w.device)),
                                      ctypes.addressof(geom), _ptr(dw), w.stride(k_axis), w.stride(n_axis), w.stride(2),
                                      w.stride(3), _ptr(ws), nbytes, _stream()), "wc_conv_wrw_f16x3")
@@ -271,18 +289,24 @@ class _FastConv(torch.autograd.Function):
     def backward(ctx, gy):
         w, xh, xl, xs = ctx.saved_tensors[:4]
         kind, plan = ctx.kind, ctx.plan
-        g_planes = split_planes(gy.contiguous())
+        gy = gy.contiguous()
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        fused_db = want_db and ctx.needs_input_grad[1] and _colsum_ok(gy.shape[-1])    # db rides on the split + the dW reduction
+        g_planes = split_planes(gy, colsum=fused_db)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             gb, kb, nb = plan.bwd
             image = ctx.bwd_image if ctx.bwd_image is not None else weight_image(w, gb, kb, nb)
-            dx = run(g_planes, image, gb, nbytes=plan.bwd_ws)
+            dx = run(g_planes[:3], image, gb, nbytes=plan.bwd_ws)
             if ctx.relu_input:
                 dx = torch.ops.aten.threshold_backward(dx, ctx.saved_tensors[4], 0)
         if ctx.needs_input_grad[1]:
             gf, kf, nf = plan.fwd
-            dw = weight_gradient((xh, xl, xs), g_planes, gf, w, kf, nf, nbytes=plan.wrw_ws)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            if fused_db:
+                dw, db = weight_gradient((xh, xl, xs), g_planes, gf, w, kf, nf, nbytes=plan.wrw_ws, colsum=g_planes[3])
+            else:
+                dw = weight_gradient((xh, xl, xs), g_planes, gf, w, kf, nf, nbytes=plan.wrw_ws)
+        if want_db and not fused_db:
             db = gy.sum((0, 1, 2))
         return dx, dw, db, None, None, None
 

@@ -299,20 +299,33 @@ __global__ __launch_bounds__(256) void conv_ksplit_reduce_kernel(const float* __
 // ---- max |x|: one partial per workgroup (no atomics: deterministic, nothing to clear); the consumers fold the partials ---
 constexpr int kAmaxBlocks = 512;
 
-__global__ __launch_bounds__(256) void conv_absmax_kernel(const float* __restrict__ x, int64_t n4, int64_t n, float* __restrict__ partial)
+__global__ __launch_bounds__(256) void conv_absmax_kernel(const float* __restrict__ x, int64_t n4, int64_t n, float* __restrict__ partial,
+                                                          float* __restrict__ colsum = nullptr, int c4n = 0)
 {
     __shared__ float red[4];
+    __shared__ f32x4 red4[256];
     float m = 0.f;
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f};
     for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * i);
         m = fmaxf(fmaxf(m, fabsf(v[0])), fmaxf(fabsf(v[1]), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        cs += v;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) for (int64_t i = 4 * n4; i < n; ++i) m = fmaxf(m, fabsf(x[i]));
     #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    if (colsum) red4[threadIdx.x] = cs;
     __syncthreads();
     if (threadIdx.x == 0) partial[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    // column sums of a [rows][C] tensor (the bias gradient) while it streams by: a thread always sees the same 4 channels
+    // (256 and the grid stride are multiples of C/4); the threads of a channel group meet in LDS, the workgroups' partial
+    // rows are added up behind the weight-gradient reduction (conv_wrw_reduce_kernel) in a fixed order
+    if (colsum && (int)threadIdx.x < c4n) {
+        f32x4 t = red4[threadIdx.x];
+        for (int p = threadIdx.x + c4n; p < 256; p += c4n) t += red4[p];
+        *reinterpret_cast<f32x4*>(colsum + (int64_t)blockIdx.x * 4 * c4n + 4 * threadIdx.x) = t;
+    }
 }
 
 // power-of-two scale that puts max|x| into [2^13, 2^14); every thread of a workgroup folds the partials (L2 hits)
@@ -670,6 +683,7 @@ struct WrwReduceArgs {
     const float* xscale; const float* gscale;
     float* dw; int64_t sa, sb, sr, ss;                   // element (a, b, r, s) -> dw[a*sa + b*sb + r*sr + s*ss]
     float coef;
+    const float* colsum; float* db; int c4n, main_blocks;   // optional bias gradient: kAmaxBlocks partial rows [C] -> db[C]
     int nout;                                            // source taps of the weight; each collects the slices built from it
     signed char r[kMaxTaps], s[kMaxTaps], cnt[kMaxTaps], slice[kMaxTaps][4];
 };
@@ -678,10 +692,23 @@ __global__ __launch_bounds__(256) void conv_wrw_reduce_kernel(WrwReduceArgs a)
 {
     // four lanes per output float4: each takes every fourth range, a fixed two-step butterfly joins them (the order of the
     // additions is the same in every run) -- four times the loads in flight of one thread walking all the ranges
+    if ((int)blockIdx.x >= a.main_blocks) {
+        // bias gradient: one wave per 4 channels, a lane adds every 64th partial row, fixed butterfly
+        const int u = ((int)blockIdx.x - a.main_blocks) * 256 + threadIdx.x, cg = u >> 6, lane = u & 63;
+        if (cg >= a.c4n) return;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int b = lane; b < kAmaxBlocks; b += 64) v += *reinterpret_cast<const f32x4*>(a.colsum + (int64_t)b * 4 * a.c4n + 4 * cg);
+        #pragma unroll
+        for (int j = 0; j < 4; ++j)
+            #pragma unroll
+            for (int o = 1; o < 64; o <<= 1) v[j] += __shfl_xor(v[j], o);
+        if (lane == 0) *reinterpret_cast<f32x4*>(a.db + 4 * cg) = v;
+        return;
+    }
     const int64_t plane = (int64_t)a.Ca * a.Cb, per = (int64_t)a.nslice * plane, total4 = (int64_t)a.nout * plane >> 2;
     const float inv = a.coef / (a.xscale[0] * a.gscale[0]);
     const int part = threadIdx.x & 3;
-    for (int64_t e4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 2; e4 < total4; e4 += (int64_t)gridDim.x * 64) {
+    for (int64_t e4 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 2; e4 < total4; e4 += (int64_t)a.main_blocks * 64) {
         const int64_t e = e4 * 4;
         const int o = e / plane; const int64_t w = e - o * plane;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -739,9 +766,17 @@ extern "C" {
 
 int wc_conv_split_f32(const float* x, int64_t n, int relu, void* hi, void* lo, float* scale, void* amax_scratch, wc_stream_t stream)
 {
+    return wc_conv_split_colsum_f32(x, n, relu, hi, lo, scale, amax_scratch, nullptr, 0, stream);
+}
+
+int wc_conv_split_colsum_f32(const float* x, int64_t n, int relu, void* hi, void* lo, float* scale, void* amax_scratch,
+                             float* colsum_partials, int C, wc_stream_t stream)
+{
     hipStream_t st = (hipStream_t)stream;
     if (!x || !hi || !lo || !scale || !amax_scratch || n <= 0 || (n & 3)) return WC_ERR_ARG;
-    hipLaunchKernelGGL(conv_absmax_kernel, dim3(kAmaxBlocks), dim3(256), 0, st, x, n / 4, n, (float*)amax_scratch);
+    if (colsum_partials && (C <= 0 || (C & 3) || 256 % (C >> 2) != 0 || n % C != 0)) return WC_ERR_SHAPE;
+    hipLaunchKernelGGL(conv_absmax_kernel, dim3(kAmaxBlocks), dim3(256), 0, st, x, n / 4, n, (float*)amax_scratch,
+                       colsum_partials, colsum_partials ? C >> 2 : 0);
     hipLaunchKernelGGL(conv_split_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, x, n / 4, (const float*)amax_scratch, relu,
                        (_Float16*)hi, (_Float16*)lo, scale);
     return (int)hipGetLastError();
@@ -918,6 +953,15 @@ int wc_conv_wrw_f16x3(const void* xhi, const void* xlo, const float* xscale, con
                       const void* zero_line, const wc_conv_geom* g, float* dw, int64_t stride_k, int64_t stride_n,
                       int64_t stride_r, int64_t stride_s, void* ws, size_t ws_bytes, wc_stream_t stream)
 {
+    return wc_conv_wrw_bias_f16x3(xhi, xlo, xscale, ghi, glo, gscale, zero_line, g, dw, stride_k, stride_n, stride_r, stride_s,
+                                  nullptr, nullptr, ws, ws_bytes, stream);
+}
+
+int wc_conv_wrw_bias_f16x3(const void* xhi, const void* xlo, const float* xscale, const void* ghi, const void* glo, const float* gscale,
+                           const void* zero_line, const wc_conv_geom* g, float* dw, int64_t stride_k, int64_t stride_n,
+                           int64_t stride_r, int64_t stride_s, const float* colsum_partials, float* db,
+                           void* ws, size_t ws_bytes, wc_stream_t stream)
+{
     hipStream_t st = (hipStream_t)stream;
     if (!xhi || !xlo || !xscale || !ghi || !glo || !gscale || !zero_line || !g || !dw || !ws) return WC_ERR_NULL;
     if (!wc_conv_supported(g) || (g->Cin & 127) || g->W < 2 || g->H * g->W < 2) return WC_ERR_SHAPE;
@@ -977,7 +1021,12 @@ int wc_conv_wrw_f16x3(const void* xhi, const void* xlo, const float* xscale, con
     r.partial = (const float*)ws; r.splits = splits; r.nslice = nslice; r.Ca = a.A.C; r.Cb = a.B.C;
     r.xscale = xscale; r.gscale = gscale; r.dw = dw;
     r.sa = x_cols ? stride_n : stride_k; r.sb = x_cols ? stride_k : stride_n; r.sr = stride_r; r.ss = stride_s;
-    hipLaunchKernelGGL(conv_wrw_reduce_kernel, dim3(grid_for((int64_t)r.nout * g->Cin * g->Cout)), dim3(256), 0, st, r);
+    if ((colsum_partials == nullptr) != (db == nullptr)) return WC_ERR_NULL;
+    if (db && ((g->Cout & 3) || 256 % (g->Cout >> 2) != 0)) return WC_ERR_SHAPE;
+    r.colsum = colsum_partials; r.db = db; r.c4n = db ? g->Cout >> 2 : 0;
+    r.main_blocks = grid_for((int64_t)r.nout * g->Cin * g->Cout);
+    const int extra = db ? (r.c4n * 64 + 255) / 256 : 0;
+    hipLaunchKernelGGL(conv_wrw_reduce_kernel, dim3(r.main_blocks + extra), dim3(256), 0, st, r);
     return (int)hipGetLastError();
 }
 
