@@ -2,7 +2,8 @@
 
 The discriminator holds NO whitening-and-coloring site in any shipped recipe (`--discriminator_norm`
 defaults to 'n', run.py:298), so it is the stock-torch part of the surrounding step: SN-ResNet blocks
-on MIOpen convolutions with the fused spectral-norm op (wc_gan_amd/spectral.py) standing in for gan.SNConv2D /
+on the block convolutions of wc_gan_amd/conv.py (MIOpen for the 3-channel first layers) with the fused spectral-norm op
+(wc_gan_amd/spectral.py) standing in for gan.SNConv2D /
 SNDense / SNEmbeding (discriminator.py:26-33).  Three heads as in discriminator.py:73-85.
 """
 from __future__ import annotations

@@ -36,7 +36,7 @@ AFTER_NORMS = ['ucs', 'ccs', 'uccs', 'uconv', 'fconv', 'ufconv', 'cconv', 'uccon
 
 
 # ---------------------------------------------------------------------------------------------
-# NHWC plumbing around torch's convolutions (the surrounding step is stock torch / MIOpen)
+# NHWC plumbing around the convolutions (wc_gan_amd/conv.py where the kernel takes the shape, torch / MIOpen otherwise)
 # ---------------------------------------------------------------------------------------------
 def to_nchw_view(x):
     return x.permute(0, 3, 1, 2)          # NHWC-contiguous -> channels_last NCHW view, zero copy
