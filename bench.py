@@ -1,43 +1,101 @@
 #!/usr/bin/env python3
-"""bench.py -- images/sec of the G+D training step, CIFAR-10 ResNet-SN + WC, batch 64 per GPU.
+"""bench.py -- images/sec of the G+D training step, ResNet-SN + WC, batch 64 per GPU (default: CIFAR-10 uncond).
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched through
-torch.distributed.run, one rank per GPU over RCCL.  Rank 0 prints ONE JSON line.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`.  With N > 1 and no WORLD_SIZE in the environment
+this process only LAUNCHES the job -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py ...`
+as a child, before anything here touches the GPU -- and exits with the child's code; when the driver starts the ranks
+itself (WORLD_SIZE set) each rank checks WORLD_SIZE == --gpus.  One rank per GPU over RCCL; rank 0 prints ONE JSON line.
 
   step      one "G+D step" = training_ratio critic updates (64 real + 64 generated, generator forward in
             train mode) + one generator update at batch 64 x 2 (run.py:101,293-294); images/sec = 64 x steps/s
             per GPU (weak scaling: every GPU keeps batch 64).
   roofline  the dominant hand-written kernel, the fused WC apply (K3) at the headline site
             128 x 32 x 32 x 256: algorithmic bytes 2*M*C*4 + (C*C + C)*4 per launch over the launch time
-            measured here with HIP events on the launching stream, against the 8 TB/s HBM3E peak.
-  cpu_baseline  the float64 numpy oracle (kind "port") timed on this box's host cores over the WC sites of
-            one G+D step -- the hot path only, the convolutions are not part of it.
+            measured here with HIP events on the launching stream, against the 8 TB/s HBM3E peak (and against the
+            same-run stream copy).
+  cpu_baseline  the reference's UNFUSED fp32 op order (SURVEY.md rows a2 + a6: transpose -> mean -> f f^T/(M-1) ->
+            shrink -> cholesky -> triangular solve vs I -> W f -> transpose back -> 1x1 conv + bias; autograd for the
+            backward) as the torch-CPU sequence of BASELINE.md section 3, timed on this box's host cores over the WC
+            sites of one G+D step; the float64 oracle only CHECKS its output.
+
+--config picks one of BASELINE.json's GPU configurations (wc_gan_amd.train.CONFIGS); the default is the headline one.
+--dry-run is the CPU rehearsal of the N-rank path (gloo, a tiny model without HIP layers): launch, rendezvous, the
+flat gradient buckets and the place of every all-reduce -- what tests/test_bench_launch.py checks with two ranks.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 os.environ.setdefault("PYTORCH_MIOPEN_SUGGEST_NHWC", "1")
 
-import torch
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 TRAINING_RATIO = 5             # default of the missing gan.cmd parser [UPSTREAM-RECALL]; ratio 1 also reported
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md); the power-limited sustained rate measured here is 1430
+CONFIG_NAMES = ("cifar10_uncond", "cifar10_cond", "stl10_uncond", "tinyimagenet_cond_sa")
+WORKLOADS = {
+    "cifar10_uncond": "CIFAR-10 ResNet SN uncond + WC (scripts/cifar10_resnet_sn_uncond.sh)",
+    "cifar10_cond": "CIFAR-10 ResNet SN conditional, class-conditional coloring (scripts/cifar10_resnet_sn_cond.sh)",
+    "stl10_uncond": "STL-10 ResNet SN uncond + WC, 48x48 (scripts/stl10_resnet_sn_uncond.sh)",
+    "tinyimagenet_cond_sa": "Tiny-ImageNet ResNet SN cond-SA, 64x64, 200 classes (scripts/tinyimagenet_resnet_sn_cond_sa.sh)",
+}
 
-# WC sites of the CIFAR-10 unconditional generator: (H=W, C) per site
-CIFAR_SITES = [(4, 256), (8, 256), (8, 256), (16, 256), (16, 256), (32, 256), (32, 256)]
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", choices=CONFIG_NAMES, default="cifar10_uncond",
+                    help="which BASELINE.json configuration to step (default: the headline one)")
+    ap.add_argument("--training-ratio", type=int, default=TRAINING_RATIO)
+    ap.add_argument("--sync-wc", action="store_true", help="all-reduce WC statistics across replicas")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the whole G+D step as one hipGraph.  The default on one GPU: with ~2000 launches per step the "
+                         "eager loop is at the edge of host-bound; the eager step is reported next to it")
+    ap.add_argument("--segments", action="store_true",
+                    help="replay the step as a chain of hipGraphs cut at the gradient all-reduces, which stay plain RCCL calls "
+                         "(the default with several GPUs, unless --sync-wc puts collectives inside the WC layers); if any "
+                         "rank fails to record its chain, ALL ranks run eagerly")
+    ap.add_argument("--eager", action="store_true", help="launch kernel by kernel from Python")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU rehearsal of the N-rank launch path: gloo backend, a tiny model without HIP layers")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args, argv):
+    """--gpus N > 1 without a launcher around us: start N fresh rank processes.  Nothing in THIS process has touched
+    the GPU (no torch.cuda call so far), and it never execs: it waits for the child and returns its exit code."""
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    print(f"[bench] launching {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
 
 
 def time_kernel(fn, iters=20, warm=3):
+    import torch
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -51,6 +109,7 @@ def time_kernel(fn, iters=20, warm=3):
 
 
 def roofline_apply(dev):
+    import torch
     from wc_gan_amd import ops
     N, H, C = 128, 32, 256
     M = N * H * H
@@ -71,24 +130,35 @@ def roofline_apply(dev):
     y2 = torch.empty_like(x)
     t_copy = time_kernel(lambda: ops.stream_copy(x, y2))
     achieved = alg_bytes / t / 1e9
-    traffic = None          # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see the file)
-    pmc = os.path.join(ROOT, "profiles", "r1_apply_k3_pmc.json")
-    if os.path.exists(pmc):
-        traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
+    # HBM bytes per launch: NOT measured in this run -- read from the committed PMC passes of the same command
+    # (FETCH_SIZE x2 + WRITE_SIZE, collected as MI355X_MICROARCH.md's HBM section prescribes; see the file)
+    traffic = src = None
+    for name in ("r2_apply_k3_pmc.json", "r1_apply_k3_pmc.json"):
+        pmc = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(pmc):
+            traffic, src = json.load(open(pmc)).get("traffic_bytes_per_launch"), "profiles/" + name
+            break
+    # the whole forward site as the layer runs it (K1 -> K2 -> color -> K3), for the record: 3*M*C*4 algorithmic bytes
+    def site():
+        s_, xtx_ = ops.stats(x.view(M, C))
+        mu_, _, W_, cs_ = ops.factor(s_, xtx_, M, C, 1e-3, 0.99, 1, True, None, None, dev, want_scale=True)
+        A_, _, plan_ = ops.color(W_, gamma, cs_)
+        ops.apply(x, mu_, A_, b, None, out=y, plan=plan_)
+    t_site = time_kernel(site, iters=10)
     return {"bound": "hbm", "kernel": "affine_ring_kernel<256,false> (wc_apply_f32 with plan, 128x32x32x256 fp32)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_from_committed_profile": src,
             "launch_us": round(t * 1e6, 2), "algorithmic_bytes": alg_bytes,
             "stream_copy_GBs": round(2 * M * C * 4 / t_copy / 1e9, 1),
-            "frac_of_stream_copy": round(achieved / (2 * M * C * 4 / t_copy / 1e9), 4)}
-
-
-MFMA_F16_PEAK_TFLOPS = 2500.0      # dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md); the power-limited sustained rate measured here is 1430
+            "frac_of_stream_copy": round(achieved / (2 * M * C * 4 / t_copy / 1e9), 4),
+            "forward_site_us": round(t_site * 1e6, 1),
+            "forward_site_frac_of_peak": round(3 * M * C * 4 / t_site / 1e9 / HBM_PEAK_GBS, 4)}
 
 
 def conv_roofline(dev):
     """The kernel the step spends most time in after the WC path: the 3x3 256->256 block convolution at 128x32x32
     (conv_f16x3_kernel<4,4>), MFMA-bound: 3 fp16 MFMA products per fp32 product."""
+    import torch
     from wc_gan_amd import conv as C
     N, H, Cc = 128, 32, 256
     g = torch.Generator(device="cpu"); g.manual_seed(1234)
@@ -104,17 +174,23 @@ def conv_roofline(dev):
             "fp32_equivalent_TFLOPs": round(flop32 / t / 1e12, 1), "frac_of_sustained_1430": round(3 * flop32 / t / 1e12 / 1430.0, 4)}
 
 
-def wc_sites_gpu(dev, ratio):
-    """GPU time of the WC sites of one G+D step (what cpu_baseline times on the host)."""
+def site_list(config_name):
+    from wc_gan_amd.train import CONFIGS, wc_sites
+    return [(h, w, c) for _, _, h, w, c in wc_sites(CONFIGS[config_name], 64)]
+
+
+def wc_sites_gpu(dev, ratio, sites):
+    """GPU time of the WC sites of one G+D step (what cpu_baseline times on the host), unconditional coloring."""
+    import torch
     from wc_gan_amd.functional import whiten_color, whiten_color_grouped
     g = torch.Generator(device="cpu"); g.manual_seed(1234)
     work = []
-    for H, C in CIFAR_SITES:
+    for H, W, C in sites:
         G = (torch.randn(1, C, C, generator=g) / C ** 0.5).to(dev).requires_grad_(True)
         B = torch.zeros(1, C, device=dev, requires_grad=True)
-        xd = torch.randn(64 * ratio, H, H, C, generator=g).to(dev)      # the critic-phase passes, stacked (train.generate)
-        x128 = torch.randn(128, H, H, C, generator=g).to(dev).requires_grad_(True)
-        work.append((xd, x128, G, B, torch.randn(128, H, H, C, generator=g).to(dev)))
+        xd = torch.randn(64 * ratio, H, W, C, generator=g).to(dev)      # the critic-phase passes, stacked (train.generate)
+        x128 = torch.randn(128, H, W, C, generator=g).to(dev).requires_grad_(True)
+        work.append((xd, x128, G, B, torch.randn(128, H, W, C, generator=g).to(dev)))
 
     def one():
         for xd, x128, G, B, gy in work:
@@ -124,53 +200,170 @@ def wc_sites_gpu(dev, ratio):
     return time_kernel(one, iters=5, warm=2)
 
 
-def cpu_baseline(ratio):
+# ---------------------------------------------------------------------------------------------------------------------
+# cpu_baseline: the reference's unfused fp32 op order on the host cores
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_unfused_site(x, kernel, bias, eps=1e-3):
+    """DecorelationNormalization.call + Conv2D 1x1 as the TF graph runs them, op by op, fp32:
+    transpose to (C, M) -> mean -> centre -> f f^T/(M-1) -> (1-eps) Sigma + eps I -> cholesky -> triangular solve
+    against I -> W f -> reshape/transpose back to NHWC -> 1x1 convolution + bias."""
+    import torch
+    N, H, W_, C = x.shape
+    xt = x.permute(3, 0, 1, 2).reshape(C, -1)
+    M = xt.shape[1]
+    mu = xt.mean(dim=1, keepdim=True)
+    f = xt - mu
+    sigma = (f @ f.t()) / (M - 1)
+    eye = torch.eye(C, dtype=x.dtype)
+    T = (1.0 - eps) * sigma + eps * eye
+    L = torch.linalg.cholesky(T)
+    Wm = torch.linalg.solve_triangular(L, eye, upper=False)
+    xh = (Wm @ f).reshape(C, N, H, W_).permute(1, 2, 3, 0)
+    return xh @ kernel + bias                   # Keras Conv2D(kernel_size=(1,1)) on NHWC: a per-pixel (C_in, C_out) product
+
+
+def cpu_baseline(ratio, sites, config_name):
     import numpy as np
+    import torch
     from oracle import wc_oracle as o
-    rng = np.random.default_rng(1234)
-    t_total = 0.0
-    for H, C in CIFAR_SITES:
-        G, B = o.synth_coloring(rng, C, 1)
-        x64 = rng.standard_normal((64, H, H, C)).astype(np.float32)
-        x128 = rng.standard_normal((128, H, H, C)).astype(np.float32)
-        gy = rng.standard_normal((128, H, H, C)).astype(np.float32)
-        t0 = time.perf_counter()
-        for _ in range(ratio):
-            o.wc_forward(x64, G, B)
-        y, cache = o.wc_forward(x128, G, B)
-        o.wc_backward(gy, cache)
-        t_total += time.perf_counter() - t0
     cores = os.cpu_count() or 1
-    return {"value": round(64.0 / t_total, 3), "unit": "images/sec (WC sites of one G+D step only)",
-            "cores": cores, "kind": "port",
-            "sample": f"float64 numpy oracle, 7 generator WC sites, {ratio} forward passes at N=64 + 1 forward+backward "
-                      f"at N=128 = the WC work of one G+D step ({t_total:.1f} s), BLAS threads = {cores}"}
+    g = torch.Generator(device="cpu"); g.manual_seed(1234)
+    work = []
+    for H, W, C in sites:
+        k = torch.randn(C, C, generator=g) / C ** 0.5
+        b = torch.zeros(C)
+        work.append((torch.randn(64, H, W, C, generator=g), torch.randn(128, H, W, C, generator=g),
+                     torch.randn(128, H, W, C, generator=g), k, b))
+
+    def one():
+        for x64, x128, gy, k, b in work:
+            with torch.no_grad():
+                for _ in range(ratio):
+                    cpu_unfused_site(x64, k, b)
+            xr = x128.detach().requires_grad_(True); kr = k.detach().requires_grad_(True); br = b.detach().requires_grad_(True)
+            cpu_unfused_site(xr, kr, br).backward(gy)
+
+    def timed(n):
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter(); one(); ts.append(time.perf_counter() - t0)
+        return sorted(ts)[len(ts) // 2]
+
+    # the checker: the float64 oracle on the baseline's own output (one mid-sized site)
+    H, W, C = sites[min(2, len(sites) - 1)]
+    rng = np.random.default_rng(7)
+    xs = o.synth_activation(rng, (64, H, W, C), "well").astype(np.float32)
+    Gs, Bs = o.synth_coloring(rng, C, 1)
+    y_cpu = cpu_unfused_site(torch.from_numpy(xs), torch.from_numpy(Gs[0].astype(np.float32)), torch.from_numpy(Bs[0].astype(np.float32)))
+    y_ref, _ = o.wc_forward(xs, Gs, Bs)
+    err = float(np.abs(y_cpu.numpy() - y_ref).max() / np.abs(y_ref).max())
+
+    prev = torch.get_num_threads()
+    cands = sorted({t for t in (8, 16, 32, 64, 128) if t <= cores} | {min(cores, 128)})
+    sweep = {}
+    for t in cands:                       # short sweep (1 warm-up + 2 runs each), then the median of 10 at the best count
+        torch.set_num_threads(t)
+        one()
+        sweep[t] = timed(2)
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    one(); one()
+    t_med = timed(10)
+    torch.set_num_threads(prev)
+    return {"value": round(64.0 / t_med, 3), "unit": "images/sec (WC sites of one G+D step only)",
+            "cores": best, "host_cores": cores, "kind": "unfused-fp32",
+            "threads_sweep_s": {str(k): round(v, 3) for k, v in sweep.items()},
+            "checked_vs_oracle_rel_err": err,
+            "sample": f"torch-CPU fp32, the reference's unfused op order (transpose, mean, f f^T/(M-1), shrink, cholesky, "
+                      f"solve_triangular vs I, W f, transpose, 1x1 conv + bias; autograd backward) over the {len(sites)} generator "
+                      f"WC sites of {config_name}: {ratio} forward passes at N=64 + 1 forward+backward at N=128 = the WC work "
+                      f"of one G+D step; median of 10 after 2 warm-ups = {t_med:.3f} s on {best} threads"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--training-ratio", type=int, default=TRAINING_RATIO)
-    ap.add_argument("--sync-wc", action="store_true", help="all-reduce WC statistics across replicas")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay the whole G+D step as one hipGraph.  The default on one GPU: with ~2000 launches per step the "
-                         "eager loop is at the edge of host-bound (26-32 ms per step depending on the box's CPU, against "
-                         "26.5 ms of GPU work); the eager step is reported next to it")
-    ap.add_argument("--segments", action="store_true",
-                    help="replay the step as a chain of hipGraphs cut at the gradient all-reduces, which stay plain RCCL calls "
-                         "(the default with several GPUs, unless --sync-wc puts collectives inside the WC layers)")
-    ap.add_argument("--eager", action="store_true", help="launch kernel by kernel from Python (the default with several GPUs: "
-                    "capturing the RCCL all-reduces could not be tried on the one-GPU development box)")
-    args = ap.parse_args()
+# ---------------------------------------------------------------------------------------------------------------------
+def dry_run(args, world, rank):
+    """The N-rank path on the CPU: rendezvous over gloo, flat gradient buckets, GanTrainer.step with the all-reduces,
+    the cut points capture_segments() would use -- with a tiny model that contains no HIP layer (batch norm + diagonal
+    coloring, plain convolutions), since the WC path has no CPU fallback."""
+    import torch
+    import torch.distributed as dist
+    from wc_gan_amd.discriminator import make_discriminator
+    from wc_gan_amd.generator import make_generator
+    from wc_gan_amd.train import GanTrainer, broadcast_state
+    group = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        group = dist.group.WORLD
+        assert dist.get_world_size() == args.gpus
+    torch.manual_seed(1234)
+    G = make_generator(block_sizes=(8, 8), resamples=("UP", "UP"), first_block_shape=(4, 4, 8), block_norm='b',
+                       block_after_norm='ucs', last_norm='b', last_after_norm='ucs')
+    D = make_discriminator(input_image_shape=(16, 16, 3), block_sizes=(8, 8), resamples=('DOWN', 'SAME'), type=None,
+                           spectral=False, sum_pool=True)
+    with torch.no_grad():                        # build the lazy layers, then make the replicas identical
+        G(torch.zeros(2, 128), torch.zeros(2, 1, dtype=torch.int32))
+    broadcast_state(G, group=group); broadcast_state(D, group=group)
+    ratio = min(args.training_ratio, 2)
+    tr = GanTrainer(G, D, batch_size=4, training_ratio=ratio, process_group=group, seed=1234, flat_buckets=True)
+    g = torch.Generator(device="cpu"); g.manual_seed(1234 + rank)
+    reals = [torch.rand(4, 16, 16, 3, generator=g) * 2 - 1 for _ in range(ratio)]
+    for _ in range(args.warmup):
+        tr.step(reals)
+    order, _ = tr.trace_boundaries(reals)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.step(reals)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    w = torch.cat([p.detach().reshape(-1) for p in list(G.parameters()) + list(D.parameters())])
+    same = True
+    orders = [order]
+    if world > 1:
+        ws = [torch.zeros_like(w) for _ in range(world)]
+        dist.all_gather(ws, w)
+        same = all(torch.equal(ws[0], t) for t in ws)          # averaged gradients + identical start -> identical replicas
+        orders = [None] * world
+        dist.all_gather_object(orders, order)
+        tmax = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank == 0:
+        print(json.dumps({"metric": "images/sec G+D step (dry run: tiny CPU model, not a measurement)", "dry_run": True,
+                          "value": round(4.0 * world * args.steps / dt, 2), "unit": "images/sec", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+                          "replicas_identical": bool(same), "allreduce_order": orders, "finite": bool(torch.isfinite(w).all())}),
+              flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if same and all(o_ == orders[0] for o_ in orders) else 1
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        return launch_ranks(args, argv)           # before any GPU call in this process
+    world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: refusing to report a {world}-rank run as {args.gpus} GPUs",
+              file=sys.stderr)
+        return 2
+    if args.dry_run:
+        return dry_run(args, world, rank)
+
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the WC path has no CPU fallback")
+        raise SystemExit("bench.py needs an MI355X: the WC path has no CPU fallback (--dry-run rehearses the launch path)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     group = None
@@ -179,51 +372,72 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29577")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         group = dist.group.WORLD
+        if dist.get_world_size() != args.gpus:
+            print(f"[bench] RCCL sees {dist.get_world_size()} ranks, --gpus {args.gpus}", file=sys.stderr)
+            return 2
 
     from wc_gan_amd import _lib
-    from wc_gan_amd.train import CIFAR10_UNCOND, build_trainer
+    from wc_gan_amd.train import CONFIGS, build_trainer
     _lib.load()
+    cfg = CONFIGS[args.config]
     torch.manual_seed(1234)
     kw = dict(flat_buckets=True) if os.environ.get("WC_FORCE_COLLECTIVES") == "1" else {}      # development: the N > 1 layout on one GPU
-    trainer = build_trainer(CIFAR10_UNCOND, dev, process_group=group, sync_wc=args.sync_wc, **kw,
-                            training_ratio=args.training_ratio, seed=1234 + rank)
+    trainer = build_trainer(cfg, dev, process_group=group, sync_wc=args.sync_wc, **kw,
+                            training_ratio=args.training_ratio, seed=1234)      # (the trainer adds the rank to the seed)
+    H, W, Ci = cfg['image_shape']
+    K = cfg['generator']['number_of_classes']
     g = torch.Generator(device="cpu"); g.manual_seed(1234 + rank)
-    reals = [(torch.rand(64, 32, 32, 3, generator=g) * 2 - 1).to(dev) for _ in range(args.training_ratio)]
+    reals = [(torch.rand(64, H, W, Ci, generator=g) * 2 - 1).to(dev) for _ in range(args.training_ratio)]
+    labels = None
+    if cfg['conditional']:            # real images come with their labels (run.py:317 supervised=True)
+        labels = [torch.randint(0, K, (64, 1), generator=g, dtype=torch.int32).to(dev) for _ in range(args.training_ratio)]
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    step = lambda: trainer.step(reals)
+    def all_ok(ok):
+        """the launch mode is agreed by ALL ranks: one rank replaying graphs next to an eager one is not a supported mix"""
+        if group is None:
+            return ok
+        flag = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item())
+
+    eager_step = lambda: trainer.step(reals, labels)
+    step = eager_step
     for _ in range(args.warmup):
         step()
     launch_mode = "eager"
-    eager_step = step
-    in_group = dist.is_available() and dist.is_initialized()
+    in_group = group is not None
     if args.graph and in_group:
         # tried on one GPU with a one-rank group: capturing the RCCL all-reduce aborts the process (SIGABRT inside the
         # capture) -- the chain of graphs with the collectives between them is the supported form
         print("[bench] --graph with a process group: using --segments (collectives cannot be captured)", file=sys.stderr)
         args.graph, args.segments = False, True
     if args.segments or (world > 1 and not args.eager and not args.sync_wc):
+        replay, ok = None, True
         try:
-            step = trainer.capture_segments(reals)
-            launch_mode = "hipgraph-segments"
-            step()
+            replay = trainer.capture_segments(reals, labels)
         except Exception as exc:
-            print(f"[bench] segment capture failed ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
+            ok = False
+            print(f"[bench] rank {rank}: segment capture failed ({type(exc).__name__}: {exc})", file=sys.stderr)
             torch.cuda.synchronize()
-            step = lambda: trainer.step(reals)
+        if all_ok(ok):
+            step, launch_mode = replay, "hipgraph-segments"
+            step()
+        else:
+            print("[bench] segment capture did not succeed on every rank: all ranks run eagerly", file=sys.stderr)
     elif args.graph or (world == 1 and not args.eager):
         try:
-            step = trainer.capture(reals)        # the whole G+D step as one hipGraph: the host leaves the loop
+            step = trainer.capture(reals, labels)        # the whole G+D step as one hipGraph: the host leaves the loop
             launch_mode = "hipgraph"
             step()
-        except Exception as exc:                 # e.g. a collective that refuses capture: fall back, say so
+        except Exception as exc:                 # fall back, say so
             print(f"[bench] graph capture failed ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
             torch.cuda.synchronize()
-            step = lambda: trainer.step(reals)
+            step = eager_step
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -240,12 +454,12 @@ def main():
     if args.training_ratio != 1:
         trainer.training_ratio = 1
         for _ in range(2):
-            trainer.step(reals)
+            eager_step()
         barrier()
         t1 = time.perf_counter()
         n1 = max(3, args.steps // 2)
         for _ in range(n1):
-            trainer.step(reals)
+            eager_step()
         barrier()
         dt1 = (time.perf_counter() - t1) / n1
         if world > 1:
@@ -264,38 +478,43 @@ def main():
         barrier()
         dt_eager = (time.perf_counter() - te) / ne
 
-    extra = {}
     if rank == 0:
+        extra = {}
         if dt_eager is not None:
             extra["eager_launch"] = {"value": round(64.0 * world / dt_eager, 2), "unit": "images/sec", "ms_per_step": round(dt_eager * 1e3, 3)}
         if dt1 is not None:
-            extra["training_ratio_1"] = {"value": round(64.0 * world / dt1, 2), "unit": "images/sec", "ms_per_step": round(dt1 * 1e3, 3)}
+            extra["training_ratio_1"] = {"value": round(64.0 * world / dt1, 2), "unit": "images/sec", "ms_per_step": round(dt1 * 1e3, 3),
+                                         "launch": "eager"}
         roof = roofline_apply(dev)
-        extra["roofline_conv"] = conv_roofline(dev)
-        wc_gpu = wc_sites_gpu(dev, args.training_ratio)
-        extra["wc_sites_gpu"] = {"value": round(64.0 / wc_gpu, 1), "unit": "images/sec (WC sites of one G+D step only)",
-                                 "ms": round(wc_gpu * 1e3, 3)}
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(args.training_ratio)
+        if world == 1:
+            sites = site_list(args.config)
+            extra["roofline_conv"] = conv_roofline(dev)
+            wc_gpu = wc_sites_gpu(dev, args.training_ratio, sites)
+            extra["wc_sites_gpu"] = {"value": round(64.0 / wc_gpu, 1), "unit": "images/sec (WC sites of one G+D step only)",
+                                     "ms": round(wc_gpu * 1e3, 3)}
+            if not args.no_cpu_baseline:
+                cpu = cpu_baseline(args.training_ratio, sites, args.config)
         out = {
-            "metric": "images/sec G+D step, CIFAR-10 ResNet-SN+WC, batch 64",
+            "metric": "images/sec G+D step, CIFAR-10 ResNet-SN+WC, batch 64" if args.config == "cifar10_uncond"
+                      else f"images/sec G+D step, {args.config} ResNet-SN+WC, batch 64",
             "value": round(64.0 * world * args.steps / dt, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "CIFAR-10 ResNet SN uncond + WC (scripts/cifar10_resnet_sn_uncond.sh), batch 64/GPU, "
-                                   f"training_ratio {args.training_ratio}, generator_batch_multiple 2",
-                       "parallelism": f"dp{world}", "wc_statistics": "sync" if args.sync_wc else "per-replica",
-                       "launch": launch_mode},
+            "config": {"workload": f"{WORKLOADS[args.config]}, batch 64/GPU, training_ratio {args.training_ratio}, "
+                                   "generator_batch_multiple 2",
+                       "name": args.config, "parallelism": f"dp{world}",
+                       "wc_statistics": "sync" if args.sync_wc else "per-replica", "launch": launch_mode},
             "roofline": roof, "cpu_baseline": cpu,
         }
         out.update(extra)
         print(json.dumps(out), flush=True)
-    if dist.is_available() and dist.is_initialized():
+    if in_group:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

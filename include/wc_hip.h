@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define WC_ABI_VERSION 1
+#define WC_ABI_VERSION 2
 
 #define WC_OK                 0
 #define WC_ERR_NULL          -1   /* a required pointer is NULL                     */
@@ -95,22 +95,29 @@ int wc_factor_f64(const double* sum, const double* xtx, int64_t M /*rows per gro
  * apply multiplies by; At may be NULL).  gamma == NULL means Gamma = I (whitening only, Kc = 1).
  * With chan_scale (from wc_factor_f64) and a buffer of wc_apply_plan_bytes(C, Kc) it also prepares the
  * "plan" of A -- split-fp16 tables of the fast apply -- so that wc_apply_f32 is a single kernel launch. */
-int wc_color_f32(const double* W /*[groups,C,C]*/, const float* gamma /*[Kc,C,C] or NULL*/, int Kc, int C, int groups,
+/* per_group != 0: gamma holds groups*Kc tables and group g takes its own run, A[g*Kc+k] = W_g^T Gamma[g*Kc+k]
+ * (per-SAMPLE coloring tables of a grouped batch: ConditionalConv11 / FactorizedConv11 with more classes than
+ * samples, generator.py:52-60,69-78 at run.py:172-173's 200 / 1000 classes); 0: every group takes the same Kc tables. */
+int wc_color_f32(const double* W /*[groups,C,C]*/, const float* gamma /*[Kc,C,C] ([groups*Kc,C,C] if per_group) or NULL*/,
+                 int Kc, int C, int groups, int per_group,
                  float* A /*[groups*Kc,C,C] out, index g*Kc+k*/, float* At /*same shape, nullable*/,
                  const float* chan_scale /*[C], nullable*/, void* plan /*out, nullable*/,
                  void* ws, size_t ws_bytes, wc_stream_t stream);
 
 /* Grouped forward glue: center[c] = mean_g mu[g,c] and bias[g*Kc+k] = beta[k] - (mu[g] - center) A[g*Kc+k], so that
- * wc_apply_f32(x, center, A, bias, slot = g*Kc + k) equals (x - mu_g) A[g*Kc+k] + beta[k] for every group. */
-int wc_group_bias_f32(const float* mu /*[groups,C]*/, const float* A /*[groups*Kc,C,C]*/, const float* beta /*[Kc,C] nullable*/,
-                      int groups, int Kc, int C, float* center /*[C] out*/, float* bias /*[groups*Kc,C] out*/,
+ * wc_apply_f32(x, center, A, bias, slot = g*Kc + k) equals (x - mu_g) A[g*Kc+k] + beta[k] for every group.
+ * per_group != 0: beta is [groups*Kc,C] and slot g*Kc+k takes beta[g*Kc+k] (see wc_color_f32). */
+int wc_group_bias_f32(const float* mu /*[groups,C]*/, const float* A /*[groups*Kc,C,C]*/,
+                      const float* beta /*[Kc,C] ([groups*Kc,C] if per_group), nullable*/,
+                      int groups, int Kc, int C, int per_group, float* center /*[C] out*/, float* bias /*[groups*Kc,C] out*/,
                       wc_stream_t stream);
 
 /* K3: y[n] = (x[n] - mu) A[slot[n]] + bias[slot[n]]   (bias NULL = 0; mu NULL = 0).
  * With a workspace of wc_apply_workspace_bytes() the split-fp16 MFMA fast path runs when the shape allows
- * (C in {32,64,128,256}, N*HW >= 16384, HW a multiple of the row tile when slot != NULL); ws == NULL
- * (and no plan) always takes the exact f32-MFMA kernel.  Both give fp32-GEMM accuracy; a row tile holding an
- * element outside the fp16 range is detected on the device and recomputed in fp32 by the same kernel. */
+ * (C in {32,64,128,256}, N*HW >= 16384 and a multiple of 16384/C rows); ws == NULL (and no plan) always takes the
+ * exact f32-MFMA kernel.  Both give fp32-GEMM accuracy; a row tile holding an element outside the fp16 range -- or,
+ * with slot != NULL and HW not a multiple of the 8192/C-row tile, a tile that straddles samples of different slots --
+ * is detected on the device and recomputed in fp32 by the same kernel. */
 int wc_apply_f32(const float* x, const float* mu, const float* A, const float* bias,
                  const int32_t* slot, int64_t N, int64_t HW, int C, int Kc,
                  float* y, const void* plan /*from wc_color_f32, nullable*/,

@@ -35,7 +35,8 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version_and_error_strings(lib):
-    assert lib.wc_abi_version() == 1
+    from wc_gan_amd import _lib
+    assert lib.wc_abi_version() == _lib.ABI_VERSION == 2
     assert b"multiple of 32" in lib.wc_error_string(-3)
     assert lib.wc_error_string(0) == b"ok"
 
@@ -59,7 +60,7 @@ def test_argument_checks_return_codes_without_touching_the_gpu(lib):
     assert lib.wc_stats_f32(one, 64, 64, 1, one, one, one, 16, None) == -4
     assert lib.wc_factor_f64(one, one, 64, 64, 1, 0.0, 0.99, 1, 1, None, None, one, None, one, one, one, 1 << 30, None) == -5
     assert lib.wc_factor_f64(one, one, 1, 64, 1, 1e-3, 0.99, 1, 1, None, None, one, None, one, one, one, 1 << 30, None) == -2
-    assert lib.wc_color_f32(one, None, 2, 64, 1, one, None, None, None, None, 0, None) == -2
+    assert lib.wc_color_f32(one, None, 2, 64, 1, 0, one, None, None, None, None, 0, None) == -2
     assert lib.wc_bwd_reduce_f32(one, None, one, None, 4, 16, 64, 3, one, one, one, 1 << 30, None) == -2
     assert lib.wc_stream_copy_f32(one, one, 6, None) == -2
 
@@ -69,3 +70,13 @@ def test_host_wrappers_refuse_cpu_tensors():
     from wc_gan_amd import _lib, ops
     with pytest.raises(_lib.WcHipError):
         ops.stats(torch.zeros(64, 32))
+
+
+def test_fast_apply_takes_the_grouped_and_conditional_sites(lib):
+    """wc_apply_workspace_bytes > 256 <=> the split-fp16 kernel takes the shape.  The grouped / conditional sites of the
+    STL-10 and CIFAR-10-cond recipes (HW = 144 or 64 rows per sample, not a multiple of the 2 x 8192/C-row register
+    tile) used to fall back to the f32-MFMA kernel."""
+    assert lib.wc_apply_workspace_bytes(320, 144, 256, 5) > 256       # STL-10 12x12, five statistic groups
+    assert lib.wc_apply_workspace_bytes(320, 64, 128, 50) > 256       # CIFAR-10 cond 8x8, 5 groups x 10 classes
+    assert lib.wc_apply_workspace_bytes(128, 144, 256, 7) > 256       # per-class tables, tiles straddle samples
+    assert lib.wc_apply_workspace_bytes(128, 36, 256, 1) == 256       # 4608 rows: below the fast path's minimum

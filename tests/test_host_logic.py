@@ -60,7 +60,7 @@ def test_coloring_table_equals_oracle_table(after_norm):
             params['c_beta'] = br.beta.detach().numpy().astype(np.float64)
     x = torch.zeros(N, 2, 2, C)
     cls = torch.tensor(rng.integers(0, K, (N, 1)), dtype=torch.int32)
-    gamma, beta, slot = stack.coloring_table(x, cls)
+    gamma, beta, slot, _ps = stack.coloring_table(x, cls)
     G_ref, B_ref = o.coloring_table(after_norm, C, params, K)
     if after_norm == 'n':
         assert gamma is None and beta is None
@@ -78,7 +78,7 @@ def test_more_classes_than_samples_switches_to_per_sample_slots():
     C, K, N = 32, 50, 4
     stack = create_norm('d', 'ucconv', number_of_classes=K)(axis=-1, name='s', channels=C)
     cls = torch.tensor([[3], [49], [3], [0]], dtype=torch.int32)
-    gamma, beta, slot = stack.coloring_table(torch.zeros(N, 1, 1, C), cls)
+    gamma, beta, slot, _ps = stack.coloring_table(torch.zeros(N, 1, 1, C), cls)
     assert gamma.shape == (N, C, C) and beta.shape == (N, C)
     assert torch.equal(slot, torch.arange(N, dtype=torch.int32))
     full = stack.branches[0].kernel + stack.branches[1].kernel.view(1, C, C)
@@ -144,3 +144,77 @@ def test_keras_named_checkpoint_roundtrip(tmp_path):
         assert np.array_equal(v, st[k])
     with pytest.raises(KeyError):
         load_keras_named(G2, {k: v for k, v in list(st.items())[:-1]})
+
+
+def test_all_four_gpu_configs_and_their_site_lists():
+    """BASELINE.json:configs 2-5 as wc_gan_amd.train.CONFIGS, shapes per run.py:147-237 and the four scripts."""
+    from wc_gan_amd.train import CONFIGS, wc_sites
+    assert sorted(CONFIGS) == ['cifar10_cond', 'cifar10_uncond', 'stl10_uncond', 'tinyimagenet_cond_sa']
+    hw = lambda name, n: [(h, w, c) for _, _, h, w, c in wc_sites(CONFIGS[name], n)]
+    assert hw('cifar10_uncond', 128) == [(4, 4, 256), (8, 8, 256), (8, 8, 256), (16, 16, 256), (16, 16, 256), (32, 32, 256), (32, 32, 256)]
+    # run.py:152 first_block_w = 6 for stl10, run.py:333 48 x 48 images
+    assert hw('stl10_uncond', 128) == [(6, 6, 256), (12, 12, 256), (12, 12, 256), (24, 24, 256), (24, 24, 256), (48, 48, 256), (48, 48, 256)]
+    # run.py:155-158 four UP blocks, run.py:335 64 x 64 images
+    assert hw('tinyimagenet_cond_sa', 128)[-1] == (64, 64, 128) and len(hw('tinyimagenet_cond_sa', 128)) == 9
+    t = CONFIGS['tinyimagenet_cond_sa']
+    assert t['generator']['number_of_classes'] == 200 and t['generator']['filters_emb'] == 15          # run.py:172-173, script line 7
+    assert t['discriminator']['block_sizes'] == (256, 512, 1024, 1024, 1024)                              # run.py:205-208 at filters 1024
+    assert t['discriminator']['resamples'] == ('DOWN', 'DOWN', 'DOWN', 'SAME', 'SAME')
+    G = make_generator(**t['generator'])
+    kinds = [type(b).__name__ for b in G.blocks[0].bn1.branches]
+    assert kinds == ['FactorizedConv11', 'Conv11']                                                       # ufconv, generator.py:69-78
+    assert G.blocks[0].bn1.branches[0].class_matrix.shape == (200, 15)
+    sites = [m for m in G.modules() if isinstance(m, WhiteningColoring)]
+    assert [s.npart.layer_name for s in sites][-1] == 'Generator.BN.Final_npart' and len(sites) == 9
+
+
+def test_per_sample_tables_are_decided_per_statistic_group():
+    """200 classes against a grouped batch of 5 x 64: 200 > 64 samples per group -> per-sample tables (320), not 5 x 200."""
+    from wc_gan_amd.layers import statistic_groups
+    C, K, N = 32, 200, 320
+    stack = create_norm('d', 'ufconv', number_of_classes=K, filters_emb=4)(axis=-1, name='s', channels=C)
+    cls = torch.randint(0, K, (N, 1), dtype=torch.int32)
+    gamma, beta, slot, per_sample = stack.coloring_table(torch.zeros(N, 1, 1, C), cls)
+    assert not per_sample and gamma.shape[0] == K                    # ungrouped: 200 classes <= 320 samples
+    with statistic_groups(5):
+        gamma, beta, slot, per_sample = stack.coloring_table(torch.zeros(N, 1, 1, C), cls)
+    assert per_sample and gamma.shape == (N, C, C) and torch.equal(slot, torch.arange(N, dtype=torch.int32))
+
+
+def test_supports_statistic_groups_and_refusals():
+    from wc_gan_amd.layers import statistic_groups, supports_statistic_groups
+    from wc_gan_amd.train import CONFIGS
+    assert supports_statistic_groups(make_generator(**CONFIGS['cifar10_uncond']['generator']))
+    assert not supports_statistic_groups(make_generator(block_sizes=(32,), resamples=("UP",), first_block_shape=(4, 4, 32),
+                                                        block_norm='dr', block_after_norm='uconv', last_norm='d', last_after_norm='uconv'))
+    assert not supports_statistic_groups(make_generator(block_sizes=(48,), resamples=("UP",), first_block_shape=(4, 4, 48),
+                                                        block_norm='d', block_after_norm='uconv', last_norm='d', last_after_norm='uconv'))
+    G_b = make_generator(block_sizes=(8,), resamples=("UP",), first_block_shape=(4, 4, 8), block_norm='b', block_after_norm='ucs',
+                         last_norm='b', last_after_norm='ucs')
+    with torch.no_grad():
+        G_b(torch.zeros(2, 128), torch.zeros(2, 1, dtype=torch.int32))
+    assert not supports_statistic_groups(G_b)
+    # a layer without the grouped form raises inside the context instead of pooling the statistics
+    layer = DecorelationNormalization(name='r', renorm=True, channels=32)
+    with statistic_groups(2), pytest.raises(RuntimeError):
+        layer.transform(torch.zeros(4, 2, 2, 32))
+    # the setting is per host thread
+    import threading
+    seen = []
+    with statistic_groups(3):
+        t = threading.Thread(target=lambda: seen.append(__import__('wc_gan_amd.layers', fromlist=['x'])._stat_groups()))
+        t.start(); t.join()
+    assert seen == [1]
+
+
+def test_discriminator_keyword_defaults_are_the_references():
+    import inspect
+    from wc_gan_amd.discriminator import make_discriminator
+    d = {k: v.default for k, v in inspect.signature(make_discriminator).parameters.items()}
+    # discriminator.py:15-20
+    assert d['type'] == 'AC_GAN' and d['spectral'] is False and d['sum_pool'] is False and d['norm'] == 'n'
+    assert d['conv_singular'] is True and d['block_sizes'] == (128, 128, 128, 128)
+    D = make_discriminator(input_image_shape=(8, 8, 3), block_sizes=(8, 8), resamples=('DOWN', 'SAME'))
+    out, cls_out = D(torch.zeros(2, 8, 8, 3))
+    assert out.shape == (2, 1) and cls_out.shape == (2, 10)
+    assert type(D.cls_out) is torch.nn.Linear                          # plain Dense class head, discriminator.py:74

@@ -54,7 +54,7 @@ def test_fused_stack_matches_oracle(after_norm):
     y = stack(xt, dev(cls, torch.int32))
     gy = rng.standard_normal(x.shape).astype(np.float32)
     y.backward(dev(gy))
-    gamma, beta, slot = stack.coloring_table(xt, dev(cls, torch.int32))
+    gamma, beta, slot, _ps = stack.coloring_table(xt, dev(cls, torch.int32))
     Gn = None if gamma is None else gamma.detach().cpu().numpy()
     Bn = None if beta is None else beta.detach().cpu().numpy()
     sn = None if slot is None else slot.cpu().numpy()
@@ -154,7 +154,8 @@ def test_generator_step_runs_and_trains():
     tr = build_trainer(cfg, 'cuda', batch_size=8, training_ratio=1)
     real = torch.rand(8, 32, 32, 3, device='cuda') * 2 - 1
     before = [p.detach().clone() for p in tr.G.parameters()]
-    d, g = tr.step([real])
+    labels = torch.randint(0, 10, (8, 1), device='cuda', dtype=torch.int32)
+    d, g = tr.step([real], [labels])
     assert torch.isfinite(d) and torch.isfinite(g)
     assert any(not torch.equal(a, b) for a, b in zip(before, tr.G.parameters()))
     img = tr.G(torch.randn(4, 128, device='cuda'), torch.zeros(4, 1, dtype=torch.int32, device='cuda'))
@@ -206,7 +207,7 @@ def test_eval_mode_plan_is_cached_and_invalidated():
         key1 = stack.npart._eval_plan.key
         y2 = stack(dev(x), cls)
         assert stack.npart._eval_plan.key == key1 and torch.equal(y1, y2)
-        gamma, beta, slot = stack.coloring_table(dev(x), cls)
+        gamma, beta, slot, _ps = stack.coloring_table(dev(x), cls)
         y_ref, _ = o.wc_forward(x, gamma.cpu().numpy(), beta.cpu().numpy(), slot.cpu().numpy(), training=False,
                                 moving_mean=stack.npart.moving_mean.cpu().numpy().reshape(-1),
                                 moving_cov=stack.npart.moving_cov.cpu().numpy())

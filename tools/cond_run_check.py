@@ -7,7 +7,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 tr = build_trainer(CIFAR10_COND, 'cuda', batch_size=64, training_ratio=5)
 g = torch.Generator(device='cpu'); g.manual_seed(0)
 reals = [torch.rand(64, 32, 32, 3, generator=g).cuda() * 2 - 1 for _ in range(5)]
-replay = tr.capture(reals)
+labels = [torch.randint(0, 10, (64, 1), generator=g, dtype=torch.int32).cuda() for _ in range(5)]
+replay = tr.capture(reals, labels)
 for _ in range(5): replay()
 torch.cuda.synchronize(); t = time.perf_counter()
 for _ in range(n): d, gl = replay()

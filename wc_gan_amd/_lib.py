@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwc_hip.so")
 
 WC_OK = 0
+ABI_VERSION = 2          # WC_ABI_VERSION of include/wc_hip.h
 ERRORS = {-1: "WC_ERR_NULL", -2: "WC_ERR_SHAPE", -3: "WC_ERR_CHANNELS", -4: "WC_ERR_WORKSPACE", -5: "WC_ERR_ARG"}
 
 # name -> (restype, argtypes); mirrors include/wc_hip.h one to one
@@ -28,10 +29,10 @@ SIGNATURES = {
     "wc_apply_plan_bytes": (c_size_t, [c_int, c_int]),
     "wc_bwd_apply_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int]),
     "wc_stats_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "wc_group_bias_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "wc_group_bias_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "wc_factor_f64": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_double, c_double, c_int, c_int,
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "wc_color_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+    "wc_color_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_void_p, c_size_t, c_void_p]),
     "wc_apply_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,
                              c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -118,8 +119,9 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)          # AttributeError here = header and library out of sync
         fn.restype = res
         fn.argtypes = args
-    if lib.wc_abi_version() != 1:
-        raise WcHipError(f"libwc_hip.so ABI version {lib.wc_abi_version()} != 1")
+    if lib.wc_abi_version() != ABI_VERSION:
+        raise WcHipError(f"libwc_hip.so ABI version {lib.wc_abi_version()} != {ABI_VERSION}: rebuild it "
+                         "(python -m wc_gan_amd.build)")
     _lib = lib
     return lib
 

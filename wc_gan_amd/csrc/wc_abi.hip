@@ -59,7 +59,7 @@ size_t wc_stats_workspace_bytes(int64_t M, int C, int groups)
 {
     if (M <= 0 || groups <= 0 || (M % groups) != 0 || bad_channels(C)) return 0;
     const XtyPlan p = plan_xty(groups, M / groups, C, groups > 1, 1);
-    return 256 + 2 * slot_bytes(C, 4) + slot_bytes((size_t)groups * C, 8) + slot_bytes((size_t)p.nslab * C, 4) +
+    return 256 + 2 * slot_bytes(C, 4) + slot_bytes((size_t)groups * C, 8) + slot_bytes((size_t)p.nslab * C, 4) + slot_bytes((size_t)p.nslab * C, 8) +
            slot_bytes((size_t)p.nslab * C * C, 8);
 }
 
@@ -81,6 +81,7 @@ int wc_stats_f32(const float* x, int64_t M, int C, int groups, double* sum, doub
     float* scale = cv.take<float>(C);
     double* Sp = cv.take<double>((size_t)groups * C);
     float* colsum = cv.take<float>((size_t)p.nslab * C);
+    double* dfix = cv.take<double>((size_t)p.nslab * C);
     double* P = cv.take<double>((size_t)p.nslab * C * C);
 
     if (p.fast) WC_TRY(wc_launch_subsample_mean_scale(x, M, C, shift, scale, gate, st));    // shift, scale, gate := 0
@@ -90,11 +91,12 @@ int wc_stats_f32(const float* x, int64_t M, int C, int groups, double* sum, doub
     a.rows_per_slab = p.rps; a.C = C; a.sym = 1; a.P = P; a.colsum = colsum;
     if (p.fast) {
         WC_TRY(wc_launch_fast_xty(x, x, shift, shift, scale, scale, Ns, HWs, C, per_seg, p.nsplit, p.rps, p.nslab, p.ntypes,
-                                  P, colsum, gate, st));
+                                  P, colsum, dfix, gate, st));
         a.gate = gate;                       // exact redo, a no-op unless the fp16 range was exceeded
     }
     WC_TRY(wc_launch_xty(a, p.nslab, st));
-    WC_TRY(wc_launch_stats_finalize(P, colsum, shift, p.nslab / groups, HWs, C, groups, Sp, sum, xtx, st));
+    WC_TRY(wc_launch_stats_finalize(P, colsum, shift, p.nslab / groups, HWs, C, groups, Sp, sum, xtx,
+                                    p.fast ? dfix : nullptr, p.fast ? gate : nullptr, st));
     return WC_OK;
 }
 
@@ -139,7 +141,7 @@ size_t wc_apply_plan_bytes(int C, int Kc)
     return wc_fast_affine_workspace(C, Kc);
 }
 
-int wc_color_f32(const double* W, const float* gamma, int Kc, int C, int groups, float* A, float* At,
+int wc_color_f32(const double* W, const float* gamma, int Kc, int C, int groups, int per_group, float* A, float* At,
                  const float* chan_scale, void* plan, void* ws, size_t ws_bytes, wc_stream_t stream)
 {
     (void)ws; (void)ws_bytes;
@@ -166,7 +168,7 @@ int wc_color_f32(const double* W, const float* gamma, int Kc, int C, int groups,
     g.Cm = A; g.c_is_f32 = 1; g.c_rs = C; g.c_cs = 1; g.c_bs = CC;
     g.Cm2 = At; g.c2_rs = 1; g.c2_cs = C; g.c2_bs = CC;
     g.m = C; g.n = C; g.k = C; g.batch = Kc; g.nred = 1; g.alpha = 1.0; g.epi = WC_EPI_NONE;
-    g.batch2 = groups; g.a_b2s = CC; g.b_b2s = 0; g.c_b2s = (int64_t)Kc * CC;      // A[g*Kc + k] = W_g^T Gamma_k
+    g.batch2 = groups; g.a_b2s = CC; g.b_b2s = per_group ? (int64_t)Kc * CC : 0; g.c_b2s = (int64_t)Kc * CC;      // A[g*Kc + k] = W_g^T Gamma_k (Gamma_{g*Kc+k} if per_group)
     WC_TRY(wc_launch_gemm(g, st));
     if (want_plan) {     // the apply's fp16 tables, built once here instead of inside every wc_apply_f32 call
         WC_TRY(hipMemcpyAsync(wc_fast_plan_scale(plan), chan_scale, (size_t)C * 4, hipMemcpyDeviceToDevice, st));
@@ -177,13 +179,13 @@ int wc_color_f32(const double* W, const float* gamma, int Kc, int C, int groups,
 
 // grouped forward: one common centre + per-slot bias so that y = (x - center) A[s] + bias[s] equals
 // (x - mu_g) A[g*Kc+k] + beta_k for every sample of group g and class slot k
-int wc_group_bias_f32(const float* mu, const float* A, const float* beta, int groups, int Kc, int C,
+int wc_group_bias_f32(const float* mu, const float* A, const float* beta, int groups, int Kc, int C, int per_group,
                       float* center, float* bias, wc_stream_t stream)
 {
     if (!mu || !A || !center || !bias) return WC_ERR_NULL;
     if (groups <= 0 || Kc <= 0) return WC_ERR_SHAPE;
     if (bad_channels(C)) return WC_ERR_CHANNELS;
-    WC_TRY(wc_launch_group_bias(mu, A, beta, groups, Kc, C, center, bias, static_cast<hipStream_t>(stream)));
+    WC_TRY(wc_launch_group_bias(mu, A, beta, groups, Kc, C, per_group, center, bias, static_cast<hipStream_t>(stream)));
     return WC_OK;
 }
 
@@ -260,7 +262,7 @@ int wc_bwd_reduce_f32(const float* x, const float* mu, const float* gy, const in
     if (p.fast) {
         WC_TRY(wc_launch_channel_scale2(x, mu, sx, gy, nullptr, sy, N * HW, C, gate, st));      // both scales, gate := 0
         WC_TRY(wc_launch_fast_xty(x, gy, mu, nullptr, sx, sy, Ns, HWs, C, per_sample, p.nsplit, p.rps, p.nslab, p.ntypes,
-                                  P, colsum, gate, st));
+                                  P, colsum, nullptr, gate, st));
         a.gate = gate;
     }
     WC_TRY(wc_launch_xty(a, p.nslab, st));

@@ -83,7 +83,7 @@ int wc_fast_xty_plan(int64_t N, int64_t HW, int C, int per_sample, int two, int*
 hipError_t wc_launch_fast_xty(const float* X, const float* Y, const float* cx, const float* cy,
                               const float* sx, const float* sy, int64_t N, int64_t HW, int C,
                               int per_sample, int nsplit, int64_t rows_per_slab, int nslab, int ntypes,
-                              double* P, float* colsum, int* gate, hipStream_t st);
+                              double* P, float* colsum, double* dfix /*[nslab][C], covariance only, nullable*/, int* gate, hipStream_t st);
 hipError_t wc_launch_fast_plan_tables(const float* B, int Kc, int C, void* plan, hipStream_t st);
 float* wc_fast_plan_scale(void* plan);
 hipError_t wc_launch_fast_affine_planned(const float* in, const float* center, const float* B, int Kc, bool shared_table,
@@ -98,7 +98,9 @@ hipError_t wc_launch_channel_scale2(const float* in, const float* center, float*
 
 // K1 tail: shifted fp32 partials -> raw float64 moments
 hipError_t wc_launch_stats_finalize(const double* P, const float* colsum, const float* shift, int nslab,
-                                    int64_t M, int C, int groups, double* Sp /*[groups*C] scratch*/, double* sum, double* xtx, hipStream_t st);
+                                    int64_t M, int C, int groups, double* Sp /*[groups*C] scratch*/, double* sum, double* xtx,
+                                    const double* dfix /*[groups*nslab][C] the fast path's VALU diagonal, nullable*/,
+                                    const int* gate /*dfix is void when *gate != 0 (the exact redo ran)*/, hipStream_t st);
 // K4 tail: per-slab partials -> per-slot float64 R, gsum
 hipError_t wc_launch_bwd_combine(const double* P, const float* colsum, const int32_t* slot, int64_t N, int nsplit,
                                  int per_sample, int C, int Kc, double* R, double* gsum, hipStream_t st);
@@ -127,6 +129,6 @@ hipError_t wc_launch_gemm(const WcGemm& g, hipStream_t st);
 hipError_t wc_launch_transpose_to_f32(const double* W, int C, float* A, float* At, hipStream_t st);  // A = W^T, At = W
 hipError_t wc_launch_sym_scale_f32(const double* Q, int C, double scale, float* S, hipStream_t st);   // S = scale*(Q+Q^T)/2
 hipError_t wc_launch_gmean(const double* gsum, const float* A, int Kc, int C, int64_t M, float* gmean, hipStream_t st);
-hipError_t wc_launch_group_bias(const float* mu, const float* A, const float* beta, int G, int Kc, int C,
+hipError_t wc_launch_group_bias(const float* mu, const float* A, const float* beta, int G, int Kc, int C, int per_group,
                                 float* center, float* bias, hipStream_t st);
 hipError_t wc_launch_f64_to_f32(const double* src, float* dst, int64_t n, hipStream_t st);

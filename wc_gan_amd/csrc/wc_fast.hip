@@ -139,6 +139,7 @@ struct FastArgs {
     int bias_on, sub_on;                                             // ring kernel: bias/sub are then pointed at `scale` and ignored
     int64_t M, HW;
     int accumulate;
+    int mixed;                                                       // slots given and HW % tile != 0: a tile may straddle samples of different slots
     int relu;                                                        // epilogue: out = max(out, 0) (NaN stays NaN)
     const float* Bf; int64_t bf_stride;                             // the fp32 table [slot][k][n] for the exact path
     float* out;
@@ -789,21 +790,33 @@ __global__ __launch_bounds__(512, 1) void affine_ring_kernel(FastArgs a)
         reinterpret_cast<unsigned*>(a.dbg + 256)[blockIdx.x] = (unsigned)((rt1 - rt0) & 0xFFFF) | (xcc << 16) | (((hwid >> 8) & 0xFF) << 20);
     }
 
-    // exact redo of the whole workgroup if anything it staged was outside the fp16 range (rare)
+    // Exact redo (rare): of the whole workgroup if anything it staged was outside the fp16 range; and, with slots, of
+    // every tile that STRADDLES samples of different slots (HW not a multiple of the tile; the MFMA pass above used the
+    // table of the tile's first sample for all of its rows).  Same thread, same element as the MFMA pass, so the
+    // second store wins by program order.  Here the slot is looked up per ROW.
     if (overflow) cnt[2] = 1;
     __syncthreads();
-    if (cnt[2]) {
+    const bool redo_all = cnt[2] != 0;
+    if (redo_all || (HAS_SLOT && a.mixed)) {
         for (int t = 0; t < n; ++t) {
-            int slot = 0;
-            if (HAS_SLOT) slot = a.slot[((int64_t)tile_of(t) * TR) / a.HW];
-            const float* xin = a.in + (int64_t)tile_of(t) * (TR * C);
-            float* out_tile = a.out + (int64_t)tile_of(t) * (TR * C);
-            const float* Bf = a.Bf + (int64_t)slot * a.bf_stride + col;
-            float add = 0.f;
-            if (a.bias_on) add += a.bias[(int64_t)slot * C + col];
-            if (a.sub_on) add -= a.sub[col];
+            const int64_t r0 = (int64_t)tile_of(t) * TR;
+            bool mixed = false;
+            if (HAS_SLOT && a.mixed) {
+                const int64_t n0 = r0 / a.HW, n1 = (r0 + TR - 1) / a.HW;
+                const int s0 = a.slot[n0];
+                for (int64_t q = n0 + 1; q <= n1; ++q) mixed |= (a.slot[q] != s0);
+            }
+            if (!redo_all && !mixed) continue;
+            const float* xin = a.in + r0 * C;
+            float* out_tile = a.out + r0 * C;
             for (int i = 0; i < 16; ++i) {
                 const int row = rbase + (i & 3) + 8 * (i >> 2) + 4 * lh;
+                int slot = 0;
+                if (HAS_SLOT) slot = a.slot[(r0 + row) / a.HW];
+                const float* Bf = a.Bf + (int64_t)slot * a.bf_stride + col;
+                float add = 0.f;
+                if (a.bias_on) add += a.bias[(int64_t)slot * C + col];
+                if (a.sub_on) add -= a.sub[col];
                 const float* xrow = xin + row * C;
                 float accf = 0.f;
                 for (int k = 0; k < C; ++k) accf = fmaf(xrow[k] - (a.center ? a.center[k] : 0.f), Bf[(int64_t)k * C], accf);
@@ -872,13 +885,21 @@ hipError_t launch_affine(const FastArgs& a, hipStream_t st)
 
 }  // namespace
 
+static bool use_ring()
+{
+    static const bool on = getenv("WC_NO_RING") == nullptr;      // development: the register-staged kernel everywhere
+    return on;
+}
+
 bool wc_fast_affine_supported(int64_t N, int64_t HW, int C, bool has_slot)
 {
     if (!(C == 32 || C == 64 || C == 128 || C == 256)) return false;
     const int64_t M = N * HW;
     if (M < WC_FAST_MIN_ROWS) return false;
     const int BM = 64 * 256 / C;
-    if (has_slot && (HW % BM) != 0) return false;            // a tile must not straddle two samples
+    // slots: the ring kernel (every non-accumulating call) redoes tiles that straddle samples of different slots; the
+    // register-staged kernel cannot, so without the ring a tile must not straddle two samples
+    if (has_slot && !use_ring() && (HW % BM) != 0) return false;
     if ((M % BM) != 0) return false;                         // whole tiles only (keeps the kernel free of masked accesses)
     return true;
 }
@@ -941,8 +962,10 @@ hipError_t wc_launch_fast_affine_planned(const float* in, const float* center, c
     a.slot_stride = shared_table ? 0 : (int64_t)C * C;
     a.bias = bias; a.sub = sub; a.slot = shared_table ? nullptr : slot; a.M = N * HW; a.HW = HW;
     a.accumulate = accumulate & 1; a.relu = (accumulate >> 1) & 1; a.Bf = B; a.bf_stride = shared_table ? 0 : (int64_t)C * C; a.out = out; a.dbg = v.dbg;
-    static const bool use_ring = getenv("WC_NO_RING") == nullptr;
-    if (!(accumulate & 1) && use_ring && (HW % (8192 / C)) == 0) {
+    // the ring kernel takes any HW: tiles are cut from the M rows, and tiles that straddle samples of different slots
+    // are redone with per-row tables at the end of the launch (rare shapes; none of the shipped recipes)
+    a.mixed = (a.slot != nullptr && (HW % (8192 / C)) != 0) ? 1 : 0;
+    if (!(accumulate & 1) && use_ring() && ((N * HW) % (8192 / C)) == 0) {
         switch (C) {
             case 32: return launch_affine_ring<32>(a, st);
             case 64: return launch_affine_ring<64>(a, st);

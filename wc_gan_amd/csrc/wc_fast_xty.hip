@@ -33,6 +33,7 @@ __device__ __forceinline__ unsigned pk_rne(float a, float b)
 constexpr float kGuard = 60000.0f;
 constexpr int BW = 3;                      // 32x32 blocks per wave
 
+
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
 struct FastXtyArgs {
@@ -45,6 +46,7 @@ struct FastXtyArgs {
     int nslab, ntypes;
     double* P;                             // [nslab][C][C]
     float* colsum;                         // [nslab][C]: sum of (X-cx) (covariance) or of (Y-cy) (two-operand)
+    double* dfix;                          // [nslab][C], covariance only: the diagonal, sum_m g_i[m]^2 on the VALU (see stage_write)
     int* flag;
 };
 
@@ -127,6 +129,19 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
     };
     bool overflow = false;
     f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+    // The DIAGONAL of the covariance does not come from the matrix pipe.  Two systematic errors meet there, both
+    // measured on MI355X (tools/probe/mfma_gram_probe.hip, tools/k1_bias.py):
+    //  * the product the three MFMAs drop, lo*lo, is zero-mean everywhere except on the diagonal, where it is
+    //    sum_m lo_i[m]^2 > 0: -(2..8)e-8 of every variance;
+    //  * v_mfma_f32_32x32x16_f16 is NOT a correctly rounded dot product (a third of its outputs differ from
+    //    RNE_fp32(C + exact sum)); its error is zero-mean for products of mixed sign, but adding 16 POSITIVE products
+    //    to a positive accumulator comes out 0.04 ulp low per instruction: -8e-9 of every variance at this chain length.
+    // Either is harmless for the covariance itself, but at cond(Sigma~) ~ 1e6 the whitening amplifies a uniform
+    // relative error of the variances by ~3e3: y was off by 0.8-2e-4 and dx by up to 3e-4 at the full-size sites.
+    // The scaled values are at hand here, so the lightest workgroup of the slab sums their squares per channel with
+    // IEEE fp32 FMAs (round to nearest even: unbiased) and the combine takes the diagonal from there.
+    const bool want_dfix = !TWO && a.dfix != nullptr && type == a.ntypes - 1;
+    double lsq[4] = {0.0, 0.0, 0.0, 0.0};      // per stage: a fresh 8-term fp32 chain, folded into float64
     auto stage_write = [&](int buf) {
         char* img = smem + buf * (NOP * 2 * IMG);
         f32x4 g[8];
@@ -135,6 +150,13 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
             g[p] = xr[p] * scl + ncs;
             csum += g[p];
             overflow |= (fabsf(g[p][0]) > kGuard) | (fabsf(g[p][1]) > kGuard) | (fabsf(g[p][2]) > kGuard) | (fabsf(g[p][3]) > kGuard);
+        }
+        if (want_dfix) {
+            f32x4 sq = g[0] * g[0];
+#pragma unroll
+            for (int p = 1; p < 8; ++p) sq += g[p] * g[p];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) lsq[j] += (double)sq[j];
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -221,6 +243,11 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
 #pragma unroll
         for (int j = 0; j < 4; ++j) red[rgrp * C + 4 * c4 + j] = csum[j];
     }
+    if (want_dfix) {
+        double* red2 = reinterpret_cast<double*>(smem + RGRP * C * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red2[rgrp * C + 4 * c4 + j] = lsq[j];
+    }
     __syncthreads();
     if (type == 0 && a.colsum) {
         constexpr int RG_USED = TWO ? RGRP / 2 : RGRP;
@@ -229,6 +256,14 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
             float s = 0.f;
             for (int g = 0; g < RG_USED; ++g) s += red[g * C + c];
             a.colsum[z * C + c] = s / (TWO ? a.sy[c] : a.sx[c]);
+        }
+    }
+    if (want_dfix) {
+        const double* red2 = reinterpret_cast<const double*>(smem + RGRP * C * 4);
+        for (int c = tid; c < C; c += 512) {
+            double s = 0.0;
+            for (int g = 0; g < RGRP; ++g) s += red2[g * C + c];
+            a.dfix[z * C + c] = s / ((double)a.sx[c] * (double)a.sx[c]);
         }
     }
     if (overflow) atomicOr(a.flag, 1);
@@ -292,9 +327,10 @@ int wc_fast_xty_plan(int64_t N, int64_t HW, int C, int per_sample, int two, int*
 hipError_t wc_launch_fast_xty(const float* X, const float* Y, const float* cx, const float* cy,
                               const float* sx, const float* sy, int64_t N, int64_t HW, int C,
                               int per_sample, int nsplit, int64_t rows_per_slab, int nslab, int ntypes,
-                              double* P, float* colsum, int* gate, hipStream_t st)
+                              double* P, float* colsum, double* dfix, int* gate, hipStream_t st)
 {
     FastXtyArgs a = {};
+    a.dfix = (Y == X) ? dfix : nullptr;
     a.X = X; a.Y = Y; a.cx = cx; a.cy = cy; a.sx = sx; a.sy = sy; a.N = N; a.HW = HW;
     a.per_sample = per_sample; a.nsplit = nsplit; a.rows_per_slab = rows_per_slab; a.nslab = nslab; a.ntypes = ntypes;
     a.P = P; a.colsum = colsum; a.flag = gate;

@@ -51,7 +51,8 @@ __global__ __launch_bounds__(1024) void stats_colsum_kernel(const float* __restr
 // block = 64 columns x 4 slab groups, one row i per blockIdx.y
 __global__ __launch_bounds__(256) void stats_xtx_kernel(const double* __restrict__ P, const float* __restrict__ shift,
                                                         const double* __restrict__ Sp, int nslab, int64_t M, int C,
-                                                        double* __restrict__ xtx)
+                                                        double* __restrict__ xtx, const double* __restrict__ dfix,
+                                                        const int* __restrict__ gate)
 {
     __shared__ double red[4][64];
     const int j = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -65,6 +66,13 @@ __global__ __launch_bounds__(256) void stats_xtx_kernel(const double* __restrict
         const double* p = P + (int64_t)i * C + j;
 #pragma unroll 4
         for (int z = part; z < nslab; z += 4) g += p[z * CC];
+        // the fast reduction's diagonal comes from its VALU sums of squares, not from the matrix pipe (wc_fast_xty.hip:
+        // the MFMA's rounding is biased for all-positive products) -- unless the exact redo has replaced the partials
+        if (j == i && dfix && !(gate && *gate != 0)) {
+            const double* d = dfix + (int64_t)blockIdx.z * nslab * C + i;
+            g = 0.0;
+            for (int z = part; z < nslab; z += 4) g += d[(int64_t)z * C];
+        }
     }
     red[part][threadIdx.x & 63] = g;
     __syncthreads();
@@ -649,7 +657,7 @@ __global__ void gmean_kernel(const double* __restrict__ gsum, const float* __res
 // grouped forward: center[c] = mean_g mu[g][c];  bias[s][n] = beta[s % Kc][n] - sum_c (mu[g][c] - center[c]) A[s][c][n],
 // s = g*Kc + k.  One block per slot s.
 __global__ __launch_bounds__(256) void group_bias_kernel(const float* __restrict__ mu, const float* __restrict__ A,
-                                                         const float* __restrict__ beta, int G, int Kc, int C,
+                                                         const float* __restrict__ beta, int G, int Kc, int C, int per_group,
                                                          float* __restrict__ center, float* __restrict__ bias)
 {
     __shared__ double dm[1024];
@@ -664,7 +672,7 @@ __global__ __launch_bounds__(256) void group_bias_kernel(const float* __restrict
     __syncthreads();
     const float* As = A + (int64_t)s_ * C * C;
     for (int n = threadIdx.x; n < C; n += 256) {
-        double acc = beta ? (double)beta[(int64_t)k * C + n] : 0.0;
+        double acc = beta ? (double)beta[(int64_t)(per_group ? s_ : k) * C + n] : 0.0;
         for (int c = 0; c < C; ++c) acc -= dm[c] * (double)As[(int64_t)c * C + n];
         bias[(int64_t)s_ * C + n] = (float)acc;
     }
@@ -679,11 +687,12 @@ __global__ void f64_to_f32_kernel(const double* __restrict__ src, float* __restr
 }  // namespace
 
 hipError_t wc_launch_stats_finalize(const double* P, const float* colsum, const float* shift, int nslab,
-                                    int64_t M, int C, int groups, double* Sp, double* sum, double* xtx, hipStream_t st)
+                                    int64_t M, int C, int groups, double* Sp, double* sum, double* xtx,
+                                    const double* dfix, const int* gate, hipStream_t st)
 {
     // nslab and M are PER GROUP; group g owns slabs [g*nslab, (g+1)*nslab)
     hipLaunchKernelGGL(stats_colsum_kernel, dim3((C + 63) / 64, groups), dim3(1024), 0, st, colsum, shift, nslab, M, C, Sp, sum);
-    hipLaunchKernelGGL(stats_xtx_kernel, dim3((C + 63) / 64, C, groups), dim3(256), 0, st, P, shift, (const double*)Sp, nslab, M, C, xtx);
+    hipLaunchKernelGGL(stats_xtx_kernel, dim3((C + 63) / 64, C, groups), dim3(256), 0, st, P, shift, (const double*)Sp, nslab, M, C, xtx, dfix, gate);
     return hipGetLastError();
 }
 
@@ -795,10 +804,10 @@ hipError_t wc_launch_gmean(const double* gsum, const float* A, int Kc, int C, in
     return hipGetLastError();
 }
 
-hipError_t wc_launch_group_bias(const float* mu, const float* A, const float* beta, int G, int Kc, int C,
+hipError_t wc_launch_group_bias(const float* mu, const float* A, const float* beta, int G, int Kc, int C, int per_group,
                                 float* center, float* bias, hipStream_t st)
 {
-    hipLaunchKernelGGL(group_bias_kernel, dim3(G * Kc), dim3(256), 0, st, mu, A, beta, G, Kc, C, center, bias);
+    hipLaunchKernelGGL(group_bias_kernel, dim3(G * Kc), dim3(256), 0, st, mu, A, beta, G, Kc, C, per_group, center, bias);
     return hipGetLastError();
 }
 

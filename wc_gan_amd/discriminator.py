@@ -70,7 +70,9 @@ class Discriminator(nn.Module):
         self.dropout = nn.Dropout(dropout) if dropout else None
         self.out = dense(ch, 1)
         if type == 'AC_GAN':
-            self.cls_out = dense(ch, number_of_classes)
+            # the class head is a plain Dense in the reference even when spectral=True (discriminator.py:74)
+            self.cls_out = nn.Linear(ch, number_of_classes)
+            nn.init.xavier_uniform_(self.cls_out.weight); nn.init.zeros_(self.cls_out.bias)
         elif type == 'PROJECTIVE':
             self.emb = emb(number_of_classes, ch)
 
@@ -94,11 +96,20 @@ class Discriminator(nn.Module):
 
 def make_discriminator(input_image_shape=(32, 32, 3), input_cls_shape=(1,), block_sizes=(128, 128, 128, 128),
                        resamples=('DOWN', 'DOWN', 'SAME', 'SAME'), number_of_classes=10,
-                       type=None, norm='n', after_norm='n', spectral=True,
+                       type='AC_GAN', norm='n', after_norm='n', spectral=False,
                        fully_diff_spectral=False, spectral_iterations=1, conv_singular=True,
-                       sum_pool=True, dropout=False, arch='res', filters_emb=10):
+                       sum_pool=False, dropout=False, arch='res', filters_emb=10):
+    """Keyword surface AND defaults of discriminator.py:15-20.  The shipped recipes pass type / spectral / sum_pool
+    explicitly (run.py:230-233 from --gan_type, --discriminator_spectral, --sum_pool default 1), as wc_gan_amd.train's
+    configs do.  `conv_singular=True` (the reference's default here; run.py:270 passes 0) asks for the
+    convolution-operator singular value of SNConv2D, which this harness does not build: it warns and uses the
+    reshaped-kernel sigma of the SN-GAN paper."""
     assert arch == 'res', "only the ResNet critic is built for the harness (dcgan critic: out of the WC path)"
     assert type in [None, 'AC_GAN', 'PROJECTIVE']
+    if spectral and conv_singular:
+        import warnings
+        warnings.warn("conv_singular=True is not built: spectral normalisation uses the reshaped-kernel singular value",
+                      stacklevel=2)
     sn_kw = dict(spectral_iterations=spectral_iterations, fully_diff_spectral=fully_diff_spectral)
     conv_layer = partial(Conv2D, spectral=bool(spectral), conv_singular=conv_singular, **sn_kw)
 

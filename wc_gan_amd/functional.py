@@ -96,11 +96,13 @@ class WhitenColorFunction(torch.autograd.Function):
 
 
 def whiten_color_grouped(x, groups, gamma=None, beta=None, slot=None, moving_mean=None, moving_cov=None,
-                         eps=1e-3, momentum=0.99, ddof=1, relu=False):
+                         eps=1e-3, momentum=0.99, ddof=1, relu=False, per_sample=False):
     """Training-mode forward of `groups` INDEPENDENT batches stacked along N (no autograd): each run of N/groups
     samples is whitened with its own batch statistics, exactly as `groups` separate calls would be, but the
     covariance / Cholesky / inverse problems of the groups are solved side by side in one set of launches.
-    Used for the generator passes inside the critic updates (fixed generator weights, no graph)."""
+    Used for the generator passes inside the critic updates (fixed generator weights, no graph).
+    per_sample: gamma (N, C, C) / beta (N, C) hold one coloring table per SAMPLE (more classes than samples per batch,
+    layers.WhiteningColoring.coloring_table); sample n of group g is coloured by W_g^T gamma[n]."""
     N, C = x.shape[0], x.shape[-1]
     if N % groups != 0:
         raise ValueError("N must be a multiple of groups")
@@ -114,6 +116,14 @@ def whiten_color_grouped(x, groups, gamma=None, beta=None, slot=None, moving_mea
     _touched(moving_mean, moving_cov)
     g = gamma.detach().contiguous() if gamma is not None else None
     b = beta.detach().contiguous() if beta is not None else None
+    if per_sample:
+        if g is None or g.shape[0] != N:
+            raise ValueError("per_sample needs one coloring table per sample")
+        Kc = N // groups
+        A, At, plan = ops.color(W, g, cs, groups, per_group=True)
+        center, bias = ops.group_bias(mu.view(groups, C), A, b, groups, Kc, per_group=True)
+        full_slot = torch.arange(N, device=dev, dtype=torch.int32)
+        return ops.apply(x, center, A, bias, full_slot, plan=plan, relu=relu)
     Kc = 1 if g is None else g.shape[0]
     A, At, plan = ops.color(W, g, cs, groups)
     center, bias = ops.group_bias(mu.view(groups, C), A, b, groups, Kc)

@@ -22,6 +22,7 @@ and runs them as ONE statistics pass, one small float64 stage and ONE affine pas
 from __future__ import annotations
 
 import math
+import threading
 
 import torch
 import torch.nn as nn
@@ -31,25 +32,45 @@ from . import _state
 from . import functional as WF
 
 
-_STAT_GROUPS = 1
+_TLS = threading.local()          # per host thread: two trainers on two threads do not see each other's setting
+
+
+def _stat_groups():
+    return getattr(_TLS, 'groups', 1)
 
 
 class statistic_groups:
     """Context: WC layers treat the batch as `n` independent, equally sized batches stacked along N, each whitened
-    with its own statistics (training mode, no autograd).  Equivalent to n separate forward passes."""
+    with its own statistics (training mode, no autograd).  Equivalent to n separate forward passes -- for the layers
+    that have the grouped form (`supports_statistic_groups`); every other normalisation layer RAISES inside the
+    context instead of silently pooling the statistics of the n batches."""
 
     def __init__(self, n):
         self.n = int(n)
 
     def __enter__(self):
-        global _STAT_GROUPS
-        self.prev, _STAT_GROUPS = _STAT_GROUPS, self.n
+        self.prev = _stat_groups()
+        _TLS.groups = self.n
         return self
 
     def __exit__(self, *exc):
-        global _STAT_GROUPS
-        _STAT_GROUPS = self.prev
+        _TLS.groups = self.prev
         return False
+
+
+def supports_statistic_groups(module):
+    """True when every batch-statistics layer under `module` honours statistic_groups(): the fused Cholesky whitening at
+    C % 32 == 0 without renorm.  ZCA, renorm ('dr'), zero-padded widths and plain batch norm ('b') do not -- callers run
+    separate passes instead (GanTrainer.generate)."""
+    for m in module.modules():
+        if isinstance(m, DecorelationNormalization):
+            if m.renorm or m.decomposition != 'cholesky' or (m.channels is not None and m.channels % 32 != 0):
+                return False
+            if m.channels is None:
+                return False                      # not built yet: width unknown
+        elif isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)) or type(m).__name__ == '_BatchNormNoAffine':
+            return False
+    return True
 
 
 def _glorot_uniform_(t, fan_in, fan_out):
@@ -111,11 +132,16 @@ class DecorelationNormalization(_Lazy):
         self.register_buffer('moving_mean', torch.zeros(C, 1, device=device))
         self.register_buffer('moving_cov', torch.eye(C, device=device))
 
-    def transform(self, x, gamma=None, beta=None, slot=None, gamma_key=None, relu=False):
+    def transform(self, x, gamma=None, beta=None, slot=None, gamma_key=None, relu=False, per_sample=False):
         """Whitening fused with an optional coloring table (gamma (Kc,C,C), beta (Kc,C), slot (N,)); relu=True also
-        folds the ReLU that follows the site into the apply kernel where that path has it (else applied after)."""
+        folds the ReLU that follows the site into the apply kernel where that path has it (else applied after).
+        per_sample: the table holds one entry per sample (slot = arange(N)); only the grouped path needs to know."""
         self._ensure(x)
         C = self.channels
+        groups = _stat_groups() if self.training else 1
+        if groups > 1 and (C % 32 != 0 or self.decomposition != 'cholesky' or self.renorm):
+            raise RuntimeError(f"{self.layer_name}: statistic_groups({groups}) has no grouped form for this layer "
+                               "(zca / renorm / a width that is not a multiple of 32): run separate passes")
         if C % 32 != 0:
             y = self._padded(x, gamma, beta, slot)
             return F.relu(y) if relu else y
@@ -125,11 +151,11 @@ class DecorelationNormalization(_Lazy):
             y = WF.whiten_color_modular(x, gamma, beta, slot, self.moving_mean, self.moving_cov, self.training,
                                         self.epsilon, self.momentum, 1, 'zca')
             return F.relu(y) if relu else y
-        if _STAT_GROUPS > 1 and self.training and not self.renorm:
+        if groups > 1:
             if torch.is_grad_enabled() and (x.requires_grad or (gamma is not None and gamma.requires_grad)):
                 raise RuntimeError("statistic_groups() is a forward-only path: wrap the call in torch.no_grad()")
-            return WF.whiten_color_grouped(x, _STAT_GROUPS, gamma, beta, slot, self.moving_mean, self.moving_cov,
-                                           self.epsilon, self.momentum, 1, relu=relu)
+            return WF.whiten_color_grouped(x, groups, gamma, beta, slot, self.moving_mean, self.moving_cov,
+                                           self.epsilon, self.momentum, 1, relu=relu, per_sample=per_sample)
         if not self.training and not torch.is_grad_enabled():
             # inference (scorer.py:60,72): moving statistics are constants -> cached factorisation, one K3 launch
             if not hasattr(self, '_eval_plan'):
@@ -159,6 +185,9 @@ class DecorelationNormalization(_Lazy):
 
     def _padded(self, x, gamma, beta, slot):
         # zero channels whiten to zero and leave the real channels' Cholesky rows untouched
+        if self.decomposition != 'cholesky' or self.renorm:
+            raise NotImplementedError(f"{self.layer_name}: widths that are not a multiple of 32 are built for "
+                                      "decomposition='cholesky' without renorm only")
         C = self.channels
         xp, _ = _pad_channels(x)
         Cp = xp.shape[-1]
@@ -327,28 +356,31 @@ class WhiteningColoring(nn.Module):
             gamma = g if gamma is None else gamma + g          # (1,C,C) broadcasts against (K,C,C)
             if b is not None:
                 beta = b if beta is None else beta + b
+        per_sample = False
         if gamma is not None and slot is not None:
             K, N = gamma.shape[0], x.shape[0]
-            if K > N:                                           # more classes than samples: per-sample slots
+            groups = _stat_groups() if self.npart.training else 1
+            # more classes than samples (per statistic group: the table of a grouped batch is groups x Kc entries):
+            # one table per SAMPLE instead of one per class (run.py:172-173: 200 / 1000 classes at batch 64)
+            if K > N // max(groups, 1):
                 idx = slot.long()
                 gamma = gamma.expand(K, -1, -1)[idx] if gamma.shape[0] == K else gamma
                 if beta is not None:
                     beta = beta.expand(K, -1)[idx]
                 slot = torch.arange(N, dtype=torch.int32, device=x.device)
+                per_sample = True
         if gamma is not None and beta is not None and beta.shape[0] != gamma.shape[0]:
             beta = beta.expand(gamma.shape[0], -1)
-        return gamma, beta, slot
+        return gamma, beta, slot, per_sample
 
     def forward(self, x, cls=None, relu=False):
         if isinstance(x, (list, tuple)):
             x, cls = x
-        gamma, beta, slot = self.coloring_table(x, cls)
+        gamma, beta, slot, per_sample = self.coloring_table(x, cls)
         if gamma is not None:
             gamma = gamma.contiguous()
         if beta is not None:
             beta = beta.contiguous()
         # identity of the coloring weights (for the eval-mode plan cache); per-sample tables depend on cls -> no key
-        per_sample = gamma is not None and slot is not None and gamma.shape[0] == x.shape[0] and \
-            any(getattr(b, 'number_of_classes', 0) > x.shape[0] for b in self.branches)
         key = None if per_sample else (_state.replays,) + tuple((p.data_ptr(), p._version) for p in self.parameters())
-        return self.npart.transform(x, gamma, beta, slot, gamma_key=key, relu=relu)
+        return self.npart.transform(x, gamma, beta, slot, gamma_key=key, relu=relu, per_sample=per_sample)

@@ -80,34 +80,39 @@ def factor(s, xtx, M, C, eps, momentum, ddof, training, moving_mean, moving_cov,
     return mu, L, W
 
 
-def color(W, gamma, chan_scale=None, groups=1):
+def color(W, gamma, chan_scale=None, groups=1, per_group=False):
     """A_k = W^T Gamma_k and At_k = A_k^T.  gamma (Kc, C, C) float32 or None (whitening only).
-    With chan_scale also returns the apply plan (opaque uint8 tensor) -> (A, At, plan)."""
+    With chan_scale also returns the apply plan (opaque uint8 tensor) -> (A, At, plan).
+    per_group: gamma is (groups*Kc, C, C) and group g takes its own run of Kc tables (per-sample tables of a grouped batch)."""
     lib = _lib.load()
     C = W.shape[-1]
     Kc = 1 if gamma is None else gamma.shape[0]
     if gamma is not None:
         _need(gamma, torch.float32, "gamma", 3)
+    if per_group:
+        if gamma is None or Kc % groups != 0:
+            raise ValueError("per_group needs groups*Kc coloring tables")
+        Kc //= groups
     A = torch.empty(groups * Kc, C, C, dtype=torch.float32, device=W.device)      # index g*Kc + k
     At = torch.empty(groups * Kc, C, C, dtype=torch.float32, device=W.device)
     ws = _workspace(lib.wc_color_workspace_bytes(C, Kc), W.device)
     plan = None
     if chan_scale is not None and C in (32, 64, 128, 256):
         plan = _workspace(lib.wc_apply_plan_bytes(C, groups * Kc), W.device)
-    _lib.check(lib.wc_color_f32(_ptr(W), _ptr(gamma), Kc, C, groups, _ptr(A), _ptr(At), _ptr(chan_scale), _ptr(plan),
+    _lib.check(lib.wc_color_f32(_ptr(W), _ptr(gamma), Kc, C, groups, int(bool(per_group)), _ptr(A), _ptr(At), _ptr(chan_scale), _ptr(plan),
                                 _ptr(ws), ws.numel(), _stream()), "wc_color_f32")
     if chan_scale is not None:
         return A, At, plan
     return A, At
 
 
-def group_bias(mu, A, beta, groups, Kc):
+def group_bias(mu, A, beta, groups, Kc, per_group=False):
     """Grouped forward glue -> (center (C,), bias (groups*Kc, C)); see wc_group_bias_f32."""
     lib = _lib.load()
     C = mu.shape[-1]
     center = torch.empty(C, dtype=torch.float32, device=mu.device)
     bias = torch.empty(groups * Kc, C, dtype=torch.float32, device=mu.device)
-    _lib.check(lib.wc_group_bias_f32(_ptr(mu), _ptr(A), _ptr(beta), groups, Kc, C, _ptr(center), _ptr(bias), _stream()),
+    _lib.check(lib.wc_group_bias_f32(_ptr(mu), _ptr(A), _ptr(beta), groups, Kc, C, int(bool(per_group)), _ptr(center), _ptr(bias), _stream()),
                "wc_group_bias_f32")
     return center, bias
 

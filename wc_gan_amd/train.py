@@ -98,7 +98,9 @@ class GanTrainer:
         self.opt_g = torch.optim.Adam(self.g_bucket.params, lr=lr, betas=(beta1, beta2), capturable=cap, **kw)
         self.opt_d = torch.optim.Adam(self.d_bucket.params, lr=lr, betas=(beta1, beta2), capturable=cap, **kw)
         if cap:
-            torch.cuda.manual_seed(seed)         # the default device generator: its Philox offset is graph-safe
+            # the default device generator (its Philox offset is graph-safe); every replica draws its own noise
+            rank = dist.get_rank(process_group) if (dist.is_available() and dist.is_initialized()) else 0
+            torch.cuda.manual_seed(seed + rank)
         self._graph = None
         self._side = None
         self.overlap_g_forward = True
@@ -127,8 +129,13 @@ class GanTrainer:
         while the critic trains, so its `rounds` forward passes are independent; they run as a single batch of
         rounds x batch_size whose WC layers keep per-round statistics (layers.statistic_groups) -- the same numbers
         as separate passes, with the covariance / Cholesky problems of the rounds solved side by side."""
-        from .layers import statistic_groups
+        from .layers import statistic_groups, supports_statistic_groups
         z, cls = self._noise(self.batch_size * rounds)
+        if rounds > 1 and not supports_statistic_groups(self.G):
+            # a norm layer without the grouped form (zca, renorm, padded widths, plain batch norm): `rounds` real passes
+            with torch.no_grad():
+                fakes = [self.G(zz, cc) for zz, cc in zip(z.split(self.batch_size), cls.split(self.batch_size))]
+            return fakes, cls.split(self.batch_size)
         with torch.no_grad(), statistic_groups(rounds):
             fake = self.G(z, cls)                      # train-mode WC forward (batch statistics), no graph
         return fake.split(self.batch_size), cls.split(self.batch_size)
@@ -141,7 +148,12 @@ class GanTrainer:
         # layer (discriminator_norm is 'n' in every recipe), so this equals two applications with shared weights,
         # with one spectral-norm power iteration per update and convolutions at twice the batch
         n = real.shape[0]
-        both_cls = torch.cat([real_cls if real_cls is not None else cls, cls], dim=0)
+        if self.conditional:
+            if real_cls is None:      # run.py:317 get_dataset(supervised=True): real images come with their labels
+                raise ValueError("conditional critic: d_step needs the labels of the real batch (real_cls)")
+            both_cls = torch.cat([real_cls.reshape(-1, 1).to(cls.dtype), cls], dim=0)
+        else:
+            both_cls = None
         out = self._d(torch.cat([real, fake], dim=0), both_cls)
         loss = F.relu(1.0 - out[:n]).mean() + F.relu(1.0 + out[n:]).mean()
         loss.backward()
@@ -168,8 +180,12 @@ class GanTrainer:
         _bump_versions(self.g_bucket.params)
         return loss.detach()
 
-    def step(self, real_batches):
-        """One G+D step: training_ratio critic updates, then one generator update."""
+    def step(self, real_batches, real_labels=None):
+        """One G+D step: training_ratio critic updates, then one generator update.  `real_labels`: one int (64,) or
+        (64, 1) tensor per real batch -- required by the conditional recipes (the projection critic must see true
+        (image, label) pairs; run.py:317)."""
+        if self.conditional and real_labels is None:
+            raise ValueError("conditional recipe: step() needs real_labels (one label tensor per real batch)")
         fakes, clss = self.generate(self.training_ratio)
         generated = None
         if self.overlap_g_forward and self.dev.type == 'cuda':
@@ -185,7 +201,8 @@ class GanTrainer:
                 generated = (self.G(z, cls), cls)
             self._side_pending = True
         for r in range(self.training_ratio):
-            d_loss = self.d_step(real_batches[r % len(real_batches)], fake=fakes[r], cls=clss[r])
+            rl = real_labels[r % len(real_labels)] if real_labels is not None else None
+            d_loss = self.d_step(real_batches[r % len(real_batches)], real_cls=rl, fake=fakes[r], cls=clss[r])
         if generated is not None:
             if self._side_pending:                   # (a graph segment that ended in between has joined it already)
                 torch.cuda.current_stream().wait_stream(self._side)
@@ -195,25 +212,42 @@ class GanTrainer:
         g_loss = self.g_step(generated)
         return d_loss, g_loss
 
-    def capture(self, real_batches, warmup=3):
+    def trace_boundaries(self, real_batches, real_labels=None):
+        """One eager step that also records where the gradient all-reduces sit: ['d', ..., 'd', 'g'] -- the cut points of
+        capture_segments().  Every rank must report the same list (tests/test_dp_gloo.py, bench.py --dry-run)."""
+        order = []
+
+        def boundary(bucket):
+            order.append('d' if bucket is self.d_bucket else 'g')
+            bucket.allreduce_mean()
+
+        self._boundary = boundary
+        try:
+            losses = self.step(real_batches, real_labels)
+        finally:
+            self._boundary = None
+        return order, losses
+
+    def capture(self, real_batches, real_labels=None, warmup=3):
         """Record one whole G+D step (~1700 kernel launches) into ONE hipGraph -- single process only: capturing an RCCL
         all-reduce aborts the process (tried with a one-rank group), so with gradient collectives use capture_segments().
 
         The C-ABI stages never synchronise or allocate and the gate of the fast path is a device flag, so the
-        step is capturable as is; `real_batches` become the graph's static inputs (copy new data into them).
-        Returns a callable that replays the step.  Every replay draws fresh noise and updates the weights."""
+        step is capturable as is; `real_batches` (and `real_labels`, for the conditional recipes) become the graph's
+        static inputs: copy new data into them.  Returns a callable that replays the step.  Every replay draws fresh
+        noise and updates the weights."""
         if (self.g_bucket.world > 1 or _FORCE_COLLECTIVES) and self.g_bucket.flat is not None:
             raise RuntimeError("capture(): gradient all-reduces cannot be captured; use capture_segments()")
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                self.step(real_batches)
+                self.step(real_batches, real_labels)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            self._static_losses = self.step(real_batches)
+            self._static_losses = self.step(real_batches, real_labels)
         self._graph = graph
 
         def replay():
@@ -222,21 +256,26 @@ class GanTrainer:
             return self._static_losses
         return replay
 
-
-    def capture_segments(self, real_batches, warmup=3):
+    def capture_segments(self, real_batches, real_labels=None, warmup=3):
         """The step as a CHAIN of hipGraphs cut at the gradient all-reduces, which stay ordinary RCCL calls between the
-        replays: no collective is ever captured (that could not be tried on the one-GPU development box), yet the
-        ~2000 kernel launches of a step leave the host loop -- the eager loop is at the edge of host-bound.  Segments:
+        replays: no collective is ever captured, yet the ~2000 kernel launches of a step leave the host loop -- the
+        eager loop is at the edge of host-bound.  Segments:
         [generated batches + first critic pass] | [critic update + next pass] x (training_ratio - 1) |
         [critic update + generator pass] | [generator update]; the generator forward of the update still forks onto the
         second stream, but joins at the first cut (a captured graph must end with its branches joined).  The graphs share
         one memory pool and are replayed in capture order; autograd state crosses the cuts as ordinary tensors of that
-        pool.  Returns a callable that replays the chain."""
+        pool.  Returns a callable that replays the chain.
+
+        If recording fails, the open capture is closed (the stream leaves capture mode), the partial graphs and their
+        pool are dropped and the exception is re-raised: the caller can then run eagerly.  With several ranks the
+        caller has to AGREE on the mode afterwards (bench.py all-reduces an ok flag): a rank that replays graphs while
+        another runs eagerly would still issue the same collectives in the same order, but only by construction of
+        step() -- do not rely on it."""
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                self.step(real_batches)
+                self.step(real_batches, real_labels)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         pool = torch.cuda.graph_pool_handle()
@@ -254,19 +293,33 @@ class GanTrainer:
             if self._side_pending:                   # join the forked generator forward before the graph ends
                 torch.cuda.current_stream().wait_stream(self._side)
                 self._side_pending = False
-            cur['ctx'].__exit__(None, None, None)
-            segments.append((cur['g'], bucket))
+            ctx = cur.pop('ctx')
+            ctx.__exit__(None, None, None)
+            segments.append((cur.pop('g'), bucket))
 
         def boundary(bucket):
+            # no collective while recording: the captured kernels have not run, there is nothing to reduce -- and a rank
+            # whose recording fails half-way must not leave its peers inside an all-reduce
             end(bucket)
-            bucket.allreduce_mean()                  # (on buffers the recording never filled: only its place matters)
             begin()
 
         self._boundary = boundary
         try:
             begin()
-            losses = self.step(real_batches)
+            losses = self.step(real_batches, real_labels)
             end(None)
+        except BaseException as exc:
+            ctx = cur.pop('ctx', None)
+            if ctx is not None:                      # leave capture mode, as the context manager does on an error
+                try:
+                    ctx.__exit__(type(exc), exc, exc.__traceback__)
+                except Exception:
+                    pass
+            self._side_pending = False
+            segments.clear()
+            cur.clear()
+            del pool
+            raise
         finally:
             self._boundary = None
         self._segments = segments
@@ -286,7 +339,8 @@ CIFAR10_UNCOND = dict(          # scripts/cifar10_resnet_sn_uncond.sh:4-7 + run.
                    number_of_classes=10, block_norm='d', block_after_norm='uconv', last_norm='d',
                    last_after_norm='uconv', gan_type=None),
     discriminator=dict(input_image_shape=(32, 32, 3), block_sizes=(128, 128, 128, 128),
-                       resamples=('DOWN', 'DOWN', 'SAME', 'SAME'), number_of_classes=10, type=None, spectral=True),
+                       resamples=('DOWN', 'DOWN', 'SAME', 'SAME'), number_of_classes=10, type=None, spectral=True,
+                       sum_pool=True, conv_singular=False),
     image_shape=(32, 32, 3), conditional=False)
 
 CIFAR10_COND = dict(            # scripts/cifar10_resnet_sn_cond.sh:5-8
@@ -294,8 +348,54 @@ CIFAR10_COND = dict(            # scripts/cifar10_resnet_sn_cond.sh:5-8
                    number_of_classes=10, block_norm='d', block_after_norm='ucconv', last_norm='d',
                    last_after_norm='uconv', gan_type='PROJECTIVE'),
     discriminator=dict(input_image_shape=(32, 32, 3), block_sizes=(256, 256, 256, 256),
-                       resamples=('DOWN', 'DOWN', 'SAME', 'SAME'), number_of_classes=10, type='PROJECTIVE', spectral=True),
+                       resamples=('DOWN', 'DOWN', 'SAME', 'SAME'), number_of_classes=10, type='PROJECTIVE', spectral=True,
+                       sum_pool=True, conv_singular=False),
     image_shape=(32, 32, 3), conditional=True)
+
+
+# scripts/stl10_resnet_sn_uncond.sh:4-7 (generator_filters 256, discriminator_filters 128); run.py:152 first_block_w = 6,
+# run.py:165-166 three UP blocks, run.py:333 images 48 x 48 x 3.  WC sites (N = 128): 6, 12, 12, 24, 24, 48, 48(final) at C = 256
+STL10_UNCOND = dict(
+    generator=dict(block_sizes=(256, 256, 256), resamples=("UP", "UP", "UP"), first_block_shape=(6, 6, 256),
+                   number_of_classes=10, block_norm='d', block_after_norm='uconv', last_norm='d',
+                   last_after_norm='uconv', gan_type=None),
+    discriminator=dict(input_image_shape=(48, 48, 3), block_sizes=(128, 128, 128, 128),
+                       resamples=('DOWN', 'DOWN', 'SAME', 'SAME'), number_of_classes=10, type=None, spectral=True,
+                       sum_pool=True, conv_singular=False),
+    image_shape=(48, 48, 3), conditional=False)
+
+# scripts/tinyimagenet_resnet_sn_cond_sa.sh:4-7 (generator_filters 128, discriminator_filters 1024, ufconv, filters_emb 15,
+# PROJECTIVE); run.py:155-158 four UP blocks, run.py:172-173 200 classes, run.py:205-208 five critic blocks
+# (filters/4, /2, 1, 1, 1; DOWN x3, SAME x2), run.py:335 images 64 x 64 x 3.  WC sites: 4, 8, 8, 16, 16, 32, 32, 64, 64(final)
+# at C = 128; 200 classes > 64 samples per batch, so the block sites run per-sample coloring tables.
+TINYIMAGENET_COND_SA = dict(
+    generator=dict(block_sizes=(128, 128, 128, 128), resamples=("UP", "UP", "UP", "UP"), first_block_shape=(4, 4, 128),
+                   number_of_classes=200, block_norm='d', block_after_norm='ufconv', filters_emb=15, last_norm='d',
+                   last_after_norm='uconv', gan_type='PROJECTIVE'),
+    discriminator=dict(input_image_shape=(64, 64, 3), block_sizes=(256, 512, 1024, 1024, 1024),
+                       resamples=('DOWN', 'DOWN', 'DOWN', 'SAME', 'SAME'), number_of_classes=200, type='PROJECTIVE',
+                       spectral=True, sum_pool=True, conv_singular=False, filters_emb=15),
+    image_shape=(64, 64, 3), conditional=True)
+
+# the four GPU configurations of BASELINE.json:configs, by the name bench.py --config takes
+CONFIGS = {'cifar10_uncond': CIFAR10_UNCOND, 'cifar10_cond': CIFAR10_COND, 'stl10_uncond': STL10_UNCOND,
+           'tinyimagenet_cond_sa': TINYIMAGENET_COND_SA}
+
+
+def wc_sites(config, batch):
+    """(name, N, H, W, C) of every WC site of the config's generator at batch size `batch` (bn1 on the
+    block input, bn2 after the upsampling conv1, then the final site generator.py:154)."""
+    g = config['generator']
+    h, w, c = g['first_block_shape']
+    sites = []
+    for i, (bs, rs) in enumerate(zip(g['block_sizes'], g['resamples'])):
+        sites.append((f'Generator.{i}.bn1', batch, h, w, c))
+        if rs == 'UP':
+            h, w = 2 * h, 2 * w
+        c = int(bs)
+        sites.append((f'Generator.{i}.bn2', batch, h, w, c))
+    sites.append(('Generator.BN.Final', batch, h, w, c))
+    return sites
 
 
 def build_trainer(config=CIFAR10_UNCOND, device='cuda', process_group=None, sync_wc=False, **kw):
