@@ -10,6 +10,7 @@
 // (hard part 2); the flops are negligible (O(C^3)) next to the M*C^2 kernels.
 #include "wc_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -489,6 +490,393 @@ __global__ __launch_bounds__(512) void cholesky_reg_kernel(double* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// K2 for C <= 256, second form (round 2): ONE launch factors T = L L^T and inverts the 16 x 16 diagonal blocks of
+// L; a second launch builds W = L^-1 column block by column block.  What changed against cholesky_reg_kernel + the
+// seven block-doubling launches below:
+//  * The serial part -- factoring AND inverting the 16 x 16 diagonal block -- runs on DPP row broadcasts
+//    (gfx90a+: v_fmac_f64_dpp / v_mov_b64_dpp with row_newbcast:k read lane k of the 16-lane row, which IS "row k
+//    of the block" when lane = row): one instruction where the v_readlane form needed three, no SGPR round trip, and
+//    the inverse's rows are taken as the factor's pivots complete (their fmacs fill the pivots' dependency stalls).
+//  * Look-ahead: wave 0 owns no block of the trailing matrix and runs at raised priority.  Once the next panel's
+//    blocks (block column j+1) have taken the rank-16 update of step j, wave 0 factors the next diagonal block WHILE
+//    waves 1-15 update the rest of the trailing matrix: three LDS-only barriers per step, the serial part off the
+//    other waves' critical path.  The roles run different code between the same barriers, so the register allocator
+//    never sees wave 0's working set next to the trailing blocks (together they spilled).
+//  * 16 waves of 128 registers instead of 8 of 256: 8 blocks per owner wave, three to four waves per SIMD to cover
+//    the LDS and f64-MFMA latencies of the update.
+// Operand maps of v_mfma_f64_16x16x4_f64 as in gemm_f64_kernel: a = A[i = lane&15][k = lane>>4],
+// b = B[k = lane>>4][j = lane&15], D register r of lane l = D[(l>>4) + 4r][l&15].
+// ---------------------------------------------------------------------------------------------
+template <int K> __device__ __forceinline__ double row_bcast(double v)
+{
+    double r;      // (s_nop: a VALU write of the source needs two wait states before a DPP read; inline asm gets no hazard pass)
+    asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(K));
+    return r;
+}
+// acc += (lane K of this lane's 16-lane row).src * mul.  NO wait states inside: the caller guarantees that `src` was not
+// written by the two instructions in front (dpp_settle below, or a value that has been final for a while)
+template <int K> __device__ __forceinline__ void fmac_bcast(double& acc, double src, double mul)
+{
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(K));
+}
+// two wait states between the write of v and every DPP read that follows ("modifies" v, so its readers are ordered behind it)
+__device__ __forceinline__ void dpp_settle(double& v) { asm("s_nop 1" : "+v"(v)); }
+template <int B, int E, typename F> __device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (B < E) { f(std::integral_constant<int, B>{}); static_for<B + 1, E>(f); }
+}
+
+#ifndef CF_OWN
+#define CF_OWN 15                   // waves that own trailing blocks and solve the panel.  (12 = all but 4, 8, 12, which share wave 0's
+#endif                              // SIMD: measured 74 against 69 us -- the early steps are bound by the CU's f64-MFMA rate and lose a quarter of it)
+constexpr int CF_SLOTS = (120 + CF_OWN - 1) / CF_OWN;      // 120 blocks at C = 256 (16 waves x 128 VGPRs: 10 blocks = 80 of them)
+
+#ifndef CF_STAMPS
+#define CF_STAMPS 0      // development: s_memtime stamps around every barrier of waves 0, 1 and 5 into the workspace behind Linv
+#endif
+// LDS hand-off only: every wave's LDS traffic has completed, then the barrier.  (__syncthreads() would also wait for the
+// global stores of L in flight, half a microsecond per step for nothing: nobody reads them inside this launch.)
+#define CF_BARRIER() do { if (CF_STAMPS && stamp_ok) stamps[nstamp++] = __builtin_amdgcn_s_memtime();              \
+                          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                          \
+                          if (CF_STAMPS && stamp_ok) stamps[nstamp++] = __builtin_amdgcn_s_memtime(); } while (0)
+
+__global__ __launch_bounds__(1024) void cholesky_fused_kernel(double* __restrict__ T, double* __restrict__ Linv, int C, int ldp)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double* Praw = sm;                          // [2][C][17]  the current / next panel as its owners hold it (row-major)
+    double* Pn = Praw + 2 * C * 17;             // [16][ldp]   solved panel, column-major: the update's MFMA operands
+    double* Dinv = Pn + 16 * ldp;               // [2][16][17] INVERSE of the factored diagonal block (even / odd steps)
+    double* Dpre = Dinv + 2 * 16 * 17;          // [2][16][17] diagonal block (b, b) with every update but the last one, b even / odd
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lq = lane >> 4;
+    T += (int64_t)blockIdx.x * C * C;           // one matrix (statistic group) per workgroup
+    Linv += (int64_t)blockIdx.x * C * 16;
+    const int nb = C >> 4;
+    const int nblk = (nb - 1) * nb / 2;         // blocks (bi >= bj >= 1); block column 0 goes straight to LDS
+
+    for (int e = tid; e < C * 16; e += 1024) Praw[(e >> 4) * 17 + (e & 15)] = T[(int64_t)(e >> 4) * C + (e & 15)];
+    if (nb > 1)
+        for (int e = tid; e < 256; e += 1024) Dpre[16 * 17 + (e >> 4) * 17 + (e & 15)] = T[(int64_t)(16 + (e >> 4)) * C + 16 + (e & 15)];    // block (1,1) as it stands
+    __syncthreads();
+    const bool stamp_ok = CF_STAMPS && lane == 0 && (wave == 0 || wave == 1 || wave == 5) && blockIdx.x == 0;
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(Linv + 8192) + (wave == 0 ? 0 : wave == 1 ? 128 : 256);
+    int nstamp = 0;
+    (void)stamps; (void)nstamp; (void)stamp_ok;
+
+    // Two barriers per step.  (A): the inverse of L_jj is in LDS and panel j is complete.  (B): panel j is solved.
+    // Between (B) and the next (A) wave 0 gives the next diagonal block its last update itself and factors it, while the
+    // other waves update the trailing matrix and publish the next panel.
+    if (wave == 0) {
+        // wave 0: factor a 16 x 16 diagonal block (src: [16][17]) and invert the factor, lane = row / column (all four 16-lane
+        // rows of the wave do the same work).  Pivot: v_rsq_f64 + two Newton steps.  Row jj of the inverse (lane = its
+        // column c): w[jj] = -rd_jj sum_{k<jj} l[jj][k] w[k], taken as soon as row jj of L is final.
+        __builtin_amdgcn_s_setprio(3);
+        auto factor = [&](int j, const double* src) __attribute__((always_inline)) {
+            double a[16], w[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) a[c] = src[li * 17 + c];
+            static_for<0, 16>([&](auto J) {
+                constexpr int jj = decltype(J)::value;
+                const double p = row_bcast<jj>(a[jj]);
+                double rd = __builtin_amdgcn_rsq(p);
+                rd = rd * (1.5 - 0.5 * p * rd * rd);
+                rd = rd * (1.5 - 0.5 * p * rd * rd);
+                a[jj] = (li == jj) ? p * rd : a[jj] * rd;
+                dpp_settle(a[jj]);
+                const double nj = -a[jj];
+                static_for<jj + 1, 16>([&](auto K) {
+                    constexpr int k = decltype(K)::value;
+                    fmac_bcast<k>(a[k], a[jj], nj);                    // a[li][k] -= l[k][jj] * l[li][jj]
+                });
+                double acc = 0.0;
+                static_for<0, jj>([&](auto K) {
+                    constexpr int k = decltype(K)::value;
+                    fmac_bcast<jj>(acc, a[k], w[k]);                   // acc += l[jj][k] * w[k][c]
+                });
+                w[jj] = (li == jj) ? rd : (li < jj ? -acc * rd : 0.0);
+            });
+            double* dv = Dinv + (j & 1) * (16 * 17);
+            if (lane < 16) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) T[(int64_t)(16 * j + lane) * C + 16 * j + c] = (c <= lane) ? a[c] : 0.0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { dv[i * 17 + lane] = w[i]; Linv[j * 256 + i * 16 + lane] = w[i]; }   // [i][c], zero above the diagonal
+            }
+        };
+        factor(0, Praw);
+#pragma unroll 1
+        for (int j = 0; j < nb; ++j) {
+            CF_BARRIER();                                          // (A)
+            if (C - 16 * (j + 1) <= 0) break;
+            CF_BARRIER();                                          // (B) the others have solved panel j
+            // the last update of block (j+1, j+1): D -= X X^T with X = rows 16(j+1).. of the solved panel; through LDS into
+            // the lane = row layout of the factorisation
+            double* dp = Dpre + ((j + 1) & 1) * (16 * 17);
+            const double* px = Pn + lq * ldp + 16 * (j + 1) + li;
+            f64x4 d4, d5 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d4[r] = dp[(lq + 4 * r) * 17 + li];
+            d4 = __builtin_amdgcn_mfma_f64_16x16x4f64(-px[0], px[0], d4, 0, 0, 0);
+            d5 = __builtin_amdgcn_mfma_f64_16x16x4f64(-px[4 * ldp], px[4 * ldp], d5, 0, 0, 0);
+            d4 = __builtin_amdgcn_mfma_f64_16x16x4f64(-px[8 * ldp], px[8 * ldp], d4, 0, 0, 0);
+            d5 = __builtin_amdgcn_mfma_f64_16x16x4f64(-px[12 * ldp], px[12 * ldp], d5, 0, 0, 0);
+            d4 += d5;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dp[(lq + 4 * r) * 17 + li] = d4[r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // own LDS writes before own reads (one wave: no barrier needed)
+            factor(j + 1, dp);
+        }
+    } else if (CF_OWN == 15 || (wave & 3) != 0) {
+        const int ow = CF_OWN == 15 ? wave - 1 : wave - 1 - (wave >> 2);        // owner index 0..CF_OWN-1
+        // the owner waves hold the trailing blocks: ranked by block column, LAST column first, the diagonal block first within a
+        // column, dealt round-robin -- the blocks still active at a step are a prefix of every wave's slots.
+        // One packed SGPR per slot (bi << 8 | bj), integer arithmetic only.
+        int bc_[CF_SLOTS];
+        f64x4 blk[CF_SLOTS];
+#pragma unroll
+        for (int q = 0; q < CF_SLOTS; ++q) {
+            const int r = ow + CF_OWN * q;
+            bc_[q] = 0;
+            blk[q] = f64x4{0.0, 0.0, 0.0, 0.0};
+            if (r < nblk) {
+                int m = 0;
+                while ((m + 1) * (m + 2) / 2 <= r) ++m;             // column nb-1-m holds m+1 blocks
+                const int bj = nb - 1 - m, bi = bj + (r - m * (m + 1) / 2);
+                bc_[q] = (bi << 8) | bj;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) blk[q][e] = T[(int64_t)(16 * bi + lq + 4 * e) * C + 16 * bj + li];
+            }
+        }
+        int li_t = li, lq_t = lq;       // per-step opaque copies of the lane constants (see the loop)
+        // the rank-16 update of one block: block(bi, bj) -= P[bi] P[bj]^T, operands from the solved panel in LDS
+        auto update = [&](auto Q) __attribute__((always_inline)) {
+            constexpr int q = decltype(Q)::value;
+            const int bc = bc_[q];
+            const double* pa = Pn + lq_t * ldp + 16 * (bc >> 8) + li_t;
+            const double* pb = Pn + lq_t * ldp + 16 * (bc & 255) + li_t;
+            double av[4], bv[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) { av[kk] = -pa[4 * kk * ldp]; bv[kk] = pb[4 * kk * ldp]; }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) blk[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], blk[q], 0, 0, 0);
+        };
+        int cur = 0;
+#pragma unroll 1
+        for (int j = 0; j < nb; ++j) {
+            CF_BARRIER();                                          // (A) the inverse of L_jj and panel j are in LDS
+            const int j0 = 16 * j, g0 = j0 + 16, rows = C - g0;
+            if (rows <= 0) break;
+            // every LDS address below is loop-invariant per slot; left alone, hipcc hoists all of them out of the step loop
+            // (~40 VGPRs) and spills the blocks instead
+            asm volatile("" : "+v"(li_t), "+v"(lq_t));
+            const double* pan = Praw + cur * (C * 17);
+            double* nxt = Praw + (cur ^ 1) * (C * 17);
+            // (S2) panel solve X = P L_jj^-T as a product with the inverted diagonal block: X[r][c] = sum_k P[r][k] Linv[c][k],
+            //      one 16-row block per wave, four f64 MFMAs.  (Row block 0 = the rows of the next diagonal block: from
+            //      panel j's own rows, which hold block (j+1, j).)
+            {
+                const double* dv = Dinv + (j & 1) * (16 * 17);
+                for (int rb = ow; 16 * rb < rows; rb += CF_OWN) {
+                    const int row0 = g0 + 16 * rb;
+                    f64x4 x = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk += 2) {
+                        x = __builtin_amdgcn_mfma_f64_16x16x4f64(pan[(row0 + li_t) * 17 + 4 * kk + lq_t], dv[li_t * 17 + 4 * kk + lq_t], x, 0, 0, 0);
+                        x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(pan[(row0 + li_t) * 17 + 4 * kk + 4 + lq_t], dv[li_t * 17 + 4 * kk + 4 + lq_t], x1, 0, 0, 0);
+                    }
+                    x += x1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = row0 + lq_t + 4 * e;
+                        T[(int64_t)r * C + j0 + li_t] = x[e];
+                        Pn[li_t * ldp + r] = x[e];
+                    }
+                }
+            }
+            CF_BARRIER();                                          // (B) panel j is solved
+            // (S4) this wave's active slots are [0, n34): ranks below R4 lie right of the next panel, the next nb-j-1 ranks ARE
+            // the next panel (column j+1; rank = owner index + CF_OWN * slot).  The next panel's blocks go first and leave for the other
+            // panel buffer -- except the diagonal one, which wave 0 updates and factors itself.  The diagonal block after
+            // that, (j+2, j+2), leaves a copy behind once it has this step's update: wave 0's input at the next step.
+            const int R4 = (nb - j - 2) * (nb - j - 1) / 2, w1 = ow;
+            const int n4 = R4 > w1 ? (R4 - w1 + CF_OWN - 1) / CF_OWN : 0;
+            const int n34 = R4 + nb - j - 1 > w1 ? (R4 + nb - j - 1 - w1 + CF_OWN - 1) / CF_OWN : 0;
+            const int R5 = (nb - j - 3) * (nb - j - 2) / 2;        // rank of block (j+2, j+2), the first of its column
+            const int qd = (j + 2 < nb && R5 % CF_OWN == w1) ? R5 / CF_OWN : -1;
+            static_for<0, CF_SLOTS>([&](auto Q) {                  // next panel first (the highest active slots)
+                constexpr int q = CF_SLOTS - 1 - decltype(Q)::value;
+                if (q >= n4 && q < n34 && (bc_[q] >> 8) != (bc_[q] & 255)) {
+                    update(std::integral_constant<int, q>{});
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) nxt[(16 * (bc_[q] >> 8) + lq_t + 4 * e) * 17 + li_t] = blk[q][e];
+                }
+            });
+            static_for<0, CF_SLOTS>([&](auto Q) {
+                constexpr int q = decltype(Q)::value;
+                if (q < n4) {
+                    update(std::integral_constant<int, q>{});
+                    if (q == qd) {
+                        double* dp = Dpre + (j & 1) * (16 * 17);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dp[(lq_t + 4 * e) * 17 + li_t] = blk[q][e];
+                    }
+                }
+            });
+            cur ^= 1;
+        }
+    }
+    else {
+        // waves 4, 8, 12: on wave 0's SIMD; they only keep the barrier count
+#pragma unroll 1
+        for (int j = 0; j < nb; ++j) {
+            CF_BARRIER();
+            if (C - 16 * (j + 1) <= 0) break;
+            CF_BARRIER();
+        }
+    }
+    if (CF_STAMPS && stamp_ok) { stamps[nstamp++] = __builtin_amdgcn_s_memtime(); stamps[127] = nstamp; }
+    __syncthreads();
+    // strict upper triangle of L := 0 (the diagonal blocks were written whole)
+    for (int e = tid; e < nb * nb * 32; e += 1024) {           // (block row, block column, row in block, half row): 8 doubles each
+        const int half = e & 1, rr = (e >> 1) & 15, bb = e >> 5;
+        const int bi = bb / nb, bj = bb % nb;
+        if (bj > bi) {
+            double* p = T + (int64_t)(16 * bi + rr) * C + 16 * bj + 8 * half;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) p[c] = 0.0;
+        }
+    }
+}
+
+// W = L^-1 from L and the inverses of its 16 x 16 diagonal blocks, one WAVE per block column j:
+//   X_j = Linv_jj;   X_i = -Linv_ii sum_{k=j}^{i-1} L_ik X_k   (i > j),   W[i][j] = X_i.
+// The X blocks of a column stay in its wave's registers in the MFMA accumulator layout, which is at the same time a valid
+// B-operand layout (the four MFMAs of a 16-deep product take k' = (lane>>4) + 4r for r = 0..3; the order in which a
+// contraction index is visited is free).  All columns walk the row blocks i in lock-step: row block i of L (16 x C, 32 KB) is
+// staged through LDS once per workgroup, one step ahead of its use (fed straight from L2 the MFMAs waited ~240 cycles each
+// for their operands: 54 us instead of 18).  Column 0 is the longest chain (540 MFMAs); columns j and nb-1-j share a SIMD.
+template <int PER>        // 16-byte pieces of a row block per thread: ceil(8 C / 512)
+__global__ __launch_bounds__(512) void tri_inverse_cols_kernel(const double* __restrict__ L, const double* __restrict__ Linv,
+                                                               double* __restrict__ W, int C)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int ldr = C + 2;
+    double* Lrow = sm;                          // [2][16][ldr]  row block i of L, even / odd i
+    double* Dv = Lrow + 2 * 16 * ldr;           // [nb][16][17]  the inverted diagonal blocks
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lq = lane >> 4;
+    const int nb = C >> 4;
+    L += (int64_t)blockIdx.y * C * C; W += (int64_t)blockIdx.y * C * C; Linv += (int64_t)blockIdx.y * C * 16;
+    const int idx = 4 * blockIdx.x + (wave & 3);
+    const bool has_col = idx < (nb >> 1);
+    const int j = has_col ? ((wave < 4) ? idx : nb - 1 - idx) : nb;       // idle waves: a column beyond the matrix
+
+    // cooperative staging of a row block: 16 x C doubles = C/2 float4-sized pieces per row, 8 * C / 512 = C/64 per thread
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    // (no predication: a surplus thread repeats the last piece.  Exec-masked loads made hipcc wait for each one before it
+    // issued the next -- four serial L2 round trips, 2100 cycles per step)
+    const int pieces = 8 * C;                   // 16-byte pieces of a row block
+    f64x2 st[PER];
+    auto fetch = [&](int i) {
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {
+            int e = tid + 512 * p; e = e < pieces ? e : pieces - 1;
+            const int row = e / (C >> 1), c2 = e % (C >> 1);
+            st[p] = *reinterpret_cast<const f64x2*>(L + (int64_t)(16 * i + row) * C + 2 * c2);
+        }
+    };
+    auto stash = [&](int i) {
+        double* dst = Lrow + (i & 1) * 16 * ldr;
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {
+            int e = tid + 512 * p; e = e < pieces ? e : pieces - 1;
+            const int row = e / (C >> 1), c2 = e % (C >> 1);
+            *reinterpret_cast<f64x2*>(dst + row * ldr + 2 * c2) = st[p];
+        }
+    };
+    for (int e = tid; e < nb * 256; e += 512) Dv[(e >> 8) * (16 * 17) + ((e >> 4) & 15) * 17 + (e & 15)] = Linv[e];
+    if (nb > 1) { fetch(1); stash(1); }
+    if (nb > 2) fetch(2);                       // (head(1) stashes it)
+    __syncthreads();
+
+    f64x4 X[16];
+    auto store = [&](int i, const f64x4& v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) W[(int64_t)(16 * i + lq + 4 * r) * C + 16 * j + li] = v[r];
+    };
+    if (has_col) {
+        for (int i = 0; i < j; ++i) store(i, f64x4{0.0, 0.0, 0.0, 0.0});      // blocks above the diagonal block: zero
+#pragma unroll
+        for (int r = 0; r < 4; ++r) X[0][r] = Dv[j * (16 * 17) + (lq + 4 * r) * 17 + li];
+        store(j, X[0]);
+    }
+    // global step i, head: row block i+1 (fetched one step ago) into the other buffer -- its last readers passed the barrier that
+    // ended step i-1 -- and row block i+2 on its way.  Tail: the barrier.
+    auto head = [&](int i) {
+        if (i + 1 < nb) stash(i + 1);
+        if (i + 2 < nb) fetch(i + 2);
+    };
+    const bool stamp_ok = CF_STAMPS && lane == 0 && blockIdx.x == 0 && blockIdx.y == 0 && (wave == 0 || wave == 4);
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(W + (int64_t)C * C) + (wave == 0 ? 0 : 128);   // (the workspace behind W: development builds only)
+    int nstamp = 0;
+    (void)stamps; (void)nstamp; (void)stamp_ok;
+#define TI_STAMP() do { if (CF_STAMPS && stamp_ok) stamps[nstamp++] = __builtin_amdgcn_s_memtime(); } while (0)
+    auto tail = [&]() { TI_STAMP(); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); TI_STAMP(); };
+    for (int i = 1; i <= j && i < nb; ++i) { head(i); tail(); }                 // steps before this column starts
+    static_for<1, 16>([&](auto D) {
+        constexpr int d = decltype(D)::value;
+        const int i = j + d;
+        if (i < nb) {
+            head(i);
+            TI_STAMP();
+            const double* lr = Lrow + (i & 1) * 16 * ldr + li * ldr + lq + 16 * j;
+            // the A operands of product e+1 are read from LDS before the MFMAs of product e issue
+            f64x4 S = {0.0, 0.0, 0.0, 0.0}, S1 = {0.0, 0.0, 0.0, 0.0};
+            double an[4], ac[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) an[r] = lr[4 * r];
+            static_for<0, d>([&](auto E) {
+                constexpr int e = decltype(E)::value;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ac[r] = an[r];
+                if constexpr (e + 1 < d) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) an[r] = lr[16 * (e + 1) + 4 * r];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                S = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[0], X[e][0], S, 0, 0, 0);
+                S1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[1], X[e][1], S1, 0, 0, 0);
+                S = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[2], X[e][2], S, 0, 0, 0);
+                S1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[3], X[e][3], S1, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            S += S1;
+            f64x4 Xi = {0.0, 0.0, 0.0, 0.0}, Xi1 = {0.0, 0.0, 0.0, 0.0};
+            const double* pi = Dv + i * (16 * 17) + li * 17 + lq;
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {
+                Xi = __builtin_amdgcn_mfma_f64_16x16x4f64(-pi[4 * r], S[r], Xi, 0, 0, 0);
+                Xi1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-pi[4 * r + 4], S[r + 1], Xi1, 0, 0, 0);
+            }
+            Xi += Xi1;
+            X[d] = Xi;
+            TI_STAMP();
+            tail();
+        }
+    });
+    // the column leaves the registers at the end, in one burst: a store inside the loop sits in the same in-order memory
+    // counter as the row-block fetches, and every wait for fetched data then also waited ~2000 cycles for the store before it
+    static_for<1, 16>([&](auto D) {
+        constexpr int d = decltype(D)::value;
+        if (j + d < nb) store(j + d, X[d]);
+    });
+    if (CF_STAMPS && stamp_ok) stamps[127] = nstamp;
+#undef TI_STAMP
+}
+
 // inverse of each 32 x 32 diagonal block of L (lower): one wave per block, lane = column of the inverse
 __global__ __launch_bounds__(256) void tri_inv_diag_kernel(const double* __restrict__ L, double* __restrict__ W, int C)
 {
@@ -713,6 +1101,43 @@ hipError_t wc_launch_factor_prepare(const double* sum, const double* xtx, int64_
                        sum, xtx, M, C, eps, momentum, ddof, training, groups, moving_mean, moving_cov, mu, chan_scale, T);
     return hipGetLastError();
 }
+
+// C <= 256: Cholesky with look-ahead + the inverses of the diagonal blocks in one launch, W in a second one
+static bool use_fused_factor(int C)
+{
+    static const bool off = getenv("WC_CHOL_OLD") != nullptr;             // development: the round-1 kernels
+    return C <= 256 && !off;
+}
+
+hipError_t wc_launch_factor_fused(double* T, double* W, double* tmp, int C, int groups, hipStream_t st)
+{
+    const int nb = C >> 4, ldp = C + 2;
+    const size_t lds = (size_t)(2 * C * 17 + 16 * ldp + 4 * 16 * 17) * sizeof(double);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cholesky_fused_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(cholesky_fused_kernel, dim3(groups), dim3(1024), lds, st, T, tmp, C, ldp);
+    const int nwg = ((nb >> 1) + 3) / 4;
+    const size_t lds2 = (size_t)(2 * 16 * (C + 2) + nb * 16 * 17) * sizeof(double);
+#define WC_TI_LAUNCH(PER_)                                                                                             \
+    do {                                                                                                                \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(tri_inverse_cols_kernel<PER_>),                           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);                                 \
+        if (e != hipSuccess) return e;                                                                                  \
+        hipLaunchKernelGGL((tri_inverse_cols_kernel<PER_>), dim3(nwg, groups), dim3(512), lds2, st, (const double*)T,   \
+                           (const double*)tmp, W, C);                                                                   \
+    } while (0)
+    switch ((C + 63) / 64) {
+        case 1: WC_TI_LAUNCH(1); break;
+        case 2: WC_TI_LAUNCH(2); break;
+        case 3: WC_TI_LAUNCH(3); break;
+        default: WC_TI_LAUNCH(4); break;
+    }
+#undef WC_TI_LAUNCH
+    return hipGetLastError();
+}
+
+bool wc_factor_is_fused(int C) { return use_fused_factor(C); }
 
 hipError_t wc_launch_cholesky(double* T, int C, int groups, hipStream_t st)
 {
