@@ -229,6 +229,35 @@ def wc_backward(gy, cache):
 
 
 # --------------------------------------------------------------------------
+# renorm=True ('dr', generator.py:26) [UPSTREAM-RECALL]: the batch-renormalisation analogue
+#   W_eff = L_mov^-1 . stop_gradient(L_batch) . L_batch^-1
+# Its VALUE is the moving-statistics whitening (L_b L_b^-1 = I), its GRADIENT flows through the batch factor only.
+# With C0 = L_mov^-1 L_batch held constant:  xhat = f W_b^T C0^T,  y = xhat Gamma + beta = f W_b^T (C0^T Gamma) + beta,
+# i.e. the plain transform with the coloring Gamma' = C0^T Gamma -- which is how wc_gan_amd.layers folds it.
+# The moving statistics used for L_mov are the ones BEFORE this batch's update.
+# --------------------------------------------------------------------------
+def wc_forward_renorm(x, gamma=None, beta=None, idx=None, *, moving_mean, moving_cov, eps=DEFAULT_EPS,
+                      momentum=DEFAULT_MOMENTUM, ddof=1):
+    x = np.asarray(x, dtype=np.float64)
+    C = x.shape[-1]
+    _, c0 = wc_forward(x, None, None, None, training=True, eps=eps, ddof=ddof)
+    _, Wm = whitening_matrix(np.asarray(moving_cov, np.float64), eps)
+    C0 = Wm @ c0['L']
+    G = np.eye(C)[None] if gamma is None else np.asarray(gamma, np.float64).reshape(-1, C, C)
+    Geff = np.einsum('ji,kjo->kio', C0, G)                      # C0^T Gamma_k
+    y, cache = wc_forward(x, Geff, beta, idx, training=True, moving_mean=moving_mean, moving_cov=moving_cov,
+                          eps=eps, momentum=momentum, ddof=ddof)
+    cache['C0'] = C0
+    return y, cache
+
+
+def wc_backward_renorm(gy, cache):
+    """(dx, dgamma, dbeta) of wc_forward_renorm: C0 is a constant of the step."""
+    dx, dGeff, dB = wc_backward(gy, cache)
+    return dx, np.einsum('ij,kjo->kio', cache['C0'], dGeff), dB
+
+
+# --------------------------------------------------------------------------
 # the reference's UNFUSED op order (row a2 + a6), used to show fused == unfused
 # --------------------------------------------------------------------------
 def wc_forward_unfused(x, kernel, bias, eps=DEFAULT_EPS, ddof=1):

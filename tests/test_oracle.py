@@ -158,3 +158,39 @@ def test_golden_fixtures_reproduce():
             assert np.abs(got - want).max() <= 2e-6 * max(np.abs(want).max(), 1e-30), n
         if training:
             assert np.allclose(cache['moving_cov'], a['mc1'], rtol=1e-6, atol=1e-7)
+
+
+def test_renorm_oracle_matches_torch_autograd_with_stop_gradient():
+    """Row a4: W_eff = L_mov^-1 . stop_gradient(L_b) . L_b^-1 -- value and gradients against torch float64 autograd with
+    L_b.detach() in the middle factor."""
+    rng = np.random.default_rng(3)
+    shape, C, Kc, eps = (6, 4, 4, 16), 16, 3, 1e-3
+    x = o.synth_activation(rng, shape)
+    G, B = o.synth_coloring(rng, C, Kc)
+    slot = rng.integers(0, Kc, shape[0])
+    gy = rng.standard_normal(shape)
+    ref = o.synth_activation(rng, (500, C))
+    mm, mc = o.moments_to_stats(*o.batch_moments(ref))
+    y, cache = o.wc_forward_renorm(x, G, B, slot, moving_mean=mm, moving_cov=mc, eps=eps)
+    dx, dG, dB = o.wc_backward_renorm(gy, cache)
+    eye = torch.eye(C, dtype=torch.float64)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    Gt = torch.tensor(G, dtype=torch.float64, requires_grad=True); Bt = torch.tensor(B, dtype=torch.float64, requires_grad=True)
+    X = xt.reshape(-1, C); M = X.shape[0]
+    f = X - X.mean(0)
+    Lb = torch.linalg.cholesky((1 - eps) * (f.T @ f / (M - 1)) + eps * eye)
+    Wb = torch.linalg.solve_triangular(Lb, eye, upper=False)
+    Lm = torch.linalg.cholesky((1 - eps) * torch.tensor(mc) + eps * eye)
+    Wm = torch.linalg.solve_triangular(Lm, eye, upper=False)
+    Weff = Wm @ Lb.detach() @ Wb
+    it = torch.tensor(slot).long()
+    yt = torch.einsum('npc,nco->npo', (f @ Weff.T).reshape(shape[0], -1, C), Gt[it]) + Bt[it][:, None, :]
+    yt.backward(torch.tensor(gy).reshape(shape[0], -1, C))
+    assert np.abs(y.reshape(yt.shape) - yt.detach().numpy()).max() < 1e-10
+    # the value is the moving-statistics whitening of the batch-centred activation
+    assert np.abs((f.detach().numpy() @ Wm.numpy().T) - cache['f'] @ cache['W'].T @ cache['C0'].T).max() < 1e-9
+    assert np.abs(dx - xt.grad.numpy()).max() < 1e-9
+    assert np.abs(dG - Gt.grad.numpy()).max() < 1e-9 and np.abs(dB - Bt.grad.numpy()).max() < 1e-10
+    # moving statistics take the batch's update (un-shrunk covariance), as in the plain layer
+    mm1, mc1 = o.update_moving(mm, mc, cache['mu'], cache['sigma'])
+    assert np.allclose(cache['moving_mean'], mm1) and np.allclose(cache['moving_cov'], mc1)
