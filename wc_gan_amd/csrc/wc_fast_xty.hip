@@ -31,6 +31,9 @@ __device__ __forceinline__ unsigned pk_rne(float a, float b)
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
 }
 constexpr float kGuard = 60000.0f;
+#ifndef XTY_STAMPS
+#define XTY_STAMPS 0      // development: s_memtime stamps of wave 0 / workgroup 0 behind the partials (the caller adds 2 KiB to the workspace)
+#endif
 constexpr int BW = 3;                      // 32x32 blocks per wave
 
 
@@ -127,7 +130,13 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
 #pragma unroll
         for (int p = 0; p < 8; ++p) xr[p] = ldg4(base + p * C);
     };
-    bool overflow = false;
+    // The staging is what bounds this kernel: 16 (K1) to 22 (K4) vector instructions per MFMA before this trim (rocprofv3
+    // SQ_INSTS_VALU / SQ_INSTS_MFMA, profiles/r2_k1_xty_pmc.json), every row converted by each workgroup of its slab.  So:
+    // the range guard is a running max (v_max3_f32 with |.| modifiers, one instruction per two elements), the split
+    // remainder is one v_fma_mix_f32 per element (it reads the fp16 half directly), and the column sums / squares are
+    // taken only by the workgroup that reports them.
+    float gmax = 0.f;
+    const bool want_csum = a.colsum != nullptr && type == 0 && (!TWO || op == 1);
     f32x4 csum = {0.f, 0.f, 0.f, 0.f};
     // The DIAGONAL of the covariance does not come from the matrix pipe.  Two systematic errors meet there, both
     // measured on MI355X (tools/probe/mfma_gram_probe.hip, tools/k1_bias.py):
@@ -148,8 +157,12 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             g[p] = xr[p] * scl + ncs;
-            csum += g[p];
-            overflow |= (fabsf(g[p][0]) > kGuard) | (fabsf(g[p][1]) > kGuard) | (fabsf(g[p][2]) > kGuard) | (fabsf(g[p][3]) > kGuard);
+            gmax = __builtin_fmaxf(__builtin_fmaxf(gmax, fabsf(g[p][0])), fabsf(g[p][1]));
+            gmax = __builtin_fmaxf(__builtin_fmaxf(gmax, fabsf(g[p][2])), fabsf(g[p][3]));
+        }
+        if (want_csum) {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) csum += g[p];
         }
         if (want_dfix) {
             f32x4 sq = g[0] * g[0];
@@ -165,8 +178,10 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
             for (int pp = 0; pp < 4; ++pp) {
                 const float v0 = g[2 * pp][j], v1 = g[2 * pp + 1][j];
                 hw[pp] = pk_rne(v0, v1);
-                const f16x2 h = __builtin_bit_cast(f16x2, hw[pp]);
-                lw[pp] = pk_rne(v0 - (float)h[0], v1 - (float)h[1]);
+                float r0_, r1_;         // remainder = v - float(hi) in one mixed-precision FMA per element
+                asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0_) : "v"(hw[pp]), "v"(v0));
+                asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1_) : "v"(hw[pp]), "v"(v1));
+                lw[pp] = pk_rne(r0_, r1_);
             }
             *reinterpret_cast<uint4*>(img + st_off[j]) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
             *reinterpret_cast<uint4*>(img + st_off[j] + IMG) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
@@ -195,10 +210,22 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
         if (nst > 1) stage_load(1);
     }
     __syncthreads();
+    const bool stamp_ok = XTY_STAMPS && tid == 0 && blockIdx.x == 0;
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(a.P + (int64_t)a.nslab * C * C);     // just past P: stamp builds get a larger workspace
+    int nstamp = 0;
+    (void)stamps; (void)nstamp; (void)stamp_ok;
+#define XS() do { if (XTY_STAMPS && stamp_ok && nstamp < 250) stamps[nstamp++] = __builtin_amdgcn_s_memtime(); } while (0)
+    // (Tried and dropped, measured: the stage as two half-steps in which waves 0-3 convert while their SIMD partners 4-7 run the
+    // MFMAs and vice versa -- both halves slowed down by more than 2x, K1 89 -> 127 us: the ds_write_b128 bursts of the
+    // converting waves and the fragment reads of the MFMA waves fight over the LDS.  An L2 prefetch of the stage three steps
+    // ahead: 89 -> 100 us.)
     for (int st = 0; st < nst; ++st) {
         const int cur = st & 1;
+        XS();
         if (st + 1 < nst) stage_write(cur ^ 1);
+        XS();
         if (st + 2 < nst) stage_load(st + 2);
+        XS();
         const char* img = smem + cur * (NOP * 2 * IMG);
 #pragma unroll 4
         for (int ks = 0; ks < KS; ++ks) {
@@ -215,13 +242,18 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
                 acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[b], 0, 0, 0);
             }
         }
+        XS();
         // float64 flush: the fp32 rounding chain never exceeds one stage (3*KS MFMA accumulations)
 #pragma unroll
         for (int b = 0; b < BW; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc64[b][r] += (double)acc[b][r]; acc[b][r] = 0.f; }
-        __syncthreads();
+        XS();
+        // LDS hand-off only (__syncthreads() would also drain vmcnt, i.e. wait for the loads of stage st+2 issued a moment ago)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
+    if (XTY_STAMPS && stamp_ok) { stamps[nstamp++] = __builtin_amdgcn_s_memtime(); stamps[255] = nstamp; }
+#undef XS
 
     // partial blocks out, scales undone exactly (powers of two)
     double* P = a.P + z * (int64_t)C * C;
@@ -237,7 +269,7 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
         }
     }
     // column sums (type-0 workgroups): of the single operand, or of Y when there are two
-    if (type == 0 && a.colsum && (!TWO || op == 1)) {
+    if (want_csum) {
         // csum holds sums of SCALED values of channels 4*c4.. over this thread's rows; reduce over the row groups in LDS
         float* red = reinterpret_cast<float*>(smem);            // [row groups][C], free after the last barrier
 #pragma unroll
@@ -266,7 +298,7 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
             a.dfix[z * C + c] = s / ((double)a.sx[c] * (double)a.sx[c]);
         }
     }
-    if (overflow) atomicOr(a.flag, 1);
+    if (!(gmax <= kGuard)) atomicOr(a.flag, 1);
 }
 
 template <int C, bool TWO>

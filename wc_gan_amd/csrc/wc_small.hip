@@ -780,22 +780,22 @@ __global__ __launch_bounds__(512) void tri_inverse_cols_kernel(const double* __r
     // issued the next -- four serial L2 round trips, 2100 cycles per step)
     const int pieces = 8 * C;                   // 16-byte pieces of a row block
     f64x2 st[PER];
+    int soff[PER], doff[PER];                   // the piece's place in a row block of L / in its LDS image: computed ONCE (two
+#pragma unroll                                  // integer divisions per piece; left inside fetch / stash they ran every step)
+    for (int p = 0; p < PER; ++p) {
+        int e = tid + 512 * p; e = e < pieces ? e : pieces - 1;
+        const int row = e / (C >> 1), c2 = e % (C >> 1);
+        soff[p] = row * C + 2 * c2; doff[p] = row * ldr + 2 * c2;
+    }
     auto fetch = [&](int i) {
+        const double* src = L + (int64_t)16 * i * C;
 #pragma unroll
-        for (int p = 0; p < PER; ++p) {
-            int e = tid + 512 * p; e = e < pieces ? e : pieces - 1;
-            const int row = e / (C >> 1), c2 = e % (C >> 1);
-            st[p] = *reinterpret_cast<const f64x2*>(L + (int64_t)(16 * i + row) * C + 2 * c2);
-        }
+        for (int p = 0; p < PER; ++p) st[p] = *reinterpret_cast<const f64x2*>(src + soff[p]);
     };
     auto stash = [&](int i) {
         double* dst = Lrow + (i & 1) * 16 * ldr;
 #pragma unroll
-        for (int p = 0; p < PER; ++p) {
-            int e = tid + 512 * p; e = e < pieces ? e : pieces - 1;
-            const int row = e / (C >> 1), c2 = e % (C >> 1);
-            *reinterpret_cast<f64x2*>(dst + row * ldr + 2 * c2) = st[p];
-        }
+        for (int p = 0; p < PER; ++p) *reinterpret_cast<f64x2*>(dst + doff[p]) = st[p];
     };
     for (int e = tid; e < nb * 256; e += 512) Dv[(e >> 8) * (16 * 17) + ((e >> 4) & 15) * 17 + (e & 15)] = Linv[e];
     if (nb > 1) { fetch(1); stash(1); }

@@ -16,6 +16,8 @@ from . import _state, ops
 
 
 def _allreduce_(tensors, group):
+    """Sum over the replicas, in place.  (General form: pack, reduce, unpack.  The WC path itself hands over tensors that are
+    already views of one buffer -- ops.stats / ops.bwd_reduce with flat=True -- and all-reduces that buffer directly.)"""
     flat = torch.cat([t.reshape(-1) for t in tensors])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     off = 0
@@ -35,11 +37,14 @@ class WhitenColorFunction(torch.autograd.Function):
         dev = x.device
         M = M_local
         if training:
-            s, xtx = ops.stats(x.view(M_local, C))
             if process_group is not None:
-                # every replica holds the same number of rows (fixed per-GPU batch): no host sync for the count
-                _allreduce_([s, xtx], process_group)
+                # sync-WC: the additive moments of all replicas, ONE collective on the buffer K1 wrote them into (no pack /
+                # unpack launches); every replica holds the same number of rows (fixed per-GPU batch): no host sync for the count
+                s, xtx, buf = ops.stats(x.view(M_local, C), flat=True)
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=process_group)
                 M = M_local * dist.get_world_size(process_group)
+            else:
+                s, xtx = ops.stats(x.view(M_local, C))
         else:
             s = xtx = None
         mm = moving_mean.view(-1) if moving_mean is not None else None
@@ -76,7 +81,10 @@ class WhitenColorFunction(torch.autograd.Function):
         want_g = ctx.has_gamma and need_g
         want_b = ctx.has_beta and need_b
         if want_g or want_b or stats_path:
-            R, gsum = ops.bwd_reduce(x, mu, gy, slot, Kc)
+            if ctx.group is None:
+                R, gsum = ops.bwd_reduce(x, mu, gy, slot, Kc)
+            else:
+                R, gsum, rbuf = ops.bwd_reduce(x, mu, gy, slot, Kc, flat=True)
             if ctx.group is None:
                 dgamma, dbeta, S, gmean = ops.bwd_factor(R, gsum, W, L, g, A, ctx.M, ctx.eps, ctx.ddof, stats_path,
                                                          want_dgamma=want_g, want_dbeta=want_b)
@@ -87,7 +95,7 @@ class WhitenColorFunction(torch.autograd.Function):
                     dgamma, dbeta, _, _ = ops.bwd_factor(R, gsum, W, L, g, A, ctx.M, ctx.eps, ctx.ddof, False,
                                                          want_dgamma=want_g, want_dbeta=want_b)
                 if stats_path:
-                    _allreduce_([R, gsum], ctx.group)
+                    dist.all_reduce(rbuf, op=dist.ReduceOp.SUM, group=ctx.group)
                     _, _, S, gmean = ops.bwd_factor(R, gsum, W, L, g, A, ctx.M, ctx.eps, ctx.ddof, True,
                                                     want_dgamma=False, want_dbeta=False)
         if need_x:

@@ -42,21 +42,27 @@ def _workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
-def stats(x2d, groups=1):
+def stats(x2d, groups=1, flat=False):
     """K1: x2d (M, C) float32 -> (sum (C,) f64, xtx (C, C) f64), the raw additive moments.
-    groups > 1: M/groups consecutive rows per statistic group -> sum (G, C), xtx (G, C, C)."""
+    groups > 1: M/groups consecutive rows per statistic group -> sum (G, C), xtx (G, C, C).
+    flat=True (groups == 1): both are views of ONE buffer, returned third -- what sync-WC all-reduces in a single call."""
     lib = _lib.load()
     _need(x2d, torch.float32, "x", 2)
     M, C = x2d.shape
     lead = (groups,) if groups > 1 else ()
-    s = torch.empty(*lead, C, dtype=torch.float64, device=x2d.device)
-    xtx = torch.empty(*lead, C, C, dtype=torch.float64, device=x2d.device)
+    buf = None
+    if flat and groups == 1:
+        buf = torch.empty(C + C * C, dtype=torch.float64, device=x2d.device)
+        s, xtx = buf[:C], buf[C:].view(C, C)
+    else:
+        s = torch.empty(*lead, C, dtype=torch.float64, device=x2d.device)
+        xtx = torch.empty(*lead, C, C, dtype=torch.float64, device=x2d.device)
     nb = lib.wc_stats_workspace_bytes(M, C, groups)
     if nb == 0:
         _lib.check(-3 if M % groups == 0 else -2, "wc_stats_f32")
     ws = _workspace(nb, x2d.device)
     _lib.check(lib.wc_stats_f32(_ptr(x2d), M, C, groups, _ptr(s), _ptr(xtx), _ptr(ws), ws.numel(), _stream()), "wc_stats_f32")
-    return s, xtx
+    return (s, xtx, buf) if buf is not None else (s, xtx)
 
 
 def factor(s, xtx, M, C, eps, momentum, ddof, training, moving_mean, moving_cov, device, want_scale=False, groups=1):
@@ -137,19 +143,24 @@ def apply(x, mu, A, bias, slot, out=None, fast=True, plan=None, relu=False):
     return y
 
 
-def bwd_reduce(x, mu, gy, slot, Kc):
-    """K4: -> (R (Kc,C,C) f64, gsum (Kc,C) f64)."""
+def bwd_reduce(x, mu, gy, slot, Kc, flat=False):
+    """K4: -> (R (Kc,C,C) f64, gsum (Kc,C) f64); flat=True: views of one buffer, returned third (sync-WC's single all-reduce)."""
     lib = _lib.load()
     _need(x, torch.float32, "x")
     _need(gy, torch.float32, "gy")
     N, C = x.shape[0], x.shape[-1]
     HW = x.numel() // (N * C)
-    R = torch.empty(Kc, C, C, dtype=torch.float64, device=x.device)
-    gsum = torch.empty(Kc, C, dtype=torch.float64, device=x.device)
+    buf = None
+    if flat:
+        buf = torch.empty(Kc * (C * C + C), dtype=torch.float64, device=x.device)
+        R, gsum = buf[:Kc * C * C].view(Kc, C, C), buf[Kc * C * C:].view(Kc, C)
+    else:
+        R = torch.empty(Kc, C, C, dtype=torch.float64, device=x.device)
+        gsum = torch.empty(Kc, C, dtype=torch.float64, device=x.device)
     ws = _workspace(lib.wc_bwd_reduce_workspace_bytes(N, HW, C, Kc, int(slot is not None)), x.device)
     _lib.check(lib.wc_bwd_reduce_f32(_ptr(x), _ptr(mu), _ptr(gy), _ptr(slot), N, HW, C, Kc, _ptr(R), _ptr(gsum),
                                      _ptr(ws), ws.numel(), _stream()), "wc_bwd_reduce_f32")
-    return R, gsum
+    return (R, gsum, buf) if buf is not None else (R, gsum)
 
 
 def bwd_factor(R, gsum, W, L, gamma, A, M, eps, ddof, training, want_dgamma=True, want_dbeta=True):
