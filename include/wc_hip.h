@@ -114,7 +114,7 @@ int wc_group_bias_f32(const float* mu /*[groups,C]*/, const float* A /*[groups*K
 
 /* K3: y[n] = (x[n] - mu) A[slot[n]] + bias[slot[n]]   (bias NULL = 0; mu NULL = 0).
  * With a workspace of wc_apply_workspace_bytes() the split-fp16 MFMA fast path runs when the shape allows
- * (C in {32,64,128,256}, N*HW >= 16384 and a multiple of 16384/C rows); ws == NULL (and no plan) always takes the
+ * (C in {32,64,128,256}, N*HW >= 1024 and a multiple of 16384/C rows); ws == NULL (and no plan) always takes the
  * exact f32-MFMA kernel.  Both give fp32-GEMM accuracy; a row tile holding an element outside the fp16 range -- or,
  * with slot != NULL and HW not a multiple of the 8192/C-row tile, a tile that straddles samples of different slots --
  * is detected on the device and recomputed in fp32 by the same kernel. */

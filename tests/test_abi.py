@@ -79,4 +79,5 @@ def test_fast_apply_takes_the_grouped_and_conditional_sites(lib):
     assert lib.wc_apply_workspace_bytes(320, 144, 256, 5) > 256       # STL-10 12x12, five statistic groups
     assert lib.wc_apply_workspace_bytes(320, 64, 128, 50) > 256       # CIFAR-10 cond 8x8, 5 groups x 10 classes
     assert lib.wc_apply_workspace_bytes(128, 144, 256, 7) > 256       # per-class tables, tiles straddle samples
-    assert lib.wc_apply_workspace_bytes(128, 36, 256, 1) == 256       # 4608 rows: below the fast path's minimum
+    assert lib.wc_apply_workspace_bytes(128, 16, 256, 1) > 256        # 2048 rows (the 4x4 site): one planned launch since round 2
+    assert lib.wc_apply_workspace_bytes(8, 36, 256, 1) == 256         # 288 rows: below the fast path's minimum

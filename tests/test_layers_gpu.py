@@ -541,3 +541,36 @@ def test_eval_plan_follows_training_updates_of_the_moving_statistics():
         stack.npart._eval_plan.key = None          # force a rebuild: the reference
         y3 = stack(x, None).clone()
     assert torch.equal(y2, y3) and not torch.equal(y1, y2)
+
+
+@pytest.mark.gpu
+def test_sync_wc_path_with_a_one_rank_rccl_group(tmp_path):
+    """process_group=... (sync-WC): the moments (K1) and the backward reductions (K4) are all-reduced over RCCL on the
+    buffers the kernels wrote them into.  With ONE rank the sum is the identity, so values and gradients must equal the
+    per-replica path bit for bit -- this runs the collective code path on the GPU (the two-rank arithmetic is covered
+    on the CPU by tests/test_dp_gloo.py)."""
+    import torch.distributed as dist
+    from wc_gan_amd.functional import whiten_color
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method=f"file://{tmp_path}/rdzv", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        rng = np.random.default_rng(31)
+        shape, C, Kc = (16, 8, 8, 64), 64, 3
+        x = o.synth_activation(rng, shape, "ill").astype(np.float32)
+        G, B = o.synth_coloring(rng, C, Kc)
+        slot = dev(rng.integers(0, Kc, shape[0]), torch.int32)
+        gy = dev(rng.standard_normal(shape))
+        outs = []
+        for group in (None, dist.group.WORLD):
+            xt = dev(x).requires_grad_(True); Gt = dev(G).requires_grad_(True); Bt = dev(B).requires_grad_(True)
+            mm = torch.zeros(C, 1, device="cuda"); mc = torch.eye(C, device="cuda")
+            y = whiten_color(xt, Gt, Bt, slot, mm, mc, True, process_group=group)
+            y.backward(gy)
+            outs.append((y.detach(), xt.grad, Gt.grad, Bt.grad, mc))
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
+    finally:
+        dist.destroy_process_group()

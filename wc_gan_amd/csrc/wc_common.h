@@ -70,7 +70,12 @@ hipError_t wc_launch_spectral_norm_bwd(const float* g, const float* w_sn, const 
                                        int R, int K, int fully_diff, float* dW, void* ws, hipStream_t st);
 
 // ----- fast split-fp16 affine (wc_fast.hip) ---------------------------------------------------
-constexpr int64_t WC_FAST_MIN_ROWS = 16384;     // below this the launch-count overhead of the fast path is not repaid
+constexpr int64_t WC_FAST_MIN_ROWS = 16384;     // reductions (K1/K4): below this the exact float64-MFMA kernel runs (development: WC_XTY_MIN_ROWS)
+// apply (K3/K6): below this the f32-MFMA kernel runs.  1024 since round 2: with the plan built by wc_color_f32 the split-fp16
+// apply is ONE launch whatever the size -- 8 against 35-43 us at the 4x4 / 8x8 sites of the generator (M = 2048..8192)
+constexpr int64_t WC_AFFINE_MIN_ROWS = 1024;
+int64_t wc_fast_xty_min_rows();
+int64_t wc_fast_affine_min_rows();
 bool   wc_fast_affine_supported(int64_t N, int64_t HW, int C, bool has_slot);
 size_t wc_fast_affine_workspace(int C, int Kc);
 hipError_t wc_launch_fast_affine(const float* in, const float* center, const float* B, int Kc, bool shared_table,

@@ -885,6 +885,13 @@ hipError_t launch_affine(const FastArgs& a, hipStream_t st)
 
 }  // namespace
 
+int64_t wc_fast_affine_min_rows()
+{
+    // development: WC_AFFINE_MIN_ROWS overrides the smallest M the split-fp16 apply takes
+    static const int64_t v = getenv("WC_AFFINE_MIN_ROWS") ? atoll(getenv("WC_AFFINE_MIN_ROWS")) : WC_AFFINE_MIN_ROWS;
+    return v;
+}
+
 static bool use_ring()
 {
     static const bool on = getenv("WC_NO_RING") == nullptr;      // development: the register-staged kernel everywhere
@@ -895,7 +902,7 @@ bool wc_fast_affine_supported(int64_t N, int64_t HW, int C, bool has_slot)
 {
     if (!(C == 32 || C == 64 || C == 128 || C == 256)) return false;
     const int64_t M = N * HW;
-    if (M < WC_FAST_MIN_ROWS) return false;
+    if (M < wc_fast_affine_min_rows()) return false;
     const int BM = 64 * 256 / C;
     // slots: the ring kernel (every non-accumulating call) redoes tiles that straddle samples of different slots; the
     // register-staged kernel cannot, so without the ring a tile must not straddle two samples

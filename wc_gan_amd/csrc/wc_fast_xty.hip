@@ -17,6 +17,7 @@
 //  * fp16 range: per-channel power-of-two scales from a row subsample, undone exactly in the float64 flush; an
 //    out-of-range element raises the same device gate as in wc_fast.hip and the exact kernel redoes the call.
 #include "wc_common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -218,7 +219,8 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
     // (Tried and dropped, measured: the stage as two half-steps in which waves 0-3 convert while their SIMD partners 4-7 run the
     // MFMAs and vice versa -- both halves slowed down by more than 2x, K1 89 -> 127 us: the ds_write_b128 bursts of the
     // converting waves and the fragment reads of the MFMA waves fight over the LDS.  An L2 prefetch of the stage three steps
-    // ahead: 89 -> 100 us.)
+    // ahead: 89 -> 100 us.  Reading the A fragments once for a wave's blocks of the same block row (12 -> 9 ds_read_b128 per
+    // k-step): no change, +18 spilled registers.)
     for (int st = 0; st < nst; ++st) {
         const int cur = st & 1;
         XS();
@@ -330,12 +332,18 @@ static int xty_stage_rows(int C, bool two)
     return two ? rg * 4 : rg * 8;
 }
 
+int64_t wc_fast_xty_min_rows()
+{
+    static const int64_t v = getenv("WC_XTY_MIN_ROWS") ? atoll(getenv("WC_XTY_MIN_ROWS")) : WC_FAST_MIN_ROWS;
+    return v;
+}
+
 // Plan: slabs of whole stages; total workgroups ~ one per CU.  Returns nslab (0 = shape not eligible).
 int wc_fast_xty_plan(int64_t N, int64_t HW, int C, int per_sample, int two, int* nsplit, int64_t* rows_per_slab, int* ntypes)
 {
     if (!(C == 32 || C == 64 || C == 128 || C == 256)) return 0;
     const int64_t M = N * HW;
-    if (M < WC_FAST_MIN_ROWS) return 0;
+    if (M < wc_fast_xty_min_rows()) return 0;
     const int R = xty_stage_rows(C, two != 0);
     const int64_t seg = per_sample ? HW : M;                  // rows of one segment (slabs never cross segments)
     if (seg % R != 0) return 0;
