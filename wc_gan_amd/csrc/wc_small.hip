@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void bwd_combine_kernel(const double* __restri
 __global__ void factor_prepare_kernel(const double* __restrict__ sum, const double* __restrict__ xtx, int64_t M, int C,
                                       double eps, double momentum, int ddof, int training, int groups,
                                       float* __restrict__ moving_mean, float* __restrict__ moving_cov,
-                                      float* __restrict__ mu, float* __restrict__ chan_scale, double* __restrict__ T)
+                                      float* __restrict__ mu, float* __restrict__ chan_scale, double* __restrict__ T, int lower_only)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y;
@@ -156,7 +156,9 @@ __global__ void factor_prepare_kernel(const double* __restrict__ sum, const doub
             if (i == 0) mu[(int64_t)g * C + j] = moving_mean[j];
         }
         const double t = (1.0 - eps) * sig + (i == j ? eps : 0.0);
-        T[g * CC + e] = t;
+        // lower_only: the fused Cholesky reads block rows at and below the diagonal only and leaves the rest as it finds
+        // it -- the zeros of L's upper triangle are written here, off its critical path
+        T[g * CC + e] = (lower_only && (j >> 4) > (i >> 4)) ? 0.0 : t;
         tmax = t > tmax ? t : tmax;
     }
     if (chan_scale && i == j) {
@@ -532,6 +534,9 @@ template <int B, int E, typename F> __device__ __forceinline__ void static_for(F
 #endif                              // SIMD: measured 74 against 69 us -- the early steps are bound by the CU's f64-MFMA rate and lose a quarter of it)
 constexpr int CF_SLOTS = (120 + CF_OWN - 1) / CF_OWN;      // 120 blocks at C = 256 (16 waves x 128 VGPRs: 10 blocks = 80 of them)
 
+#ifndef CF_NEWTON
+#define CF_NEWTON 1        // Newton steps on v_rsq_f64 per pivot (measured: L to 1e-13 with one, 1e-7 with none)
+#endif
 #ifndef CF_STAMPS
 #define CF_STAMPS 0      // development: s_memtime stamps around every barrier of waves 0, 1 and 5 into the workspace behind Linv
 #endif
@@ -570,7 +575,7 @@ __global__ __launch_bounds__(1024) void cholesky_fused_kernel(double* __restrict
     // other waves update the trailing matrix and publish the next panel.
     if (wave == 0) {
         // wave 0: factor a 16 x 16 diagonal block (src: [16][17]) and invert the factor, lane = row / column (all four 16-lane
-        // rows of the wave do the same work).  Pivot: v_rsq_f64 + two Newton steps.  Row jj of the inverse (lane = its
+        // rows of the wave do the same work).  Pivot: v_rsq_f64 + one Newton step.  Row jj of the inverse (lane = its
         // column c): w[jj] = -rd_jj sum_{k<jj} l[jj][k] w[k], taken as soon as row jj of L is final.
         __builtin_amdgcn_s_setprio(3);
         auto factor = [&](int j, const double* src) __attribute__((always_inline)) {
@@ -581,8 +586,12 @@ __global__ __launch_bounds__(1024) void cholesky_fused_kernel(double* __restrict
                 constexpr int jj = decltype(J)::value;
                 const double p = row_bcast<jj>(a[jj]);
                 double rd = __builtin_amdgcn_rsq(p);
+#if CF_NEWTON >= 1
                 rd = rd * (1.5 - 0.5 * p * rd * rd);
+#endif
+#if CF_NEWTON >= 2
                 rd = rd * (1.5 - 0.5 * p * rd * rd);
+#endif
                 a[jj] = (li == jj) ? p * rd : a[jj] * rd;
                 dpp_settle(a[jj]);
                 const double nj = -a[jj];
@@ -737,17 +746,8 @@ __global__ __launch_bounds__(1024) void cholesky_fused_kernel(double* __restrict
         }
     }
     if (CF_STAMPS && stamp_ok) { stamps[nstamp++] = __builtin_amdgcn_s_memtime(); stamps[127] = nstamp; }
-    __syncthreads();
-    // strict upper triangle of L := 0 (the diagonal blocks were written whole)
-    for (int e = tid; e < nb * nb * 32; e += 1024) {           // (block row, block column, row in block, half row): 8 doubles each
-        const int half = e & 1, rr = (e >> 1) & 15, bb = e >> 5;
-        const int bi = bb / nb, bj = bb % nb;
-        if (bj > bi) {
-            double* p = T + (int64_t)(16 * bi + rr) * C + 16 * bj + 8 * half;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) p[c] = 0.0;
-        }
-    }
+    // L's upper triangle: the blocks above the diagonal were zero on entry (factor_prepare_kernel), the diagonal blocks
+    // were written whole
 }
 
 // W = L^-1 from L and the inverses of its 16 x 16 diagonal blocks, one WAVE per block column j:
@@ -1093,20 +1093,21 @@ hipError_t wc_launch_bwd_combine(const double* P, const float* colsum, const int
     return hipGetLastError();
 }
 
-hipError_t wc_launch_factor_prepare(const double* sum, const double* xtx, int64_t M, int C, double eps, double momentum,
-                                    int ddof, int training, int groups, float* moving_mean, float* moving_cov, float* mu,
-                                    float* chan_scale, double* T, hipStream_t st)
-{
-    hipLaunchKernelGGL(factor_prepare_kernel, dim3((C + 127) / 128, C), dim3(128), 0, st,
-                       sum, xtx, M, C, eps, momentum, ddof, training, groups, moving_mean, moving_cov, mu, chan_scale, T);
-    return hipGetLastError();
-}
-
 // C <= 256: Cholesky with look-ahead + the inverses of the diagonal blocks in one launch, W in a second one
 static bool use_fused_factor(int C)
 {
     static const bool off = getenv("WC_CHOL_OLD") != nullptr;             // development: the round-1 kernels
     return C <= 256 && !off;
+}
+
+hipError_t wc_launch_factor_prepare(const double* sum, const double* xtx, int64_t M, int C, double eps, double momentum,
+                                    int ddof, int training, int groups, float* moving_mean, float* moving_cov, float* mu,
+                                    float* chan_scale, double* T, hipStream_t st)
+{
+    hipLaunchKernelGGL(factor_prepare_kernel, dim3((C + 127) / 128, C), dim3(128), 0, st,
+                       sum, xtx, M, C, eps, momentum, ddof, training, groups, moving_mean, moving_cov, mu, chan_scale, T,
+                       use_fused_factor(C) ? 1 : 0);
+    return hipGetLastError();
 }
 
 hipError_t wc_launch_factor_fused(double* T, double* W, double* tmp, int C, int groups, hipStream_t st)
