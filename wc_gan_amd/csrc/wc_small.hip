@@ -48,14 +48,33 @@ __global__ __launch_bounds__(1024) void stats_colsum_kernel(const float* __restr
     }
 }
 
-// xtx = G' + s Sp^T + Sp s^T + M s s^T with G' = sum_z P[z]; only block-upper tiles of P were written.
-// block = 64 columns x 4 slab groups, one row i per blockIdx.y
-__global__ __launch_bounds__(256) void stats_xtx_kernel(const double* __restrict__ P, const float* __restrict__ shift,
-                                                        const double* __restrict__ Sp, int nslab, int64_t M, int C,
-                                                        double* __restrict__ xtx, const double* __restrict__ dfix,
-                                                        const int* __restrict__ gate)
+// Sum of up to 16 strided terms p[z * stride], z = z0, z0 + step, ... (< n), with all the loads in flight at once: the slab
+// reductions below are latency-bound otherwise (4 loads in flight per thread: 15 us for 34 MB at C = 256).  The index is
+// clamped instead of predicated -- hipcc puts an s_waitcnt vmcnt(0) between exec-masked loads.  Fixed order: deterministic.
+template <typename T>
+__device__ __forceinline__ double strided_sum16(const T* __restrict__ p, int64_t stride, int z0, int step, int n)
 {
-    __shared__ double red[4][64];
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int z = z0 + u * step;
+        v[u] = (double)p[(int64_t)(z < n ? z : n - 1) * stride];
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += (z0 + u * step < n) ? v[u] : 0.0;
+    return s;
+}
+
+// xtx = G' + s Sp^T + Sp s^T + M s s^T with G' = sum_z P[z]; only block-upper tiles of P were written.
+// block = 64 columns x 8 slab groups, one row i per blockIdx.y
+constexpr int SX_PARTS = 8;
+__global__ __launch_bounds__(64 * SX_PARTS) void stats_xtx_kernel(const double* __restrict__ P, const float* __restrict__ shift,
+                                                                  const double* __restrict__ Sp, int nslab, int64_t M, int C,
+                                                                  double* __restrict__ xtx, const double* __restrict__ dfix,
+                                                                  const int* __restrict__ gate)
+{
+    __shared__ double red[SX_PARTS][64];
     const int j = blockIdx.x * 64 + (threadIdx.x & 63);
     const int part = threadIdx.x >> 6;
     const int i = blockIdx.y;
@@ -64,21 +83,19 @@ __global__ __launch_bounds__(256) void stats_xtx_kernel(const double* __restrict
     P += (int64_t)blockIdx.z * nslab * CC; Sp += (int64_t)blockIdx.z * C; xtx += (int64_t)blockIdx.z * CC;   // group
     double g = 0.0;
     if (j < C && j >= i) {
-        const double* p = P + (int64_t)i * C + j;
-#pragma unroll 4
-        for (int z = part; z < nslab; z += 4) g += p[z * CC];
         // the fast reduction's diagonal comes from its VALU sums of squares, not from the matrix pipe (wc_fast_xty.hip:
         // the MFMA's rounding is biased for all-positive products) -- unless the exact redo has replaced the partials
-        if (j == i && dfix && !(gate && *gate != 0)) {
-            const double* d = dfix + (int64_t)blockIdx.z * nslab * C + i;
-            g = 0.0;
-            for (int z = part; z < nslab; z += 4) g += d[(int64_t)z * C];
-        }
+        const bool diag = j == i && dfix && !(gate && *gate != 0);
+        const double* p = diag ? dfix + (int64_t)blockIdx.z * nslab * C + i : P + (int64_t)i * C + j;
+        const int64_t stride = diag ? C : CC;
+        for (int z0 = part; z0 < nslab; z0 += 16 * SX_PARTS) g += strided_sum16(p, stride, z0, SX_PARTS, nslab);
     }
     red[part][threadIdx.x & 63] = g;
     __syncthreads();
     if (threadIdx.x < 64 && j < C && j >= i) {
-        g = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        g = 0.0;
+#pragma unroll
+        for (int q = 0; q < SX_PARTS; ++q) g += red[q][threadIdx.x];
         const double si = shift[i], sj = shift[j];
         const double v = g + si * Sp[j] + Sp[i] * sj + (double)M * si * sj;
         xtx[(int64_t)i * C + j] = v;
@@ -87,14 +104,14 @@ __global__ __launch_bounds__(256) void stats_xtx_kernel(const double* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------
-// K4 tail: per-slab partials -> per-slot R, gsum.  block = 64 elements x 4 slab groups.
+// K4 tail: per-slab partials -> per-slot R, gsum.  block = 64 elements x 8 slab groups.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bwd_combine_kernel(const double* __restrict__ P, const float* __restrict__ colsum,
-                                                          const int32_t* __restrict__ slot, int64_t N, int nsplit,
-                                                          int per_sample, int C, double* __restrict__ R,
-                                                          double* __restrict__ gsum)
+__global__ __launch_bounds__(64 * SX_PARTS) void bwd_combine_kernel(const double* __restrict__ P, const float* __restrict__ colsum,
+                                                                    const int32_t* __restrict__ slot, int64_t N, int nsplit,
+                                                                    int per_sample, int C, double* __restrict__ R,
+                                                                    double* __restrict__ gsum)
 {
-    __shared__ double red[4][64];
+    __shared__ double red[SX_PARTS][64];
     const int64_t CC = (int64_t)C * C;
     const int64_t e = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);    // element of C*C (+ C for gsum)
     const int part = threadIdx.x >> 6;
@@ -102,22 +119,29 @@ __global__ __launch_bounds__(256) void bwd_combine_kernel(const double* __restri
     const bool live = e < CC + C;
     const bool is_sum = e >= CC;
     double acc = 0.0;
-    auto term = [&](int64_t z) { return is_sum ? (double)colsum[z * C + (e - CC)] : P[z * CC + e]; };
+    auto terms = [&](int64_t zbase, int n) {           // sum over z = zbase + part, + SX_PARTS, ... < zbase + n
+        double t = 0.0;
+        for (int z0 = part; z0 < n; z0 += 16 * SX_PARTS)
+            t += is_sum ? strided_sum16(colsum + zbase * C + (e - CC), (int64_t)C, z0, SX_PARTS, n)
+                        : strided_sum16(P + zbase * CC + e, CC, z0, SX_PARTS, n);
+        return t;
+    };
     if (live) {
         if (per_sample) {
             for (int64_t n = 0; n < N; ++n) {
                 if (slot[n] != k) continue;
-                for (int q = part; q < nsplit; q += 4) acc += term(n * nsplit + q);
+                acc += terms(n * nsplit, nsplit);
             }
         } else {
-#pragma unroll 4
-            for (int z = part; z < nsplit; z += 4) acc += term(z);
+            acc = terms(0, nsplit);
         }
     }
     red[part][threadIdx.x & 63] = acc;
     __syncthreads();
     if (threadIdx.x < 64 && live) {
-        acc = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < SX_PARTS; ++q) acc += red[q][threadIdx.x];
         if (is_sum) gsum[(int64_t)k * C + (e - CC)] = acc;
         else R[k * CC + e] = acc;
     }
@@ -1080,7 +1104,7 @@ hipError_t wc_launch_stats_finalize(const double* P, const float* colsum, const 
 {
     // nslab and M are PER GROUP; group g owns slabs [g*nslab, (g+1)*nslab)
     hipLaunchKernelGGL(stats_colsum_kernel, dim3((C + 63) / 64, groups), dim3(1024), 0, st, colsum, shift, nslab, M, C, Sp, sum);
-    hipLaunchKernelGGL(stats_xtx_kernel, dim3((C + 63) / 64, C, groups), dim3(256), 0, st, P, shift, (const double*)Sp, nslab, M, C, xtx, dfix, gate);
+    hipLaunchKernelGGL(stats_xtx_kernel, dim3((C + 63) / 64, C, groups), dim3(64 * SX_PARTS), 0, st, P, shift, (const double*)Sp, nslab, M, C, xtx, dfix, gate);
     return hipGetLastError();
 }
 
@@ -1088,7 +1112,7 @@ hipError_t wc_launch_bwd_combine(const double* P, const float* colsum, const int
                                  int per_sample, int C, int Kc, double* R, double* gsum, hipStream_t st)
 {
     const int64_t total = (int64_t)C * C + C;
-    hipLaunchKernelGGL(bwd_combine_kernel, dim3((unsigned)((total + 63) / 64), Kc), dim3(256), 0, st,
+    hipLaunchKernelGGL(bwd_combine_kernel, dim3((unsigned)((total + 63) / 64), Kc), dim3(64 * SX_PARTS), 0, st,
                        P, colsum, slot, N, nsplit, per_sample, C, R, gsum);
     return hipGetLastError();
 }
