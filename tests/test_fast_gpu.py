@@ -142,6 +142,30 @@ def test_fast_bwd_reduce_matches_float64(ops, shape, Kc):
         assert rel(gsum[k].cpu().numpy(), g[sel].sum((0, 1))) < 1e-5
 
 
+@pytest.mark.parametrize("shape", [(32, 32, 32, 256), (64, 32, 32, 128), (16, 64, 64, 64)])
+def test_fast_reductions_out_of_range_take_the_exact_redo(ops, shape):
+    """One activation beyond the fp16 range of the scaled operands: the fast K1 / K4 kernels raise their gate and the gated
+    exact kernels (a few workgroups walking every (slab, tile) pair) replace all partials."""
+    rng = np.random.default_rng(23)
+    N, C = shape[0], shape[-1]
+    x = (rng.standard_normal(shape) + 0.3).astype(np.float32)
+    x[1, 2, 3, 5] = 4.0e7
+    gy = (rng.standard_normal(shape) * 1e-3).astype(np.float32)
+    gy[2, 1, 0, 7] = 3.0e6
+    X = x.reshape(-1, C).astype(np.float64)
+    s, xtx = ops.stats(dev(x).view(-1, C))
+    nat = np.sqrt(np.outer((X ** 2).sum(0), (X ** 2).sum(0)))
+    assert np.abs((xtx.cpu().numpy() - X.T @ X) / nat).max() < 1e-6
+    assert np.abs((s.cpu().numpy() - X.sum(0)) / np.sqrt((X ** 2).sum(0) * X.shape[0])).max() < 1e-6
+    mu = x.reshape(-1, C).mean(0).astype(np.float32)
+    R, gsum = ops.bwd_reduce(dev(x), dev(mu), dev(gy), None, 1)
+    f = X - mu.astype(np.float64)
+    g = gy.astype(np.float64).reshape(-1, C)
+    nat = np.sqrt(np.outer((f ** 2).sum(0), (g ** 2).sum(0)))
+    assert np.abs((R[0].cpu().numpy() - f.T @ g) / nat).max() < 1e-6
+    assert np.abs((gsum[0].cpu().numpy() - g.sum(0)) / np.sqrt((g ** 2).sum(0) * g.shape[0])).max() < 1e-6
+
+
 @pytest.mark.parametrize("shape,Kc", [((16, 32, 32, 256), 1), ((17, 32, 32, 256), 1), ((128, 32, 32, 128), 10), ((4, 64, 64, 32), 2),
                                       ((8, 8, 8, 64), 3), ((33, 24, 24, 128), 1)])
 def test_apply_with_fused_relu(ops, shape, Kc):
