@@ -79,7 +79,7 @@ int wc_stats_f32(const float* x, int64_t M, int C, int groups, double* sum, doub
     int* gate = cv.take<int>(64);
     float* shift = cv.take<float>(C);
     float* scale = cv.take<float>(C);
-    (void)cv.take<double>((size_t)groups * C);       // (was: the column sums' scratch; kept so that workspace sizes do not change)
+    double* Sp = cv.take<double>((size_t)groups * C);
     float* colsum = cv.take<float>((size_t)p.nslab * C);
     double* dfix = cv.take<double>((size_t)p.nslab * C);
     double* P = cv.take<double>((size_t)p.nslab * C * C);
@@ -95,7 +95,7 @@ int wc_stats_f32(const float* x, int64_t M, int C, int groups, double* sum, doub
         a.gate = gate;                       // exact redo, a no-op unless the fp16 range was exceeded
     }
     WC_TRY(wc_launch_xty(a, p.nslab, st));
-    WC_TRY(wc_launch_stats_finalize(P, colsum, shift, p.nslab / groups, HWs, C, groups, sum, xtx,
+    WC_TRY(wc_launch_stats_finalize(P, colsum, shift, p.nslab / groups, HWs, C, groups, Sp, sum, xtx,
                                     p.fast ? dfix : nullptr, p.fast ? gate : nullptr, st));
     return WC_OK;
 }

@@ -103,7 +103,7 @@ hipError_t wc_launch_channel_scale2(const float* in, const float* center, float*
 
 // K1 tail: shifted fp32 partials -> raw float64 moments
 hipError_t wc_launch_stats_finalize(const double* P, const float* colsum, const float* shift, int nslab,
-                                    int64_t M, int C, int groups, double* sum, double* xtx,
+                                    int64_t M, int C, int groups, double* Sp /*[groups*C] scratch*/, double* sum, double* xtx,
                                     const double* dfix /*[groups*nslab][C] the fast path's VALU diagonal, nullable*/,
                                     const int* gate /*dfix is void when *gate != 0 (the exact redo ran)*/, hipStream_t st);
 // K4 tail: per-slab partials -> per-slot float64 R, gsum

@@ -24,6 +24,30 @@ __device__ __forceinline__ double readlane64(double v, int l)
 // ---------------------------------------------------------------------------------------------
 // K1 tail
 // ---------------------------------------------------------------------------------------------
+// 16 slab groups x 64 channels per block; partial sums meet in LDS (fixed order: deterministic)
+__global__ __launch_bounds__(1024) void stats_colsum_kernel(const float* __restrict__ colsum, const float* __restrict__ shift,
+                                                            int nslab, int64_t M, int C, double* __restrict__ Sp,
+                                                            double* __restrict__ sum)
+{
+    __shared__ double red[16][64];
+    // statistic group = blockIdx.y: its nslab partial slabs, its Sp / sum rows (shift is common to all groups)
+    colsum += (int64_t)blockIdx.y * nslab * C; Sp += (int64_t)blockIdx.y * C; sum += (int64_t)blockIdx.y * C;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int part = threadIdx.x >> 6;
+    double s = 0.0;
+    if (c < C)
+        for (int z = part; z < nslab; z += 16) s += (double)colsum[(int64_t)z * C + c];
+    red[part][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (threadIdx.x < 64 && c < C) {
+        double t = 0.0;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) t += red[p][threadIdx.x];
+        Sp[c] = t;
+        sum[c] = t + (double)M * (double)shift[c];
+    }
+}
+
 // Sum of up to 16 strided terms p[z * stride], z = z0, z0 + step, ... (< n), with all the loads in flight at once: the slab
 // reductions below are latency-bound otherwise (4 loads in flight per thread: 15 us for 34 MB at C = 256).  The index is
 // clamped instead of predicated -- hipcc puts an s_waitcnt vmcnt(0) between exec-masked loads.  Fixed order: deterministic.
@@ -42,51 +66,40 @@ __device__ __forceinline__ double strided_sum16(const T* __restrict__ p, int64_t
     return s;
 }
 
-// xtx = G' + s Sp^T + Sp s^T + M s s^T with G' = sum_z P[z] and Sp = sum_z colsum[z] (sum = Sp + M s); only block-upper
-// tiles of P were written.  block = 64 columns x 8 slab groups, one row i per blockIdx.y.  Every workgroup reduces the
-// column sums it needs itself (columns j and i: 2 x 16 more loads per thread from a 128 KB array, against one more launch
-// on the critical path of the site); row 0's workgroups write `sum`.
+// xtx = G' + s Sp^T + Sp s^T + M s s^T with G' = sum_z P[z]; only block-upper tiles of P were written.
+// block = 64 columns x 8 slab groups, one row i per blockIdx.y
 constexpr int SX_PARTS = 8;
-__global__ __launch_bounds__(64 * SX_PARTS) void stats_xtx_kernel(const double* __restrict__ P, const float* __restrict__ colsum,
-                                                                  const float* __restrict__ shift, int nslab, int64_t M, int C,
-                                                                  double* __restrict__ sum, double* __restrict__ xtx,
-                                                                  const double* __restrict__ dfix, const int* __restrict__ gate)
+__global__ __launch_bounds__(64 * SX_PARTS) void stats_xtx_kernel(const double* __restrict__ P, const float* __restrict__ shift,
+                                                                  const double* __restrict__ Sp, int nslab, int64_t M, int C,
+                                                                  double* __restrict__ xtx, const double* __restrict__ dfix,
+                                                                  const int* __restrict__ gate)
 {
-    __shared__ double red[3][SX_PARTS][64];
+    __shared__ double red[SX_PARTS][64];
     const int j = blockIdx.x * 64 + (threadIdx.x & 63);
     const int part = threadIdx.x >> 6;
     const int i = blockIdx.y;
     if (blockIdx.x * 64 + 63 < i) return;          // whole block below the diagonal
     const int64_t CC = (int64_t)C * C;
-    // statistic group = blockIdx.z: its nslab partial slabs, its sum / xtx (shift is common to all groups)
-    P += (int64_t)blockIdx.z * nslab * CC; colsum += (int64_t)blockIdx.z * nslab * C;
-    sum += (int64_t)blockIdx.z * C; xtx += (int64_t)blockIdx.z * CC;
-    double g = 0.0, cj = 0.0, ci = 0.0;
-    if (j < C) {
+    P += (int64_t)blockIdx.z * nslab * CC; Sp += (int64_t)blockIdx.z * C; xtx += (int64_t)blockIdx.z * CC;   // group
+    double g = 0.0;
+    if (j < C && j >= i) {
         // the fast reduction's diagonal comes from its VALU sums of squares, not from the matrix pipe (wc_fast_xty.hip:
         // the MFMA's rounding is biased for all-positive products) -- unless the exact redo has replaced the partials
         const bool diag = j == i && dfix && !(gate && *gate != 0);
         const double* p = diag ? dfix + (int64_t)blockIdx.z * nslab * C + i : P + (int64_t)i * C + j;
         const int64_t stride = diag ? C : CC;
-        for (int z0 = part; z0 < nslab; z0 += 16 * SX_PARTS) {
-            if (j >= i) g += strided_sum16(p, stride, z0, SX_PARTS, nslab);
-            cj += strided_sum16(colsum + j, (int64_t)C, z0, SX_PARTS, nslab);
-            ci += strided_sum16(colsum + i, (int64_t)C, z0, SX_PARTS, nslab);
-        }
+        for (int z0 = part; z0 < nslab; z0 += 16 * SX_PARTS) g += strided_sum16(p, stride, z0, SX_PARTS, nslab);
     }
-    red[0][part][threadIdx.x & 63] = g; red[1][part][threadIdx.x & 63] = cj; red[2][part][threadIdx.x & 63] = ci;
+    red[part][threadIdx.x & 63] = g;
     __syncthreads();
-    if (threadIdx.x < 64 && j < C) {
-        g = cj = ci = 0.0;
+    if (threadIdx.x < 64 && j < C && j >= i) {
+        g = 0.0;
 #pragma unroll
-        for (int q = 0; q < SX_PARTS; ++q) { g += red[0][q][threadIdx.x]; cj += red[1][q][threadIdx.x]; ci += red[2][q][threadIdx.x]; }
+        for (int q = 0; q < SX_PARTS; ++q) g += red[q][threadIdx.x];
         const double si = shift[i], sj = shift[j];
-        if (i == 0) sum[j] = cj + (double)M * sj;
-        if (j >= i) {
-            const double v = g + si * cj + ci * sj + (double)M * si * sj;
-            xtx[(int64_t)i * C + j] = v;
-            if (j != i) xtx[(int64_t)j * C + i] = v;   // mirrored by the same thread: exact symmetry
-        }
+        const double v = g + si * Sp[j] + Sp[i] * sj + (double)M * si * sj;
+        xtx[(int64_t)i * C + j] = v;
+        if (j != i) xtx[(int64_t)j * C + i] = v;   // mirrored by the same thread: exact symmetry
     }
 }
 
@@ -1086,12 +1099,12 @@ __global__ void f64_to_f32_kernel(const double* __restrict__ src, float* __restr
 }  // namespace
 
 hipError_t wc_launch_stats_finalize(const double* P, const float* colsum, const float* shift, int nslab,
-                                    int64_t M, int C, int groups, double* sum, double* xtx,
+                                    int64_t M, int C, int groups, double* Sp, double* sum, double* xtx,
                                     const double* dfix, const int* gate, hipStream_t st)
 {
     // nslab and M are PER GROUP; group g owns slabs [g*nslab, (g+1)*nslab)
-    hipLaunchKernelGGL(stats_xtx_kernel, dim3((C + 63) / 64, C, groups), dim3(64 * SX_PARTS), 0, st, P, colsum, shift, nslab, M, C,
-                       sum, xtx, dfix, gate);
+    hipLaunchKernelGGL(stats_colsum_kernel, dim3((C + 63) / 64, groups), dim3(1024), 0, st, colsum, shift, nslab, M, C, Sp, sum);
+    hipLaunchKernelGGL(stats_xtx_kernel, dim3((C + 63) / 64, C, groups), dim3(64 * SX_PARTS), 0, st, P, shift, (const double*)Sp, nslab, M, C, xtx, dfix, gate);
     return hipGetLastError();
 }
 
