@@ -1,6 +1,8 @@
-R=$PWD
+#!/bin/bash
+# steady-state step profile only (rocprofv3 kernel trace of tools/step_only.py) -> gpurun_out/<tag>_step{,.md}
+R=$PWD; TAG=${1:-r2g}
+mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/step_prof_v19 -o s -- python3 $R/tools/step_only.py 3 > $R/gpurun_out/step_prof_v19.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_step -o s -- python3 $R/tools/step_only.py 3 > $R/gpurun_out/${TAG}_step.log 2>&1
 cd $R
-tail -1 gpurun_out/step_prof_v19.log
-python tools/summarize_profile.py gpurun_out/step_prof_v19 gpurun_out/step_prof_v19.md gap >/dev/null; head -60 gpurun_out/step_prof_v19.md | cut -c1-150
+python tools/summarize_profile.py gpurun_out/${TAG}_step gpurun_out/${TAG}_step.md gap > /dev/null

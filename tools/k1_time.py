@@ -10,7 +10,7 @@ def t(fn, it=20):
     for _ in range(it): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / it * 1e3
-for shape in ((128, 32, 32, 256), (64, 32, 32, 256), (128, 16, 16, 256), (128, 32, 32, 128), (128, 48, 48, 256), (128, 64, 64, 128)):
+for shape in ((64, 4, 4, 256), (64, 8, 8, 256), (64, 16, 16, 256), (128, 4, 4, 128), (128, 32, 32, 256), (64, 32, 32, 256), (128, 16, 16, 256), (128, 32, 32, 128), (128, 48, 48, 256), (128, 64, 64, 128)):
     C = shape[-1]
     x = torch.randn(*shape, device='cuda'); gy = torch.randn(*shape, device='cuda'); mu = torch.zeros(C, device='cuda')
     print(shape, "K1 stage %.1f us   K4 stage %.1f us" % (t(lambda: ops.stats(x.view(-1, C))), t(lambda: ops.bwd_reduce(x, mu, gy, None, 1))))

@@ -291,14 +291,23 @@ __global__ __launch_bounds__(256) void xty_kernel(WcXtyArgs a, int ntiles, int n
 // ---------------------------------------------------------------------------------------------
 // xty, exact variant for small M: products of float32 values are exact in float64, and the float64
 // MFMA (v_mfma_f64_16x16x4_f64) accumulates them in float64, so the partials carry no fp32 rounding
-// at all.  Half the rate of the f32 MFMA -- used only when M <= WC_EXACT_ROWS, where the statistics
-// of few rows get no help from averaging and the whole reduction is a few microseconds anyway.
+// at all.  Used when M <= WC_EXACT_ROWS (the 4x4 .. 16x16 sites of a batch of 64), where the statistics
+// of few rows get no help from averaging.
 //   a = A[i = lane&15][k = lane>>4], b = B[k = lane>>4][j = lane&15], D reg r = D[(lane>>4) + 4r][lane&15]
+// The float64 MFMA takes 64 cycles per 16 x 16 x 4 product, so what decides the time of these small calls is how many
+// SIMDs work on them: 64 x 64 tiles (4 waves, 32 x 32 each) give 10 (covariance) / 16 workgroups per slab of 256 rows at
+// C = 256 instead of 3 / 4 with the 128 x 128 tiles of xty_kernel (measured in the CIFAR-10 step: 57-70 us per call
+// with those, 7 calls per step).  Rows come in chunks of 128 (all of a thread's loads of a chunk in flight at once).
 // ---------------------------------------------------------------------------------------------
+constexpr int XT = 64;            // tile edge (channels)
+constexpr int XK = 128;           // rows per LDS chunk
+constexpr int XLD = XT + 16;      // chunk row pitch in floats: the four k rows of one ds_read_b32 land on different banks
+
 __global__ __launch_bounds__(256) void xty_f64_kernel(WcXtyArgs a, int ntiles, int nb)
 {
-    __shared__ __attribute__((aligned(16))) float Xs[BK * BM];
-    __shared__ __attribute__((aligned(16))) float Ys[BK * BN];
+    extern __shared__ __attribute__((aligned(16))) float xty_lds[];      // Xs[XK][XLD] | Ys[XK][XLD]
+    float* Xs = xty_lds;
+    float* Ys = xty_lds + XK * XLD;
 
     if (a.gate && *a.gate == 0) return;      // exact redo of a fast-path call: only when it flagged an overflow
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -330,60 +339,67 @@ __global__ __launch_bounds__(256) void xty_f64_kernel(WcXtyArgs a, int ntiles, i
         if (r1 > M) r1 = M;
     }
 
-    const int q4 = tid & 31;
-    const int rbase = tid >> 5;
-    const int ci = ib * BM + 4 * q4, cj = jb * BN + 4 * q4;
+    const int q4 = tid & 15;          // float4 column group inside the tile
+    const int rbase = tid >> 4;       // + 16*p
+    const int ci = ib * XT + 4 * q4, cj = jb * XT + 4 * q4;
     const bool vi = ci < C, vj = cj < C;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const f32x4 cx = (a.cx && vi) ? ld4(a.cx + ci) : zero4;
     const f32x4 cy = (a.cy && vj) ? ld4(a.cy + cj) : zero4;
 
-    f64x4 acc[4][4];
+    f64x4 acc[2][2];
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt)
+    for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc[tt][u] = f64x4{0.0, 0.0, 0.0, 0.0};
+        for (int u = 0; u < 2; ++u) acc[tt][u] = f64x4{0.0, 0.0, 0.0, 0.0};
     f32x4 csum = zero4;
 
-    const bool t_ok = (ib * BM + wr * 64) < C && (jb * BN + wc * 64) < C;
+    const bool t_ok = (ib * XT + wr * 32) < C && (jb * XT + wc * 32) < C;
     const int li = lane & 15, lq = lane >> 4;
 
-    f32x4 xv[4], yv[4];
+    f32x4 xv[8], yv[8];
     auto load_chunk = [&](int64_t m0) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int64_t m = m0 + rbase + 8 * p;
+        for (int p = 0; p < 8; ++p) {
+            const int64_t m = m0 + rbase + 16 * p;
             const bool ok = m < r1;
-            xv[p] = (ok && vi) ? ld4(a.X + m * C + ci) - cx : zero4;
-            if (!diag) yv[p] = (ok && vj) ? ld4(a.Y + m * C + cj) - cy : zero4;
+            const int64_t mc = ok ? m : r0;             // clamped, not predicated: keeps the eight loads in flight together
+            const f32x4 vx = vi ? ld4(a.X + mc * C + ci) - cx : zero4;
+            xv[p] = ok ? vx : zero4;
+            if (!diag) {
+                const f32x4 vy = vj ? ld4(a.Y + mc * C + cj) - cy : zero4;
+                yv[p] = ok ? vy : zero4;
+            }
         }
     };
 
     if (r0 < r1) load_chunk(r0);
-    for (int64_t m0 = r0; m0 < r1; m0 += BK) {
+    for (int64_t m0 = r0; m0 < r1; m0 += XK) {
         __syncthreads();
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            *reinterpret_cast<f32x4*>(&Xs[(rbase + 8 * p) * BM + 4 * q4]) = xv[p];
-            if (!diag) *reinterpret_cast<f32x4*>(&Ys[(rbase + 8 * p) * BN + 4 * q4]) = yv[p];
+        for (int p = 0; p < 8; ++p) {
+            *reinterpret_cast<f32x4*>(&Xs[(rbase + 16 * p) * XLD + 4 * q4]) = xv[p];
+            if (!diag) *reinterpret_cast<f32x4*>(&Ys[(rbase + 16 * p) * XLD + 4 * q4]) = yv[p];
             csum += a.sym ? xv[p] : yv[p];
         }
         __syncthreads();
-        if (m0 + BK < r1) load_chunk(m0 + BK);
+        if (m0 + XK < r1) load_chunk(m0 + XK);
         if (t_ok) {
             const float* Bsrc = diag ? Xs : Ys;
-#pragma unroll 2
-            for (int kk = 0; kk < BK; kk += 4) {
-                double av[4], bv[4];
+            const int64_t left = r1 - m0;
+            const int kend = left >= XK ? XK : (int)((left + 3) & ~(int64_t)3);      // rows past r1 are zero in the chunk
+#pragma unroll 4
+            for (int kk = 0; kk < kend; kk += 4) {
+                double av[2], bv[2];
 #pragma unroll
-                for (int tt = 0; tt < 4; ++tt) {
-                    av[tt] = (double)Xs[(kk + lq) * BM + wr * 64 + tt * 16 + li];
-                    bv[tt] = (double)Bsrc[(kk + lq) * BN + wc * 64 + tt * 16 + li];
+                for (int tt = 0; tt < 2; ++tt) {
+                    av[tt] = (double)Xs[(kk + lq) * XLD + wr * 32 + tt * 16 + li];
+                    bv[tt] = (double)Bsrc[(kk + lq) * XLD + wc * 32 + tt * 16 + li];
                 }
 #pragma unroll
-                for (int tt = 0; tt < 4; ++tt)
+                for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
+                    for (int u = 0; u < 2; ++u)
                         acc[tt][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[tt], bv[u], acc[tt][u], 0, 0, 0);
             }
         }
@@ -391,30 +407,31 @@ __global__ __launch_bounds__(256) void xty_f64_kernel(WcXtyArgs a, int ntiles, i
 
     double* P = a.P + z * (int64_t)C * C;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int j = jb * BN + wc * 64 + u * 16 + li;
+    for (int u = 0; u < 2; ++u) {
+        const int j = jb * XT + wc * 32 + u * 16 + li;
         if (j >= C) continue;
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt)
+        for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int i = ib * BM + wr * 64 + tt * 16 + lq + 4 * r;
+                const int i = ib * XT + wr * 32 + tt * 16 + lq + 4 * r;
                 if (i < C) P[(int64_t)i * C + j] = acc[tt][u][r];
             }
     }
 
+    // column sums: X columns on diagonal tiles (sym), Y columns on the ib == 0 tiles (non-sym)
     const bool want = a.sym ? diag : (ib == 0);
     if (want && a.colsum) {
         __syncthreads();
-        float* red = Xs;
+        float* red = Xs;                           // [16][64]
 #pragma unroll
-        for (int j = 0; j < 4; ++j) red[rbase * 128 + 4 * q4 + j] = csum[j];
+        for (int j = 0; j < 4; ++j) red[rbase * XT + 4 * q4 + j] = csum[j];
         __syncthreads();
-        if (tid < 128) {
+        if (tid < XT) {
             float sacc = 0.f;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) sacc += red[r * 128 + tid];
-            const int col = (a.sym ? ib : jb) * 128 + tid;
+            for (int r = 0; r < 16; ++r) sacc += red[r * XT + tid];
+            const int col = (a.sym ? ib : jb) * XT + tid;
             if (col < C) a.colsum[z * C + col] = sacc;
         }
     }
@@ -543,13 +560,24 @@ int wc_xty_plan(int64_t N, int64_t HW, int C, int per_sample, int sym, int* nspl
 
 hipError_t wc_launch_xty(const WcXtyArgs& a, int nslab, hipStream_t st)
 {
+    if (a.N * a.HW <= WC_EXACT_ROWS) {
+        const int nb = (a.C + XT - 1) / XT;
+        const int ntiles = a.sym ? nb * (nb + 1) / 2 : nb * nb;
+        constexpr size_t lds = (size_t)2 * XK * XLD * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(xty_f64_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(xty_f64_kernel, dim3((unsigned)((int64_t)nslab * ntiles)), dim3(256), lds, st, a, ntiles, nb);
+        return hipGetLastError();
+    }
     const int nb = (a.C + BM - 1) / BM;
     const int ntiles = a.sym ? nb * (nb + 1) / 2 : nb * nb;
     const int64_t grid = (int64_t)nslab * ntiles;
-    if (a.N * a.HW <= WC_EXACT_ROWS)
-        hipLaunchKernelGGL(xty_f64_kernel, dim3((unsigned)grid), dim3(256), 0, st, a, ntiles, nb);
-    else
-        hipLaunchKernelGGL(xty_kernel, dim3((unsigned)grid), dim3(256), 0, st, a, ntiles, nb);
+    hipLaunchKernelGGL(xty_kernel, dim3((unsigned)grid), dim3(256), 0, st, a, ntiles, nb);
     return hipGetLastError();
 }
 

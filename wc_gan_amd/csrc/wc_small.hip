@@ -48,21 +48,32 @@ __global__ __launch_bounds__(1024) void stats_colsum_kernel(const float* __restr
     }
 }
 
-// Sum of up to 16 strided terms p[z * stride], z = z0, z0 + step, ... (< n), with all the loads in flight at once: the slab
+// Sum of the strided terms p[z * stride], z = z0, z0 + step, ... (< n), with up to 16 loads in flight at once: the slab
 // reductions below are latency-bound otherwise (4 loads in flight per thread: 15 us for 34 MB at C = 256).  The index is
-// clamped instead of predicated -- hipcc puts an s_waitcnt vmcnt(0) between exec-masked loads.  Fixed order: deterministic.
-template <typename T>
-__device__ __forceinline__ double strided_sum16(const T* __restrict__ p, int64_t stride, int z0, int step, int n)
+// clamped instead of predicated -- hipcc puts an s_waitcnt vmcnt(0) between exec-masked loads -- so the batch shrinks
+// with n (the grouped critic-phase sites have 26 slabs per group: no 12 idle loads per thread).  Fixed order: deterministic.
+template <int UB, typename T>
+__device__ __forceinline__ double strided_batch(const T* __restrict__ p, int64_t stride, int z0, int step, int n)
 {
-    double v[16];
+    double v[UB];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
+    for (int u = 0; u < UB; ++u) {
         const int z = z0 + u * step;
         v[u] = (double)p[(int64_t)(z < n ? z : n - 1) * stride];
     }
     double s = 0.0;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) s += (z0 + u * step < n) ? v[u] : 0.0;
+    for (int u = 0; u < UB; ++u) s += (z0 + u * step < n) ? v[u] : 0.0;
+    return s;
+}
+template <typename T>
+__device__ __forceinline__ double strided_sum(const T* __restrict__ p, int64_t stride, int part, int step, int n)
+{
+    double s = 0.0;
+    if (n <= 4 * step) { if (part < n) s = strided_batch<4>(p, stride, part, step, n); }
+    else if (n <= 8 * step) s = strided_batch<8>(p, stride, part, step, n);
+    else
+        for (int z0 = part; z0 < n; z0 += 16 * step) s += strided_batch<16>(p, stride, z0, step, n);
     return s;
 }
 
@@ -88,7 +99,7 @@ __global__ __launch_bounds__(64 * SX_PARTS) void stats_xtx_kernel(const double* 
         const bool diag = j == i && dfix && !(gate && *gate != 0);
         const double* p = diag ? dfix + (int64_t)blockIdx.z * nslab * C + i : P + (int64_t)i * C + j;
         const int64_t stride = diag ? C : CC;
-        for (int z0 = part; z0 < nslab; z0 += 16 * SX_PARTS) g += strided_sum16(p, stride, z0, SX_PARTS, nslab);
+        g = strided_sum(p, stride, part, SX_PARTS, nslab);
     }
     red[part][threadIdx.x & 63] = g;
     __syncthreads();
@@ -120,10 +131,8 @@ __global__ __launch_bounds__(64 * SX_PARTS) void bwd_combine_kernel(const double
     const bool is_sum = e >= CC;
     double acc = 0.0;
     auto terms = [&](int64_t zbase, int n) {           // sum over z = zbase + part, + SX_PARTS, ... < zbase + n
-        double t = 0.0;
-        for (int z0 = part; z0 < n; z0 += 16 * SX_PARTS)
-            t += is_sum ? strided_sum16(colsum + zbase * C + (e - CC), (int64_t)C, z0, SX_PARTS, n)
-                        : strided_sum16(P + zbase * CC + e, CC, z0, SX_PARTS, n);
+        const double t = is_sum ? strided_sum(colsum + zbase * C + (e - CC), (int64_t)C, part, SX_PARTS, n)
+                                : strided_sum(P + zbase * CC + e, CC, part, SX_PARTS, n);
         return t;
     };
     if (live) {
