@@ -305,7 +305,7 @@ constexpr int XLD = XT + 16;      // chunk row pitch in floats: the four k rows 
 
 __global__ __launch_bounds__(256) void xty_f64_kernel(WcXtyArgs a, int ntiles, int nb)
 {
-    extern __shared__ __attribute__((aligned(16))) float xty_lds[];      // Xs[XK][XLD] | Ys[XK][XLD]
+    extern __shared__ __attribute__((aligned(16))) float xty_lds[];      // Xs[XK][XLD] | Ys[XK][XLD]: 80 KB, two workgroups per CU
     float* Xs = xty_lds;
     float* Ys = xty_lds + XK * XLD;
 
@@ -343,6 +343,7 @@ __global__ __launch_bounds__(256) void xty_f64_kernel(WcXtyArgs a, int ntiles, i
     const int rbase = tid >> 4;       // + 16*p
     const int ci = ib * XT + 4 * q4, cj = jb * XT + 4 * q4;
     const bool vi = ci < C, vj = cj < C;
+    const int cic = vi ? ci : 0, cjc = vj ? cj : 0;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const f32x4 cx = (a.cx && vi) ? ld4(a.cx + ci) : zero4;
     const f32x4 cy = (a.cy && vj) ? ld4(a.cy + cj) : zero4;
@@ -363,12 +364,13 @@ __global__ __launch_bounds__(256) void xty_f64_kernel(WcXtyArgs a, int ntiles, i
         for (int p = 0; p < 8; ++p) {
             const int64_t m = m0 + rbase + 16 * p;
             const bool ok = m < r1;
-            const int64_t mc = ok ? m : r0;             // clamped, not predicated: keeps the eight loads in flight together
-            const f32x4 vx = vi ? ld4(a.X + mc * C + ci) - cx : zero4;
-            xv[p] = ok ? vx : zero4;
+            // clamped addresses, not predicated loads (hipcc branches around those one by one): all in flight together
+            const int64_t mc = ok ? m : r0;
+            const f32x4 vx = ld4(a.X + mc * C + cic) - cx;
+            xv[p] = (ok && vi) ? vx : zero4;
             if (!diag) {
-                const f32x4 vy = vj ? ld4(a.Y + mc * C + cj) - cy : zero4;
-                yv[p] = ok ? vy : zero4;
+                const f32x4 vy = ld4(a.Y + mc * C + cjc) - cy;
+                yv[p] = (ok && vj) ? vy : zero4;
             }
         }
     };
@@ -388,19 +390,23 @@ __global__ __launch_bounds__(256) void xty_f64_kernel(WcXtyArgs a, int ntiles, i
             const float* Bsrc = diag ? Xs : Ys;
             const int64_t left = r1 - m0;
             const int kend = left >= XK ? XK : (int)((left + 3) & ~(int64_t)3);      // rows past r1 are zero in the chunk
-#pragma unroll 4
+            // one wave per SIMD: nothing else hides the LDS latency, so the operands of k-step kk + 4 are read before the
+            // MFMAs of k-step kk are issued (sched_barrier: hipcc otherwise moves each read back next to its use)
+            const float* xa = Xs + lq * XLD + wr * 32 + li;
+            const float* xb = Bsrc + lq * XLD + wc * 32 + li;
+            float a0 = xa[0], a1 = xa[16], b0 = xb[0], b1 = xb[16];
+#pragma unroll 2
             for (int kk = 0; kk < kend; kk += 4) {
-                double av[2], bv[2];
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    av[tt] = (double)Xs[(kk + lq) * XLD + wr * 32 + tt * 16 + li];
-                    bv[tt] = (double)Bsrc[(kk + lq) * XLD + wc * 32 + tt * 16 + li];
-                }
+                const double av[2] = {(double)a0, (double)a1}, bv[2] = {(double)b0, (double)b1};
+                const int kn = (kk + 4 < XK ? kk + 4 : kk) * XLD;          // the last prefetch re-reads its own rows
+                a0 = xa[kn]; a1 = xa[kn + 16]; b0 = xb[kn]; b1 = xb[kn + 16];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                     for (int u = 0; u < 2; ++u)
                         acc[tt][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[tt], bv[u], acc[tt][u], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
