@@ -974,18 +974,44 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(WcGemm g)
         const TA* A1 = A0 + 16 * g.a_rs;
         const TB* B0 = B + (int64_t)(bn * 32 + li) * g.b_cs;
         const TB* B1 = B0 + 16 * g.b_cs;
-        // the loop is load latency, not flops: 16 k at a time, every load of the group ahead of its MFMAs
+        // the loop is load latency, not flops: 16 k at a time, every load of the group ahead of its MFMAs and the NEXT group's
+        // loads issued before this group's MFMAs (one exposed L2 latency per call instead of one per group: the chains of
+        // six to nine of these launches in K5 and the coloring are what their 7-9 us each add up to)
         // (the trip count is a run-time value, so the unrolling is spelled out: hipcc declines it otherwise)
         const int kend = (wave + 1) * kper;
         int kk = wave * kper;
-        for (; kk + 16 <= kend; kk += 16) {
-            double a0[4], a1[4], b0[4], b1[4];
+        double a0[4], a1[4], b0[4], b1[4];
+        auto load16 = [&](int k0, double (&x0)[4], double (&x1)[4], double (&y0)[4], double (&y1)[4]) __attribute__((always_inline)) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int64_t ka = kk + 4 * u + lq;
-                a0[u] = (double)A0[ka * g.a_cs]; a1[u] = (double)A1[ka * g.a_cs];
-                b0[u] = (double)B0[ka * g.b_rs]; b1[u] = (double)B1[ka * g.b_rs];
+                const int64_t ka = k0 + 4 * u + lq;
+                x0[u] = (double)A0[ka * g.a_cs]; x1[u] = (double)A1[ka * g.a_cs];
+                y0[u] = (double)B0[ka * g.b_rs]; y1[u] = (double)B1[ka * g.b_rs];
             }
+        };
+        // 64 k at once when the wave's share allows (C = 256: all of it): every load of the call in flight together
+        for (; kk + 64 <= kend; kk += 64) {
+            double wa0[16], wa1[16], wb0[16], wb1[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int64_t ka = kk + 4 * u + lq;
+                wa0[u] = (double)A0[ka * g.a_cs]; wa1[u] = (double)A1[ka * g.a_cs];
+                wb0[u] = (double)B0[ka * g.b_rs]; wb1[u] = (double)B1[ka * g.b_rs];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(wa0[u], wb0[u], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(wa0[u], wb1[u], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(wa1[u], wb0[u], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(wa1[u], wb1[u], acc[1][1], 0, 0, 0);
+            }
+        }
+        if (kk + 16 <= kend) load16(kk, a0, a1, b0, b1);
+        for (; kk + 16 <= kend; kk += 16) {
+            double na0[4], na1[4], nb0[4], nb1[4];
+            const bool more = kk + 32 <= kend;
+            load16(more ? kk + 16 : kk, na0, na1, nb0, nb1);         // (the last group re-reads itself: no predicated loads)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], acc[0][0], 0, 0, 0);
@@ -993,6 +1019,9 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(WcGemm g)
                 acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b0[u], acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], acc[1][1], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a0[u] = na0[u]; a1[u] = na1[u]; b0[u] = nb0[u]; b1[u] = nb1[u]; }
         }
         for (; kk < kend; kk += 4) {
             const int64_t ka = kk + lq;
