@@ -35,7 +35,8 @@ constexpr float kGuard = 60000.0f;
 #ifndef XTY_STAMPS
 #define XTY_STAMPS 0      // development: s_memtime stamps of wave 0 / workgroup 0 behind the partials (the caller adds 2 KiB to the workspace)
 #endif
-constexpr int BW = 3;                      // 32x32 blocks per wave
+constexpr int BW_PLAIN = 3;                // 32x32 blocks per wave
+template <int C, bool TWO> constexpr bool xty_quad() { return TWO && C == 256; }
 
 
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -57,12 +58,19 @@ struct FastXtyArgs {
 template <int C, bool TWO>
 __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
 {
-    constexpr int C4 = C / 4;
+    // QUAD (two operands at C = 256): the 8 x 8 blocks are cut into four 4 x 4 quadrants, one workgroup type each.  A
+    // quadrant needs only 128 channels of X and 128 of Y, so a workgroup converts HALF of every row (the three types of
+    // the plain scheme convert all of it three times), its images hold twice the rows (64 per stage: half the barriers)
+    // and a wave owns 2 blocks instead of 3 (no idle block slots: 64 = 4 x 8 x 2).
+    constexpr bool QUAD = xty_quad<C, TWO>();
+    constexpr int BW = QUAD ? 2 : BW_PLAIN;           // 32x32 blocks per wave
+    constexpr int CS = QUAD ? C / 2 : C;              // channels of an operand that this workgroup stages
+    constexpr int C4 = CS / 4;
     constexpr int RGRP = 512 / C4;                    // 8-row groups covered by the 512 threads
     constexpr int R = TWO ? RGRP * 4 : RGRP * 8;      // rows per stage and operand (TWO: half the threads per operand)
     constexpr int CPR = R / 8;                        // 16-byte chunks per channel row of an image
     constexpr int KS = R / 16;                        // MFMA k-steps per stage
-    constexpr int IMG = C * R * 2;                    // bytes of one fp16 image
+    constexpr int IMG = CS * R * 2;                   // bytes of one fp16 image
     constexpr int NOP = TWO ? 2 : 1;
     constexpr int NB = C / 32;
     constexpr int NBLK = TWO ? NB * NB : NB * (NB + 1) / 2;
@@ -93,14 +101,24 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
     const int nst = (int)((r1 - r0) / R);             // whole stages only (the launcher guarantees it)
 
     // this wave's blocks
-    int ib[BW], jb[BW]; bool live[BW];
+    // ib / jb: block coordinates in the C/32 x C/32 grid (outputs, scales); il / jl: channel-block rows of the staged images
+    int ib[BW], jb[BW], il[BW], jl[BW]; bool live[BW];
+    const int qi = QUAD ? (type >> 1) : 0, qj = QUAD ? (type & 1) : 0;       // quadrant of this workgroup type
 #pragma unroll
     for (int b = 0; b < BW; ++b) {
-        int L = (type * 8 + wave) * BW + b;
-        live[b] = L < NBLK;
-        if (!live[b]) L = 0;
-        if (TWO) { ib[b] = L / NB; jb[b] = L % NB; }
-        else { int i = 0; while (L >= NB - i) { L -= NB - i; ++i; } ib[b] = i; jb[b] = i + L; }
+        if (QUAD) {
+            const int L = wave * BW + b;                 // 16 blocks of the quadrant on 8 waves x 2
+            live[b] = true;
+            il[b] = L >> 2; jl[b] = L & 3;
+            ib[b] = qi * (NB / 2) + il[b]; jb[b] = qj * (NB / 2) + jl[b];
+        } else {
+            int L = (type * 8 + wave) * BW + b;
+            live[b] = L < NBLK;
+            if (!live[b]) L = 0;
+            if (TWO) { ib[b] = L / NB; jb[b] = L % NB; }
+            else { int i = 0; while (L >= NB - i) { L -= NB - i; ++i; } ib[b] = i; jb[b] = i + L; }
+            il[b] = ib[b]; jl[b] = jb[b];
+        }
     }
 
     // staging: thread -> operand op, float4 column c4, 8-row group rgrp
@@ -110,9 +128,10 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
     const float* src = (TWO && op) ? a.Y : a.X;
     const float* cen = (TWO && op) ? a.cy : a.cx;
     const float* scp = (TWO && op) ? a.sy : a.sx;
-    const f32x4 scl = ldg4(scp + 4 * c4);
+    const int cbase = QUAD ? (op ? qj : qi) * CS : 0;     // first channel of the operand that this workgroup stages
+    const f32x4 scl = ldg4(scp + cbase + 4 * c4);
     f32x4 ncs = {0.f, 0.f, 0.f, 0.f};
-    if (cen) ncs = -ldg4(cen + 4 * c4) * scl;
+    if (cen) ncs = -ldg4(cen + cbase + 4 * c4) * scl;
 
     auto swz = [](int c) -> int {
         if (CPR >= 16) return c & 15;
@@ -127,7 +146,7 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
 
     f32x4 xr[8];
     auto stage_load = [&](int st) {
-        const float* base = src + (r0 + (int64_t)st * R + rgrp * 8) * C + 4 * c4;
+        const float* base = src + (r0 + (int64_t)st * R + rgrp * 8) * C + cbase + 4 * c4;
 #pragma unroll
         for (int p = 0; p < 8; ++p) xr[p] = ldg4(base + p * C);
     };
@@ -137,7 +156,7 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
     // remainder is one v_fma_mix_f32 per element (it reads the fp16 half directly), and the column sums / squares are
     // taken only by the workgroup that reports them.
     float gmax = 0.f;
-    const bool want_csum = a.colsum != nullptr && type == 0 && (!TWO || op == 1);
+    const bool want_csum = a.colsum != nullptr && (QUAD ? qi == 0 : type == 0) && (!TWO || op == 1);     // QUAD: each half of Y's columns once
     f32x4 csum = {0.f, 0.f, 0.f, 0.f};
     // The DIAGONAL of the covariance does not come from the matrix pipe.  Two systematic errors meet there, both
     // measured on MI355X (tools/probe/mfma_gram_probe.hip, tools/k1_bias.py):
@@ -200,7 +219,7 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
     int a_off[BW], b_off[BW], a_sw[BW], b_sw[BW];
 #pragma unroll
     for (int b = 0; b < BW; ++b) {
-        const int ca = ib[b] * 32 + l31, cb = jb[b] * 32 + l31;
+        const int ca = il[b] * 32 + l31, cb = jl[b] * 32 + l31;
         a_off[b] = ca * (R * 2); a_sw[b] = swz(ca);
         b_off[b] = (TWO ? 2 * IMG : 0) + cb * (R * 2); b_sw[b] = swz(cb);
     }
@@ -273,9 +292,9 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
     // column sums (type-0 workgroups): of the single operand, or of Y when there are two
     if (want_csum) {
         // csum holds sums of SCALED values of channels 4*c4.. over this thread's rows; reduce over the row groups in LDS
-        float* red = reinterpret_cast<float*>(smem);            // [row groups][C], free after the last barrier
+        float* red = reinterpret_cast<float*>(smem);            // [row groups][CS], free after the last barrier
 #pragma unroll
-        for (int j = 0; j < 4; ++j) red[rgrp * C + 4 * c4 + j] = csum[j];
+        for (int j = 0; j < 4; ++j) red[rgrp * CS + 4 * c4 + j] = csum[j];
     }
     if (want_dfix) {
         double* red2 = reinterpret_cast<double*>(smem + RGRP * C * 4);
@@ -283,13 +302,14 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
         for (int j = 0; j < 4; ++j) red2[rgrp * C + 4 * c4 + j] = lsq[j];
     }
     __syncthreads();
-    if (type == 0 && a.colsum) {
+    if ((QUAD ? qi == 0 : type == 0) && a.colsum) {
         constexpr int RG_USED = TWO ? RGRP / 2 : RGRP;
         const float* red = reinterpret_cast<const float*>(smem);
-        for (int c = tid; c < C; c += 512) {
+        const int c0 = QUAD ? qj * CS : 0;
+        for (int c = tid; c < CS; c += 512) {
             float s = 0.f;
-            for (int g = 0; g < RG_USED; ++g) s += red[g * C + c];
-            a.colsum[z * C + c] = s / (TWO ? a.sy[c] : a.sx[c]);
+            for (int g = 0; g < RG_USED; ++g) s += red[g * CS + c];
+            a.colsum[z * C + c0 + c] = s / (TWO ? a.sy[c0 + c] : a.sx[c0 + c]);
         }
     }
     if (want_dfix) {
@@ -304,13 +324,13 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
 }
 
 template <int C, bool TWO>
-constexpr int stage_rows() { return TWO ? (512 / (C / 4)) * 4 : (512 / (C / 4)) * 8; }
+constexpr int stage_rows() { return xty_quad<C, TWO>() ? 64 : (TWO ? (512 / (C / 4)) * 4 : (512 / (C / 4)) * 8); }
 
 template <int C, bool TWO>
 hipError_t launch_xty_fast(const FastXtyArgs& a, hipStream_t st)
 {
     constexpr int R = stage_rows<C, TWO>();
-    constexpr size_t lds = (size_t)2 * (TWO ? 2 : 1) * 2 * C * R * 2;       // 128 KiB
+    constexpr size_t lds = (size_t)2 * (TWO ? 2 : 1) * 2 * (xty_quad<C, TWO>() ? C / 2 : C) * R * 2;       // 128 KiB
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(xty_f16x3_kernel<C, TWO>),
@@ -328,6 +348,7 @@ hipError_t launch_xty_fast(const FastXtyArgs& a, hipStream_t st)
 
 static int xty_stage_rows(int C, bool two)
 {
+    if (two && C == 256) return 64;           // quadrant scheme (xty_quad)
     const int rg = 512 / (C / 4);
     return two ? rg * 4 : rg * 8;
 }
@@ -349,7 +370,7 @@ int wc_fast_xty_plan(int64_t N, int64_t HW, int C, int per_sample, int two, int*
     if (seg % R != 0) return 0;
     const int nb = C / 32;
     const int nblk = two ? nb * nb : nb * (nb + 1) / 2;
-    *ntypes = (nblk + 8 * BW - 1) / (8 * BW);
+    *ntypes = (two && C == 256) ? 4 : (nblk + 8 * BW_PLAIN - 1) / (8 * BW_PLAIN);
     const int64_t nseg = per_sample ? N : 1;
     // 128 KiB of LDS = one workgroup per CU: keep the grid (slab groups of 8 x ntypes) within the 256 CUs when the
     // segment count allows, or the surplus workgroups would run as a second, mostly idle round
