@@ -18,6 +18,12 @@
 // Tiles are double-buffered; the loads of tile t+2 are in flight while tile t is on the matrix pipe.
 #include "wc_common.h"
 #include <stdlib.h>
+#ifndef WC_MFMA16
+#define WC_MFMA16 1     // ring kernel on v_mfma_f32_16x16x32_f16 and the fp16 tables in that shape's load order (0: 32x32x16, development)
+#endif
+#ifndef WC_M16_ORDER
+#define WC_M16_ORDER 0
+#endif
 #ifndef WC_STAMPS
 #define WC_STAMPS 0
 #endif
@@ -121,9 +127,17 @@ __global__ __launch_bounds__(64) void split_table_kernel(const float* __restrict
             const _Float16 l = (_Float16)(w - (float)h);
             // "register image" order: the 16 bytes a lane loads for MFMA fragment (column group n/32, k-step k/16) sit
             // with the other 63 lanes' in one contiguous KiB
-            const int n = (int)(row % C), KS = C / 16;
+            const int n = (int)(row % C);
+#if WC_MFMA16
+            // 16x16x32 fragments: (column group n/32, k-step k/32, column half (n/16)&1): lane = 16*((k/8)&3) + n%16
+            const int KS32 = C / 32;
+            const int64_t idx = (row / C) * (int64_t)C * C +
+                                (((((int64_t)(n >> 5) * KS32 + (k >> 5)) * 2 + ((n >> 4) & 1)) * 64 + ((k >> 3) & 3) * 16 + (n & 15)) * 8 + (k & 7));
+#else
+            const int KS = C / 16;
             const int64_t idx = (row / C) * (int64_t)C * C +
                                 ((((int64_t)(n >> 5) * KS + (k >> 4)) * 64 + ((k >> 3) & 1) * 32 + (n & 31)) * 8 + (k & 7));
+#endif
             hi[idx] = h;
             lo[idx] = l;
         }
@@ -252,6 +266,18 @@ __global__ __launch_bounds__(512, 2) void affine_f16x3_kernel(FastArgs a)
     int cur_slot = -1;
     const int col = cg * 32 + l31;
     auto load_b = [&](int slot) {
+#if WC_MFMA16
+        // the tables are stored for the ring kernel's 16x16x32 fragments; this kernel's 32x32x16 fragment (k-step s, 8 k
+        // per lane) is the same 16 bytes at: unit (s/2, column half l31/16), lane 16*(2*(s&1) + lh) + l31%16
+        const int64_t lo16 = (((int64_t)cg * (KS / 2) * 2 + (l31 >> 4)) * 64 + lh * 16 + (l31 & 15)) * 8;
+        const _Float16* ph = a.Bhi + (int64_t)slot * a.slot_stride + lo16;
+        const _Float16* pl = a.Blo + (int64_t)slot * a.slot_stride + lo16;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            bhi[s] = *reinterpret_cast<const f16x8*>(ph + 1024 * (s >> 1) + 256 * (s & 1));
+            blo[s] = *reinterpret_cast<const f16x8*>(pl + 1024 * (s >> 1) + 256 * (s & 1));
+        }
+#else
         const _Float16* ph = a.Bhi + (int64_t)slot * a.slot_stride + ((int64_t)cg * KS * 64 + lane) * 8;
         const _Float16* pl = a.Blo + (int64_t)slot * a.slot_stride + ((int64_t)cg * KS * 64 + lane) * 8;
 #pragma unroll
@@ -259,6 +285,7 @@ __global__ __launch_bounds__(512, 2) void affine_f16x3_kernel(FastArgs a)
             bhi[s] = *reinterpret_cast<const f16x8*>(ph + 512 * s);
             blo[s] = *reinterpret_cast<const f16x8*>(pl + 512 * s);
         }
+#endif
         const int64_t srow_ = a.slot_stride ? slot : 0;
         cscale = a.colscale[srow_ * C + col];
         addv = 0.f;
@@ -566,10 +593,16 @@ __global__ __launch_bounds__(512, 1) void affine_ring_kernel(FastArgs a)
         }
     };
 
+    // B' fragments.  WC_MFMA16: unit u = 2*s + ch is k-step s (32 deep) of column half ch of this wave's 32 columns; a lane's
+    // two output columns are col + 16*ch.  (32x32x16: unit s = k-step s, 16 deep, one column per lane.)
+    constexpr int NCH = WC_MFMA16 ? 2 : 1;
     f16x8 bhi[KS], blo[KS];
-    float cscale = 1.f, addv = 0.f, addv_b = 0.f, addv_s = 0.f;
+    float cscale[NCH], addv[NCH], addv_b[NCH], addv_s[NCH];
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) { cscale[h] = 1.f; addv[h] = 0.f; addv_b[h] = 0.f; addv_s[h] = 0.f; }
     int cur_slot = -1;
-    const int col = cg * 32 + l31;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int col = WC_MFMA16 ? cg * 32 + l15 : cg * 32 + l31;
     auto load_b = [&](int slot) {
         const _Float16* ph = a.Bhi + (int64_t)slot * a.slot_stride + ((int64_t)cg * KS * 64 + lane) * 8;
         const _Float16* pl = a.Blo + (int64_t)slot * a.slot_stride + ((int64_t)cg * KS * 64 + lane) * 8;
@@ -579,15 +612,20 @@ __global__ __launch_bounds__(512, 1) void affine_ring_kernel(FastArgs a)
             blo[s] = *reinterpret_cast<const f16x8*>(pl + 512 * s);
         }
         const int64_t srow_ = a.slot_stride ? slot : 0;
-        cscale = a.colscale[srow_ * C + col];
-        // loaded unconditionally from a valid address and selected afterwards: a consumed-at-once conditional load
-        // would make hipcc drain every load in flight right here
-        const float bv = a.bias[a.bias_on ? (int64_t)slot * C + col : 0];
-        const float sv = a.sub[a.sub_on ? col : 0];
-        addv_b = bv; addv_s = sv;
+#pragma unroll
+        for (int h = 0; h < NCH; ++h) {
+            cscale[h] = a.colscale[srow_ * C + col + 16 * h];
+            // loaded unconditionally from a valid address and selected afterwards: a consumed-at-once conditional load
+            // would make hipcc drain every load in flight right here
+            addv_b[h] = a.bias[a.bias_on ? (int64_t)slot * C + col + 16 * h : 0];
+            addv_s[h] = a.sub[a.sub_on ? col + 16 * h : 0];
+        }
         cur_slot = slot;
     };
-    auto finish_b = [&]() { addv = (a.bias_on ? addv_b : 0.f) - (a.sub_on ? addv_s : 0.f); };
+    auto finish_b = [&]() {
+#pragma unroll
+        for (int h = 0; h < NCH; ++h) addv[h] = (a.bias_on ? addv_b[h] : 0.f) - (a.sub_on ? addv_s[h] : 0.f);
+    };
 
     // prologue: chunks 0..6 requested, then the B' table (KS*2 + <= 3 loads per lane, in flight while tile 0 is
     // converted); each read-out slot is refilled at once (chunks 7..10).  Chunk p's DMA always has six younger DMAs
@@ -595,7 +633,7 @@ __global__ __launch_bounds__(512, 1) void affine_ring_kernel(FastArgs a)
 #pragma unroll
     for (int i = 0; i < NSLOT; ++i) if (i / 4 < n) dma_chunk(i / 4, i % 4, i, lane);
     if (!HAS_SLOT) load_b(0);
-    constexpr int TBL = HAS_SLOT ? 0 : 2 * KS + 3;      // the table's vector loads per lane: fragments, colscale, bias, sub
+    constexpr int TBL = HAS_SLOT ? 0 : 2 * KS + 3 * NCH;      // the table's vector loads per lane: fragments, colscale, bias, sub
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         if (n >= 2) {
@@ -618,9 +656,18 @@ __global__ __launch_bounds__(512, 1) void affine_ring_kernel(FastArgs a)
     if (!HAS_SLOT) finish_b();
 
     const int rbase = rg * 32;
+#if WC_MFMA16
+    // A fragment of 16 rows x 32 k: lane = row l15 (+ 16 for the second half of the block), 16-byte chunk lq of the k-step
+    const int sw = swz(rbase + l15);                    // the same for rows l15 and l15 + 16 (and any 32-row group)
+    const int rd_off = (rbase + l15) * PITCH + (PAD ? lq * 16 : 0);
+    // D register r of block (rh, ch): row 16 rh + 4 lq + r, column 16 ch + l15; after the epilogue's v_permlane16_swap a
+    // lane stores rows 16 rh + 8 lh + {0, 4} + r of column l31
+    const int out_lane = (rbase + 8 * lh) * C + cg * 32 + l31;
+#else
     const int sw = swz(rbase + l31);
     const int rd_off = (rbase + l31) * PITCH;
     const int out_lane = (rbase + 4 * lh) * C + col;
+#endif
     unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool stamp_on = false;
     unsigned long long clk0 = 0, rt0 = 0;
@@ -644,8 +691,9 @@ __global__ __launch_bounds__(512, 1) void affine_ring_kernel(FastArgs a)
         const int fnext = fcur == 2 ? 0 : fcur + 1;
         // per-tile opaque copies of the lane constants that feed LDS addresses: without them hipcc hoists every
         // address of every instantiated tile body out of the loop (~60 VGPRs) and spills them
-        int sw_t = sw, c4i_t = c4i, lane_t = lane, lh_t = lh, woff_t = woff0;
-        asm volatile("" : "+v"(sw_t), "+v"(c4i_t), "+v"(lane_t), "+v"(lh_t), "+v"(woff_t));
+        int sw_t = sw, c4i_t = c4i, lane_t = lane, lh_t = lh, woff_t = woff0, lq_t = lq;
+        asm volatile("" : "+v"(sw_t), "+v"(c4i_t), "+v"(lane_t), "+v"(lh_t), "+v"(woff_t), "+v"(lq_t));
+        (void)lq_t; (void)lh_t;
         unsigned long long w0_ = 0;
         if (WC_STAMPS) w0_ = __builtin_amdgcn_s_memrealtime();
         wait_for(0, 8 * (t + 1));                  // tile t converted by all eight waves (published in mid-loop t-1)
@@ -668,6 +716,76 @@ __global__ __launch_bounds__(512, 1) void affine_ring_kernel(FastArgs a)
         };
         const char* hrow = fbuf + fcur * FBUF + rd_off;
         const char* lrow = hrow + IMG;
+#if WC_MFMA16
+        // 16x16x32: the wave's 32 x 32 block as 2 x 2 accumulators of 16 x 16; per k-step (32 deep) two A fragments (row
+        // halves) x hi/lo = 4 ds_read_b128 (as many as two 16-deep steps took) and 12 MFMAs of 16 cycles in the order
+        // lo*Hi, hi*Lo, hi*Hi over the four blocks (a block's accumulator is reused every fourth MFMA).  The shape is
+        // worth ~10 % of the matrix pipe's time on this power-limited chip.
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int rh = 0; rh < 2; ++rh)
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) acc[rh][ch] = f32x4{0.f, 0.f, 0.f, 0.f};
+        constexpr int KS32 = KS / 2 > 0 ? KS / 2 : 1;
+        auto frag = [&](const char* base, int rh, int s) {
+            if (PAD) return *reinterpret_cast<const f16x8*>(base + rh * (16 * PITCH) + 64 * s);      // lane base + immediate
+            return *reinterpret_cast<const f16x8*>(base + rh * (16 * PITCH) + (((4 * s + lq_t) ^ sw_t) * 16));
+        };
+        f16x8 ah[2], al[2], nh[2], nl[2];
+#pragma unroll
+        for (int rh = 0; rh < 2; ++rh) { ah[rh] = frag(hrow, rh, 0); al[rh] = frag(lrow, rh, 0); nh[rh] = ah[rh]; nl[rh] = al[rh]; }
+        if (CONV_) { chunk_wait(0); craw_read(rs[0], lane_t); }
+        WC_STAMP(2);
+        // the conversion of tile t+1 as 20 small steps in the first half of the loop (chunk p: scale+refill, next
+        // chunk's read-out, split hi, split lo, write), then its publication
+        auto cstep = [&](int j) {
+            const int p = j / 5, st = j % 5;
+            if (st == 0) {
+                cv_scale();                           // consumes craw: slot rs[p] is free
+                const int tl = t + 1 + (p + NSLOT) / 4;
+                if (tl < n) dma_chunk(tl, (p + NSLOT) % 4, rs[p], lane_t);
+            } else if (st == 1) {
+                if (p + 1 < 4) { chunk_wait(p + 1); craw_read(rs[p + 1], lane_t); }
+            } else if (st == 2) cv_hi();
+            else if (st == 3) cv_lo();
+            else cv_write(fnext, p, lane_t, c4i_t, woff_t);
+        };
+        constexpr int G = 12 * KS32;         // MFMAs = issue gaps per tile
+        constexpr int H = G / 2;
+        // one issue gap = one MFMA plus whatever is listed for it; sched_barrier(0) pins the order gap by gap
+#pragma unroll
+        for (int s = 0; s < KS32; ++s) {
+#pragma unroll
+            for (int m = 0; m < 12; ++m) {
+                const int g = 12 * s + m;
+#if WC_M16_ORDER == 1      // row-half major: six MFMAs in a row share the A registers' row half
+                const int rh = m / 6, ch = m & 1, u = 2 * s + ch, pr = (m % 6) >> 1;
+#else                      // product major: a block's accumulator comes round every fourth MFMA
+                const int rh = (m >> 1) & 1, ch = m & 1, u = 2 * s + ch, pr = m >> 2;
+#endif
+                if (pr == 0) acc[rh][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[rh], bhi[u], acc[rh][ch], 0, 0, 0);
+                else if (pr == 1) acc[rh][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rh], blo[u], acc[rh][ch], 0, 0, 0);
+                else acc[rh][ch] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rh], bhi[u], acc[rh][ch], 0, 0, 0);
+                if (s + 1 < KS32) {
+                    if (m == 0) nh[0] = frag(hrow, 0, s + 1);
+                    if (m == 1) nh[1] = frag(hrow, 1, s + 1);
+                    if (m == 2) nl[0] = frag(lrow, 0, s + 1);
+                    if (m == 3) nl[1] = frag(lrow, 1, s + 1);
+                }
+                if (CONV_) {
+#pragma unroll
+                    for (int j = 0; j < 21; ++j) {
+                        if ((j * H) / 21 != g) continue;
+                        if (j < 20) cstep(j);
+                        else { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); arrive(0); }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int rh = 0; rh < 2; ++rh) { ah[rh] = nh[rh]; al[rh] = nl[rh]; }
+        }
+#else
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -726,6 +844,7 @@ __global__ __launch_bounds__(512, 1) void affine_ring_kernel(FastArgs a)
             if (AHEAD == 2) { ah = bh_; al = bl_; bh_ = nh; bl_ = nl; }
             else { ah = nh; al = nl; }
         }
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my reads of image t are done
         arrive(1);
         WC_STAMP(3);
@@ -733,16 +852,35 @@ __global__ __launch_bounds__(512, 1) void affine_ring_kernel(FastArgs a)
         float* po = a.out + (int64_t)tile_of(t) * (TR * C) + out_lane;
         unsigned long long s0_ = 0;
         if (WC_STAMPS) s0_ = __builtin_amdgcn_s_memrealtime();
+#if WC_MFMA16
+        // A D register holds 4 rows x 16 columns (64-byte pieces of 4 rows).  v_permlane16_swap of the two column halves'
+        // registers gives 2 rows x 32 columns per register again -- 128-byte pieces, the store shape of the 32x32 form.
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int rh = i >> 2, r = i & 3;
+            float v0 = acc[rh][0][r] * cscale[0] + addv[0], v1 = acc[rh][1][r] * cscale[1] + addv[1];
+            if (a.relu) {       // the ReLU that follows every WC site rides in the epilogue
+                v0 = v0 > 0.f ? v0 : (v0 == v0 ? 0.f : v0);
+                v1 = v1 > 0.f ? v1 : (v1 == v1 ? 0.f : v1);
+            }
+            // (inline asm: with __builtin_amdgcn_permlane16_swap hipcc 7.0 stored the FIRST result twice here -- the second
+            // definition of the instruction got lost; s_nop: the operands were just written by VALU instructions)
+            asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(v0), "+v"(v1));
+            po[(16 * rh + r) * C] = v0;          // rows r (lanes 0-31) and 8 + r: columns l31
+            po[(16 * rh + r + 4) * C] = v1;      // rows 4 + r and 12 + r
+        }
+#else
         if (a.relu) {       // the ReLU that follows every WC site rides in the epilogue
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float v = acc[r] * cscale + addv;
+                const float v = acc[r] * cscale[0] + addv[0];
                 po[((r & 3) + 8 * (r >> 2)) * C] = v > 0.f ? v : (v == v ? 0.f : v);
             }
         } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) po[((r & 3) + 8 * (r >> 2)) * C] = acc[r] * cscale + addv;
+            for (int r = 0; r < 16; ++r) po[((r & 3) + 8 * (r >> 2)) * C] = acc[r] * cscale[0] + addv[0];
         }
+#endif
         if (WC_STAMPS) sum_store += __builtin_amdgcn_s_memrealtime() - s0_;
         rslot = rs[3] + 1 >= NSLOT ? rs[3] + 1 - NSLOT : rs[3] + 1;
         fcur = fnext;
@@ -810,17 +948,21 @@ __global__ __launch_bounds__(512, 1) void affine_ring_kernel(FastArgs a)
             const float* xin = a.in + r0 * C;
             float* out_tile = a.out + r0 * C;
             for (int i = 0; i < 16; ++i) {
-                const int row = rbase + (i & 3) + 8 * (i >> 2) + 4 * lh;
+#if WC_MFMA16
+                const int row = rbase + 16 * (i >> 3) + 8 * lh + 4 * ((i >> 2) & 1) + (i & 3), ecol = cg * 32 + l31;
+#else
+                const int row = rbase + (i & 3) + 8 * (i >> 2) + 4 * lh, ecol = col;
+#endif
                 int slot = 0;
                 if (HAS_SLOT) slot = a.slot[(r0 + row) / a.HW];
-                const float* Bf = a.Bf + (int64_t)slot * a.bf_stride + col;
+                const float* Bf = a.Bf + (int64_t)slot * a.bf_stride + ecol;
                 float add = 0.f;
-                if (a.bias_on) add += a.bias[(int64_t)slot * C + col];
-                if (a.sub_on) add -= a.sub[col];
+                if (a.bias_on) add += a.bias[(int64_t)slot * C + ecol];
+                if (a.sub_on) add -= a.sub[ecol];
                 const float* xrow = xin + row * C;
                 float accf = 0.f;
                 for (int k = 0; k < C; ++k) accf = fmaf(xrow[k] - (a.center ? a.center[k] : 0.f), Bf[(int64_t)k * C], accf);
-                { const float v = accf + add; out_tile[row * C + col] = a.relu ? (v > 0.f ? v : (v == v ? 0.f : v)) : v; }
+                { const float v = accf + add; out_tile[row * C + ecol] = a.relu ? (v > 0.f ? v : (v == v ? 0.f : v)) : v; }
             }
         }
     }
