@@ -14,3 +14,7 @@ for shape in ((64, 4, 4, 256), (64, 8, 8, 256), (64, 16, 16, 256), (128, 4, 4, 1
     C = shape[-1]
     x = torch.randn(*shape, device='cuda'); gy = torch.randn(*shape, device='cuda'); mu = torch.zeros(C, device='cuda')
     print(shape, "K1 stage %.1f us   K4 stage %.1f us" % (t(lambda: ops.stats(x.view(-1, C))), t(lambda: ops.bwd_reduce(x, mu, gy, None, 1))))
+for shape in ((320, 32, 32, 256), (320, 16, 16, 256), (320, 8, 8, 256)):
+    C = shape[-1]
+    x = torch.randn(*shape, device='cuda')
+    print(shape, "groups=5 K1 stage %.1f us" % t(lambda: ops.stats(x.view(-1, C), groups=5)))

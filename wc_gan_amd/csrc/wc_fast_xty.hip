@@ -375,7 +375,9 @@ int wc_fast_xty_plan(int64_t N, int64_t HW, int C, int per_sample, int two, int*
     // 128 KiB of LDS = one workgroup per CU: keep the grid (slab groups of 8 x ntypes) within the 256 CUs when the
     // segment count allows, or the surplus workgroups would run as a second, mostly idle round
     const int64_t target = (256 / (8 * *ntypes)) * 8;
-    int64_t per_seg = (target + nseg - 1) / nseg;
+    // rounded DOWN: five statistic groups at 26 slabs each made 130 slabs = 272 workgroups, i.e. a second round of 16 on a
+    // chip of 256 CUs and nearly twice the time (measured 280 us at 320x32x32x256 where 2.5 x the headline's 61 is 152)
+    int64_t per_seg = target / nseg;
     if (per_seg < 1) per_seg = 1;
     const int64_t stages = seg / R;
     if (per_seg > stages) per_seg = stages;
