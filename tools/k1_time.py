@@ -18,3 +18,10 @@ for shape in ((320, 32, 32, 256), (320, 16, 16, 256), (320, 8, 8, 256)):
     C = shape[-1]
     x = torch.randn(*shape, device='cuda')
     print(shape, "groups=5 K1 stage %.1f us" % t(lambda: ops.stats(x.view(-1, C), groups=5)))
+from wc_gan_amd import functional as F
+for shape in ((320, 32, 32, 256), (320, 16, 16, 256)):
+    C = shape[-1]
+    x = torch.randn(*shape, device='cuda')
+    mm = torch.zeros(C, device='cuda'); mc = torch.eye(C, device='cuda')
+    with torch.no_grad():
+        print(shape, "groups=5 whole grouped forward site %.1f us" % t(lambda: F.whiten_color_grouped(x, 5, None, None, None, mm, mc)))
