@@ -1,0 +1,17 @@
+"""One WC site through the layer path (functional.whiten_color with autograd, ReLU epilogue, and the grouped critic-phase
+form): run under rocprofv3 --kernel-trace; tools/site_timeline_print.py lists the launches of the last call of each."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from wc_gan_amd import functional as F
+C = 256
+gamma = (torch.randn(1, C, C, device='cuda') / 16).requires_grad_(True); beta = torch.zeros(1, C, device='cuda', requires_grad=True)
+mm = torch.zeros(C, device='cuda'); mc = torch.eye(C, device='cuda')
+x = torch.randn(128, 32, 32, C, device='cuda', requires_grad=True); gy = torch.randn(128, 32, 32, C, device='cuda')
+for _ in range(6):
+    y = F.whiten_color(x, gamma, beta, None, mm, mc, True, relu=True)
+    y.backward(gy)
+torch.cuda.synchronize()
+xg = torch.randn(320, 32, 32, C, device='cuda')
+with torch.no_grad():
+    for _ in range(6): F.whiten_color_grouped(xg, 5, gamma.detach(), beta.detach(), None, mm, mc, relu=True)
+torch.cuda.synchronize()

@@ -1,0 +1,12 @@
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r['Start_Timestamp']))
+names = [r['Kernel_Name'] for r in rows]
+idx = [i for i, n in enumerate(names) if 'subsample_mean' in n]
+def show(i0, i1, title):
+    t0 = int(rows[i0]['Start_Timestamp']); print(title)
+    for r in rows[i0:i1]:
+        print('  %-70s start %7.1f dur %6.1f' % (r['Kernel_Name'][:68], (int(r['Start_Timestamp']) - t0) / 1e3, (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3))
+    print('  total %.1f us, %d launches' % ((int(rows[i1]['Start_Timestamp']) - t0) / 1e3, i1 - i0))
+show(idx[4], idx[5], 'forward + backward, 128x32x32x256, ReLU epilogue')
+show(idx[-2], idx[-1], 'grouped forward (5 groups), 320x32x32x256')

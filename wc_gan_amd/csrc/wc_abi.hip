@@ -156,12 +156,9 @@ int wc_color_f32(const double* W, const float* gamma, int Kc, int C, int groups,
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool want_plan = plan && chan_scale && (C == 32 || C == 64 || C == 128 || C == 256);
     if (!gamma) {
-        for (int g = 0; g < groups; ++g)
-            WC_TRY(wc_launch_transpose_to_f32(W + (int64_t)g * C * C, C, A + (int64_t)g * C * C,
-                                              At ? At + (int64_t)g * C * C : nullptr, st));
+        WC_TRY(wc_launch_transpose_to_f32(W, C, groups, A, At, st));        // all groups in one launch
         if (want_plan) {
-            WC_TRY(hipMemcpyAsync(wc_fast_plan_scale(plan), chan_scale, (size_t)C * 4, hipMemcpyDeviceToDevice, st));
-            WC_TRY(wc_launch_fast_plan_tables(A, slots, C, plan, st));
+            WC_TRY(wc_launch_fast_plan_tables(A, slots, C, plan, st, chan_scale));      // + the scales into the plan
         }
         return WC_OK;
     }
@@ -175,8 +172,7 @@ int wc_color_f32(const double* W, const float* gamma, int Kc, int C, int groups,
     g.batch2 = groups; g.a_b2s = CC; g.b_b2s = per_group ? (int64_t)Kc * CC : 0; g.c_b2s = (int64_t)Kc * CC;      // A[g*Kc + k] = W_g^T Gamma_k (Gamma_{g*Kc+k} if per_group)
     WC_TRY(wc_launch_gemm(g, st));
     if (want_plan) {     // the apply's fp16 tables, built once here instead of inside every wc_apply_f32 call
-        WC_TRY(hipMemcpyAsync(wc_fast_plan_scale(plan), chan_scale, (size_t)C * 4, hipMemcpyDeviceToDevice, st));
-        WC_TRY(wc_launch_fast_plan_tables(A, slots, C, plan, st));
+        WC_TRY(wc_launch_fast_plan_tables(A, slots, C, plan, st, chan_scale));      // + the scales into the plan
     }
     return WC_OK;
 }

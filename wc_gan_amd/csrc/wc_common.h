@@ -89,7 +89,7 @@ hipError_t wc_launch_fast_xty(const float* X, const float* Y, const float* cx, c
                               const float* sx, const float* sy, int64_t N, int64_t HW, int C,
                               int per_sample, int nsplit, int64_t rows_per_slab, int nslab, int ntypes,
                               double* P, float* colsum, double* dfix /*[nslab][C], covariance only, nullable*/, int* gate, hipStream_t st);
-hipError_t wc_launch_fast_plan_tables(const float* B, int Kc, int C, void* plan, hipStream_t st);
+hipError_t wc_launch_fast_plan_tables(const float* B, int Kc, int C, void* plan, hipStream_t st, const float* scale = nullptr);
 float* wc_fast_plan_scale(void* plan);
 hipError_t wc_launch_fast_affine_planned(const float* in, const float* center, const float* B, int Kc, bool shared_table,
                                          const float* bias, const float* sub, const int32_t* slot,
@@ -134,7 +134,7 @@ struct WcGemm {
 };
 hipError_t wc_launch_gemm(const WcGemm& g, hipStream_t st);
 
-hipError_t wc_launch_transpose_to_f32(const double* W, int C, float* A, float* At, hipStream_t st);  // A = W^T, At = W
+hipError_t wc_launch_transpose_to_f32(const double* W, int C, int groups, float* A, float* At, hipStream_t st);  // A = W^T, At = W
 hipError_t wc_launch_sym_scale_f32(const double* Q, int C, double scale, float* S, hipStream_t st);   // S = scale*(Q+Q^T)/2
 hipError_t wc_launch_gmean(const double* gsum, const float* A, int Kc, int C, int64_t M, float* gmean, hipStream_t st);
 hipError_t wc_launch_group_bias(const float* mu, const float* A, const float* beta, int G, int Kc, int C, int per_group,

@@ -99,9 +99,15 @@ __global__ __launch_bounds__(1024) void channel_scale_kernel(const float* __rest
 // --------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void split_table_kernel(const float* __restrict__ B, const float* __restrict__ scale,
                                                          int C, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
-                                                         float* __restrict__ colscale)
+                                                         float* __restrict__ colscale, float* __restrict__ scale_out)
 {
     const int64_t row = blockIdx.x;                 // slot * C + n
+    // scale_out: the plan's own copy of the input scales (the apply kernel reads them from the plan) -- written here by the
+    // first workgroups instead of by a device-to-device copy in front of this launch
+    if (scale_out && row * 64 < C) {
+        const int k = (int)row * 64 + threadIdx.x;
+        if (k < C) scale_out[k] = scale[k];
+    }
     const float* src = B + (row / C) * (int64_t)C * C + (row % C);     // column n of B[slot]
     const int lane = threadIdx.x;
     float v[16];
@@ -1089,11 +1095,13 @@ static PlanView plan_view(void* plan, int C, int Kc)
     return v;
 }
 
-// Build the fp16 tables of B ([slot][k][n] fp32) for the per-channel scales already stored in plan.scale.
-hipError_t wc_launch_fast_plan_tables(const float* B, int Kc, int C, void* plan, hipStream_t st)
+// Build the fp16 tables of B ([slot][k][n] fp32) for the per-channel scales `scale` (nullptr: already stored in
+// plan.scale; otherwise they are copied into the plan by the same launch).
+hipError_t wc_launch_fast_plan_tables(const float* B, int Kc, int C, void* plan, hipStream_t st, const float* scale)
 {
     const PlanView v = plan_view(plan, C, Kc);
-    hipLaunchKernelGGL(split_table_kernel, dim3((unsigned)(Kc * C)), dim3(64), 0, st, B, (const float*)v.scale, C, v.hi, v.lo, v.colscale);
+    hipLaunchKernelGGL(split_table_kernel, dim3((unsigned)(Kc * C)), dim3(64), 0, st, B, scale ? scale : (const float*)v.scale, C,
+                       v.hi, v.lo, v.colscale, scale ? v.scale : (float*)nullptr);
     return hipGetLastError();
 }
 

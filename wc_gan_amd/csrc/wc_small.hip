@@ -1065,6 +1065,8 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(WcGemm g)
 __global__ void transpose_to_f32_kernel(const double* __restrict__ W, int C, float* __restrict__ A, float* __restrict__ At)
 {
     __shared__ double tile[32][33];
+    W += (int64_t)blockIdx.z * C * C; A += (int64_t)blockIdx.z * C * C;          // one matrix (statistic group) per blockIdx.z
+    if (At) At += (int64_t)blockIdx.z * C * C;
     const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 256 threads: ty in 0..7
     for (int r = ty; r < 32; r += 8) {
@@ -1274,9 +1276,9 @@ hipError_t wc_launch_tri_inverse(const double* L, double* W, double* tmp, int C,
     return hipGetLastError();
 }
 
-hipError_t wc_launch_transpose_to_f32(const double* W, int C, float* A, float* At, hipStream_t st)
+hipError_t wc_launch_transpose_to_f32(const double* W, int C, int groups, float* A, float* At, hipStream_t st)
 {
-    hipLaunchKernelGGL(transpose_to_f32_kernel, dim3(C / 32, C / 32), dim3(256), 0, st, W, C, A, At);
+    hipLaunchKernelGGL(transpose_to_f32_kernel, dim3(C / 32, C / 32, groups), dim3(256), 0, st, W, C, A, At);
     return hipGetLastError();
 }
 

@@ -73,7 +73,7 @@ class WhitenColorFunction(torch.autograd.Function):
         slot = slot if ctx.has_slot else None
         gy = gy.contiguous()
         if ctx.relu:                      # the fused activation's gradient: the mask in front of the unchanged backward
-            gy = torch.where(y > 0, gy, torch.zeros((), dtype=gy.dtype, device=gy.device))
+            gy = torch.ops.aten.threshold_backward(gy, y, 0.0)      # gy where y > 0, else 0: ONE elementwise pass (where(y > 0, ...) took three launches)
         need_x, need_g, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         Kc = A.shape[0]
         dgamma = dbeta = dx = S = gmean = None
@@ -103,6 +103,23 @@ class WhitenColorFunction(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
+_SLOT_BASE = {}
+
+
+def _group_slot_base(N, groups, Kc, dev):
+    """int32 (N,): group(n) * Kc, the table index of sample n before its class slot is added.  It depends on the shapes
+    only, and building it took four elementwise launches per site and step (arange, //, *, cast: ~20 us of the grouped
+    forward site), so it is kept per (N, groups, Kc, device) -- except while a graph is being recorded, whose private pool
+    must not hand memory to later eager calls."""
+    key = (N, groups, Kc, str(dev))
+    t = _SLOT_BASE.get(key)
+    if t is None:
+        t = ((torch.arange(N, device=dev, dtype=torch.int32) // (N // groups)) * Kc).to(torch.int32).contiguous()
+        if not (t.is_cuda and torch.cuda.is_current_stream_capturing()):
+            _SLOT_BASE[key] = t
+    return t
+
+
 def whiten_color_grouped(x, groups, gamma=None, beta=None, slot=None, moving_mean=None, moving_cov=None,
                          eps=1e-3, momentum=0.99, ddof=1, relu=False, per_sample=False):
     """Training-mode forward of `groups` INDEPENDENT batches stacked along N (no autograd): each run of N/groups
@@ -130,14 +147,14 @@ def whiten_color_grouped(x, groups, gamma=None, beta=None, slot=None, moving_mea
         Kc = N // groups
         A, At, plan = ops.color(W, g, cs, groups, per_group=True)
         center, bias = ops.group_bias(mu.view(groups, C), A, b, groups, Kc, per_group=True)
-        full_slot = torch.arange(N, device=dev, dtype=torch.int32)
-        return ops.apply(x, center, A, bias, full_slot, plan=plan, relu=relu)
+        return ops.apply(x, center, A, bias, _group_slot_base(N, N, 1, dev), plan=plan, relu=relu)
     Kc = 1 if g is None else g.shape[0]
     A, At, plan = ops.color(W, g, cs, groups)
     center, bias = ops.group_bias(mu.view(groups, C), A, b, groups, Kc)
-    grp = torch.arange(N, device=dev, dtype=torch.int32) // (N // groups)
-    full_slot = grp * Kc + (slot if slot is not None else 0)
-    return ops.apply(x, center, A, bias, full_slot.to(torch.int32).contiguous(), plan=plan, relu=relu)
+    full_slot = _group_slot_base(N, groups, Kc, dev)
+    if slot is not None:
+        full_slot = (full_slot + slot.view(-1)).to(torch.int32).contiguous()
+    return ops.apply(x, center, A, bias, full_slot, plan=plan, relu=relu)
 
 
 def _touched(*tensors):
