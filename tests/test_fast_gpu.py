@@ -99,6 +99,32 @@ def test_fast_bwd_apply_matches_float64(ops, shape, Kc, train):
     assert rel(dx_exact.cpu().numpy().reshape(ref.shape), ref) < 3e-6
 
 
+@pytest.mark.parametrize("shape", [(16, 32, 32, 256), (32, 32, 32, 128), (96, 32, 32, 64)])
+def test_fast_bwd_apply_out_of_range_in_the_accumulating_pass(ops, shape):
+    """K6's second pass (dx += (x - mu) S) on the ring kernel adds with atomics, so a tile that holds an element beyond the
+    fp16 range must be kept out of the MFMA pass altogether and added exactly: outliers in x (second pass), in gy (first
+    pass, second-store-wins redo), in the first and the last tile of a workgroup and in neighbouring tiles."""
+    rng = np.random.default_rng(31)
+    N, H, _, C = shape
+    x = rng.standard_normal(shape).astype(np.float32) + 0.5
+    gy = (rng.standard_normal(shape) * 1e-3).astype(np.float32)
+    x[0, 0, 0, 1] = 4.0e7; x[0, 1, 3, 5] = -2.0e8; x[N // 2, 7, 9, 3] = 3.0e7; x[N - 1, H - 1, H - 1, C - 1] = 6.0e7
+    gy[3, 2, 1, 0] = 5.0e4
+    mu = np.full(C, 0.5, np.float32)
+    A = (rng.standard_normal((1, C, C)) / np.sqrt(C)).astype(np.float32)
+    At = np.ascontiguousarray(np.transpose(A, (0, 2, 1)))
+    S = rng.standard_normal((C, C)).astype(np.float32) * 1e-4; S = (S + S.T) / 2
+    gm = (rng.standard_normal(C) * 1e-4).astype(np.float32)
+    dx = ops.bwd_apply(dev(gy), dev(x), dev(mu), dev(At), dev(S), dev(gm), None, fast=True)
+    ref = gy.astype(np.float64).reshape(-1, C) @ At[0].astype(np.float64) \
+        + (x.astype(np.float64).reshape(-1, C) - mu) @ S.astype(np.float64) - gm.astype(np.float64)
+    got = dx.cpu().numpy().reshape(ref.shape)
+    assert np.isfinite(got).all()
+    # row-wise: the outlier rows are 1e8 times larger than the others, which must be right too
+    err = np.abs(got - ref).max(1) / np.maximum(np.abs(ref).max(1), 1e-30)
+    assert err.max() < 1e-5, (err.max(), int(err.argmax()))
+
+
 # ---- fast reductions (wc_fast_xty.hip) -------------------------------------------------------------------------
 XTY_CASES = [((16, 32, 32, 256), 1), ((128, 32, 32, 256), 1), ((32, 32, 32, 128), 1), ((16, 64, 64, 64), 1), ((8, 64, 64, 32), 1)]
 
@@ -150,8 +176,10 @@ def test_fast_reductions_out_of_range_take_the_exact_redo(ops, shape):
     N, C = shape[0], shape[-1]
     x = (rng.standard_normal(shape) + 0.3).astype(np.float32)
     x[1, 2, 3, 5] = 4.0e7
+    x[0, 0, 0, 9] = -6.0e7                       # on a SAMPLED row (row 0): the scales and the shift come from 256 sampled rows
     gy = (rng.standard_normal(shape) * 1e-3).astype(np.float32)
     gy[2, 1, 0, 7] = 3.0e6
+    gy[0, 0, 0, 11] = 2.0e5                      # sampled row too
     X = x.reshape(-1, C).astype(np.float64)
     s, xtx = ops.stats(dev(x).view(-1, C))
     nat = np.sqrt(np.outer((X ** 2).sum(0), (X ** 2).sum(0)))

@@ -5,6 +5,35 @@
 #include <stddef.h>
 
 typedef float  f32x4  __attribute__((ext_vector_type(4)));
+
+// Row-subsample statistics that survive an outlier ON a sampled row (the fp16 paths take their per-channel scales and
+// the covariance's shift from <= 256 sampled rows in 16 groups; one 1e7-sigma element there used to set the channel's scale
+// by itself -- every ordinary value of the channel then sat in fp16's subnormal range, silently: only overflow raises
+// the exact path).  The median of the 16 group values is the reference: untouched by up to seven bad groups.
+__device__ __forceinline__ float wc_median16(const float (&v)[16])
+{
+    float lo = 0.f, hi = 0.f;          // the 8th and 9th smallest: every element's rank by counting (ties by index)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        int rank = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) rank += (v[j] < v[i]) || (v[j] == v[i] && j < i);
+        if (rank == 7) lo = v[i];
+        if (rank == 8) hi = v[i];
+    }
+    return 0.5f * (lo + hi);
+}
+// the sampled maximum, unless it is more than 64 x the median of the 16 group maxima: then 4 x that median
+// (ordinary data: unchanged, bit for bit; a group maximum of 16 normal rows is ~1.9 sigma, the maximum of 256 ~2.8)
+__device__ __forceinline__ float wc_robust_max16(const float (&gmax)[16])
+{
+    float m = 0.f;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) m = fmaxf(m, gmax[p]);
+    const float med = wc_median16(gmax);
+    return (med > 0.f && m > 64.f * med) ? 4.f * med : m;
+}
+
 typedef float  f32x16 __attribute__((ext_vector_type(16)));
 typedef double f64x4  __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));

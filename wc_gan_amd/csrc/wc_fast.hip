@@ -75,9 +75,10 @@ __global__ __launch_bounds__(1024) void channel_scale_kernel(const float* __rest
     red[part][threadIdx.x & 63] = mx;
     __syncthreads();
     if (threadIdx.x < 64 && c < C) {
-        float m = 0.f;
+        float gm[16];
 #pragma unroll
-        for (int p = 0; p < 16; ++p) m = fmaxf(m, red[p][threadIdx.x]);
+        for (int p = 0; p < 16; ++p) gm[p] = red[p][threadIdx.x];
+        const float m = wc_robust_max16(gm);     // the sampled max, unless an outlier sits on a sampled row (wc_common.h)
         float s = 1.0f;
         if (m > 0.f && m < 3.0e38f) {
             int e;

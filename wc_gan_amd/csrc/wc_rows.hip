@@ -488,30 +488,47 @@ __global__ __launch_bounds__(1024) void subsample_mean_scale_kernel(const float*
     }
     red[part][threadIdx.x & 63] = s;
     __syncthreads();
-    float t = 0.f;
+    float t = 0.f, pm[16];
 #pragma unroll
-    for (int p = 0; p < 16; ++p) t += red[p][threadIdx.x & 63];
+    for (int p = 0; p < 16; ++p) {
+        const float ps = red[p][threadIdx.x & 63];
+        t += ps;
+        const int64_t cnt = (nsamp - p + 15) / 16;                     // rows of group p
+        pm[p] = cnt > 0 ? ps / (float)cnt : 0.f;
+    }
     const float mean = t / (float)nsamp;
+    const float med = nsamp >= 16 ? wc_median16(pm) : mean;         // median of the 16 group means: the outlier-proof centre
     __syncthreads();
-    float mx = 0.f;
+    // group maxima of |v - mean| and of |v - med|: the first decides (and is the only one used on ordinary data), the
+    // second replaces it when an outlier sits on a sampled row (it would have moved the mean by 1/256 of itself)
+    float mx = 0.f, mx2 = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int64_t r = part + 16 * i;
-        if (c < C && r < nsamp) mx = fmaxf(mx, fabsf(v[i] - mean));
+        if (c < C && r < nsamp) { mx = fmaxf(mx, fabsf(v[i] - mean)); mx2 = fmaxf(mx2, fabsf(v[i] - med)); }
     }
+    __shared__ float red2[16][64];
     red[part][threadIdx.x & 63] = mx;
+    red2[part][threadIdx.x & 63] = mx2;
     __syncthreads();
     if (threadIdx.x < 64 && c < C) {
+        float g1[16], g2[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) { g1[p] = red[p][threadIdx.x]; g2[p] = red2[p][threadIdx.x]; }
         float m = 0.f;
 #pragma unroll
-        for (int p = 0; p < 16; ++p) m = fmaxf(m, red[p][threadIdx.x]);
+        for (int p = 0; p < 16; ++p) m = fmaxf(m, g1[p]);
+        const float med1 = wc_median16(g1);
+        const bool outlier = nsamp >= 16 && med1 > 0.f && m > 64.f * med1;
+        float centre = mean;
+        if (outlier) { centre = med; m = wc_robust_max16(g2); }
         float sc = 1.0f;
         if (m > 0.f && m < 3.0e38f) {
             int e;
             frexpf(m, &e);
             sc = ldexpf(1.0f, 4 - e);
         }
-        shift[c] = mean;
+        shift[c] = centre;
         scale[c] = sc;
     }
 }
