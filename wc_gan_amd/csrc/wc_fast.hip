@@ -494,7 +494,10 @@ __global__ __launch_bounds__(512, 1) void affine_ring_kernel(FastArgs a)
     // fp16 image rows: C >= 128 pads every row by one 16-byte chunk (row r starts r chunks further round the 64 banks,
     // conflict-free for the ds_read_b128 lane groups, and every fragment address is lane base + immediate); the
     // narrower tiles have no LDS to spare for that and XOR-swizzle the chunks of a row instead
-    constexpr int PAD = C >= 128 ? 16 : 0;
+    // (C = 256 on the 16x16x32 shape: 32 bytes -- a row then starts two 16-byte slots further round the banks and the
+    // fragment reads of 16 rows x 4 chunks are conflict-free; with 16 bytes every 16-lane group had one 2-way conflict,
+    // SQ_LDS_BANK_CONFLICT 40 % of the LDS cycles.  C = 128 has no LDS to spare for the wider pad.)
+    constexpr int PAD = (C == 256 && WC_MFMA16) ? 32 : (C >= 128 ? 16 : 0);
     constexpr int PITCH = C * 2 + PAD;
     constexpr int IMG = TR * PITCH;           // one fp16 image: 16 KiB (+ padding)
     constexpr int FBUF = 2 * IMG;             // hi | lo
@@ -979,7 +982,7 @@ template <int C>
 hipError_t launch_affine_ring(const FastArgs& a, hipStream_t st)
 {
     constexpr int TR = 8192 / C;
-    constexpr size_t lds = 3 * 2 * (size_t)(TR * (C * 2 + (C >= 128 ? 16 : 0))) + 8 * 7 * 1024 + 64;   // 3 image buffers + 8 x 7 raw chunk slots + counters
+    constexpr size_t lds = 3 * 2 * (size_t)(TR * (C * 2 + ((C == 256 && WC_MFMA16) ? 32 : (C >= 128 ? 16 : 0)))) + 8 * 7 * 1024 + 64;   // 3 image buffers + 8 x 7 raw chunk slots + counters
     FastArgs b = a;
     b.bias_on = a.bias != nullptr; b.sub_on = a.sub != nullptr;
     if (!b.bias_on) b.bias = a.scale;       // any valid address: loaded and ignored
