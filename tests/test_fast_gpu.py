@@ -149,7 +149,8 @@ def test_fast_stats_matches_float64(ops, shape, _k):
     assert np.abs(xtx.cpu().numpy() - xtx.cpu().numpy().T).max() == 0.0
 
 
-@pytest.mark.parametrize("shape,Kc", [((16, 32, 32, 256), 1), ((32, 32, 32, 128), 5), ((128, 32, 32, 128), 10), ((16, 64, 64, 64), 3)])
+@pytest.mark.parametrize("shape,Kc", [((16, 32, 32, 256), 1), ((32, 32, 32, 128), 5), ((128, 32, 32, 128), 10), ((16, 64, 64, 64), 3),
+                                      ((32, 32, 32, 256), 4), ((128, 16, 16, 256), 10)])      # C = 256 with class slots: the quadrant scheme per sample
 def test_fast_bwd_reduce_matches_float64(ops, shape, Kc):
     rng = np.random.default_rng(22)
     N, C = shape[0], shape[-1]
