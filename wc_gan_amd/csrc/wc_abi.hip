@@ -305,19 +305,22 @@ int wc_bwd_factor_f64(const double* R, const double* gsum, const double* W, cons
         return g;
     };
 
-    if (dgamma && gamma) {                          // dgamma[k] = W R[k]
-        WcGemm g = sq(W, 0, C, 1, R, 0, C, 1, dgamma, 1, 1.0, WC_EPI_NONE);
-        g.a_bs = 0; g.b_bs = CC; g.c_bs = CC; g.batch = Kc;
-        WC_TRY(wc_launch_gemm(g, st));
+    WcGemm gd = {};
+    const bool want_dgamma = dgamma && gamma;
+    if (want_dgamma) {                              // dgamma[k] = W R[k]
+        gd = sq(W, 0, C, 1, R, 0, C, 1, dgamma, 1, 1.0, WC_EPI_NONE);
+        gd.a_bs = 0; gd.b_bs = CC; gd.c_bs = CC; gd.batch = Kc;
+        if (!training) WC_TRY(wc_launch_gemm(gd, st));          // training: in one launch with Wbar below
     }
-    if (dbeta) WC_TRY(wc_launch_f64_to_f32(gsum, dbeta, (int64_t)Kc * C, st));
+    if (dbeta && !training) WC_TRY(wc_launch_f64_to_f32(gsum, dbeta, (int64_t)Kc * C, st));      // training: in the tail launch
     if (!training) return WC_OK;
 
     const double* Wbar; int64_t wb_rs, wb_cs;
     if (gamma) {                                    // Wbar = sum_k Gamma_k R_k^T
         WcGemm g = sq(gamma, 1, C, 1, R, 0, 1, C, buf0, 0, 1.0, WC_EPI_NONE);
         g.a_red = CC; g.b_red = CC; g.nred = Kc;
-        WC_TRY(wc_launch_gemm(g, st));
+        if (want_dgamma) WC_TRY(wc_launch_gemm_pair_dd_fd(gd, g, st));      // dgamma and Wbar: neither waits for the other
+        else WC_TRY(wc_launch_gemm(g, st));
         Wbar = buf0; wb_rs = C; wb_cs = 1;
     } else {                                        // Gamma = I: Wbar = R^T, read through swapped strides
         Wbar = R; wb_rs = 1; wb_cs = C;
@@ -343,8 +346,7 @@ int wc_bwd_factor_f64(const double* R, const double* gsum, const double* W, cons
         WC_TRY(wc_launch_gemm(g, st));
     }
     const double scale = 2.0 * (1.0 - eps) / (double)(M - ddof);
-    WC_TRY(wc_launch_sym_scale_f32(buf2, C, scale, S, st));
-    WC_TRY(wc_launch_gmean(gsum, A, Kc, C, M, gmean, st));
+    WC_TRY(wc_launch_bwd_tail(buf2, C, scale, S, gsum, A, Kc, M, gmean, dbeta, st));      // S, gmean, dbeta
     return WC_OK;
 }
 

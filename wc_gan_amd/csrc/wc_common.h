@@ -162,10 +162,11 @@ struct WcGemm {
     int epi;
 };
 hipError_t wc_launch_gemm(const WcGemm& g, hipStream_t st);
+hipError_t wc_launch_gemm_pair_dd_fd(const WcGemm& g0, const WcGemm& g1, hipStream_t st);      // two independent products (double x double, float x double) in one launch
 
 hipError_t wc_launch_transpose_to_f32(const double* W, int C, int groups, float* A, float* At, hipStream_t st);  // A = W^T, At = W
-hipError_t wc_launch_sym_scale_f32(const double* Q, int C, double scale, float* S, hipStream_t st);   // S = scale*(Q+Q^T)/2
-hipError_t wc_launch_gmean(const double* gsum, const float* A, int Kc, int C, int64_t M, float* gmean, hipStream_t st);
 hipError_t wc_launch_group_bias(const float* mu, const float* A, const float* beta, int G, int Kc, int C, int per_group,
                                 float* center, float* bias, hipStream_t st);
 hipError_t wc_launch_f64_to_f32(const double* src, float* dst, int64_t n, hipStream_t st);
+hipError_t wc_launch_bwd_tail(const double* Q, int C, double scale, float* S, const double* gsum, const float* A, int Kc,
+                              int64_t M, float* gmean, float* dbeta, hipStream_t st);      // S = scale sym(Q), gmean, dbeta = float(gsum) in one launch

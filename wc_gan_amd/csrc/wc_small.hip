@@ -952,13 +952,12 @@ __global__ __launch_bounds__(256) void tri_inv_diag_kernel(const double* __restr
 // One 32 x 32 output block per 256-thread workgroup; the four waves split K and meet in LDS.
 // ---------------------------------------------------------------------------------------------
 template <typename TA, typename TB>
-__global__ __launch_bounds__(256) void gemm_f64_kernel(WcGemm g)
+__device__ __forceinline__ void gemm_f64_body(const WcGemm& g, int bz, double (&red)[4][32 * 32])
 {
-    __shared__ double red[4][32 * 32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
     const int bm = blockIdx.x, bn = blockIdx.y;
-    const int b = blockIdx.z % g.batch, b2 = blockIdx.z / g.batch;       // two batch levels (e.g. class x group)
+    const int b = bz % g.batch, b2 = bz / g.batch;       // two batch levels (e.g. class x group)
     const int kper = g.k >> 2;
 
     f64x4 acc[2][2];
@@ -1059,6 +1058,23 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(WcGemm g)
     }
 }
 
+template <typename TA, typename TB>
+__global__ __launch_bounds__(256) void gemm_f64_kernel(WcGemm g)
+{
+    __shared__ double red[4][32 * 32];
+    gemm_f64_body<TA, TB>(g, blockIdx.z, red);
+}
+
+// two independent products of the same output tiling in ONE launch (blockIdx.z < nz0: the first): K5 starts with
+// dgamma = W R[k] and Wbar = sum_k Gamma_k R_k^T, neither of which waits for the other
+template <typename TA0, typename TB0, typename TA1, typename TB1>
+__global__ __launch_bounds__(256) void gemm_f64_pair_kernel(WcGemm g0, WcGemm g1, int nz0)
+{
+    __shared__ double red[4][32 * 32];
+    if ((int)blockIdx.z < nz0) gemm_f64_body<TA0, TB0>(g0, blockIdx.z, red);
+    else gemm_f64_body<TA1, TB1>(g1, blockIdx.z - nz0, red);
+}
+
 // ---------------------------------------------------------------------------------------------
 // element-wise helpers
 // ---------------------------------------------------------------------------------------------
@@ -1078,28 +1094,31 @@ __global__ void transpose_to_f32_kernel(const double* __restrict__ W, int C, flo
     for (int r = ty; r < 32; r += 8) A[(int64_t)(bx + r) * C + by + tx] = (float)tile[tx][r];
 }
 
-__global__ void sym_scale_f32_kernel(const double* __restrict__ Q, int C, double scale, float* __restrict__ S)
+// K5's tail in one launch: S = scale * sym(Q) (rows y < C), gmean[c] = (1/M) sum_k sum_j gsum[k][j] A[k][c][j] (rows y >= C,
+// first column block) and dbeta = float(gsum) (same rows) -- three launches of ~5 us each on the backward's critical path before
+__global__ __launch_bounds__(128) void bwd_tail_kernel(const double* __restrict__ Q, int C, double scale, float* __restrict__ S,
+                                                       const double* __restrict__ gsum, const float* __restrict__ A, int Kc,
+                                                       int64_t M, float* __restrict__ gmean, float* __restrict__ dbeta)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = blockIdx.y;
-    if (j >= C) return;
-    S[(int64_t)i * C + j] = (float)(scale * 0.5 * (Q[(int64_t)i * C + j] + Q[(int64_t)j * C + i]));
-}
-
-// gmean[c] = (1/M) sum_k sum_j gsum[k][j] A[k][c][j]
-__global__ void gmean_kernel(const double* __restrict__ gsum, const float* __restrict__ A, int Kc, int C, int64_t M,
-                             float* __restrict__ gmean)
-{
-    __shared__ double red[256];
-    const int c = blockIdx.x;
+    __shared__ double red[128];
+    const int y = blockIdx.y;
+    if (y < C) {
+        const int j = blockIdx.x * 128 + threadIdx.x;
+        if (j < C) S[(int64_t)y * C + j] = (float)(scale * 0.5 * (Q[(int64_t)y * C + j] + Q[(int64_t)j * C + y]));
+        return;
+    }
+    if (blockIdx.x != 0) return;
+    const int c = y - C;
+    if (dbeta)
+        for (int64_t e = (int64_t)c * 128 + threadIdx.x; e < (int64_t)Kc * C; e += (int64_t)C * 128) dbeta[e] = (float)gsum[e];
     double s = 0.0;
-    for (int64_t e = threadIdx.x; e < (int64_t)Kc * C; e += 256) {
+    for (int64_t e = threadIdx.x; e < (int64_t)Kc * C; e += 128) {
         const int64_t k = e / C, j = e % C;
         s += gsum[e] * (double)A[(k * C + c) * C + j];
     }
     red[threadIdx.x] = s;
     __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
+    for (int w = 64; w > 0; w >>= 1) {
         if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
         __syncthreads();
     }
@@ -1239,6 +1258,15 @@ hipError_t wc_launch_gemm(const WcGemm& g, hipStream_t st)
     return hipGetLastError();
 }
 
+// K5's head: g0 = (double A, double B), g1 = (float A, double B), same m x n tiling
+hipError_t wc_launch_gemm_pair_dd_fd(const WcGemm& g0, const WcGemm& g1, hipStream_t st)
+{
+    const int nz0 = g0.batch * (g0.batch2 > 0 ? g0.batch2 : 1), nz1 = g1.batch * (g1.batch2 > 0 ? g1.batch2 : 1);
+    const dim3 grid(g0.m / 32, g0.n / 32, nz0 + nz1);
+    hipLaunchKernelGGL((gemm_f64_pair_kernel<double, double, float, double>), grid, dim3(256), 0, st, g0, g1, nz0);
+    return hipGetLastError();
+}
+
 // W = L^-1: invert the 32-wide diagonal blocks, then double the block size level by level:
 //   [L11 0; L21 L22]^-1 = [W11 0; -W22 L21 W11, W22]
 hipError_t wc_launch_tri_inverse(const double* L, double* W, double* tmp, int C, int groups, hipStream_t st)
@@ -1282,15 +1310,10 @@ hipError_t wc_launch_transpose_to_f32(const double* W, int C, int groups, float*
     return hipGetLastError();
 }
 
-hipError_t wc_launch_sym_scale_f32(const double* Q, int C, double scale, float* S, hipStream_t st)
+hipError_t wc_launch_bwd_tail(const double* Q, int C, double scale, float* S, const double* gsum, const float* A, int Kc,
+                              int64_t M, float* gmean, float* dbeta, hipStream_t st)
 {
-    hipLaunchKernelGGL(sym_scale_f32_kernel, dim3((C + 127) / 128, C), dim3(128), 0, st, Q, C, scale, S);
-    return hipGetLastError();
-}
-
-hipError_t wc_launch_gmean(const double* gsum, const float* A, int Kc, int C, int64_t M, float* gmean, hipStream_t st)
-{
-    hipLaunchKernelGGL(gmean_kernel, dim3(C), dim3(256), 0, st, gsum, A, Kc, C, M, gmean);
+    hipLaunchKernelGGL(bwd_tail_kernel, dim3((C + 127) / 128, 2 * C), dim3(128), 0, st, Q, C, scale, S, gsum, A, Kc, M, gmean, dbeta);
     return hipGetLastError();
 }
 
