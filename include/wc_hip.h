@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define WC_ABI_VERSION 2
+#define WC_ABI_VERSION 3
 
 #define WC_OK                 0
 #define WC_ERR_NULL          -1   /* a required pointer is NULL                     */
@@ -137,6 +137,21 @@ int wc_bwd_reduce_f32(const float* x, const float* mu, const float* gy, const in
                       int64_t N, int64_t HW, int C, int Kc,
                       double* R /*[Kc,C,C]*/, double* gsum /*[Kc,C]*/,
                       void* ws, size_t ws_bytes, wc_stream_t stream);
+
+/* K4 / K6 sharing the fp16 paths' per-channel input scales (ABI 3).  Both stages scale (x - mu) and gy by per-channel powers
+ * of two sampled from <= 256 rows; K4 samples them anyway.  `scales` = float[2*C]: the scales of (x - mu), then those of gy.
+ * wc_bwd_reduce_scaled_f32 writes them (also when its own reduction takes the exact path); wc_bwd_apply_scaled_f32 takes them
+ * instead of sampling the same two tensors again and builds the tables of both its passes in one launch: three launches
+ * instead of six.  scales == NULL: exactly wc_bwd_reduce_f32 / wc_bwd_apply_f32.  Results are identical either way (the same
+ * samples give the same scales). */
+int wc_bwd_reduce_scaled_f32(const float* x, const float* mu, const float* gy, const int32_t* slot,
+                             int64_t N, int64_t HW, int C, int Kc,
+                             double* R /*[Kc,C,C]*/, double* gsum /*[Kc,C]*/, float* scales_out /*[2C], nullable*/,
+                             void* ws, size_t ws_bytes, wc_stream_t stream);
+int wc_bwd_apply_scaled_f32(const float* gy, const float* x, const float* mu, const float* At,
+                            const float* S, const float* gmean, const int32_t* slot,
+                            int64_t N, int64_t HW, int C, int Kc, const float* scales /*[2C], nullable*/, float* dx,
+                            void* ws, size_t ws_bytes, wc_stream_t stream);
 
 /* K5: dgamma[k] = W R[k];  and, when training != 0, the statistics path
  *     Wbar = sum_k Gamma_k R_k^T;  Lbar = -tril(W^T Wbar W^T);  P = Phi(L^T Lbar);

@@ -97,6 +97,12 @@ def test_fast_bwd_apply_matches_float64(ops, shape, Kc, train):
         ref = ref + (x.astype(np.float64).reshape(N, -1, C) - mu) @ S.astype(np.float64) - gm.astype(np.float64)
     assert rel(dx_fast.cpu().numpy().reshape(ref.shape), ref) < 3e-6
     assert rel(dx_exact.cpu().numpy().reshape(ref.shape), ref) < 3e-6
+    if train:
+        # ABI 3: K4 hands its sampled input scales to K6 (three launches instead of six) -- the same samples, the same result
+        scales = ops.bwd_reduce(dev(x), dev(mu), dev(gy), st, Kc, want_scales=True)[-1]
+        assert scales.shape == (2 * C,) and bool((scales > 0).all())
+        dx_shared = ops.bwd_apply(*args, fast=True, scales=scales)
+        assert torch.equal(dx_shared, dx_fast)
 
 
 @pytest.mark.parametrize("shape", [(16, 32, 32, 256), (32, 32, 32, 128), (96, 32, 32, 64)])

@@ -242,6 +242,13 @@ int wc_bwd_reduce_f32(const float* x, const float* mu, const float* gy, const in
                       int64_t N, int64_t HW, int C, int Kc, double* R, double* gsum,
                       void* ws, size_t ws_bytes, wc_stream_t stream)
 {
+    return wc_bwd_reduce_scaled_f32(x, mu, gy, slot, N, HW, C, Kc, R, gsum, nullptr, ws, ws_bytes, stream);
+}
+
+int wc_bwd_reduce_scaled_f32(const float* x, const float* mu, const float* gy, const int32_t* slot,
+                             int64_t N, int64_t HW, int C, int Kc, double* R, double* gsum, float* scales_out,
+                             void* ws, size_t ws_bytes, wc_stream_t stream)
+{
     if (!x || !gy || !R || !gsum || !ws) return WC_ERR_NULL;
     if (N <= 0 || HW <= 0 || Kc <= 0 || (!slot && Kc != 1)) return WC_ERR_SHAPE;
     if (bad_channels(C)) return WC_ERR_CHANNELS;
@@ -254,11 +261,13 @@ int wc_bwd_reduce_f32(const float* x, const float* mu, const float* gy, const in
     int* gate = cv.take<int>(64);
     float* sx = cv.take<float>(C);
     float* sy = cv.take<float>(C);
+    if (scales_out) { sx = scales_out; sy = scales_out + C; }      // the caller keeps them for wc_bwd_apply_scaled_f32
     float* colsum = cv.take<float>((size_t)p.nslab * C);
     double* P = cv.take<double>((size_t)p.nslab * C * C);
     WcXtyArgs a = {};
     a.X = x; a.Y = gy; a.cx = mu; a.cy = nullptr; a.N = Ns; a.HW = HWs;
     a.per_sample = per_sample; a.nsplit = p.nsplit; a.rows_per_slab = p.rps; a.C = C; a.sym = 0; a.P = P; a.colsum = colsum;
+    if (!p.fast && scales_out) WC_TRY(wc_launch_channel_scale2(x, mu, sx, gy, nullptr, sy, N * HW, C, gate, st));   // asked for: sampled anyway
     if (p.fast) {
         WC_TRY(wc_launch_channel_scale2(x, mu, sx, gy, nullptr, sy, N * HW, C, gate, st));      // both scales, gate := 0
         WC_TRY(wc_launch_fast_xty(x, gy, mu, nullptr, sx, sy, Ns, HWs, C, per_sample, p.nsplit, p.rps, p.nslab, p.ntypes,
@@ -353,12 +362,22 @@ int wc_bwd_factor_f64(const double* R, const double* gsum, const double* W, cons
 // ---------------------------------------------------------------------------------------------
 size_t wc_bwd_apply_workspace_bytes(int64_t N, int64_t HW, int C, int Kc)
 {
-    return wc_apply_workspace_bytes(N, HW, C, Kc);
+    // two plans side by side (At's tables, S's table): with given scales both are built in one launch
+    const size_t one = wc_apply_workspace_bytes(N, HW, C, Kc);
+    if (N <= 0 || HW <= 0 || Kc <= 0 || bad_channels(C) || !wc_fast_affine_supported(N, HW, C, Kc > 1)) return one;
+    return one + wc_fast_affine_workspace(C, 1);
 }
 
 int wc_bwd_apply_f32(const float* gy, const float* x, const float* mu, const float* At, const float* S,
                      const float* gmean, const int32_t* slot, int64_t N, int64_t HW, int C, int Kc,
                      float* dx, void* ws, size_t ws_bytes, wc_stream_t stream)
+{
+    return wc_bwd_apply_scaled_f32(gy, x, mu, At, S, gmean, slot, N, HW, C, Kc, nullptr, dx, ws, ws_bytes, stream);
+}
+
+int wc_bwd_apply_scaled_f32(const float* gy, const float* x, const float* mu, const float* At, const float* S,
+                            const float* gmean, const int32_t* slot, int64_t N, int64_t HW, int C, int Kc,
+                            const float* scales, float* dx, void* ws, size_t ws_bytes, wc_stream_t stream)
 {
     if (!gy || !At || !dx) return WC_ERR_NULL;
     if (S && !x) return WC_ERR_NULL;
@@ -374,6 +393,16 @@ int wc_bwd_apply_f32(const float* gy, const float* x, const float* mu, const flo
     }
     a.bias = nullptr; a.sub = gmean; a.slot = slot; a.N = N; a.HW = HW; a.C = C; a.out = dx;
     const bool fast = ws && wc_fast_affine_supported(N, HW, C, slot != nullptr) && ws_bytes >= wc_fast_affine_workspace(C, Kc);
+    if (fast && scales && S && ws_bytes >= wc_fast_affine_workspace(C, Kc) + wc_fast_affine_workspace(C, 1)) {
+        // the scales of both inputs are the caller's (K4 sampled the same two tensors): no sampling launches, and the tables
+        // of both passes from one launch -- three launches instead of six
+        void* plan0 = ws;
+        void* plan1 = static_cast<char*>(ws) + wc_fast_affine_workspace(C, Kc);
+        WC_TRY(wc_launch_fast_plan_tables2(At, Kc, plan0, scales + C, S, 1, plan1, scales, C, st));
+        WC_TRY(wc_launch_fast_affine_planned(gy, nullptr, At, Kc, false, nullptr, gmean, slot, N, HW, C, 0, dx, plan0, st));
+        WC_TRY(wc_launch_fast_affine_planned(x, mu, S, 1, true, nullptr, nullptr, nullptr, N, HW, C, 1, dx, plan1, st));
+        return WC_OK;
+    }
     if (fast) {
         // two passes over dx (the B' fragments of both streams do not fit one wave's registers at C = 256):
         //   dx  = gy At[slot] - gmean ;   dx += (x - mu) S

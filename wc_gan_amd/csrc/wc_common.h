@@ -12,16 +12,23 @@ typedef float  f32x4  __attribute__((ext_vector_type(4)));
 // the exact path).  The median of the 16 group values is the reference: untouched by up to seven bad groups.
 __device__ __forceinline__ float wc_median16(const float (&v)[16])
 {
-    float lo = 0.f, hi = 0.f;          // the 8th and 9th smallest: every element's rank by counting (ties by index)
+    float s[16];          // bitonic sorting network: 80 compare-exchanges, every index a compile-time constant
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        int rank = 0;
+    for (int i = 0; i < 16; ++i) s[i] = v[i];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) rank += (v[j] < v[i]) || (v[j] == v[i] && j < i);
-        if (rank == 7) lo = v[i];
-        if (rank == 8) hi = v[i];
-    }
-    return 0.5f * (lo + hi);
+    for (int k = 2; k <= 16; k <<= 1)
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const float lo = fminf(s[i], s[l]), hi = fmaxf(s[i], s[l]);
+                    const bool up = (i & k) == 0;
+                    s[i] = up ? lo : hi; s[l] = up ? hi : lo;
+                }
+            }
+    return 0.5f * (s[7] + s[8]);
 }
 // the sampled maximum, unless it is more than 64 x the median of the 16 group maxima: then 4 x that median
 // (ordinary data: unchanged, bit for bit; a group maximum of 16 normal rows is ~1.9 sigma, the maximum of 256 ~2.8)
@@ -119,6 +126,8 @@ hipError_t wc_launch_fast_xty(const float* X, const float* Y, const float* cx, c
                               int per_sample, int nsplit, int64_t rows_per_slab, int nslab, int ntypes,
                               double* P, float* colsum, double* dfix /*[nslab][C], covariance only, nullable*/, int* gate, hipStream_t st);
 hipError_t wc_launch_fast_plan_tables(const float* B, int Kc, int C, void* plan, hipStream_t st, const float* scale = nullptr);
+hipError_t wc_launch_fast_plan_tables2(const float* B0, int Kc0, void* plan0, const float* scale0,
+                                       const float* B1, int Kc1, void* plan1, const float* scale1, int C, hipStream_t st);
 float* wc_fast_plan_scale(void* plan);
 hipError_t wc_launch_fast_affine_planned(const float* in, const float* center, const float* B, int Kc, bool shared_table,
                                          const float* bias, const float* sub, const int32_t* slot,

@@ -98,11 +98,18 @@ __global__ __launch_bounds__(1024) void channel_scale_kernel(const float* __rest
 // at C = 256 (measured); in this order each byte crosses the L2 -> CU path once per workgroup.
 // one wave per (slot, n)
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void split_table_kernel(const float* __restrict__ B, const float* __restrict__ scale,
-                                                         int C, _Float16* __restrict__ hi, _Float16* __restrict__ lo,
-                                                         float* __restrict__ colscale, float* __restrict__ scale_out)
+// (two tables in one launch: K6 builds At's and S's together; a single table passes rows1 = 0)
+struct SplitJob { const float* B; const float* scale; _Float16* hi; _Float16* lo; float* colscale; float* scale_out; int rows; };
+__global__ __launch_bounds__(64) void split_table_kernel(SplitJob j0, SplitJob j1, int C)
 {
-    const int64_t row = blockIdx.x;                 // slot * C + n
+    const bool second = (int)blockIdx.x >= j0.rows;
+    const float* __restrict__ B = second ? j1.B : j0.B;
+    const float* __restrict__ scale = second ? j1.scale : j0.scale;
+    _Float16* __restrict__ hi = second ? j1.hi : j0.hi;
+    _Float16* __restrict__ lo = second ? j1.lo : j0.lo;
+    float* __restrict__ colscale = second ? j1.colscale : j0.colscale;
+    float* __restrict__ scale_out = second ? j1.scale_out : j0.scale_out;
+    const int64_t row = second ? blockIdx.x - j0.rows : blockIdx.x;                 // slot * C + n
     // scale_out: the plan's own copy of the input scales (the apply kernel reads them from the plan) -- written here by the
     // first workgroups instead of by a device-to-device copy in front of this launch
     if (scale_out && row * 64 < C) {
@@ -1101,11 +1108,24 @@ static PlanView plan_view(void* plan, int C, int Kc)
 
 // Build the fp16 tables of B ([slot][k][n] fp32) for the per-channel scales `scale` (nullptr: already stored in
 // plan.scale; otherwise they are copied into the plan by the same launch).
-hipError_t wc_launch_fast_plan_tables(const float* B, int Kc, int C, void* plan, hipStream_t st, const float* scale)
+static SplitJob split_job(const float* B, int Kc, int C, void* plan, const float* scale)
 {
     const PlanView v = plan_view(plan, C, Kc);
-    hipLaunchKernelGGL(split_table_kernel, dim3((unsigned)(Kc * C)), dim3(64), 0, st, B, scale ? scale : (const float*)v.scale, C,
-                       v.hi, v.lo, v.colscale, scale ? v.scale : (float*)nullptr);
+    SplitJob j = {B, scale ? scale : (const float*)v.scale, v.hi, v.lo, v.colscale, scale ? v.scale : (float*)nullptr, Kc * C};
+    return j;
+}
+hipError_t wc_launch_fast_plan_tables(const float* B, int Kc, int C, void* plan, hipStream_t st, const float* scale)
+{
+    SplitJob none = {};
+    hipLaunchKernelGGL(split_table_kernel, dim3((unsigned)(Kc * C)), dim3(64), 0, st, split_job(B, Kc, C, plan, scale), none, C);
+    return hipGetLastError();
+}
+// two plans (with their input scales given) in one launch
+hipError_t wc_launch_fast_plan_tables2(const float* B0, int Kc0, void* plan0, const float* scale0,
+                                       const float* B1, int Kc1, void* plan1, const float* scale1, int C, hipStream_t st)
+{
+    hipLaunchKernelGGL(split_table_kernel, dim3((unsigned)((Kc0 + Kc1) * C)), dim3(64), 0, st,
+                       split_job(B0, Kc0, C, plan0, scale0), split_job(B1, Kc1, C, plan1, scale1), C);
     return hipGetLastError();
 }
 

@@ -488,17 +488,22 @@ __global__ __launch_bounds__(1024) void subsample_mean_scale_kernel(const float*
     }
     red[part][threadIdx.x & 63] = s;
     __syncthreads();
-    float t = 0.f, pm[16];
+    __shared__ float centre2[2][64];             // [0] mean, [1] median of the 16 group means (the outlier-proof centre)
+    if (threadIdx.x < 64) {
+        float t = 0.f, pm[16];
 #pragma unroll
-    for (int p = 0; p < 16; ++p) {
-        const float ps = red[p][threadIdx.x & 63];
-        t += ps;
-        const int64_t cnt = (nsamp - p + 15) / 16;                     // rows of group p
-        pm[p] = cnt > 0 ? ps / (float)cnt : 0.f;
+        for (int p = 0; p < 16; ++p) {
+            const float ps = red[p][threadIdx.x];
+            t += ps;
+            const int64_t cnt = (nsamp - p + 15) / 16;                     // rows of group p
+            pm[p] = cnt > 0 ? ps / (float)cnt : 0.f;
+        }
+        const float mean_ = t / (float)nsamp;
+        centre2[0][threadIdx.x] = mean_;
+        centre2[1][threadIdx.x] = nsamp >= 16 ? wc_median16(pm) : mean_;
     }
-    const float mean = t / (float)nsamp;
-    const float med = nsamp >= 16 ? wc_median16(pm) : mean;         // median of the 16 group means: the outlier-proof centre
     __syncthreads();
+    const float mean = centre2[0][threadIdx.x & 63], med = centre2[1][threadIdx.x & 63];
     // group maxima of |v - mean| and of |v - med|: the first decides (and is the only one used on ordinary data), the
     // second replaces it when an outlier sits on a sampled row (it would have moved the mean by 1/256 of itself)
     float mx = 0.f, mx2 = 0.f;

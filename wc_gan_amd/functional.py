@@ -80,11 +80,17 @@ class WhitenColorFunction(torch.autograd.Function):
         stats_path = ctx.training and need_x
         want_g = ctx.has_gamma and need_g
         want_b = ctx.has_beta and need_b
+        scales = None          # K4 samples the fp16 scales of (x - mu) and gy; K6 reuses them (three launches instead of six)
         if want_g or want_b or stats_path:
+            share = bool(stats_path)
             if ctx.group is None:
-                R, gsum = ops.bwd_reduce(x, mu, gy, slot, Kc)
+                out = ops.bwd_reduce(x, mu, gy, slot, Kc, want_scales=share)
+                R, gsum = out[0], out[1]
             else:
-                R, gsum, rbuf = ops.bwd_reduce(x, mu, gy, slot, Kc, flat=True)
+                out = ops.bwd_reduce(x, mu, gy, slot, Kc, flat=True, want_scales=share)
+                R, gsum, rbuf = out[0], out[1], out[2]
+            if share:
+                scales = out[-1]
             if ctx.group is None:
                 dgamma, dbeta, S, gmean = ops.bwd_factor(R, gsum, W, L, g, A, ctx.M, ctx.eps, ctx.ddof, stats_path,
                                                          want_dgamma=want_g, want_dbeta=want_b)
@@ -99,7 +105,7 @@ class WhitenColorFunction(torch.autograd.Function):
                     _, _, S, gmean = ops.bwd_factor(R, gsum, W, L, g, A, ctx.M, ctx.eps, ctx.ddof, True,
                                                     want_dgamma=False, want_dbeta=False)
         if need_x:
-            dx = ops.bwd_apply(gy, x, mu, At, S, gmean, slot)
+            dx = ops.bwd_apply(gy, x, mu, At, S, gmean, slot, scales=scales)
         return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 

@@ -143,8 +143,9 @@ def apply(x, mu, A, bias, slot, out=None, fast=True, plan=None, relu=False):
     return y
 
 
-def bwd_reduce(x, mu, gy, slot, Kc, flat=False):
-    """K4: -> (R (Kc,C,C) f64, gsum (Kc,C) f64); flat=True: views of one buffer, returned third (sync-WC's single all-reduce)."""
+def bwd_reduce(x, mu, gy, slot, Kc, flat=False, want_scales=False):
+    """K4: -> (R (Kc,C,C) f64, gsum (Kc,C) f64); flat=True: views of one buffer, returned third (sync-WC's single all-reduce);
+    want_scales=True: the (2C,) per-channel input scales of (x - mu) and gy, returned last, for bwd_apply(scales=...)."""
     lib = _lib.load()
     _need(x, torch.float32, "x")
     _need(gy, torch.float32, "gy")
@@ -158,9 +159,11 @@ def bwd_reduce(x, mu, gy, slot, Kc, flat=False):
         R = torch.empty(Kc, C, C, dtype=torch.float64, device=x.device)
         gsum = torch.empty(Kc, C, dtype=torch.float64, device=x.device)
     ws = _workspace(lib.wc_bwd_reduce_workspace_bytes(N, HW, C, Kc, int(slot is not None)), x.device)
-    _lib.check(lib.wc_bwd_reduce_f32(_ptr(x), _ptr(mu), _ptr(gy), _ptr(slot), N, HW, C, Kc, _ptr(R), _ptr(gsum),
-                                     _ptr(ws), ws.numel(), _stream()), "wc_bwd_reduce_f32")
-    return (R, gsum, buf) if buf is not None else (R, gsum)
+    scales = torch.empty(2 * C, dtype=torch.float32, device=x.device) if want_scales else None
+    _lib.check(lib.wc_bwd_reduce_scaled_f32(_ptr(x), _ptr(mu), _ptr(gy), _ptr(slot), N, HW, C, Kc, _ptr(R), _ptr(gsum),
+                                            _ptr(scales), _ptr(ws), ws.numel(), _stream()), "wc_bwd_reduce_scaled_f32")
+    out = (R, gsum, buf) if buf is not None else (R, gsum)
+    return out + (scales,) if want_scales else out
 
 
 def bwd_factor(R, gsum, W, L, gamma, A, M, eps, ddof, training, want_dgamma=True, want_dbeta=True):
@@ -179,8 +182,9 @@ def bwd_factor(R, gsum, W, L, gamma, A, M, eps, ddof, training, want_dgamma=True
     return dgamma, dbeta, S, gmean
 
 
-def bwd_apply(gy, x, mu, At, S, gmean, slot, fast=True):
-    """K6: dx[n] = gy[n] At[slot[n]] + (x[n]-mu) S - gmean."""
+def bwd_apply(gy, x, mu, At, S, gmean, slot, fast=True, scales=None):
+    """K6: dx[n] = gy[n] At[slot[n]] + (x[n]-mu) S - gmean.  scales: the (2C,) input scales bwd_reduce(..., want_scales=True)
+    returned for the same x, mu, gy (three launches instead of six)."""
     lib = _lib.load()
     _need(gy, torch.float32, "gy")
     N, C = gy.shape[0], gy.shape[-1]
@@ -188,9 +192,9 @@ def bwd_apply(gy, x, mu, At, S, gmean, slot, fast=True):
     Kc = At.shape[0]
     dx = torch.empty_like(gy)
     ws = _workspace(lib.wc_bwd_apply_workspace_bytes(N, HW, C, Kc), gy.device) if fast else None
-    _lib.check(lib.wc_bwd_apply_f32(_ptr(gy), _ptr(x), _ptr(mu), _ptr(At), _ptr(S), _ptr(gmean), _ptr(slot),
-                                    N, HW, C, Kc, _ptr(dx), _ptr(ws), ws.numel() if ws is not None else 0, _stream()),
-               "wc_bwd_apply_f32")
+    _lib.check(lib.wc_bwd_apply_scaled_f32(_ptr(gy), _ptr(x), _ptr(mu), _ptr(At), _ptr(S), _ptr(gmean), _ptr(slot),
+                                           N, HW, C, Kc, _ptr(scales), _ptr(dx), _ptr(ws), ws.numel() if ws is not None else 0,
+                                           _stream()), "wc_bwd_apply_scaled_f32")
     return dx
 
 
