@@ -3,13 +3,17 @@ with `gap` as its window argument then keeps only what follows the last pause (t
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("PYTORCH_MIOPEN_SUGGEST_NHWC", "1")
-from wc_gan_amd.train import CIFAR10_UNCOND, build_trainer
+from wc_gan_amd.train import CONFIGS, build_trainer
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-tr = build_trainer(CIFAR10_UNCOND, 'cuda', batch_size=64, training_ratio=5)
+cfg = CONFIGS[sys.argv[2] if len(sys.argv) > 2 else "cifar10_uncond"]
+tr = build_trainer(cfg, 'cuda', batch_size=64, training_ratio=5)
 g = torch.Generator(device='cpu'); g.manual_seed(0)
-reals = [torch.rand(64, 32, 32, 3, generator=g).cuda() * 2 - 1 for _ in range(5)]
-for _ in range(5): tr.step(reals)
+H, W, Ci = cfg['image_shape']
+reals = [torch.rand(64, H, W, Ci, generator=g).cuda() * 2 - 1 for _ in range(5)]
+K = cfg['generator']['number_of_classes']
+labels = [torch.randint(0, K, (64, 1), generator=g, dtype=torch.int32).cuda() for _ in range(5)] if cfg['conditional'] else None
+for _ in range(5): tr.step(reals, labels)
 torch.cuda.synchronize(); time.sleep(0.5)
 t0 = time.perf_counter()
-for _ in range(n): tr.step(reals)
+for _ in range(n): tr.step(reals, labels)
 torch.cuda.synchronize(); print(f"{(time.perf_counter() - t0) / n * 1e3:.2f} ms/step over {n} steps")

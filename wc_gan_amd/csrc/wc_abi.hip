@@ -280,11 +280,15 @@ int wc_bwd_reduce_scaled_f32(const float* x, const float* mu, const float* gy, c
 }
 
 // ---------------------------------------------------------------------------------------------
+// Wbar = sum_k Gamma_k R_k^T is one workgroup grid walking all Kc terms; with many tables (per-sample tables: Kc = N) the sum
+// is cut into WC_WBAR_PARTS batches that run side by side and are added in a fixed order afterwards
+constexpr int WC_WBAR_PARTS = 16;
+static int wbar_parts(int Kc) { return Kc >= 2 * WC_WBAR_PARTS ? WC_WBAR_PARTS : 1; }
+
 size_t wc_bwd_factor_workspace_bytes(int C, int Kc)
 {
-    (void)Kc;
     if (bad_channels(C)) return 0;
-    return 3 * slot_bytes((size_t)C * C, 8);
+    return 3 * slot_bytes((size_t)C * C, 8) + (wbar_parts(Kc) > 1 ? slot_bytes((size_t)WC_WBAR_PARTS * C * C, 8) : 0);
 }
 
 int wc_bwd_factor_f64(const double* R, const double* gsum, const double* W, const double* L,
@@ -328,8 +332,16 @@ int wc_bwd_factor_f64(const double* R, const double* gsum, const double* W, cons
     if (gamma) {                                    // Wbar = sum_k Gamma_k R_k^T
         WcGemm g = sq(gamma, 1, C, 1, R, 0, 1, C, buf0, 0, 1.0, WC_EPI_NONE);
         g.a_red = CC; g.b_red = CC; g.nred = Kc;
+        const int parts = wbar_parts(Kc);
+        double* partial = nullptr;
+        if (parts > 1) {                            // many tables: `parts` partial sums side by side, added below
+            partial = cv.take<double>((size_t)parts * CC);
+            g.nred = (Kc + parts - 1) / parts; g.red_total = Kc; g.batch = parts;
+            g.a_bs = (int64_t)g.nred * CC; g.b_bs = (int64_t)g.nred * CC; g.Cm = partial; g.c_bs = CC;
+        }
         if (want_dgamma) WC_TRY(wc_launch_gemm_pair_dd_fd(gd, g, st));      // dgamma and Wbar: neither waits for the other
         else WC_TRY(wc_launch_gemm(g, st));
+        if (parts > 1) WC_TRY(wc_launch_sum_partials(partial, parts, CC, buf0, st));
         Wbar = buf0; wb_rs = C; wb_cs = 1;
     } else {                                        // Gamma = I: Wbar = R^T, read through swapped strides
         Wbar = R; wb_rs = 1; wb_cs = C;

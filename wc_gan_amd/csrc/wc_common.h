@@ -166,11 +166,13 @@ struct WcGemm {
     void* Cm2; int64_t c2_rs, c2_cs, c2_bs;                          // optional second (float) output, e.g. the transpose
     int m, n, k;            // multiples of 32
     int batch, nred;
+    int red_total;          // > 0: batch b reduces the terms r with b * nred + r < red_total (a long reduction cut into batches)
     int batch2; int64_t a_b2s, b_b2s, c_b2s;        // optional outer batch level (0 = none); c_b2s also strides Cm2
     double alpha;
     int epi;
 };
 hipError_t wc_launch_gemm(const WcGemm& g, hipStream_t st);
+hipError_t wc_launch_sum_partials(const double* part, int nparts, int64_t n, double* out, hipStream_t st);      // out[e] = sum_p part[p][e], fixed order
 hipError_t wc_launch_gemm_pair_dd_fd(const WcGemm& g0, const WcGemm& g1, hipStream_t st);      // two independent products (double x double, float x double) in one launch
 
 hipError_t wc_launch_transpose_to_f32(const double* W, int C, int groups, float* A, float* At, hipStream_t st);  // A = W^T, At = W

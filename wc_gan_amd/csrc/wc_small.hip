@@ -115,42 +115,50 @@ __global__ __launch_bounds__(64 * SX_PARTS) void stats_xtx_kernel(const double* 
 }
 
 // ---------------------------------------------------------------------------------------------
-// K4 tail: per-slab partials -> per-slot R, gsum.  block = 64 elements x 8 slab groups.
+// K4 tail: per-slab partials -> per-slot R, gsum.  A block of 512 threads is `parts` slab groups x 512/parts elements: 8 groups
+// when one long run of slabs is summed, fewer when every sample has only one or two slabs of its own (class slots) -- with
+// 8 groups and one slab per sample seven threads of eight idled and the grid was 33 000 workgroups at Kc = N = 128 (the
+// per-sample tables of K = 200 classes): 524 us.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64 * SX_PARTS) void bwd_combine_kernel(const double* __restrict__ P, const float* __restrict__ colsum,
                                                                     const int32_t* __restrict__ slot, int64_t N, int nsplit,
                                                                     int per_sample, int C, double* __restrict__ R,
-                                                                    double* __restrict__ gsum)
+                                                                    double* __restrict__ gsum, int parts)
 {
-    __shared__ double red[SX_PARTS][64];
+    __shared__ double red[64 * SX_PARTS];
     const int64_t CC = (int64_t)C * C;
-    const int64_t e = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);    // element of C*C (+ C for gsum)
-    const int part = threadIdx.x >> 6;
+    const int epw = (64 * SX_PARTS) / parts;                             // elements per workgroup
+    const int el = threadIdx.x % epw, part = threadIdx.x / epw;
+    const int64_t e = (int64_t)blockIdx.x * epw + el;                    // element of C*C (+ C for gsum)
     const int k = blockIdx.y;
     const bool live = e < CC + C;
     const bool is_sum = e >= CC;
     double acc = 0.0;
-    auto terms = [&](int64_t zbase, int n) {           // sum over z = zbase + part, + SX_PARTS, ... < zbase + n
-        const double t = is_sum ? strided_sum(colsum + zbase * C + (e - CC), (int64_t)C, part, SX_PARTS, n)
-                                : strided_sum(P + zbase * CC + e, CC, part, SX_PARTS, n);
+    auto terms = [&](int64_t zbase, int n) {           // sum over z = zbase + part, + parts, ... < zbase + n
+        const double t = is_sum ? strided_sum(colsum + zbase * C + (e - CC), (int64_t)C, part, parts, n)
+                                : strided_sum(P + zbase * CC + e, CC, part, parts, n);
         return t;
     };
-    if (live) {
-        if (per_sample) {
-            for (int64_t n = 0; n < N; ++n) {
-                if (slot[n] != k) continue;
-                acc += terms(n * nsplit, nsplit);
-            }
-        } else {
-            acc = terms(0, nsplit);
+    if (per_sample) {
+        // the samples of slot k; the slot vector goes through LDS once per workgroup
+        __shared__ int sl[1024];
+        for (int64_t n0 = 0; n0 < N; n0 += 1024) {
+            const int cnt = (int)(N - n0 < 1024 ? N - n0 : 1024);
+            __syncthreads();
+            for (int i = threadIdx.x; i < cnt; i += 64 * SX_PARTS) sl[i] = slot[n0 + i];
+            __syncthreads();
+            if (live)
+                for (int i = 0; i < cnt; ++i)
+                    if (sl[i] == k) acc += terms((n0 + i) * nsplit, nsplit);
         }
+    } else if (live) {
+        acc = terms(0, nsplit);
     }
-    red[part][threadIdx.x & 63] = acc;
+    red[threadIdx.x] = acc;
     __syncthreads();
-    if (threadIdx.x < 64 && live) {
+    if (part == 0 && live) {
         acc = 0.0;
-#pragma unroll
-        for (int q = 0; q < SX_PARTS; ++q) acc += red[q][threadIdx.x];
+        for (int q = 0; q < parts; ++q) acc += red[q * epw + el];
         if (is_sum) gsum[(int64_t)k * C + (e - CC)] = acc;
         else R[k * CC + e] = acc;
     }
@@ -967,6 +975,7 @@ __device__ __forceinline__ void gemm_f64_body(const WcGemm& g, int bz, double (&
         for (int u = 0; u < 2; ++u) acc[t][u] = f64x4{0.0, 0.0, 0.0, 0.0};
 
     for (int r = 0; r < g.nred; ++r) {
+        if (g.red_total > 0 && b * g.nred + r >= g.red_total) break;
         const TA* A = reinterpret_cast<const TA*>(g.A) + (int64_t)b * g.a_bs + (int64_t)b2 * g.a_b2s + (int64_t)r * g.a_red;
         const TB* B = reinterpret_cast<const TB*>(g.B) + (int64_t)b * g.b_bs + (int64_t)b2 * g.b_b2s + (int64_t)r * g.b_red;
         const TA* A0 = A + (int64_t)(bm * 32 + li) * g.a_rs;
@@ -1171,8 +1180,11 @@ hipError_t wc_launch_bwd_combine(const double* P, const float* colsum, const int
                                  int per_sample, int C, int Kc, double* R, double* gsum, hipStream_t st)
 {
     const int64_t total = (int64_t)C * C + C;
-    hipLaunchKernelGGL(bwd_combine_kernel, dim3((unsigned)((total + 63) / 64), Kc), dim3(64 * SX_PARTS), 0, st,
-                       P, colsum, slot, N, nsplit, per_sample, C, R, gsum);
+    int parts = SX_PARTS;                      // slab groups per block: no more than the slabs of one run, a power of two
+    while (parts > 1 && parts > nsplit) parts >>= 1;
+    const int epw = (64 * SX_PARTS) / parts;
+    hipLaunchKernelGGL(bwd_combine_kernel, dim3((unsigned)((total + epw - 1) / epw), Kc), dim3(64 * SX_PARTS), 0, st,
+                       P, colsum, slot, N, nsplit, per_sample, C, R, gsum, parts);
     return hipGetLastError();
 }
 
@@ -1255,6 +1267,20 @@ hipError_t wc_launch_gemm(const WcGemm& g, hipStream_t st)
     else if (g.a_is_f32) hipLaunchKernelGGL((gemm_f64_kernel<float, double>), grid, dim3(256), 0, st, g);
     else if (g.b_is_f32) hipLaunchKernelGGL((gemm_f64_kernel<double, float>), grid, dim3(256), 0, st, g);
     else hipLaunchKernelGGL((gemm_f64_kernel<double, double>), grid, dim3(256), 0, st, g);
+    return hipGetLastError();
+}
+
+__global__ void sum_partials_kernel(const double* __restrict__ part, int nparts, int64_t n, double* __restrict__ out)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    double s = 0.0;
+    for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * n + e];
+    out[e] = s;
+}
+hipError_t wc_launch_sum_partials(const double* part, int nparts, int64_t n, double* out, hipStream_t st)
+{
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, nparts, n, out);
     return hipGetLastError();
 }
 
