@@ -24,6 +24,9 @@
 #ifndef WC_M16_ORDER
 #define WC_M16_ORDER 0
 #endif
+#ifndef WC_CONV_NUM
+#define WC_CONV_NUM 2      // quarters of a tile's MFMA loop that carry the next tile's conversion (3: measured the same)
+#endif
 #ifndef WC_STAMPS
 #define WC_STAMPS 0
 #endif
@@ -768,7 +771,7 @@ __global__ __launch_bounds__(512, 1) void affine_ring_kernel(FastArgs a)
             else cv_write(fnext, p, lane_t, c4i_t, woff_t);
         };
         constexpr int G = 12 * KS32;         // MFMAs = issue gaps per tile
-        constexpr int H = G / 2;
+        constexpr int H = G * WC_CONV_NUM / 4;    // the conversion of tile t+1 rides in the first H gaps (WC_CONV_NUM quarters of the loop)
         // one issue gap = one MFMA plus whatever is listed for it; sched_barrier(0) pins the order gap by gap
 #pragma unroll
         for (int s = 0; s < KS32; ++s) {

@@ -131,6 +131,13 @@ class DecorelationNormalization(_Lazy):
     def build(self, C, device=None):
         self.register_buffer('moving_mean', torch.zeros(C, 1, device=device))
         self.register_buffer('moving_cov', torch.eye(C, device=device))
+        if C % 32 != 0:
+            # zero-padded fallback (_padded): its state exists from the build on -- registering buffers inside forward
+            # would allocate under a graph capture
+            Cp = (C + 31) // 32 * 32
+            self.register_buffer('_pad_mean', torch.zeros(Cp, 1, device=device), persistent=False)
+            self.register_buffer('_pad_cov', torch.eye(Cp, device=device), persistent=False)
+            self.register_buffer('_pad_eye', torch.eye(Cp, device=device), persistent=False)
 
     def transform(self, x, gamma=None, beta=None, slot=None, gamma_key=None, relu=False, per_sample=False):
         """Whitening fused with an optional coloring table (gamma (Kc,C,C), beta (Kc,C), slot (N,)); relu=True also
@@ -191,14 +198,12 @@ class DecorelationNormalization(_Lazy):
         C = self.channels
         xp, _ = _pad_channels(x)
         Cp = xp.shape[-1]
-        if not hasattr(self, '_pad_mean'):
-            self.register_buffer('_pad_mean', torch.zeros(Cp, 1, device=x.device), persistent=False)
-            self.register_buffer('_pad_cov', torch.eye(Cp, device=x.device), persistent=False)
-        self._pad_mean.zero_(); self._pad_mean[:C] = self.moving_mean
-        self._pad_cov.copy_(torch.eye(Cp, device=x.device)); self._pad_cov[:C, :C] = self.moving_cov
+        with torch.no_grad():
+            self._pad_mean.zero_(); self._pad_mean[:C] = self.moving_mean
+            self._pad_cov.copy_(self._pad_eye); self._pad_cov[:C, :C] = self.moving_cov
         Kc = 1 if gamma is None else gamma.shape[0]
-        g = torch.eye(Cp, device=x.device).repeat(Kc, 1, 1)
-        g[:, :C, :C] = gamma if gamma is not None else torch.eye(C, device=x.device)
+        g = self._pad_eye.repeat(Kc, 1, 1)
+        g[:, :C, :C] = gamma if gamma is not None else self._pad_eye[:C, :C]
         b = None if beta is None else F.pad(beta, (0, Cp - C))
         y = WF.whiten_color(xp.contiguous(), g, b, slot, self._pad_mean, self._pad_cov, self.training,
                             self.epsilon, self.momentum, 1, self.process_group)
