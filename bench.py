@@ -280,6 +280,49 @@ def cpu_baseline(ratio, sites, config_name):
                       f"of one G+D step; median of 10 after 2 warm-ups = {t_med:.3f} s on {best} threads"}
 
 
+def cpu_port_baseline(ratio, sites, config_name):
+    """The second CPU leg SURVEY.md section 8d names: the `_cpu` C-ABI restatement (oracle/wc_cpu.cpp, OpenMP, float64
+    accumulation) on the same WC work of one step.  Test infrastructure timed beside the product, never a fallback."""
+    import numpy as np
+    from oracle import cpu_port as cp
+    from oracle import wc_oracle as o
+    rng = np.random.default_rng(1234)
+    work = []
+    for H, W, C in sites:
+        G = (rng.standard_normal((1, C, C)) / C ** 0.5).astype(np.float32); B = np.zeros((1, C), np.float32)
+        work.append((rng.standard_normal((64, H, W, C), dtype=np.float32), rng.standard_normal((128, H, W, C), dtype=np.float32),
+                     rng.standard_normal((128, H, W, C), dtype=np.float32), G, B))
+
+    def one():
+        for x64, x128, gy, G, B in work:
+            C = x64.shape[-1]
+            for _ in range(ratio):
+                M = x64.size // C
+                s, xtx = cp.stats(x64.reshape(M, C))
+                mu, L, Wm, _ = cp.factor(s, xtx, M, C)
+                A, _ = cp.color(Wm, G)
+                cp.apply(x64, mu, A, B, None)
+            cp.forward_backward(x128, G, B, None, gy)
+
+    # the checker: the numpy oracle on the port's own output (one mid-sized site)
+    H, W, C = sites[min(2, len(sites) - 1)]
+    xs = o.synth_activation(rng, (16, H, W, C), "well").astype(np.float32)
+    Gs, Bs = o.synth_coloring(rng, C, 1)
+    y_port = cp.forward_backward(xs, Gs.astype(np.float32), Bs.astype(np.float32), None, np.zeros_like(xs))[0]
+    y_ref, _ = o.wc_forward(xs, Gs, Bs)
+    err = float(np.abs(y_port - y_ref).max() / np.abs(y_ref).max())
+    one()
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter(); one(); ts.append(time.perf_counter() - t0)
+    t_med = sorted(ts)[1]
+    return {"value": round(64.0 / t_med, 3), "unit": "images/sec (WC sites of one G+D step only)",
+            "cores": int(cp.load().wc_cpu_threads()), "kind": "port", "checked_vs_oracle_rel_err": err,
+            "sample": f"oracle/wc_cpu.cpp through its `_cpu` C ABI (OpenMP loops, float64 accumulation, stage by stage as the HIP "
+                      f"library) over the {len(sites)} generator WC sites of {config_name}: {ratio} forward passes at N=64 + 1 "
+                      f"forward+backward at N=128; median of 3 after 1 warm-up = {t_med:.3f} s"}
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def dry_run(args, world, rank):
     """The N-rank path on the CPU: rendezvous over gloo, flat gradient buckets, GanTrainer.step with the all-reduces,
@@ -495,6 +538,10 @@ def main(argv=None):
                                      "ms": round(wc_gpu * 1e3, 3)}
             if not args.no_cpu_baseline:
                 cpu = cpu_baseline(args.training_ratio, sites, args.config)
+                try:
+                    extra["cpu_port"] = cpu_port_baseline(args.training_ratio, sites, args.config)
+                except Exception as ex:                       # the port is test infrastructure: its absence is not an error of the bench
+                    extra["cpu_port"] = {"value": None, "kind": "port", "error": repr(ex)[:200]}
         out = {
             "metric": "images/sec G+D step, CIFAR-10 ResNet-SN+WC, batch 64" if args.config == "cifar10_uncond"
                       else f"images/sec G+D step, {args.config} ResNet-SN+WC, batch 64",
