@@ -145,7 +145,22 @@ def roofline_apply(dev):
         A_, _, plan_ = ops.color(W_, gamma, cs_)
         ops.apply(x, mu_, A_, b, None, out=y, plan=plan_)
     t_site = time_kernel(site, iters=10)
-    return {"bound": "hbm", "kernel": "affine_ring_kernel<256,false> (wc_apply_f32 with plan, 128x32x32x256 fp32)",
+    # every stage of the site on its own (HIP events, same inputs): the algorithmic bytes of SURVEY section 8d per stage
+    gy = torch.randn(N, H, H, C, generator=g).to(dev)
+    R, gsum, scales = ops.bwd_reduce(x, mu, gy, None, 1, want_scales=True)
+    dg, db, S, gm = ops.bwd_factor(R, gsum, W, L, gamma, A, M, 1e-3, 1, True)
+    xb = M * C * 4
+    stage = lambda fn, nbytes: (lambda tt: {"us": round(tt * 1e6, 1), "frac_of_peak": round(nbytes / tt / 1e9 / HBM_PEAK_GBS, 3)})(time_kernel(fn, iters=10))
+    stages = {
+        "K1 wc_stats_f32": stage(lambda: ops.stats(x.view(M, C)), xb),
+        "K2 wc_factor_f64": {"us": round(time_kernel(lambda: ops.factor(s, xtx, M, C, 1e-3, 0.99, 1, True, None, None, dev), iters=10) * 1e6, 1)},
+        "color wc_color_f32": {"us": round(time_kernel(lambda: ops.color(W, gamma, cs), iters=10) * 1e6, 1)},
+        "K3 wc_apply_f32": {"us": round(t * 1e6, 1), "frac_of_peak": round(achieved / HBM_PEAK_GBS, 3)},
+        "K4 wc_bwd_reduce_f32": stage(lambda: ops.bwd_reduce(x, mu, gy, None, 1), 2 * xb),
+        "K5 wc_bwd_factor_f64": {"us": round(time_kernel(lambda: ops.bwd_factor(R, gsum, W, L, gamma, A, M, 1e-3, 1, True), iters=10) * 1e6, 1)},
+        "K6 wc_bwd_apply_f32": stage(lambda: ops.bwd_apply(gy, x, mu, At, S, gm, None, scales=scales), 3 * xb),
+    }
+    return {"bound": "hbm", "site_stages": stages, "kernel": "affine_ring_kernel<256,false> (wc_apply_f32 with plan, 128x32x32x256 fp32)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_from_committed_profile": src,
             "launch_us": round(t * 1e6, 2), "algorithmic_bytes": alg_bytes,
