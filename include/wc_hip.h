@@ -148,6 +148,16 @@ int wc_bwd_reduce_scaled_f32(const float* x, const float* mu, const float* gy, c
                              int64_t N, int64_t HW, int C, int Kc,
                              double* R /*[Kc,C,C]*/, double* gsum /*[Kc,C]*/, float* scales_out /*[2C], nullable*/,
                              void* ws, size_t ws_bytes, wc_stream_t stream);
+/* K4 behind a site whose ReLU rode in K3's epilogue (wc_apply_act_f32, relu = 1): the activation's gradient mask
+ * gy := gy where y > 0, else 0 (generator.py:144-154 `Activation('relu')` after each norm stack) applied while K4 stages gy,
+ * instead of an elementwise pass over three tensors in front of it.  relu_y = the site's output y; gy_masked (out, same
+ * shape as gy, must not alias it) receives the masked gradient -- what K6 then takes as its gy.  R, gsum, scales_out as in
+ * wc_bwd_reduce_scaled_f32, computed from the masked gradient.  relu_y == NULL (then gy_masked must be NULL too) is that
+ * function.  Shapes whose reduction kernel does not mask in its staging take one elementwise pass inside the call. */
+int wc_bwd_reduce_relu_f32(const float* x, const float* mu, const float* gy, const float* relu_y /*nullable*/, const int32_t* slot,
+                           int64_t N, int64_t HW, int C, int Kc,
+                           double* R /*[Kc,C,C]*/, double* gsum /*[Kc,C]*/, float* gy_masked /*[N*HW*C] out, nullable*/,
+                           float* scales_out /*[2C], nullable*/, void* ws, size_t ws_bytes, wc_stream_t stream);
 int wc_bwd_apply_scaled_f32(const float* gy, const float* x, const float* mu, const float* At,
                             const float* S, const float* gmean, const int32_t* slot,
                             int64_t N, int64_t HW, int C, int Kc, const float* scales /*[2C], nullable*/, float* dx,

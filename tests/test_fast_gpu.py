@@ -131,6 +131,37 @@ def test_fast_bwd_apply_out_of_range_in_the_accumulating_pass(ops, shape):
     assert err.max() < 1e-5, (err.max(), int(err.argmax()))
 
 
+@pytest.mark.parametrize("shape,Kc", [((32, 32, 32, 256), 1), ((32, 32, 32, 256), 4), ((64, 16, 16, 128), 1), ((8, 8, 8, 256), 1),
+                                      ((128, 32, 32, 256), 1)])
+def test_bwd_reduce_with_the_relu_mask_in_its_staging(ops, shape, Kc):
+    """wc_bwd_reduce_relu_f32: gy := gy where y > 0 applied inside K4 (the quadrant kernel at C = 256 on the fast path, one
+    elementwise pass inside the call elsewhere); R, gsum and the masked gradient against float64 of the masked input, and
+    bit-identical to masking first and calling the plain function."""
+    rng = np.random.default_rng(41)
+    N, C = shape[0], shape[-1]
+    x = (rng.standard_normal(shape) * np.exp(rng.uniform(-1, 1, C)) + 0.3).astype(np.float32)
+    gy = (rng.standard_normal(shape) * 1e-2).astype(np.float32)
+    y = rng.standard_normal(shape).astype(np.float32)
+    y[0, 0, 0, :8] = 0.0; y[0, 0, 1, :8] = -0.0; y[1, 2, 3, 4] = np.nan          # the edges of `y > 0`
+    mu = x.reshape(-1, C).mean(0).astype(np.float32)
+    slot = rng.integers(0, Kc, N).astype(np.int32)
+    st = dev(slot, torch.int32) if Kc > 1 else None
+    R, gsum, gm, scales = ops.bwd_reduce(dev(x), dev(mu), dev(gy), st, Kc, want_scales=True, relu_y=dev(y))
+    g_ref = np.where(y > 0, gy, np.float32(0))
+    assert np.array_equal(gm.cpu().numpy(), g_ref)
+    R2, gsum2 = ops.bwd_reduce(dev(x), dev(mu), dev(g_ref), st, Kc)
+    f = x.astype(np.float64).reshape(N, -1, C) - mu.astype(np.float64)
+    g = g_ref.astype(np.float64).reshape(N, -1, C)
+    for k in range(Kc):
+        sel = slot == k if Kc > 1 else np.ones(N, bool)
+        R_ref = np.einsum('npi,npj->ij', f[sel], g[sel])
+        nat = np.sqrt(np.outer((f[sel] ** 2).sum((0, 1)), (g[sel] ** 2).sum((0, 1)))) + 1e-300
+        assert np.abs((R[k].cpu().numpy() - R_ref) / nat).max() < 1e-6
+        assert rel(gsum[k].cpu().numpy(), g[sel].sum((0, 1))) < 1e-5
+    # the masked-in-staging result against mask-first: same products, same order
+    assert rel(R.cpu().numpy(), R2.cpu().numpy()) < 1e-6 and bool((scales > 0).all())
+
+
 # ---- fast reductions (wc_fast_xty.hip) -------------------------------------------------------------------------
 XTY_CASES = [((16, 32, 32, 256), 1), ((128, 32, 32, 256), 1), ((32, 32, 32, 128), 1), ((16, 64, 64, 64), 1), ((8, 64, 64, 32), 1)]
 

@@ -249,6 +249,14 @@ int wc_bwd_reduce_scaled_f32(const float* x, const float* mu, const float* gy, c
                              int64_t N, int64_t HW, int C, int Kc, double* R, double* gsum, float* scales_out,
                              void* ws, size_t ws_bytes, wc_stream_t stream)
 {
+    return wc_bwd_reduce_relu_f32(x, mu, gy, nullptr, slot, N, HW, C, Kc, R, gsum, nullptr, scales_out, ws, ws_bytes, stream);
+}
+
+int wc_bwd_reduce_relu_f32(const float* x, const float* mu, const float* gy, const float* relu_y, const int32_t* slot,
+                           int64_t N, int64_t HW, int C, int Kc, double* R, double* gsum, float* gy_masked, float* scales_out,
+                           void* ws, size_t ws_bytes, wc_stream_t stream)
+{
+    if ((relu_y != nullptr) != (gy_masked != nullptr)) return WC_ERR_NULL;
     if (!x || !gy || !R || !gsum || !ws) return WC_ERR_NULL;
     if (N <= 0 || HW <= 0 || Kc <= 0 || (!slot && Kc != 1)) return WC_ERR_SHAPE;
     if (bad_channels(C)) return WC_ERR_CHANNELS;
@@ -267,12 +275,20 @@ int wc_bwd_reduce_scaled_f32(const float* x, const float* mu, const float* gy, c
     WcXtyArgs a = {};
     a.X = x; a.Y = gy; a.cx = mu; a.cy = nullptr; a.N = Ns; a.HW = HWs;
     a.per_sample = per_sample; a.nsplit = p.nsplit; a.rows_per_slab = p.rps; a.C = C; a.sym = 0; a.P = P; a.colsum = colsum;
+    // the ReLU mask: inside the staging of the quadrant kernel (C = 256 on the fast path), else one elementwise pass in front
+    const bool mask_in_kernel = relu_y && p.fast && C == 256;
+    if (relu_y && !mask_in_kernel) {
+        WC_TRY(wc_launch_relu_mask(gy, relu_y, gy_masked, N * HW * C, st));
+        gy = gy_masked; a.Y = gy_masked;
+    }
     if (!p.fast && scales_out) WC_TRY(wc_launch_channel_scale2(x, mu, sx, gy, nullptr, sy, N * HW, C, gate, st));   // asked for: sampled anyway
     if (p.fast) {
+        // (masked in the kernel: the scales are sampled from the unmasked gy -- a superset of the masked values' range)
         WC_TRY(wc_launch_channel_scale2(x, mu, sx, gy, nullptr, sy, N * HW, C, gate, st));      // both scales, gate := 0
         WC_TRY(wc_launch_fast_xty(x, gy, mu, nullptr, sx, sy, Ns, HWs, C, per_sample, p.nsplit, p.rps, p.nslab, p.ntypes,
-                                  P, colsum, nullptr, gate, st));
+                                  P, colsum, nullptr, gate, st, mask_in_kernel ? relu_y : nullptr, mask_in_kernel ? gy_masked : nullptr));
         a.gate = gate;
+        if (mask_in_kernel) a.Y = gy_masked;          // the gated exact redo reads what the fast kernel wrote
     }
     WC_TRY(wc_launch_xty(a, p.nslab, st));
     WC_TRY(wc_launch_bwd_combine(P, colsum, slot, N, p.nsplit, per_sample, C, Kc, R, gsum, st));

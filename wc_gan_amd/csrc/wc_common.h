@@ -90,6 +90,7 @@ hipError_t wc_launch_xty(const WcXtyArgs& a, int nslab, hipStream_t st);
 
 hipError_t wc_launch_subsample_mean(const float* x, int64_t M, int C, float* shift, hipStream_t st);
 hipError_t wc_launch_stream_copy(const float* src, float* dst, int64_t n, hipStream_t st);
+hipError_t wc_launch_relu_mask(const float* gy, const float* y, float* out, int64_t n, hipStream_t st);      // out = gy where y > 0, else 0
 hipError_t wc_launch_subsample_mean_scale(const float* x, int64_t M, int C, float* shift, float* scale, int* gate, hipStream_t st);
 // wc_sn.hip
 #include "../../include/wc_hip.h"
@@ -124,7 +125,8 @@ int wc_fast_xty_plan(int64_t N, int64_t HW, int C, int per_sample, int two, int*
 hipError_t wc_launch_fast_xty(const float* X, const float* Y, const float* cx, const float* cy,
                               const float* sx, const float* sy, int64_t N, int64_t HW, int C,
                               int per_sample, int nsplit, int64_t rows_per_slab, int nslab, int ntypes,
-                              double* P, float* colsum, double* dfix /*[nslab][C], covariance only, nullable*/, int* gate, hipStream_t st);
+                              double* P, float* colsum, double* dfix /*[nslab][C], covariance only, nullable*/, int* gate, hipStream_t st,
+                              const float* yrelu = nullptr, float* yout = nullptr);      // yrelu (C = 256, two operands): Y masked by yrelu > 0, written to yout
 hipError_t wc_launch_fast_plan_tables(const float* B, int Kc, int C, void* plan, hipStream_t st, const float* scale = nullptr);
 hipError_t wc_launch_fast_plan_tables2(const float* B0, int Kc0, void* plan0, const float* scale0,
                                        const float* B1, int Kc1, void* plan1, const float* scale1, int C, hipStream_t st);

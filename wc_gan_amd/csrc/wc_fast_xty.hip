@@ -53,11 +53,17 @@ struct FastXtyArgs {
     float* colsum;                         // [nslab][C]: sum of (X-cx) (covariance) or of (Y-cy) (two-operand)
     double* dfix;                          // [nslab][C], covariance only: the diagonal, sum_m g_i[m]^2 on the VALU (see stage_write)
     int* flag;
+    const float* Yrelu; float* Yout;       // RELU form (two operands, quadrant scheme): Y := Y where Yrelu > 0 else 0, written to Yout
 };
 
-template <int C, bool TWO>
+// RELU (K4 behind a site whose ReLU rode in K3's epilogue): the gradient mask gy := gy where y > 0
+// is applied to the Y operand as it is staged -- the Y threads load the matching rows of y beside those of gy (32 more
+// registers: the quadrant form has them) and the types of quadrant row 0 write the masked rows out for K6 -- instead of a
+// separate elementwise pass over three tensors in front of K4.
+template <int C, bool TWO, bool RELU = false>
 __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
 {
+    static_assert(!RELU || xty_quad<C, TWO>(), "the masked form exists for the quadrant scheme only");
     // QUAD (two operands at C = 256): the 8 x 8 blocks are cut into four 4 x 4 quadrants, one workgroup type each.  A
     // quadrant needs only 128 channels of X and 128 of Y, so a workgroup converts HALF of every row (the three types of
     // the plain scheme convert all of it three times), its images hold twice the rows (64 per stage: half the barriers)
@@ -145,10 +151,17 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
     }
 
     f32x4 xr[8];
+    f32x4 yr[RELU ? 8 : 1];
+    const bool y_wave = RELU && __builtin_amdgcn_readfirstlane(op) != 0;       // waves 4-7 stage Y (wave-uniform: a scalar branch)
     auto stage_load = [&](int st) {
-        const float* base = src + (r0 + (int64_t)st * R + rgrp * 8) * C + cbase + 4 * c4;
+        const int64_t off = (r0 + (int64_t)st * R + rgrp * 8) * C + cbase + 4 * c4;
+        const float* base = src + off;
 #pragma unroll
         for (int p = 0; p < 8; ++p) xr[p] = ldg4(base + p * C);
+        if (RELU && y_wave) {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) yr[RELU ? p : 0] = ldg4(a.Yrelu + off + p * C);
+        }
     };
     // The staging is what bounds this kernel: 16 (K1) to 22 (K4) vector instructions per MFMA before this trim (rocprofv3
     // SQ_INSTS_VALU / SQ_INSTS_MFMA, profiles/r2_k1_xty_pmc.json), every row converted by each workgroup of its slab.  So:
@@ -171,9 +184,20 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
     // IEEE fp32 FMAs (round to nearest even: unbiased) and the combine takes the diagonal from there.
     const bool want_dfix = !TWO && a.dfix != nullptr && type == a.ntypes - 1;
     double lsq[4] = {0.0, 0.0, 0.0, 0.0};      // per stage: a fresh 8-term fp32 chain, folded into float64
-    auto stage_write = [&](int buf) {
+    auto stage_write = [&](int buf, int st_of_data) {
         char* img = smem + buf * (NOP * 2 * IMG);
         f32x4 g[8];
+        if (RELU && y_wave) {
+#pragma unroll
+            for (int p = 0; p < 8; ++p)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xr[p][j] = yr[RELU ? p : 0][j] > 0.f ? xr[p][j] : 0.f;
+            if (qi == 0) {                  // each half of Y's columns is written by one type
+                float* dst = a.Yout + (r0 + (int64_t)st_of_data * R + rgrp * 8) * C + cbase + 4 * c4;
+#pragma unroll
+                for (int p = 0; p < 8; ++p) *reinterpret_cast<f32x4*>(dst + p * C) = xr[p];
+            }
+        }
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             g[p] = xr[p] * scl + ncs;
@@ -226,7 +250,7 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
 
     if (nst > 0) {
         stage_load(0);
-        stage_write(0);
+        stage_write(0, 0);
         if (nst > 1) stage_load(1);
     }
     __syncthreads();
@@ -243,7 +267,7 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
     for (int st = 0; st < nst; ++st) {
         const int cur = st & 1;
         XS();
-        if (st + 1 < nst) stage_write(cur ^ 1);
+        if (st + 1 < nst) stage_write(cur ^ 1, st + 1);
         XS();
         if (st + 2 < nst) stage_load(st + 2);
         XS();
@@ -326,21 +350,21 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
 template <int C, bool TWO>
 constexpr int stage_rows() { return xty_quad<C, TWO>() ? 64 : (TWO ? (512 / (C / 4)) * 4 : (512 / (C / 4)) * 8); }
 
-template <int C, bool TWO>
+template <int C, bool TWO, bool RELU = false>
 hipError_t launch_xty_fast(const FastXtyArgs& a, hipStream_t st)
 {
     constexpr int R = stage_rows<C, TWO>();
     constexpr size_t lds = (size_t)2 * (TWO ? 2 : 1) * 2 * (xty_quad<C, TWO>() ? C / 2 : C) * R * 2;       // 128 KiB
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(xty_f16x3_kernel<C, TWO>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(xty_f16x3_kernel<C, TWO, RELU>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const int slab_groups = (a.nslab + 7) / 8;
     const int grid = slab_groups * a.ntypes * 8;
-    hipLaunchKernelGGL((xty_f16x3_kernel<C, TWO>), dim3(grid), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((xty_f16x3_kernel<C, TWO, RELU>), dim3(grid), dim3(512), lds, st, a);
     return hipGetLastError();
 }
 
@@ -390,9 +414,11 @@ int wc_fast_xty_plan(int64_t N, int64_t HW, int C, int per_sample, int two, int*
 hipError_t wc_launch_fast_xty(const float* X, const float* Y, const float* cx, const float* cy,
                               const float* sx, const float* sy, int64_t N, int64_t HW, int C,
                               int per_sample, int nsplit, int64_t rows_per_slab, int nslab, int ntypes,
-                              double* P, float* colsum, double* dfix, int* gate, hipStream_t st)
+                              double* P, float* colsum, double* dfix, int* gate, hipStream_t st,
+                              const float* yrelu, float* yout)
 {
     FastXtyArgs a = {};
+    a.Yrelu = yrelu; a.Yout = yout;
     a.dfix = (Y == X) ? dfix : nullptr;
     a.X = X; a.Y = Y; a.cx = cx; a.cy = cy; a.sx = sx; a.sy = sy; a.N = N; a.HW = HW;
     a.per_sample = per_sample; a.nsplit = nsplit; a.rows_per_slab = rows_per_slab; a.nslab = nslab; a.ntypes = ntypes;
@@ -402,7 +428,7 @@ hipError_t wc_launch_fast_xty(const float* X, const float* Y, const float* cx, c
         case 32: return two ? launch_xty_fast<32, true>(a, st) : launch_xty_fast<32, false>(a, st);
         case 64: return two ? launch_xty_fast<64, true>(a, st) : launch_xty_fast<64, false>(a, st);
         case 128: return two ? launch_xty_fast<128, true>(a, st) : launch_xty_fast<128, false>(a, st);
-        case 256: return two ? launch_xty_fast<256, true>(a, st) : launch_xty_fast<256, false>(a, st);
+        case 256: return two ? (yrelu ? launch_xty_fast<256, true, true>(a, st) : launch_xty_fast<256, true>(a, st)) : launch_xty_fast<256, false>(a, st);
     }
     return hipErrorInvalidValue;
 }

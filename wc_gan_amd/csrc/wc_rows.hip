@@ -538,6 +538,21 @@ __global__ __launch_bounds__(1024) void subsample_mean_scale_kernel(const float*
     }
 }
 
+// gy where y > 0, else 0 (the gradient of the ReLU that rode in K3's epilogue) -- the fallback of wc_bwd_reduce_relu_f32 for
+// the shapes whose K4 kernel does not mask while it stages
+__global__ __launch_bounds__(256) void relu_mask_kernel(const f32x4* __restrict__ gy, const f32x4* __restrict__ y,
+                                                        f32x4* __restrict__ out, int64_t n4)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const f32x4 g = gy[i], v = y[i];
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = v[j] > 0.f ? g[j] : 0.f;
+        out[i] = o;
+    }
+}
+
 __global__ __launch_bounds__(256) void stream_copy_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, int64_t n4)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -618,6 +633,13 @@ hipError_t wc_launch_subsample_mean(const float* x, int64_t M, int C, float* shi
 hipError_t wc_launch_subsample_mean_scale(const float* x, int64_t M, int C, float* shift, float* scale, int* gate, hipStream_t st)
 {
     hipLaunchKernelGGL(subsample_mean_scale_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, x, M, C, shift, scale, gate);
+    return hipGetLastError();
+}
+
+hipError_t wc_launch_relu_mask(const float* gy, const float* y, float* out, int64_t n, hipStream_t st)
+{
+    hipLaunchKernelGGL(relu_mask_kernel, dim3(2048), dim3(256), 0, st, reinterpret_cast<const f32x4*>(gy),
+                       reinterpret_cast<const f32x4*>(y), reinterpret_cast<f32x4*>(out), n / 4);
     return hipGetLastError();
 }
 

@@ -72,25 +72,29 @@ class WhitenColorFunction(torch.autograd.Function):
         g = g if ctx.has_gamma else None
         slot = slot if ctx.has_slot else None
         gy = gy.contiguous()
-        if ctx.relu:                      # the fused activation's gradient: the mask in front of the unchanged backward
-            gy = torch.ops.aten.threshold_backward(gy, y, 0.0)      # gy where y > 0, else 0: ONE elementwise pass (where(y > 0, ...) took three launches)
         need_x, need_g, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         Kc = A.shape[0]
         dgamma = dbeta = dx = S = gmean = None
         stats_path = ctx.training and need_x
         want_g = ctx.has_gamma and need_g
         want_b = ctx.has_beta and need_b
+        reduce_runs = want_g or want_b or stats_path
+        if ctx.relu and not reduce_runs:  # the fused activation's gradient: the mask in front of the unchanged backward
+            gy = torch.ops.aten.threshold_backward(gy, y, 0.0)      # gy where y > 0, else 0: ONE elementwise pass (where(y > 0, ...) took three launches)
         scales = None          # K4 samples the fp16 scales of (x - mu) and gy; K6 reuses them (three launches instead of six)
-        if want_g or want_b or stats_path:
+        if reduce_runs:
             share = bool(stats_path)
+            ry = y if ctx.relu else None  # K4 applies the mask while it stages gy and hands the masked gradient on (no pass of its own)
             if ctx.group is None:
-                out = ops.bwd_reduce(x, mu, gy, slot, Kc, want_scales=share)
+                out = ops.bwd_reduce(x, mu, gy, slot, Kc, want_scales=share, relu_y=ry)
                 R, gsum = out[0], out[1]
             else:
-                out = ops.bwd_reduce(x, mu, gy, slot, Kc, flat=True, want_scales=share)
+                out = ops.bwd_reduce(x, mu, gy, slot, Kc, flat=True, want_scales=share, relu_y=ry)
                 R, gsum, rbuf = out[0], out[1], out[2]
             if share:
                 scales = out[-1]
+            if ry is not None:
+                gy = out[-2] if share else out[-1]
             if ctx.group is None:
                 dgamma, dbeta, S, gmean = ops.bwd_factor(R, gsum, W, L, g, A, ctx.M, ctx.eps, ctx.ddof, stats_path,
                                                          want_dgamma=want_g, want_dbeta=want_b)

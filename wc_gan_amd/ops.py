@@ -143,9 +143,11 @@ def apply(x, mu, A, bias, slot, out=None, fast=True, plan=None, relu=False):
     return y
 
 
-def bwd_reduce(x, mu, gy, slot, Kc, flat=False, want_scales=False):
+def bwd_reduce(x, mu, gy, slot, Kc, flat=False, want_scales=False, relu_y=None):
     """K4: -> (R (Kc,C,C) f64, gsum (Kc,C) f64); flat=True: views of one buffer, returned third (sync-WC's single all-reduce);
-    want_scales=True: the (2C,) per-channel input scales of (x - mu) and gy, returned last, for bwd_apply(scales=...)."""
+    want_scales=True: the (2C,) per-channel input scales of (x - mu) and gy, returned last, for bwd_apply(scales=...);
+    relu_y: the site's output y when its ReLU rode in K3 -- gy is masked (gy where y > 0) while it is staged, and the masked
+    gradient is returned in front of the scales (the gy that bwd_apply then takes)."""
     lib = _lib.load()
     _need(x, torch.float32, "x")
     _need(gy, torch.float32, "gy")
@@ -160,9 +162,15 @@ def bwd_reduce(x, mu, gy, slot, Kc, flat=False, want_scales=False):
         gsum = torch.empty(Kc, C, dtype=torch.float64, device=x.device)
     ws = _workspace(lib.wc_bwd_reduce_workspace_bytes(N, HW, C, Kc, int(slot is not None)), x.device)
     scales = torch.empty(2 * C, dtype=torch.float32, device=x.device) if want_scales else None
-    _lib.check(lib.wc_bwd_reduce_scaled_f32(_ptr(x), _ptr(mu), _ptr(gy), _ptr(slot), N, HW, C, Kc, _ptr(R), _ptr(gsum),
-                                            _ptr(scales), _ptr(ws), ws.numel(), _stream()), "wc_bwd_reduce_scaled_f32")
+    gm = None
+    if relu_y is not None:
+        _need(relu_y, torch.float32, "relu_y")
+        gm = torch.empty_like(gy)
+    _lib.check(lib.wc_bwd_reduce_relu_f32(_ptr(x), _ptr(mu), _ptr(gy), _ptr(relu_y), _ptr(slot), N, HW, C, Kc, _ptr(R), _ptr(gsum),
+                                          _ptr(gm), _ptr(scales), _ptr(ws), ws.numel(), _stream()), "wc_bwd_reduce_relu_f32")
     out = (R, gsum, buf) if buf is not None else (R, gsum)
+    if gm is not None:
+        out = out + (gm,)
     return out + (scales,) if want_scales else out
 
 
