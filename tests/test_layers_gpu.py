@@ -563,14 +563,15 @@ def test_sync_wc_path_with_a_one_rank_rccl_group(tmp_path):
         G, B = o.synth_coloring(rng, C, Kc)
         slot = dev(rng.integers(0, Kc, shape[0]), torch.int32)
         gy = dev(rng.standard_normal(shape))
-        outs = []
-        for group in (None, dist.group.WORLD):
-            xt = dev(x).requires_grad_(True); Gt = dev(G).requires_grad_(True); Bt = dev(B).requires_grad_(True)
-            mm = torch.zeros(C, 1, device="cuda"); mc = torch.eye(C, device="cuda")
-            y = whiten_color(xt, Gt, Bt, slot, mm, mc, True, process_group=group)
-            y.backward(gy)
-            outs.append((y.detach(), xt.grad, Gt.grad, Bt.grad, mc))
-        for a, b in zip(*outs):
-            assert torch.equal(a, b)
+        for relu in (False, True):          # relu: K4 masks the gradient in its staging and hands the masked one to K6
+            outs = []
+            for group in (None, dist.group.WORLD):
+                xt = dev(x).requires_grad_(True); Gt = dev(G).requires_grad_(True); Bt = dev(B).requires_grad_(True)
+                mm = torch.zeros(C, 1, device="cuda"); mc = torch.eye(C, device="cuda")
+                y = whiten_color(xt, Gt, Bt, slot, mm, mc, True, process_group=group, relu=relu)
+                y.backward(gy)
+                outs.append((y.detach(), xt.grad, Gt.grad, Bt.grad, mc))
+            for a, b in zip(*outs):
+                assert torch.equal(a, b)
     finally:
         dist.destroy_process_group()
