@@ -102,7 +102,10 @@ def test_fast_bwd_apply_matches_float64(ops, shape, Kc, train):
         scales = ops.bwd_reduce(dev(x), dev(mu), dev(gy), st, Kc, want_scales=True)[-1]
         assert scales.shape == (2 * C,) and bool((scales > 0).all())
         dx_shared = ops.bwd_apply(*args, fast=True, scales=scales)
-        assert torch.equal(dx_shared, dx_fast)
+        if C == 256:           # with the scales at hand C = 256 takes the ONE-pass kernel (K = 512): another summation order
+            assert rel(dx_shared.cpu().numpy().reshape(ref.shape), ref) < 3e-6
+        else:
+            assert torch.equal(dx_shared, dx_fast)
 
 
 @pytest.mark.parametrize("shape", [(16, 32, 32, 256), (32, 32, 32, 128), (96, 32, 32, 64)])
@@ -122,6 +125,8 @@ def test_fast_bwd_apply_out_of_range_in_the_accumulating_pass(ops, shape):
     S = rng.standard_normal((C, C)).astype(np.float32) * 1e-4; S = (S + S.T) / 2
     gm = (rng.standard_normal(C) * 1e-4).astype(np.float32)
     dx = ops.bwd_apply(dev(gy), dev(x), dev(mu), dev(At), dev(S), dev(gm), None, fast=True)
+    scales = ops.bwd_reduce(dev(x), dev(mu), dev(gy), None, 1, want_scales=True)[-1]
+    dx_one = ops.bwd_apply(dev(gy), dev(x), dev(mu), dev(At), dev(S), dev(gm), None, fast=True, scales=scales)   # C = 256: one pass
     ref = gy.astype(np.float64).reshape(-1, C) @ At[0].astype(np.float64) \
         + (x.astype(np.float64).reshape(-1, C) - mu) @ S.astype(np.float64) - gm.astype(np.float64)
     got = dx.cpu().numpy().reshape(ref.shape)
@@ -129,6 +134,10 @@ def test_fast_bwd_apply_out_of_range_in_the_accumulating_pass(ops, shape):
     # row-wise: the outlier rows are 1e8 times larger than the others, which must be right too
     err = np.abs(got - ref).max(1) / np.maximum(np.abs(ref).max(1), 1e-30)
     assert err.max() < 1e-5, (err.max(), int(err.argmax()))
+    got1 = dx_one.cpu().numpy().reshape(ref.shape)
+    assert np.isfinite(got1).all()
+    err1 = np.abs(got1 - ref).max(1) / np.maximum(np.abs(ref).max(1), 1e-30)
+    assert err1.max() < 1e-5, (err1.max(), int(err1.argmax()))
 
 
 @pytest.mark.parametrize("shape,Kc", [((32, 32, 32, 256), 1), ((32, 32, 32, 256), 4), ((64, 16, 16, 128), 1), ((8, 8, 8, 256), 1),

@@ -427,6 +427,10 @@ int wc_bwd_apply_scaled_f32(const float* gy, const float* x, const float* mu, co
         void* plan0 = ws;
         void* plan1 = static_cast<char*>(ws) + wc_fast_affine_workspace(C, Kc);
         WC_TRY(wc_launch_fast_plan_tables2(At, Kc, plan0, scales + C, S, 1, plan1, scales, C, st));
+        if (mu && wc_bwd_apply_onepass_supported(N, HW, C)) {       // C = 256: one pass over K = 512 (wc_fast.hip)
+            WC_TRY(wc_launch_bwd_apply_onepass(gy, x, mu, At, Kc, S, gmean, slot, N, HW, scales, dx, plan0, plan1, st));
+            return WC_OK;
+        }
         WC_TRY(wc_launch_fast_affine_planned(gy, nullptr, At, Kc, false, nullptr, gmean, slot, N, HW, C, 0, dx, plan0, st));
         WC_TRY(wc_launch_fast_affine_planned(x, mu, S, 1, true, nullptr, nullptr, nullptr, N, HW, C, 1, dx, plan1, st));
         return WC_OK;

@@ -128,6 +128,10 @@ hipError_t wc_launch_fast_xty(const float* X, const float* Y, const float* cx, c
                               double* P, float* colsum, double* dfix /*[nslab][C], covariance only, nullable*/, int* gate, hipStream_t st,
                               const float* yrelu = nullptr, float* yout = nullptr);      // yrelu (C = 256, two operands): Y masked by yrelu > 0, written to yout
 hipError_t wc_launch_fast_plan_tables(const float* B, int Kc, int C, void* plan, hipStream_t st, const float* scale = nullptr);
+bool wc_bwd_apply_onepass_supported(int64_t N, int64_t HW, int C);
+hipError_t wc_launch_bwd_apply_onepass(const float* gy, const float* x, const float* mu, const float* At, int Kc, const float* S,
+                                       const float* gmean, const int32_t* slot, int64_t N, int64_t HW, const float* scales /*[2C]: x | gy*/,
+                                       float* dx, const void* plan0, const void* plan1, hipStream_t st);
 hipError_t wc_launch_fast_plan_tables2(const float* B0, int Kc0, void* plan0, const float* scale0,
                                        const float* B1, int Kc1, void* plan1, const float* scale1, int C, hipStream_t st);
 float* wc_fast_plan_scale(void* plan);

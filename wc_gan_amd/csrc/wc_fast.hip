@@ -21,6 +21,9 @@
 #ifndef WC_MFMA16
 #define WC_MFMA16 1     // ring kernel on v_mfma_f32_16x16x32_f16 and the fp16 tables in that shape's load order (0: 32x32x16, development)
 #endif
+#ifndef WC_FENCE_DEP
+#define WC_FENCE_DEP 0     // the slot-read fence: 0 an explicit lgkmcnt(0), 1 a register dependency (measured the same)
+#endif
 #ifndef WC_M16_ORDER
 #define WC_M16_ORDER 0
 #endif
@@ -762,6 +765,7 @@ __global__ __launch_bounds__(512, 1) void affine_ring_kernel(FastArgs a)
             const int p = j / 5, st = j % 5;
             if (st == 0) {
                 cv_scale();                           // consumes craw: slot rs[p] is free
+                if (p == 0) { if (WC_FENCE_DEP) asm volatile("" :: "v"(cg4[0]) : "memory"); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }   // chunk 0's ds_read was issued a few instructions ago: it must have RETURNED before the DMA that refills its slot may issue -- with the read only issued, a DMA served from L2 overtook it (one-pass K6, the pair's second workgroup: one corrupted row in ~1e5 tiles)
                 const int tl = t + 1 + (p + NSLOT) / 4;
                 if (tl < n) dma_chunk(tl, (p + NSLOT) % 4, rs[p], lane_t);
             } else if (st == 1) {
@@ -827,6 +831,7 @@ __global__ __launch_bounds__(512, 1) void affine_ring_kernel(FastArgs a)
             const int p = j / 5, st = j % 5;
             if (st == 0) {
                 cv_scale();                           // consumes craw: slot rs[p] is free
+                if (p == 0) { if (WC_FENCE_DEP) asm volatile("" :: "v"(cg4[0]) : "memory"); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }   // chunk 0's ds_read was issued a few instructions ago: it must have RETURNED before the DMA that refills its slot may issue -- with the read only issued, a DMA served from L2 overtook it (one-pass K6, the pair's second workgroup: one corrupted row in ~1e5 tiles)
                 const int tl = t + 1 + (p + NSLOT) / 4;
                 if (tl < n) dma_chunk(tl, (p + NSLOT) % 4, rs[p], lane_t);
             } else if (st == 1) {
@@ -983,6 +988,314 @@ __global__ __launch_bounds__(512, 1) void affine_ring_kernel(FastArgs a)
                 float accf = 0.f;
                 for (int k = 0; k < C; ++k) accf = fmaf(xrow[k] - (a.center ? a.center[k] : 0.f), Bf[(int64_t)k * C], accf);
                 { const float v = accf + add; out_tile[row * C + ecol] = a.relu ? (v > 0.f ? v : (v == v ? 0.f : v)) : v; }
+            }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// K6 in ONE pass at C = 256:  dx = [gy | x - mu] . [At[slot] ; S] - gmean,  a contraction over K = 512.
+// The split tables of both streams are 512 KB -- the register file of a whole CU -- so a workgroup owns HALF of the output
+// columns (8 waves x 16 columns, 128 VGPRs of B' fragments each: 8 k-steps of At, 8 of S) and two workgroups share a row
+// tile: the pair sits on one XCD (block ids 8 apart), the second reads the tile from L2, both convert it (the price: every
+// row is converted four times over the pass instead of twice over two passes).  What it buys is the traffic: the two-pass
+// form writes dx, reads it back and writes it again right behind the first pass's write-back (670 MB, the accumulating
+// pass at 3.3 TB/s); this form reads gy and x and writes dx once (402 MB from HBM, plain stores).
+// Geometry: 16-row tiles (32 KB of fp32 input: 16 rows of gy and of x; wave w brings in rows 2w, 2w+1 of both with its
+// four 1-KiB DMA chunks), fp16 images of [16 rows][512 channels] hi | lo with a 32-byte row pad (conflict-free 16x16x32
+// A-fragment reads), three image buffers, the raw ring and the hand-off counters exactly as in affine_ring_kernel; per
+// tile and wave 16 k-steps x 3 v_mfma_f32_16x16x32_f16 on SIX accumulators (table x product: a dependent MFMA comes round
+// every third issue), summed in the epilogue with the two tables' column scales.  vmcnt by hand as there, with 4 stores per
+// tile instead of 16: 6 younger DMAs + 4 stores = vmcnt(10) in steady state.
+// ---------------------------------------------------------------------------------------------------------------
+struct OnePassArgs {
+    const float* gy; const float* x; const float* mu;      // (M, 256) row-major; mu [256]
+    const float* sg; const float* sx;                      // per-channel power-of-two scales of gy and of x - mu
+    const _Float16* hi0; const _Float16* lo0; const float* cs0; int64_t slot_stride0;   // At tables (per slot) + column scales
+    const _Float16* hi1; const _Float16* lo1; const float* cs1;                        // S table (shared)
+    const float* sub; int sub_on;                          // gmean (pointed at a valid address and ignored when absent)
+    const int32_t* slot; int64_t HW;
+    const float* Bf0; int64_t bf0_stride; const float* Bf1;   // the fp32 tables, for the exact redo
+    float* out;
+    int ntiles, tiles_per_pair, mixed;
+};
+
+template <bool HAS_SLOT>
+__global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
+{
+    constexpr int C = 256, TR = 16, K2 = 2 * C;
+    constexpr int PAD = 32, PITCH = K2 * 2 + PAD, IMG = TR * PITCH, FBUF = 2 * IMG;
+    constexpr int NSLOT = 7, RAWW = NSLOT * 1024, KS = 16;            // k-steps of 32: 8 of gy . At, 8 of (x - mu) . S
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // F0 | F1 | F2 | raw[8 waves][7 KiB] | counters
+    char* const fbuf = smem;
+    char* const ring = smem + 3 * FBUF;
+    volatile int* const cnt = reinterpret_cast<volatile int*>(smem + 3 * FBUF + 8 * RAWW);   // [0] converted, [1] read, [2] dirty
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+    // block id -> (pair, column half): ids q*16 + xcd and q*16 + 8 + xcd are the two halves of pair q*8 + xcd (same XCD)
+    const int half = (blockIdx.x >> 3) & 1;
+    const int pair = (blockIdx.x >> 4) * 8 + (blockIdx.x & 7);
+    const int npairs = gridDim.x >> 1;
+
+    int t_first, t_stride, n;
+    if (HAS_SLOT) {
+        t_first = pair * a.tiles_per_pair; t_stride = 1;
+        n = a.ntiles - t_first; if (n > a.tiles_per_pair) n = a.tiles_per_pair;
+    } else {
+        t_first = pair; t_stride = npairs;
+        n = (a.ntiles - t_first + t_stride - 1) / t_stride;
+    }
+    if (n <= 0) return;
+    auto tile_of = [&](int i) { return t_first + i * t_stride; };
+
+    if (tid < 3) cnt[tid] = 0;
+    __syncthreads();
+
+    // DMA of chunk p of this wave's share of tile tl: p = 0, 1 rows 2w, 2w+1 of gy; p = 2, 3 the same rows of x
+    const unsigned ring_w = (unsigned)(size_t)((__attribute__((address_space(3))) char*)(ring + wave * RAWW));
+    auto dma_chunk = [&](int tl, int p, int slot, int lane_) {
+        const float* src = (p & 2) ? a.x : a.gy;
+        const char* g = reinterpret_cast<const char*>(src + ((int64_t)tile_of(tl) * TR + 2 * wave + (p & 1)) * C) + lane_ * 16;
+        const unsigned l = __builtin_amdgcn_readfirstlane(ring_w + slot * 1024);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(g), "s"(l) : "memory");
+    };
+
+    // conversion of this wave's own chunks: lane = float4 of channels 4*lane.. of one row
+    const f32x4 scl_g = ld4f(a.sg + 4 * lane), scl_x = ld4f(a.sx + 4 * lane);
+    const f32x4 ncs_x = -ld4f(a.mu + 4 * lane) * scl_x;
+    float gmax = 0.f;
+    f32x4 craw, cg4;
+    unsigned chw01 = 0, chw23 = 0, clw01 = 0, clw23 = 0;
+    auto craw_read = [&](int slot, int lane_) {
+        craw = *reinterpret_cast<const f32x4*>(ring + wave * RAWW + slot * 1024 + lane_ * 16);
+    };
+    auto cv_scale = [&](int p) {
+        if (p & 2) cg4 = craw * scl_x + ncs_x; else cg4 = craw * scl_g;
+        gmax = __builtin_fmaxf(__builtin_fmaxf(gmax, fabsf(cg4[0])), fabsf(cg4[1]));
+        gmax = __builtin_fmaxf(__builtin_fmaxf(gmax, fabsf(cg4[2])), fabsf(cg4[3]));
+    };
+    auto cv_hi = [&]() { chw01 = pk_rne(cg4[0], cg4[1]); chw23 = pk_rne(cg4[2], cg4[3]); };
+    auto cv_lo = [&]() {
+        float r0, r1, r2, r3;
+        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(chw01), "v"(cg4[0]));
+        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(chw01), "v"(cg4[1]));
+        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r2) : "v"(chw23), "v"(cg4[2]));
+        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r3) : "v"(chw23), "v"(cg4[3]));
+        clw01 = pk_rne(r0, r1);
+        clw23 = pk_rne(r2, r3);
+    };
+    // image row 2w + (p & 1); gy in channels 0..255 of the row, x in 256..511
+    const int woff0 = (2 * wave) * PITCH + lane * 8;
+    auto cv_write = [&](int fb, int p, int woff0_) {
+        char* dst = fbuf + fb * FBUF + woff0_ + (p & 1) * PITCH + (p >> 1) * (C * 2);
+        *reinterpret_cast<uint2*>(dst) = make_uint2(chw01, chw23);
+        *reinterpret_cast<uint2*>(dst + IMG) = make_uint2(clw01, clw23);
+    };
+    const unsigned cnt_lds = (unsigned)(size_t)((__attribute__((address_space(3))) char*)(smem + 3 * FBUF + 8 * RAWW));
+    auto arrive = [&](int which) {
+        if (lane == 0) {
+            const unsigned one = 1u, addr = cnt_lds + 4u * which;
+            asm volatile("ds_add_u32 %0, %1" :: "v"(addr), "v"(one) : "memory");
+        }
+    };
+    auto wait_for = [&](int which, int target) {
+        const unsigned addr = cnt_lds + 4u * which;
+        for (;;) {
+            int v;
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+            if (__builtin_amdgcn_readfirstlane(v) >= target) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
+
+    // B' fragments of this wave's 16 columns: units 0..7 the k-steps of At[slot], 8..15 those of S (16x16x32 load order)
+    f16x8 bhi[KS], blo[KS];
+    float cs0v = 1.f, cs1v = 1.f, subv = 0.f;
+    int cur_slot = -1;
+    const int cb16 = half * 8 + wave, cgp = cb16 >> 1, chh = cb16 & 1;
+    const int col = cb16 * 16 + l15;
+    const int64_t unit0 = ((int64_t)(cgp * 8) * 2 + chh) * 512 + lane * 8;        // + s * 1024 halves per k-step
+    auto load_b0 = [&](int slot) {
+        const _Float16* ph = a.hi0 + (int64_t)slot * a.slot_stride0 + unit0;
+        const _Float16* pl = a.lo0 + (int64_t)slot * a.slot_stride0 + unit0;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            bhi[s] = *reinterpret_cast<const f16x8*>(ph + 1024 * s);
+            blo[s] = *reinterpret_cast<const f16x8*>(pl + 1024 * s);
+        }
+        cs0v = a.cs0[(a.slot_stride0 ? (int64_t)slot : 0) * C + col];
+        cur_slot = slot;
+    };
+    auto load_b1 = [&]() {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            bhi[8 + s] = *reinterpret_cast<const f16x8*>(a.hi1 + unit0 + 1024 * s);
+            blo[8 + s] = *reinterpret_cast<const f16x8*>(a.lo1 + unit0 + 1024 * s);
+        }
+        cs1v = a.cs1[col];
+        subv = a.sub[a.sub_on ? col : 0];
+    };
+
+#pragma unroll
+    for (int i = 0; i < NSLOT; ++i) if (i / 4 < n) dma_chunk(i / 4, i % 4, i, lane);
+    load_b1();
+    if (!HAS_SLOT) load_b0(0);
+    constexpr int TBL = 2 * 8 + 2 + (HAS_SLOT ? 0 : 2 * 8 + 1);      // the tables' vector loads per lane behind the first DMAs
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        if (n >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(TBL + 6) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        craw_read(p, lane);
+        cv_scale(p);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the slot has been read out
+        if ((p + NSLOT) / 4 < n) dma_chunk((p + NSLOT) / 4, (p + NSLOT) % 4, p, lane);
+        cv_hi(); cv_lo(); cv_write(0, p, woff0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    arrive(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0) only: hipcc must see that the table loads have completed
+    if (!a.sub_on) subv = 0.f;
+
+    const int rd_off = l15 * PITCH + lq * 16;
+    const int out_lane = (4 * lq) * C + col;          // D register r: row 4 lq + r, column l15 of this wave's 16
+    if (WC_STAGGER && wave >= 4 && n >= 4) __builtin_amdgcn_s_sleep(12);
+
+    int rslot = 4;
+    int fcur = 0;
+    using T_ = std::integral_constant<bool, true>;
+    using F_ = std::integral_constant<bool, false>;
+    auto tile_body = [&](int t, auto conv_tag, auto wm_tag) {
+        constexpr bool CONV_ = decltype(conv_tag)::value;
+        constexpr int WM_ = decltype(wm_tag)::value;
+        const int fnext = fcur == 2 ? 0 : fcur + 1;
+        int lane_t = lane, woff_t = woff0, rd_t = rd_off;
+        asm volatile("" : "+v"(lane_t), "+v"(woff_t), "+v"(rd_t));
+        wait_for(0, 8 * (t + 1));
+        if (CONV_) wait_for(1, 8 * (t - 1));
+        int rs[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { const int v = rslot + p; rs[p] = v >= NSLOT ? v - NSLOT : v; }
+        auto chunk_wait = [&](int p) {      // younger vector-memory operations behind chunk p's DMA (header)
+            if (WM_ == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else if (WM_ == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (WM_ == 4 && p == 0) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            else if (WM_ == 4 && p == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (WM_ == 4 && p == 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else if (WM_ == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (WM_ == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        const char* hrow = fbuf + fcur * FBUF + rd_t;
+        const char* lrow = hrow + IMG;
+        f32x4 acc[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto frag = [&](const char* base, int s) { return *reinterpret_cast<const f16x8*>(base + 64 * s); };
+        f16x8 ah = frag(hrow, 0), al = frag(lrow, 0), nh = ah, nl = al;
+        if (CONV_) { chunk_wait(0); craw_read(rs[0], lane_t); }
+        auto cstep = [&](int j) {
+            const int p = j / 5, st = j % 5;
+            if (st == 0) {
+                cv_scale(p);
+                if (p == 0) { if (WC_FENCE_DEP) asm volatile("" :: "v"(cg4[0]) : "memory"); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }   // chunk 0's ds_read was issued a few instructions ago: it must have RETURNED before the DMA that refills its slot may issue -- with the read only issued, a DMA served from L2 overtook it (one-pass K6, the pair's second workgroup: one corrupted row in ~1e5 tiles)
+                const int tl = t + 1 + (p + NSLOT) / 4;
+                if (tl < n) dma_chunk(tl, (p + NSLOT) % 4, rs[p], lane_t);
+            } else if (st == 1) {
+                if (p + 1 < 4) { chunk_wait(p + 1); craw_read(rs[p + 1], lane_t); }
+            } else if (st == 2) cv_hi();
+            else if (st == 3) cv_lo();
+            else cv_write(fnext, p, woff_t);
+        };
+        constexpr int G = 3 * KS;            // 48 MFMAs = issue gaps per tile
+        constexpr int H = (G * 3) / 4;       // the next tile's conversion rides in the first three quarters
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                const int g = 3 * s + m, tb = s >> 3;
+                if (m == 0) acc[tb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bhi[s], acc[tb][0], 0, 0, 0);
+                if (m == 1) acc[tb][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, blo[s], acc[tb][1], 0, 0, 0);
+                if (m == 2) acc[tb][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bhi[s], acc[tb][2], 0, 0, 0);
+                if (s + 1 < KS) {
+                    if (m == 0) nh = frag(hrow, s + 1);
+                    if (m == 1) nl = frag(lrow, s + 1);
+                }
+                if (CONV_) {
+#pragma unroll
+                    for (int j = 0; j < 21; ++j) {
+                        if ((j * H) / 21 != g) continue;
+                        if (j < 20) cstep(j);
+                        else { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); arrive(0); }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            ah = nh; al = nl;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my reads of image t are done
+        arrive(1);
+        float* po = a.out + (int64_t)tile_of(t) * (TR * C) + out_lane;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v0 = (acc[0][0][r] + acc[0][1][r]) + acc[0][2][r], v1 = (acc[1][0][r] + acc[1][1][r]) + acc[1][2][r];
+            po[r * C] = v0 * cs0v + (v1 * cs1v - subv);
+        }
+        rslot = rs[3] + 1 >= NSLOT ? rs[3] + 1 - NSLOT : rs[3] + 1;
+        fcur = fnext;
+    };
+    using W0 = std::integral_constant<int, 0>; using W1 = std::integral_constant<int, 1>;
+    using W2 = std::integral_constant<int, 2>; using W3 = std::integral_constant<int, 3>;
+    using W4 = std::integral_constant<int, 4>;
+    auto pick_table = [&](int t) {
+        if (HAS_SLOT) {
+            const int slot = a.slot[((int64_t)tile_of(t) * TR) / a.HW];
+            if (slot != cur_slot) { load_b0(slot); __builtin_amdgcn_s_waitcnt(0x0F70); }
+        }
+    };
+    for (int t = 0; t + 1 < n; ++t) {
+        pick_table(t);
+        if (t == 0) { if (t + 3 < n) tile_body(t, T_{}, W1{}); else tile_body(t, T_{}, W0{}); }
+        else if (t + 3 < n) tile_body(t, T_{}, W2{});
+        else if (t + 3 == n) tile_body(t, T_{}, W3{});
+        else tile_body(t, T_{}, W4{});
+    }
+    pick_table(n - 1);
+    tile_body(n - 1, F_{}, W0{});
+
+    // Exact redo (rare), as in affine_ring_kernel: the workgroup's tiles again in fp32 from global memory when anything it
+    // staged was outside the fp16 range; tiles that straddle samples of different slots per row.  Same thread, same element.
+    if (!(gmax <= kF16Guard)) cnt[2] = 1;
+    __syncthreads();
+    const bool redo_all = cnt[2] != 0;
+    if (redo_all || (HAS_SLOT && a.mixed)) {
+        for (int t = 0; t < n; ++t) {
+            const int64_t r0 = (int64_t)tile_of(t) * TR;
+            bool mixed = false;
+            if (HAS_SLOT && a.mixed) {
+                const int64_t n0 = r0 / a.HW, n1 = (r0 + TR - 1) / a.HW;
+                const int s0 = a.slot[n0];
+                for (int64_t q = n0 + 1; q <= n1; ++q) mixed |= (a.slot[q] != s0);
+            }
+            if (!redo_all && !mixed) continue;
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = r0 + 4 * lq + r;
+                int slot = 0;
+                if (HAS_SLOT) slot = a.slot[row / a.HW];
+                const float* B0 = a.Bf0 + (int64_t)slot * a.bf0_stride + col;
+                const float* B1 = a.Bf1 + col;
+                const float* gr = a.gy + row * C;
+                const float* xr = a.x + row * C;
+                float accf = 0.f;
+                for (int k = 0; k < C; ++k) accf = fmaf(gr[k], B0[(int64_t)k * C], accf);
+                for (int k = 0; k < C; ++k) accf = fmaf(xr[k] - a.mu[k], B1[(int64_t)k * C], accf);
+                a.out[row * C + col] = accf - (a.sub_on ? a.sub[col] : 0.f);
             }
         }
     }
@@ -1164,6 +1477,48 @@ hipError_t wc_launch_fast_affine_planned(const float* in, const float* center, c
         case 256: return launch_affine<256>(a, st);
     }
     return hipErrorInvalidValue;
+}
+
+// K6 in one pass (C = 256, both inputs' scales given, plans of At and of S built): see onepass_ring_kernel
+bool wc_bwd_apply_onepass_supported(int64_t N, int64_t HW, int C)
+{
+    static const bool off = getenv("WC_K6_TWO_PASS") != nullptr;      // development: the two-pass form
+    return !off && WC_MFMA16 && C == 256 && ((N * HW) % 16) == 0 && N * HW >= 4096;
+}
+
+hipError_t wc_launch_bwd_apply_onepass(const float* gy, const float* x, const float* mu, const float* At, int Kc, const float* S,
+                                       const float* gmean, const int32_t* slot, int64_t N, int64_t HW, const float* scales,
+                                       float* dx, const void* plan0, const void* plan1, hipStream_t st)
+{
+    constexpr int C = 256, TR = 16;
+    const PlanView v0 = plan_view(const_cast<void*>(plan0), C, Kc), v1 = plan_view(const_cast<void*>(plan1), C, 1);
+    OnePassArgs a = {};
+    a.gy = gy; a.x = x; a.mu = mu; a.sg = scales + C; a.sx = scales;
+    a.hi0 = v0.hi; a.lo0 = v0.lo; a.cs0 = v0.colscale; a.slot_stride0 = (int64_t)C * C;
+    a.hi1 = v1.hi; a.lo1 = v1.lo; a.cs1 = v1.colscale;
+    a.sub_on = gmean != nullptr; a.sub = gmean ? gmean : scales;
+    a.slot = slot; a.HW = HW; a.Bf0 = At; a.bf0_stride = (int64_t)C * C; a.Bf1 = S; a.out = dx;
+    a.ntiles = (int)(N * HW / TR);
+    a.mixed = (slot != nullptr && (HW % TR) != 0) ? 1 : 0;
+    int pairs = a.ntiles < 128 ? a.ntiles : 128;
+    const int groups16 = (pairs + 7) / 8;                 // block ids come in groups of 16: 8 pairs x 2 column halves
+    pairs = groups16 * 8;
+    a.tiles_per_pair = (a.ntiles + pairs - 1) / pairs;
+    constexpr size_t lds = 3 * 2 * (size_t)(TR * (2 * C * 2 + 32)) + 8 * 7 * 1024 + 64;
+#define WC_LAUNCH_ONEPASS(SLOT_)                                                                                       \
+    do {                                                                                                                \
+        static bool attr_set = false;                                                                                   \
+        if (!attr_set) {                                                                                                \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(onepass_ring_kernel<SLOT_>),               \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
+            if (e != hipSuccess) return e;                                                                              \
+            attr_set = true;                                                                                            \
+        }                                                                                                               \
+        hipLaunchKernelGGL((onepass_ring_kernel<SLOT_>), dim3(groups16 * 16), dim3(512), lds, st, a);                   \
+    } while (0)
+    if (slot) WC_LAUNCH_ONEPASS(true); else WC_LAUNCH_ONEPASS(false);
+#undef WC_LAUNCH_ONEPASS
+    return hipGetLastError();
 }
 
 // One stream of the affine on the fast path with no prepared plan: sample the channel scales, build the tables, run.
