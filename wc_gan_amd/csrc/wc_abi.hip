@@ -121,7 +121,7 @@ int wc_factor_f64(const double* sum, const double* xtx, int64_t M, int C, int gr
     hipStream_t st = static_cast<hipStream_t>(stream);
     Carver cv(ws, ws_bytes);
     double* tmp = cv.take<double>((size_t)groups * C * C);
-    WC_TRY(wc_launch_factor_prepare(sum, xtx, M, C, eps, momentum, ddof, training, groups, moving_mean, moving_cov, mu, chan_scale, L, st));
+    WC_TRY(wc_launch_factor_prepare(sum, xtx, M, C, eps, momentum, ddof, training, groups, moving_mean, moving_cov, mu, chan_scale, L, st, tmp));
     if (wc_factor_is_fused(C)) {
         WC_TRY(wc_launch_factor_fused(L, W, tmp, C, groups, st));
         return WC_OK;

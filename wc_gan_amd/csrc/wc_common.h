@@ -156,8 +156,9 @@ hipError_t wc_launch_bwd_combine(const double* P, const float* colsum, const int
 
 hipError_t wc_launch_factor_prepare(const double* sum, const double* xtx, int64_t M, int C, double eps, double momentum,
                                     int ddof, int training, int groups, float* moving_mean, float* moving_cov, float* mu,
-                                    float* chan_scale, double* T, hipStream_t st);
-// C <= 256: L (in place on T, upper zeroed) and W = L^-1 in two launches; tmp: [groups][C*16] doubles at least
+                                    float* chan_scale, double* T, hipStream_t st, double* tmp = nullptr);
+// C <= 256: L (in place on T, upper zeroed) and W = L^-1 in one launch (two for many groups); tmp: [groups][C*16] doubles + 64 B
+// per group at least, the SAME tmp that wc_launch_factor_prepare was given (it zeroes the launch's row-block counters there)
 bool wc_factor_is_fused(int C);
 hipError_t wc_launch_factor_fused(double* T, double* W, double* tmp, int C, int groups, hipStream_t st);
 hipError_t wc_launch_cholesky(double* T, int C, int groups, hipStream_t st);                     // in place: lower factor, upper zeroed

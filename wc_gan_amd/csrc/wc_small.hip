@@ -170,10 +170,12 @@ __global__ __launch_bounds__(64 * SX_PARTS) void bwd_combine_kernel(const double
 __global__ void factor_prepare_kernel(const double* __restrict__ sum, const double* __restrict__ xtx, int64_t M, int C,
                                       double eps, double momentum, int ddof, int training, int groups,
                                       float* __restrict__ moving_mean, float* __restrict__ moving_cov,
-                                      float* __restrict__ mu, float* __restrict__ chan_scale, double* __restrict__ T, int lower_only)
+                                      float* __restrict__ mu, float* __restrict__ chan_scale, double* __restrict__ T, int lower_only,
+                                      unsigned* __restrict__ rows, int nrows)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y;
+    if (i == 0 && j < nrows) rows[j] = 0u;       // the row-block counters of the fused factor launch (tri_inverse_role)
     if (j >= C) return;
     const int64_t e = (int64_t)i * C + j, CC = (int64_t)C * C;
     double tmax = 0.0;
@@ -570,6 +572,165 @@ template <int B, int E, typename F> __device__ __forceinline__ void static_for(F
     if constexpr (B < E) { f(std::integral_constant<int, B>{}); static_for<B + 1, E>(f); }
 }
 
+// ---------------------------------------------------------------------------------------------
+// W = L^-1 BEHIND the factorisation, in the same launch (round 2).  Row block i of W needs row block i of L and the
+// inverse of L_ii -- both final once the factorisation has passed step i -- so the inverse does not have to wait for
+// the whole factor: TI_WG more workgroups of the Cholesky launch take the role below and follow the factorisation one
+// row block behind it, told by a counter in global memory how many row blocks are complete.  28 us of a second launch
+// become a tail of a few microseconds.
+//   * X_j = Linv_jj;  X_i = -Linv_ii sum_{k=j}^{i-1} L_ik X_k  (i > j),  W[i][j] = X_i, as in tri_inverse_cols_kernel --
+//     but the launch is 1024 threads wide (the factorisation's shape), i.e. 128 VGPRs per thread, and a whole column
+//     of X blocks (up to 16 x 8 registers) no longer fits one wave.  So FOUR waves share a column: wave p keeps the
+//     blocks X_{j+e} with e = p (mod 4), adds up its own products of a step, the three that do not own the new block leave
+//     their partial sums in LDS and the owner (p = (i-j) mod 4) finishes the block.  The chain of dependent MFMAs of a
+//     step is a quarter as long (column 0, last step: 16 instead of 60), which also makes the tail behind the last panel short.
+//   * A workgroup takes the columns {w, 7-w, 8+w, 15-w} (17 blocks per pair): four workgroups per matrix.
+//   * The XCDs' L2s are not coherent with each other: the factorisation stores what this role reads (the solved panels and
+//     the inverted diagonal blocks) write-through and this role loads it past its L2 (relaxed agent-scope atomics = sc1
+//     accesses, as in wc_sn.hip); the counter is stored after an s_waitcnt vmcnt(0) of every storing wave and a barrier.
+//   * Row block i+1 is fetched while step i computes if the counter already allows it; if not, the step waits for it (the
+//     common case: the factorisation is the slower of the two except in its last steps).
+// ---------------------------------------------------------------------------------------------
+constexpr int TI_WG = 4;                         // inverse workgroups per matrix
+constexpr int TI_COLS = 4;                       // block columns per workgroup (four waves each)
+__device__ __forceinline__ double ld_sc1(const double* p)
+{ return __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+__device__ __forceinline__ void st_sc1(double* p, double v)
+{ __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__host__ __device__ constexpr size_t ti_role_lds_doubles(int C) { return (size_t)2 * 16 * (C + 2) + 2 * 16 * 17 + 2 * TI_COLS * 4 * 256 + 2; }
+
+// flag == nullptr: L is complete (a launch of its own behind the factorisation); otherwise *flag counts its complete row blocks
+__device__ __forceinline__ void tri_inverse_role(const double* __restrict__ L, const double* __restrict__ Linv, double* __restrict__ W,
+                                                 int C, int wg, const unsigned* flag, double* sm)
+{
+    const int ldr = C + 2;
+    double* Lrow = sm;                           // [2][16][ldr]  row block i of L, even / odd i
+    double* Dv = Lrow + 2 * 16 * ldr;            // [2][16][17]   inverse of L_ii, even / odd i
+    double* Part = Dv + 2 * 16 * 17;             // [2][TI_COLS][4][4 x 64] partial sums of a step, even / odd i
+    unsigned* avail = reinterpret_cast<unsigned*>(Part + 2 * TI_COLS * 4 * 256);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lq = lane >> 4;
+    const int nb = C >> 4;
+    const int p = wave & 3, cl = wave >> 2;      // a column's four waves sit on the four SIMDs
+    int j = (cl == 0) ? wg : (cl == 1) ? 7 - wg : (cl == 2) ? 8 + wg : 15 - wg;
+    const bool has_col = j < nb;
+    if (!has_col) j = nb;
+    if (wg >= nb) return;                        // (C = 32: two columns)
+
+    // staging of row block i: 16 x C doubles, 8 bytes per thread and load (the sc1 form), a surplus thread repeats the last one
+    int off[4], doff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int e = tid + 1024 * q; e = e < 16 * C ? e : 16 * C - 1;
+        off[q] = e; doff[q] = (e / C) * ldr + (e % C);
+    }
+    double st[4], dst = 0.0;
+    auto fetch = [&](int i) {
+        const double* src = L + (int64_t)16 * i * C;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) st[q] = flag ? ld_sc1(src + off[q]) : src[off[q]];
+        if (tid < 256) dst = flag ? ld_sc1(Linv + i * 256 + tid) : Linv[i * 256 + tid];
+    };
+    auto stash = [&](int i) {
+        double* d = Lrow + (i & 1) * 16 * ldr;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d[doff[q]] = st[q];
+        if (tid < 256) Dv[(i & 1) * (16 * 17) + (tid >> 4) * 17 + (tid & 15)] = dst;
+    };
+    auto wait_rows = [&](unsigned target) {
+        if (tid == 0) {
+            unsigned spins = 0;          // (bounded: a lost producer must not hang the device; the result is then wrong and the tests say so)
+            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(2);
+        }
+        __syncthreads();
+    };
+    auto store = [&](int i, const f64x4& v) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) W[(int64_t)(16 * i + lq + 4 * r) * C + 16 * j + li] = v[r];
+    };
+    if (has_col && p == 0)
+        for (int i = 0; i < j; ++i) store(i, f64x4{0.0, 0.0, 0.0, 0.0});      // blocks above the diagonal block: zero
+
+    f64x4 X[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) X[s] = f64x4{0.0, 0.0, 0.0, 0.0};
+    int have = -1;
+#pragma unroll 1
+    for (int i = 0; i < nb; ++i) {
+        if (have != i) {
+            if (flag) wait_rows((unsigned)i + 1);
+            fetch(i);
+        }
+        stash(i);
+        if (flag && tid == 0) *avail = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        have = -1;
+        if (i + 1 < nb && (!flag || *avail >= (unsigned)i + 2)) { fetch(i + 1); have = i + 1; }
+        const int d = i - j;                      // wave-uniform
+        const int own = d & 3;
+        double* part = Part + (((i & 1) * TI_COLS + cl) * 4) * 256;
+        f64x4 S = {0.0, 0.0, 0.0, 0.0}, S1 = {0.0, 0.0, 0.0, 0.0};
+        if (has_col && d >= 1) {
+            const double* lr = Lrow + (i & 1) * 16 * ldr + li * ldr + lq + 16 * j;
+            static_for<0, 4>([&](auto Sx) {
+                constexpr int s = decltype(Sx)::value;
+                const int e = 4 * s + p;
+                if (e < d) {
+                    double an[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) an[r] = lr[16 * e + 4 * r];
+                    S = __builtin_amdgcn_mfma_f64_16x16x4f64(an[0], X[s][0], S, 0, 0, 0);
+                    S1 = __builtin_amdgcn_mfma_f64_16x16x4f64(an[1], X[s][1], S1, 0, 0, 0);
+                    S = __builtin_amdgcn_mfma_f64_16x16x4f64(an[2], X[s][2], S, 0, 0, 0);
+                    S1 = __builtin_amdgcn_mfma_f64_16x16x4f64(an[3], X[s][3], S1, 0, 0, 0);
+                }
+            });
+            S += S1;
+            if (p != own && p < d) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part[p * 256 + r * 64 + lane] = S[r];
+            }
+        }
+        __syncthreads();
+        if (has_col && d >= 0 && p == own) {
+            const double* dv = Dv + (i & 1) * (16 * 17);
+            f64x4 Xi;
+            if (d == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Xi[r] = dv[(lq + 4 * r) * 17 + li];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (q != p && q < d) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) S[r] += part[q * 256 + r * 64 + lane];
+                    }
+                f64x4 Xa = {0.0, 0.0, 0.0, 0.0}, Xb = {0.0, 0.0, 0.0, 0.0};
+                const double* pi = dv + li * 17 + lq;
+                Xa = __builtin_amdgcn_mfma_f64_16x16x4f64(-pi[0], S[0], Xa, 0, 0, 0);
+                Xb = __builtin_amdgcn_mfma_f64_16x16x4f64(-pi[4], S[1], Xb, 0, 0, 0);
+                Xa = __builtin_amdgcn_mfma_f64_16x16x4f64(-pi[8], S[2], Xa, 0, 0, 0);
+                Xb = __builtin_amdgcn_mfma_f64_16x16x4f64(-pi[12], S[3], Xb, 0, 0, 0);
+                Xi = Xa + Xb;
+            }
+            static_for<0, 4>([&](auto Sx) {
+                constexpr int s = decltype(Sx)::value;
+                if ((d >> 2) == s) X[s] = Xi;
+            });
+            store(i, Xi);
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void tri_inverse_split_kernel(const double* __restrict__ L, const double* __restrict__ Linv,
+                                                                 double* __restrict__ W, int C)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    tri_inverse_role(L + (int64_t)blockIdx.y * C * C, Linv + (int64_t)blockIdx.y * C * 16, W + (int64_t)blockIdx.y * C * C, C,
+                     (int)blockIdx.x, nullptr, sm);
+}
+
 #ifndef CF_OWN
 #define CF_OWN 15                   // waves that own trailing blocks and solve the panel.  (12 = all but 4, 8, 12, which share wave 0's
 #endif                              // SIMD: measured 74 against 69 us -- the early steps are bound by the CU's f64-MFMA rate and lose a quarter of it)
@@ -587,9 +748,18 @@ constexpr int CF_SLOTS = (120 + CF_OWN - 1) / CF_OWN;      // 120 blocks at C = 
                           asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                          \
                           if (CF_STAMPS && stamp_ok) stamps[nstamp++] = __builtin_amdgcn_s_memtime(); } while (0)
 
-__global__ __launch_bounds__(1024) void cholesky_fused_kernel(double* __restrict__ T, double* __restrict__ Linv, int C, int ldp)
+// rows != nullptr: the launch carries TI_WG inverse workgroups per matrix behind the `groups` factorising ones (tri_inverse_role);
+// rows[16 g] counts the complete row blocks of matrix g (zeroed by factor_prepare_kernel)
+__global__ __launch_bounds__(1024) void cholesky_fused_kernel(double* __restrict__ T, double* __restrict__ Linv, int C, int ldp,
+                                                              double* __restrict__ Winv, unsigned* __restrict__ rows, int groups)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    if ((int)blockIdx.x >= groups) {
+        const int idx = (int)blockIdx.x - groups, g = idx / TI_WG;
+        tri_inverse_role(T + (int64_t)g * C * C, Linv + (int64_t)g * C * 16, Winv + (int64_t)g * C * C, C, idx % TI_WG, rows + 16 * g, sm);
+        return;
+    }
+    unsigned* rowflag = rows ? rows + 16 * blockIdx.x : nullptr;
     double* Praw = sm;                          // [2][C][17]  the current / next panel as its owners hold it (row-major)
     double* Pn = Praw + 2 * C * 17;             // [16][ldp]   solved panel, column-major: the update's MFMA operands
     double* Dinv = Pn + 16 * ldp;               // [2][16][17] INVERSE of the factored diagonal block (even / odd steps)
@@ -648,18 +818,30 @@ __global__ __launch_bounds__(1024) void cholesky_fused_kernel(double* __restrict
                 w[jj] = (li == jj) ? rd : (li < jj ? -acc * rd : 0.0);
             });
             double* dv = Dinv + (j & 1) * (16 * 17);
+            if (rowflag) {
+                // row blocks 0..j-1 are complete: the owners' panel stores landed before barrier (A) of step j-1, this wave's
+                // own (the inverse of block j-1) were issued a whole step ago
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(rowflag, (unsigned)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             if (lane < 16) {
 #pragma unroll
                 for (int c = 0; c < 16; ++c) T[(int64_t)(16 * j + lane) * C + 16 * j + c] = (c <= lane) ? a[c] : 0.0;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) { dv[i * 17 + lane] = w[i]; Linv[j * 256 + i * 16 + lane] = w[i]; }   // [i][c], zero above the diagonal
+                for (int i = 0; i < 16; ++i) { dv[i * 17 + lane] = w[i]; st_sc1(Linv + j * 256 + i * 16 + lane, w[i]); }   // [i][c], zero above the diagonal
             }
         };
         factor(0, Praw);
 #pragma unroll 1
         for (int j = 0; j < nb; ++j) {
             CF_BARRIER();                                          // (A)
-            if (C - 16 * (j + 1) <= 0) break;
+            if (C - 16 * (j + 1) <= 0) {
+                if (rowflag) {                                     // the last block's inverse has landed: L is complete
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_store(rowflag, (unsigned)nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                break;
+            }
             CF_BARRIER();                                          // (B) the others have solved panel j
             // the last update of block (j+1, j+1): D -= X X^T with X = rows 16(j+1).. of the solved panel; through LDS into
             // the lane = row layout of the factorisation
@@ -715,6 +897,8 @@ __global__ __launch_bounds__(1024) void cholesky_fused_kernel(double* __restrict
         int cur = 0;
 #pragma unroll 1
         for (int j = 0; j < nb; ++j) {
+            // (the panel stores of step j-1, a trailing update ago, have landed: what wave 0 counts as complete row blocks)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             CF_BARRIER();                                          // (A) the inverse of L_jj and panel j are in LDS
             const int j0 = 16 * j, g0 = j0 + 16, rows = C - g0;
             if (rows <= 0) break;
@@ -740,7 +924,7 @@ __global__ __launch_bounds__(1024) void cholesky_fused_kernel(double* __restrict
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int r = row0 + lq_t + 4 * e;
-                        T[(int64_t)r * C + j0 + li_t] = x[e];
+                        st_sc1(T + (int64_t)r * C + j0 + li_t, x[e]);      // write-through: the inverse role reads it in this launch
                         Pn[li_t * ldp + r] = x[e];
                     }
                 }
@@ -1194,25 +1378,54 @@ static bool use_fused_factor(int C)
     static const bool off = getenv("WC_CHOL_OLD") != nullptr;             // development: the round-1 kernels
     return C <= 256 && !off;
 }
+// factor and inverse in ONE launch (tri_inverse_role): every workgroup of the launch has to be resident at once (the inverse
+// workgroups spin on the factorising ones), so only for a handful of matrices.  Measured on MI355X (tools/k2_pipe_check.py), K2
+// per call, two launches -> one: C = 256: 94.4 -> 73.1 us (5 groups 96.1 -> 76.5, 8 groups 99.0 -> 77.7), C = 224 (3 groups):
+// 76.7 -> 59.6, C = 128: 35.6 -> 29.5; below that the hand-off per row block (counter, sc1 fetch: ~3 us) is longer than the
+// factorisation's step and two launches are faster (C = 64: 18.9 against 24-30 us).
+static bool factor_one_launch(int C, int groups)
+{
+    static const bool off = getenv("WC_K2_TWO_LAUNCH") != nullptr || getenv("WC_K2_SPLIT") != nullptr;
+    return use_fused_factor(C) && C >= 128 && !off && groups * (1 + TI_WG) <= 40;
+}
 
 hipError_t wc_launch_factor_prepare(const double* sum, const double* xtx, int64_t M, int C, double eps, double momentum,
                                     int ddof, int training, int groups, float* moving_mean, float* moving_cov, float* mu,
-                                    float* chan_scale, double* T, hipStream_t st)
+                                    float* chan_scale, double* T, hipStream_t st, double* tmp)
 {
+    // the row-block counters of the one-launch factor + inverse sit behind the inverted diagonal blocks in `tmp`
+    unsigned* rows = (tmp && factor_one_launch(C, groups)) ? reinterpret_cast<unsigned*>(tmp + (size_t)groups * C * 16) : nullptr;
+    if (rows && 16 * groups > 128) return hipErrorInvalidValue;
     hipLaunchKernelGGL(factor_prepare_kernel, dim3((C + 127) / 128, C), dim3(128), 0, st,
                        sum, xtx, M, C, eps, momentum, ddof, training, groups, moving_mean, moving_cov, mu, chan_scale, T,
-                       use_fused_factor(C) ? 1 : 0);
+                       use_fused_factor(C) ? 1 : 0, rows, rows ? 16 * groups : 0);
     return hipGetLastError();
 }
 
 hipError_t wc_launch_factor_fused(double* T, double* W, double* tmp, int C, int groups, hipStream_t st)
 {
     const int nb = C >> 4, ldp = C + 2;
-    const size_t lds = (size_t)(2 * C * 17 + 16 * ldp + 4 * 16 * 17) * sizeof(double);
+    size_t lds = (size_t)(2 * C * 17 + 16 * ldp + 4 * 16 * 17) * sizeof(double);
+    const bool one = factor_one_launch(C, groups);
+    static const bool split = getenv("WC_K2_SPLIT") != nullptr;         // development: the four-waves-per-column inverse as a launch of its own
+    const size_t lds_role = ti_role_lds_doubles(C) * sizeof(double);
+    if (one && lds_role > lds) lds = lds_role;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cholesky_fused_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(cholesky_fused_kernel, dim3(groups), dim3(1024), lds, st, T, tmp, C, ldp);
+    if (one) {
+        unsigned* rows = reinterpret_cast<unsigned*>(tmp + (size_t)groups * C * 16);     // zeroed by factor_prepare_kernel
+        hipLaunchKernelGGL(cholesky_fused_kernel, dim3(groups * (1 + TI_WG)), dim3(1024), lds, st, T, tmp, C, ldp, W, rows, groups);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(cholesky_fused_kernel, dim3(groups), dim3(1024), lds, st, T, tmp, C, ldp, W, (unsigned*)nullptr, groups);
+    if (split) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(tri_inverse_split_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_role);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(tri_inverse_split_kernel, dim3(TI_WG, groups), dim3(1024), lds_role, st, (const double*)T, (const double*)tmp, W, C);
+        return hipGetLastError();
+    }
     const int nwg = ((nb >> 1) + 3) / 4;
     const size_t lds2 = (size_t)(2 * 16 * (C + 2) + nb * 16 * 17) * sizeof(double);
 #define WC_TI_LAUNCH(PER_)                                                                                             \
