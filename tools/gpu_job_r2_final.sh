@@ -12,6 +12,7 @@ python tools/summarize_profile.py gpurun_out/r2z_step gpurun_out/r2z_step.md gap
 python tools/summarize_profile.py gpurun_out/r2z_site gpurun_out/r2z_site.md > /dev/null
 bash tools/gpu_job_pmc.sh tools/apply_only.py r2z_k3 > /dev/null 2>&1
 bash tools/gpu_job_pmc.sh tools/xty_only.py r2z_xty > /dev/null 2>&1
+bash tools/gpu_job_pmc.sh tools/bwd_apply_only.py r2z_k6 > /dev/null 2>&1
 bash tools/gpu_job_k2_profile.sh 256 1 > /dev/null 2>&1; cp gpurun_out/k2_prof.md gpurun_out/r2z_k2.md
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/r2z_site_tl -o s -- python3 $R/tools/site_timeline.py > /dev/null 2>&1
