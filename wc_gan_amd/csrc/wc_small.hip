@@ -640,8 +640,9 @@ __device__ __forceinline__ void tri_inverse_role(const double* __restrict__ L, c
     };
     auto wait_rows = [&](unsigned target) {
         if (tid == 0) {
-            unsigned spins = 0;          // (bounded: a lost producer must not hang the device; the result is then wrong and the tests say so)
+            unsigned spins = 0;          // (bounded: a lost producer must not hang the device -- W is poisoned below instead)
             while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(2);
+            if (spins >= (1u << 22)) avail[1] = 1u;
         }
         __syncthreads();
     };
@@ -656,6 +657,7 @@ __device__ __forceinline__ void tri_inverse_role(const double* __restrict__ L, c
 #pragma unroll
     for (int s = 0; s < 4; ++s) X[s] = f64x4{0.0, 0.0, 0.0, 0.0};
     int have = -1;
+    if (tid == 0) avail[1] = 0u;                  // set if a wait ran out (ordered before its first reader by the barriers below)
 #pragma unroll 1
     for (int i = 0; i < nb; ++i) {
         if (have != i) {
@@ -721,6 +723,10 @@ __device__ __forceinline__ void tri_inverse_role(const double* __restrict__ L, c
             store(i, Xi);
         }
     }
+    // a wait that ran out means the factorising workgroup never got there (it cannot happen while the launch is resident as a
+    // whole); fail loudly: NaN on this workgroup's first diagonal entry poisons every table built from W
+    __syncthreads();
+    if (flag && avail[1] != 0u && tid == 0) W[(int64_t)(16 * wg) * C + 16 * wg] = __builtin_nan("");
 }
 
 __global__ __launch_bounds__(1024) void tri_inverse_split_kernel(const double* __restrict__ L, const double* __restrict__ Linv,
