@@ -259,3 +259,20 @@ def test_apply_with_fused_relu(ops, shape, Kc):
         y = ops.apply(dev(x), dev(mu), dev(A), dev(b), st, fast=fast, relu=True)
         assert float(y.min()) >= 0.0
         assert rel(y.cpu().numpy().reshape(ref.shape), ref) < 3e-6
+
+
+@pytest.mark.parametrize("shape", [(16, 32, 32, 256), (16, 32, 32, 128), (8, 8, 8, 64)])
+def test_fused_relu_keeps_nan(ops, shape):
+    """relu(NaN) = NaN, as torch.relu: the epilogue's ReLU is !(v <= 0) ? v : 0, not max(v, 0) (which would return 0)"""
+    rng = np.random.default_rng(22)
+    C = shape[-1]
+    x = rng.standard_normal(shape).astype(np.float32)
+    mu = rng.standard_normal(C).astype(np.float32)
+    A = (rng.standard_normal((1, C, C)) / np.sqrt(C)).astype(np.float32)
+    b = rng.standard_normal((1, C)).astype(np.float32)
+    b[0, 7] = np.nan                                  # the bias enters in the epilogue only: the fast path stays the fast path
+    for fast in (True, False):
+        y = ops.apply(dev(x), dev(mu), dev(A), dev(b), None, fast=fast, relu=True)
+        assert bool(torch.isnan(y[..., 7]).all())
+        rest = torch.cat([y[..., :7], y[..., 8:]], dim=-1)
+        assert not bool(torch.isnan(rest).any()) and float(rest.min()) >= 0.0

@@ -10,6 +10,7 @@ b = torch.zeros(1, C).cuda(); y = torch.empty_like(x)
 s, xtx = ops.stats(x.view(M, C))
 mu, L, W, cs = ops.factor(s, xtx, M, C, 1e-3, 0.99, 1, True, None, None, x.device, want_scale=True)
 A, At, plan = ops.color(W, gamma, cs)
+relu = len(sys.argv) > 2 and sys.argv[2] == 'relu'
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 10):
-    ops.apply(x, mu, A, b, None, out=y, plan=plan)
+    ops.apply(x, mu, A, b, None, out=y, plan=plan, relu=relu)
 torch.cuda.synchronize()

@@ -4,7 +4,7 @@ R=$PWD
 mkdir -p gpurun_out
 run() {  # tag
     cd /tmp && export TMPDIR=/tmp
-    rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/k3ab_$1 -o s -- python3 $R/tools/apply_only.py 40 > $R/gpurun_out/k3ab_$1.log 2>&1
+    rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/k3ab_$1 -o s -- python3 $R/tools/apply_only.py 40 $K3AB_MODE > $R/gpurun_out/k3ab_$1.log 2>&1
     cd $R
     python - <<PY
 import csv

@@ -880,20 +880,27 @@ __global__ __launch_bounds__(512, 1) void affine_ring_kernel(FastArgs a)
 #if WC_MFMA16
         // A D register holds 4 rows x 16 columns (64-byte pieces of 4 rows).  v_permlane16_swap of the two column halves'
         // registers gives 2 rows x 32 columns per register again -- 128-byte pieces, the store shape of the 32x32 form.
+        // One scalar branch per tile, not one per value (the flag is a kernel argument: tested inside the loop it cut the epilogue
+        // into eight basic blocks).  ReLU as !(v <= 0) ? v : 0 -- one v_cmp_nle + one v_cndmask, NaN stays NaN -- instead of the
+        // four instructions of (v > 0 || isnan(v)).
+        auto leave = [&](auto RL_) __attribute__((always_inline)) {
+            constexpr bool RL = decltype(RL_)::value;       // the ReLU that follows every WC site rides in the epilogue
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int rh = i >> 2, r = i & 3;
-            float v0 = acc[rh][0][r] * cscale[0] + addv[0], v1 = acc[rh][1][r] * cscale[1] + addv[1];
-            if (a.relu) {       // the ReLU that follows every WC site rides in the epilogue
-                v0 = v0 > 0.f ? v0 : (v0 == v0 ? 0.f : v0);
-                v1 = v1 > 0.f ? v1 : (v1 == v1 ? 0.f : v1);
+            for (int i = 0; i < 8; ++i) {
+                const int rh = i >> 2, r = i & 3;
+                float v0 = acc[rh][0][r] * cscale[0] + addv[0], v1 = acc[rh][1][r] * cscale[1] + addv[1];
+                if (RL) {
+                    v0 = !(v0 <= 0.f) ? v0 : 0.f;
+                    v1 = !(v1 <= 0.f) ? v1 : 0.f;
+                }
+                // (inline asm: with __builtin_amdgcn_permlane16_swap hipcc 7.0 stored the FIRST result twice here -- the second
+                // definition of the instruction got lost; s_nop: the operands were just written by VALU instructions)
+                asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(v0), "+v"(v1));
+                po[(16 * rh + r) * C] = v0;          // rows r (lanes 0-31) and 8 + r: columns l31
+                po[(16 * rh + r + 4) * C] = v1;      // rows 4 + r and 12 + r
             }
-            // (inline asm: with __builtin_amdgcn_permlane16_swap hipcc 7.0 stored the FIRST result twice here -- the second
-            // definition of the instruction got lost; s_nop: the operands were just written by VALU instructions)
-            asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(v0), "+v"(v1));
-            po[(16 * rh + r) * C] = v0;          // rows r (lanes 0-31) and 8 + r: columns l31
-            po[(16 * rh + r + 4) * C] = v1;      // rows 4 + r and 12 + r
-        }
+        };
+        if (a.relu) leave(std::true_type{}); else leave(std::false_type{});
 #else
         if (a.relu) {       // the ReLU that follows every WC site rides in the epilogue
 #pragma unroll
