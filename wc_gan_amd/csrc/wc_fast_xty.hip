@@ -36,6 +36,9 @@ constexpr float kGuard = 60000.0f;
 #define XTY_STAMPS 0      // development: s_memtime stamps of wave 0 / workgroup 0 behind the partials (the caller adds 2 KiB to the workspace)
 #endif
 constexpr int BW_PLAIN = 3;                // 32x32 blocks per wave
+#ifndef XTY_ALLLIVE
+#define XTY_ALLLIVE 1
+#endif
 template <int C, bool TWO> constexpr bool xty_quad() { return TWO && C == 256; }
 
 
@@ -126,6 +129,12 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
             il[b] = ib[b]; jl[b] = jb[b];
         }
     }
+
+    bool all_ = true, any_ = false;
+#pragma unroll
+    for (int b = 0; b < BW; ++b) { all_ = all_ && live[b]; any_ = any_ || live[b]; }
+    const bool all_live = XTY_ALLLIVE && (QUAD || __builtin_amdgcn_readfirstlane(all_ ? 1 : 0) != 0);      // wave-uniform by construction (wave index, type)
+    const bool any_live = QUAD || __builtin_amdgcn_readfirstlane(any_ ? 1 : 0) != 0;
 
     // staging: thread -> operand op, float4 column c4, 8-row group rgrp
     const int op = TWO ? (tid >= 256) : 0;
@@ -232,20 +241,24 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
         }
     };
 
-    f32x16 acc[BW];
     double acc64[BW][16];
 #pragma unroll
     for (int b = 0; b < BW; ++b)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[b][r] = 0.f; acc64[b][r] = 0.0; }
+        for (int r = 0; r < 16; ++r) acc64[b][r] = 0.0;
 
-    // per-lane fragment addressing: channel row (block*32 + l31), chunk (2*ks + lh) ^ swz(channel)
-    int a_off[BW], b_off[BW], a_sw[BW], b_sw[BW];
+    // per-lane fragment addressing: channel row (block*32 + l31), chunk (2*ks + lh) ^ swz(channel).  With 2 ks + lh = 2 ks ^ lh
+    // and a row pitch that is a multiple of the row's 16 CPR bytes, the byte offset is  base ^ (ks << 5)  with
+    // base = row * pitch + ((lh ^ swz) << 4) kept per block: ONE v_xor per fragment address in the stage loop instead of the
+    // xor / shift / add chain (about 70 of a stage's ~370 vector instructions per wave went into these addresses), and the two
+    // buffers (64 KiB apart) ride in the same xor.
+    static_assert(NOP * 2 * IMG == 65536, "the stage buffers are 64 KiB apart: their bit is xor-ed into the fragment offsets");
+    int a_base[BW], b_base[BW];
 #pragma unroll
     for (int b = 0; b < BW; ++b) {
         const int ca = il[b] * 32 + l31, cb = jl[b] * 32 + l31;
-        a_off[b] = ca * (R * 2); a_sw[b] = swz(ca);
-        b_off[b] = (TWO ? 2 * IMG : 0) + cb * (R * 2); b_sw[b] = swz(cb);
+        a_base[b] = ca * (R * 2) + ((lh ^ swz(ca)) << 4);
+        b_base[b] = (TWO ? 2 * IMG : 0) + cb * (R * 2) + ((lh ^ swz(cb)) << 4);
     }
 
     if (nst > 0) {
@@ -271,28 +284,62 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
         XS();
         if (st + 2 < nst) stage_load(st + 2);
         XS();
-        const char* img = smem + cur * (NOP * 2 * IMG);
-#pragma unroll 4
-        for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-            for (int b = 0; b < BW; ++b) {
-                if (!live[b]) continue;
-                const int cha = ((2 * ks + lh) ^ a_sw[b]) * 16, chb = ((2 * ks + lh) ^ b_sw[b]) * 16;
-                const f16x8 ah = *reinterpret_cast<const f16x8*>(img + a_off[b] + cha);
-                const f16x8 al = *reinterpret_cast<const f16x8*>(img + a_off[b] + cha + IMG);
-                const f16x8 bh = *reinterpret_cast<const f16x8*>(img + b_off[b] + chb);
-                const f16x8 bl = *reinterpret_cast<const f16x8*>(img + b_off[b] + chb + IMG);
-                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[b], 0, 0, 0);
-                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[b], 0, 0, 0);
-                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[b], 0, 0, 0);
-            }
-        }
-        XS();
-        // float64 flush: the fp32 rounding chain never exceeds one stage (3*KS MFMA accumulations)
+        // the fp32 accumulators live for one stage only (their first MFMA takes a zero operand: no zeroing pass, and the 16 BW
+        // registers are free while the next stage is converted)
+        f32x16 acc[BW];
 #pragma unroll
         for (int b = 0; b < BW; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc64[b][r] += (double)acc[b][r]; acc[b][r] = 0.f; }
+            for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+        const int kbuf = cur << 16;
+        auto frag = [&](int base, int ks, int lo) __attribute__((always_inline)) {
+            return *reinterpret_cast<const f16x8*>(smem + (base ^ ((ks << 5) | kbuf)) + lo * IMG);
+        };
+        // ALL: every block of this wave is live (a scalar, per wave) -- the loop is then ONE basic block; with a `live` test per
+        // block and k-step (a per-lane value as far as hipcc can tell: exec-mask branches) every three MFMAs sat in a block of
+        // their own (K1 kernel 60 -> 56 us)
+        auto products = [&](auto ALL_) __attribute__((always_inline)) {
+            constexpr bool ALL = decltype(ALL_)::value;
+#pragma unroll 4
+            for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                for (int b = 0; b < BW; ++b) {
+                    if (!ALL && !live[b]) continue;
+                    const f16x8 ah = frag(a_base[b], ks, 0), al = frag(a_base[b], ks, 1);
+                    const f16x8 bh = frag(b_base[b], ks, 0), bl = frag(b_base[b], ks, 1);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[b], 0, 0, 0);
+                }
+            }
+        };
+        // Quadrant form: a wave's two blocks lie in one block row (L = 2 wave + b) and share their A fragments: 6 instead of 8
+        // ds_read_b128 per k-step.  (No measurable difference: the stage is the sum of its vector and matrix time, not LDS
+        // bound.  Also measured and dropped: reading block-step n + 1 ahead of the MFMAs of block-step n, pinned with
+        // sched_barrier: K4 75 -> 77 us.)
+        auto products_quad = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const f16x8 ah = frag(a_base[0], ks, 0), al = frag(a_base[0], ks, 1);
+#pragma unroll
+                for (int b = 0; b < BW; ++b) {
+                    const f16x8 bh = frag(b_base[b], ks, 0), bl = frag(b_base[b], ks, 1);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[b], 0, 0, 0);
+                }
+            }
+        };
+        if (QUAD) products_quad();
+        else if (all_live) products(std::true_type{}); else if (any_live) products(std::false_type{});
+        XS();
+        // float64 flush: the fp32 rounding chain never exceeds one stage (3*KS MFMA accumulations)
+        if (any_live) {
+#pragma unroll
+            for (int b = 0; b < BW; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc64[b][r] += (double)acc[b][r];
+        }
         XS();
         // LDS hand-off only (__syncthreads() would also drain vmcnt, i.e. wait for the loads of stage st+2 issued a moment ago)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
