@@ -203,7 +203,7 @@ def test_batched_layers_match_layer_by_layer(fully_diff):
 
 @pytest.mark.gpu
 def test_forward_leaves_the_maximum_of_the_normalised_weight():
-    """the 32 floats behind wc_spectral_norm_amax_offset: their maximum is max|w_sn| (the convolution's weight split reads
+    """the floats behind wc_spectral_norm_amax_offset: their maximum is max|w_sn| (the convolution's weight split reads
     them instead of sweeping the weight again)"""
     from wc_gan_amd.spectral import SNConv2d
     torch.manual_seed(4)

@@ -7,13 +7,16 @@
 // W is (R, K) row-major: a convolution kernel in the memory order it is stored in (Cout rows; the singular values do
 // not depend on the order of the columns, only v is permuted with them).  A critic step evaluates this for every
 // layer before every forward pass -- as separate launches it is ~15 small kernels per layer (GEMVs, norms, divisions);
-// here up to 32 co-resident workgroups split the matrix (L2-resident) and meet twice per power-iteration step.
+// here up to SN_MAXWG co-resident workgroups split the matrix and meet twice per power-iteration step.
 #include "wc_common.h"
 
 namespace {
 
 constexpr int SN_THREADS = 256;
-constexpr int SN_MAXWG = 32;
+#ifndef SN_MAXWG_
+#define SN_MAXWG_ 128
+#endif
+constexpr int SN_MAXWG = SN_MAXWG_;      // workgroups per weight (32 until round 2: a 1024 x 9216 critic weight of the Tiny-ImageNet recipe then streamed through 32 CUs)
 
 struct SnArgs {
     const float* W; int R, K;
@@ -63,7 +66,7 @@ __device__ __forceinline__ void grid_meet(unsigned* sync, int nwg, int phase)
     __syncthreads();
 }
 
-// One launch, nwg <= 32 workgroups.  Every workgroup owns a COLUMN slice of W for v = N(W^T u) and a ROW slice for
+// One launch, nwg <= SN_MAXWG workgroups.  Every workgroup owns a COLUMN slice of W for v = N(W^T u) and a ROW slice for
 // u = N(W v) and for the final scaling; the two products are assembled in global scratch between grid meetings and
 // each workgroup normalises them for itself (K + R floats: nothing), so all sums run in a fixed order.
 __device__ __forceinline__ void sn_forward_body(const SnArgs& a, const int b)
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(SN_THREADS) void sn_forward_kernel(SnArgs a) { sn_f
 __global__ __launch_bounds__(SN_THREADS) void sn_backward_kernel(SnBwdArgs a) { sn_backward_body(a, blockIdx.x); }
 
 // Every spectrally normalised layer of a network in ONE launch: the layers are independent of each other and of the
-// activations (they depend on the weights only), but as separate launches of <= 32 workgroups each they run one
+// activations (they depend on the weights only), but as separate launches of <= SN_MAXWG workgroups each they run one
 // after the other on a mostly idle chip.  Items ride in the kernel arguments; first[i] is the first block of item i.
 constexpr int SN_MAXITEMS = 16;
 struct SnBatch { SnArgs item[SN_MAXITEMS]; int first[SN_MAXITEMS + 1]; int count; };
@@ -241,7 +244,11 @@ __global__ __launch_bounds__(SN_THREADS) void sn_backward_batched_kernel(SnBwdBa
 
 int sn_workgroups(int R, int K)
 {
-    int nwg = (int)(((int64_t)R * K + 4095) / 4096);          // ~4096 elements per workgroup and pass
+    int nwg = (int)(((int64_t)R * K + 4095) / 4096);          // ~4096 elements per workgroup and pass, up to 32 workgroups ...
+    if (nwg > 32) {                                           // ... and beyond that ~16384 elements each, up to SN_MAXWG (the
+        nwg = (int)(((int64_t)R * K + 16383) / 16384);        // 1024-wide critic of the Tiny-ImageNet recipe: 9.4 M elements
+        if (nwg < 32) nwg = 32;                               // per weight; spectral norm 7.5 -> 4 ms of its 145 ms step)
+    }
     if (nwg > SN_MAXWG) nwg = SN_MAXWG;
     if (nwg > R) nwg = R;                                     // at least one row each
     return nwg < 1 ? 1 : nwg;
@@ -250,7 +257,7 @@ int sn_workgroups(int R, int K)
 }  // namespace
 
 size_t wc_sn_lds_bytes(int R, int K) { return (size_t)(R + K + SN_THREADS / 64 + SN_THREADS) * sizeof(float); }
-// scratch: t[K] | s[R] | partial[32] | amax[32] | sync[4] (the sync words must be zero before the first launch; every launch leaves them zero)
+// scratch: t[K] | s[R] | partial[SN_MAXWG] | amax[SN_MAXWG] | sync[4] (the sync words must be zero before the first launch; every launch leaves them zero)
 size_t wc_sn_workspace_bytes(int R, int K) { return ((size_t)(R + K + 2 * SN_MAXWG) * sizeof(float) + 15) / 16 * 16 + 16; }
 size_t wc_sn_amax_offset(int R, int K) { return (size_t)(R + K + SN_MAXWG) * sizeof(float); }
 

@@ -122,12 +122,13 @@ class _SNMixin:
         return ws
 
     def _sn_amax(self):
-        """The 32 floats of the workspace where the forward op leaves per-workgroup maxima of |w_sn|."""
+        """The floats of the workspace where the forward op leaves per-workgroup maxima of |w_sn| (between the offset the
+        library reports and the four sync words at the end; unused entries stay zero)."""
         a = getattr(self, '_sn_amax_view', None)
         ws = self._sn_workspace()
         if a is None or a.untyped_storage().data_ptr() != ws.untyped_storage().data_ptr():
             off = _lib.load().wc_spectral_norm_amax_offset(self.sn_u.numel(), self.sn_v.numel())
-            a = self._sn_amax_view = ws[off:off + 128].view(torch.float32)
+            a = self._sn_amax_view = ws[off:ws.numel() - 16].view(torch.float32)
         return a
 
     def normalized_weight(self):
