@@ -21,6 +21,12 @@
 #ifndef WC_MFMA16
 #define WC_MFMA16 1     // ring kernel on v_mfma_f32_16x16x32_f16 and the fp16 tables in that shape's load order (0: 32x32x16, development)
 #endif
+#ifndef WC_NT_STORE
+#define WC_NT_STORE 1      // nontemporal stores of y in the ring kernel's epilogue (y is streamed out: K3 53.5 -> 50.1 us, the step unchanged)
+#endif
+#ifndef WC_NT_STORE_K6
+#define WC_NT_STORE_K6 1   // the same for dx in the one-pass K6 kernel (stage 138 -> 133.5 us in bench.py's loop, 150-157 -> 138-145 in tools/onepass_time.py; the step within noise)
+#endif
 #ifndef WC_FENCE_DEP
 #define WC_FENCE_DEP 0     // the slot-read fence: 0 an explicit lgkmcnt(0), 1 a register dependency (measured the same)
 #endif
@@ -896,8 +902,13 @@ __global__ __launch_bounds__(512, 1) void affine_ring_kernel(FastArgs a)
                 // (inline asm: with __builtin_amdgcn_permlane16_swap hipcc 7.0 stored the FIRST result twice here -- the second
                 // definition of the instruction got lost; s_nop: the operands were just written by VALU instructions)
                 asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(v0), "+v"(v1));
+#if WC_NT_STORE
+                __builtin_nontemporal_store(v0, &po[(16 * rh + r) * C]);
+                __builtin_nontemporal_store(v1, &po[(16 * rh + r + 4) * C]);
+#else
                 po[(16 * rh + r) * C] = v0;          // rows r (lanes 0-31) and 8 + r: columns l31
                 po[(16 * rh + r + 4) * C] = v1;      // rows 4 + r and 12 + r
+#endif
             }
         };
         if (a.relu) leave(std::true_type{}); else leave(std::false_type{});
@@ -1252,7 +1263,11 @@ __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float v0 = (acc[0][0][r] + acc[0][1][r]) + acc[0][2][r], v1 = (acc[1][0][r] + acc[1][1][r]) + acc[1][2][r];
+#if WC_NT_STORE_K6
+            __builtin_nontemporal_store(v0 * cs0v + (v1 * cs1v - subv), &po[r * C]);
+#else
             po[r * C] = v0 * cs0v + (v1 * cs1v - subv);
+#endif
         }
         rslot = rs[3] + 1 >= NSLOT ? rs[3] + 1 - NSLOT : rs[3] + 1;
         fcur = fnext;

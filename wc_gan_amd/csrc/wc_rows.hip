@@ -556,7 +556,16 @@ __global__ __launch_bounds__(256) void relu_mask_kernel(const f32x4* __restrict_
 __global__ __launch_bounds__(256) void stream_copy_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, int64_t n4)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+#ifndef WC_NT_COPY
+#define WC_NT_COPY 1      // the stream-copy yardstick gets the same nontemporal stores as K3's epilogue (40.8 -> 40.5 us)
+#endif
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+#if WC_NT_COPY
+        __builtin_nontemporal_store(src[i], &dst[i]);
+#else
+        dst[i] = src[i];
+#endif
+    }
 }
 
 }  // namespace
