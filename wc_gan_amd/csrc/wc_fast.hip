@@ -25,7 +25,7 @@
 #define WC_NT_STORE 1      // nontemporal stores of y in the ring kernel's epilogue (y is streamed out: K3 53.5 -> 50.1 us, the step unchanged)
 #endif
 #ifndef WC_NT_STORE_K6
-#define WC_NT_STORE_K6 1   // the same for dx in the one-pass K6 kernel (stage 138 -> 133.5 us in bench.py's loop, 150-157 -> 138-145 in tools/onepass_time.py; the step within noise)
+#define WC_NT_STORE_K6 0   // the same for dx in the one-pass K6 kernel: measured (stage 138 -> 133.5 us in bench.py's loop, nothing under rocprofv3) and left off -- its stores are 64-byte pieces of a row, which leave the chip un-merged: HBM writes 134 -> 164 MB per launch (WRITE_SIZE), the step unchanged
 #endif
 #ifndef WC_FENCE_DEP
 #define WC_FENCE_DEP 0     // the slot-read fence: 0 an explicit lgkmcnt(0), 1 a register dependency (measured the same)
