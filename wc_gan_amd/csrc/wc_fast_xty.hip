@@ -36,6 +36,9 @@ constexpr float kGuard = 60000.0f;
 #define XTY_STAMPS 0      // development: s_memtime stamps of wave 0 / workgroup 0 behind the partials (the caller adds 2 KiB to the workspace)
 #endif
 constexpr int BW_PLAIN = 3;                // 32x32 blocks per wave
+#ifndef XTY_BAL
+#define XTY_BAL 1
+#endif
 #ifndef XTY_ALLLIVE
 #define XTY_ALLLIVE 1
 #endif
@@ -72,6 +75,7 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
     // the plain scheme convert all of it three times), its images hold twice the rows (64 per stage: half the barriers)
     // and a wave owns 2 blocks instead of 3 (no idle block slots: 64 = 4 x 8 x 2).
     constexpr bool QUAD = xty_quad<C, TWO>();
+    constexpr bool BAL = XTY_BAL && !TWO && C == 256;     // (two workgroup types, 36 blocks)
     constexpr int BW = QUAD ? 2 : BW_PLAIN;           // 32x32 blocks per wave
     constexpr int CS = QUAD ? C / 2 : C;              // channels of an operand that this workgroup stages
     constexpr int C4 = CS / 4;
@@ -123,6 +127,13 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
         } else {
             int L = (type * 8 + wave) * BW + b;
             live[b] = L < NBLK;
+            if (BAL) {
+                // the covariance at C = 256: 36 blocks as 18 + 18 instead of 24 + 12 -- a slab is as slow as its heavier
+                // workgroup.  Waves 0 and 1 (on different SIMDs) take three blocks, the other six take two: at most five
+                // blocks per SIMD instead of six, and every wave's blocks are a prefix (NL = 3 or 2: two branch-free loops)
+                L = type * (NBLK / 2) + (wave < 2 ? wave * 3 : 6 + (wave - 2) * 2) + b;
+                live[b] = b < (wave < 2 ? 3 : 2);
+            }
             if (!live[b]) L = 0;
             if (TWO) { ib[b] = L / NB; jb[b] = L % NB; }
             else { int i = 0; while (L >= NB - i) { L -= NB - i; ++i; } ib[b] = i; jb[b] = i + L; }
@@ -133,7 +144,8 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
     bool all_ = true, any_ = false;
 #pragma unroll
     for (int b = 0; b < BW; ++b) { all_ = all_ && live[b]; any_ = any_ || live[b]; }
-    const bool all_live = XTY_ALLLIVE && (QUAD || __builtin_amdgcn_readfirstlane(all_ ? 1 : 0) != 0);      // wave-uniform by construction (wave index, type)
+    const bool all_live = XTY_ALLLIVE && (QUAD || __builtin_amdgcn_readfirstlane(all_ ? 1 : 0) != 0);
+    const bool two_live = BAL && __builtin_amdgcn_readfirstlane((live[0] && live[1] && !live[BW - 1]) ? 1 : 0) != 0;   // blocks 0, 1 only      // wave-uniform by construction (wave index, type)
     const bool any_live = QUAD || __builtin_amdgcn_readfirstlane(any_ ? 1 : 0) != 0;
 
     // staging: thread -> operand op, float4 column c4, 8-row group rgrp
@@ -298,12 +310,13 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
         // ALL: every block of this wave is live (a scalar, per wave) -- the loop is then ONE basic block; with a `live` test per
         // block and k-step (a per-lane value as far as hipcc can tell: exec-mask branches) every three MFMAs sat in a block of
         // their own (K1 kernel 60 -> 56 us)
-        auto products = [&](auto ALL_) __attribute__((always_inline)) {
+        auto products = [&](auto ALL_, auto NL_) __attribute__((always_inline)) {
             constexpr bool ALL = decltype(ALL_)::value;
+            constexpr int NL = decltype(NL_)::value;          // blocks 0 .. NL-1 (all live when ALL)
 #pragma unroll 4
             for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-                for (int b = 0; b < BW; ++b) {
+                for (int b = 0; b < NL; ++b) {
                     if (!ALL && !live[b]) continue;
                     const f16x8 ah = frag(a_base[b], ks, 0), al = frag(a_base[b], ks, 1);
                     const f16x8 bh = frag(b_base[b], ks, 0), bl = frag(b_base[b], ks, 1);
@@ -331,10 +344,17 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
             }
         };
         if (QUAD) products_quad();
-        else if (all_live) products(std::true_type{}); else if (any_live) products(std::false_type{});
+        else if (all_live) products(std::true_type{}, std::integral_constant<int, BW>{});
+        else if (two_live) products(std::true_type{}, std::integral_constant<int, 2>{});
+        else if (any_live) products(std::false_type{}, std::integral_constant<int, BW>{});
         XS();
         // float64 flush: the fp32 rounding chain never exceeds one stage (3*KS MFMA accumulations)
-        if (any_live) {
+        if (two_live) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc64[b][r] += (double)acc[b][r];
+        } else if (any_live) {
 #pragma unroll
             for (int b = 0; b < BW; ++b)
 #pragma unroll
