@@ -76,6 +76,7 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
     // and a wave owns 2 blocks instead of 3 (no idle block slots: 64 = 4 x 8 x 2).
     constexpr bool QUAD = xty_quad<C, TWO>();
     constexpr bool BAL = XTY_BAL && !TWO && C == 256;     // (two workgroup types, 36 blocks)
+    constexpr bool BAL2 = XTY_BAL && TWO && C == 128;
     constexpr int BW = QUAD ? 2 : BW_PLAIN;           // 32x32 blocks per wave
     constexpr int CS = QUAD ? C / 2 : C;              // channels of an operand that this workgroup stages
     constexpr int C4 = CS / 4;
@@ -134,6 +135,10 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
                 L = type * (NBLK / 2) + (wave < 2 ? wave * 3 : 6 + (wave - 2) * 2) + b;
                 live[b] = b < (wave < 2 ? 3 : 2);
             }
+            if (BAL2) {       // two operands at C = 128: 16 blocks as 2 per wave instead of 3, 3, 3, 3, 3, 1, 0, 0 (one workgroup type)
+                L = wave * 2 + b;
+                live[b] = b < 2;
+            }
             if (!live[b]) L = 0;
             if (TWO) { ib[b] = L / NB; jb[b] = L % NB; }
             else { int i = 0; while (L >= NB - i) { L -= NB - i; ++i; } ib[b] = i; jb[b] = i + L; }
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
 #pragma unroll
     for (int b = 0; b < BW; ++b) { all_ = all_ && live[b]; any_ = any_ || live[b]; }
     const bool all_live = XTY_ALLLIVE && (QUAD || __builtin_amdgcn_readfirstlane(all_ ? 1 : 0) != 0);
-    const bool two_live = BAL && __builtin_amdgcn_readfirstlane((live[0] && live[1] && !live[BW - 1]) ? 1 : 0) != 0;   // blocks 0, 1 only      // wave-uniform by construction (wave index, type)
+    const bool two_live = (BAL || BAL2) && __builtin_amdgcn_readfirstlane((live[0] && live[1] && !live[BW - 1]) ? 1 : 0) != 0;   // blocks 0, 1 only      // wave-uniform by construction (wave index, type)
     const bool any_live = QUAD || __builtin_amdgcn_readfirstlane(any_ ? 1 : 0) != 0;
 
     // staging: thread -> operand op, float4 column c4, 8-row group rgrp
