@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define WC_ABI_VERSION 3
+#define WC_ABI_VERSION 4
 
 #define WC_OK                 0
 #define WC_ERR_NULL          -1   /* a required pointer is NULL                     */
@@ -131,6 +131,40 @@ int wc_apply_act_f32(const float* x, const float* mu, const float* A, const floa
                      const int32_t* slot, int64_t N, int64_t HW, int C, int Kc, int relu,
                      float* y, const void* plan /*from wc_color_f32, nullable*/,
                      void* ws, size_t ws_bytes, wc_stream_t stream);
+
+/* ---- Pre-split activations (ABI 4, additive) -------------------------------------------------------------------------
+ * The fp16 MFMA paths of this library compute with x = hi + lo (two fp16 terms, three products).  A tensor that several
+ * stages read (K1, K3, K4, K6 all read the site's input x: generator.py:83-87 `stack` and its gradient) is converted by
+ * each of them; the PRODUCER can hand it over already split instead -- the same 4 bytes per element:
+ *     x[m][c] ~= center[c] + (hi[m][c] + lo[m][c]) / scale[c],   hi = fp16(g), lo = fp16(g - hi), g = (x - center) scale
+ * `xs` = 2*M*C halves: the hi plane [M][C], then the lo plane [M][C].  scale[c]: a power of two that puts the channel's
+ * sampled maximum into [8, 16] (>= 3700 x of headroom below fp16's range); center[c]: any value near the channel mean
+ * (NULL = 0).  An element beyond +-60000 after scaling is clamped and sets *flag (device int, nullable) to 1. */
+size_t wc_split_bytes(int64_t M, int C);
+/* center, scale from <= 256 sampled rows of x (outlier-proof, as K1's own shift / scales); zeroes flag[0..63]. */
+int wc_split_scales_f32(const float* x, int64_t M, int C, float* center /*[C] out*/, float* scale /*[C] out*/,
+                        int* flag /*[64] out: zeroed*/, wc_stream_t stream);
+/* x (M, C) fp32 -> xs; relu != 0 clamps at zero first (NaN stays NaN). */
+int wc_split_f32(const float* x, const float* center /*nullable*/, const float* scale, int64_t M, int C, int relu,
+                 void* xs /*out*/, int* flag /*nullable*/, wc_stream_t stream);
+int wc_unsplit_f32(const void* xs, const float* center /*nullable*/, const float* scale, int64_t M, int C, float* x /*out*/,
+                   wc_stream_t stream);
+
+/* K3 on a pre-split input:  y[n] = (x[n] - mu) A[slot[n]] + bias[slot[n]]  with x given as (xs, xs_center, xs_scale).
+ * The staging is pure LDS-DMA into the fp16 image the MFMAs read (no conversion in the kernel).  `plan` = the tables
+ * wc_color_f32 builds when it is given chan_scale = xs_scale (NULL: built here, in ws).  C in {128, 256} and N*HW a multiple
+ * of 8192/C rows (wc_apply_split_supported; WC_ERR_SHAPE otherwise: convert with wc_unsplit_f32 and call wc_apply_f32).
+ * relu as in wc_apply_act_f32.  Replaces the same reference call site as wc_apply_f32 (generator.py:83-87). */
+/* bias_eff[k] = bias[k] + (xs_center - mu) A[k]  ([Kc, C]; bias, xs_center, mu nullable = 0): the additive term of the split
+ * apply.  A caller that passes bias = bias_eff with mu = xs_center = NULL to wc_apply_split_f16x2 gets a single launch. */
+int    wc_split_bias_f32(const float* A /*[Kc,C,C]*/, const float* bias, const float* xs_center, const float* mu, int Kc, int C,
+                         float* bias_eff /*[Kc,C] out*/, wc_stream_t stream);
+int    wc_apply_split_supported(int64_t N, int64_t HW, int C);
+size_t wc_apply_split_workspace_bytes(int C, int Kc);
+int wc_apply_split_f16x2(const void* xs, const float* xs_center /*nullable*/, const float* xs_scale,
+                         const float* mu /*nullable*/, const float* A, const float* bias /*nullable*/,
+                         const int32_t* slot, int64_t N, int64_t HW, int C, int Kc, int relu,
+                         float* y, const void* plan /*nullable*/, void* ws, size_t ws_bytes, wc_stream_t stream);
 
 /* K4: R[k] = sum_{n: slot[n]=k} (x[n]-mu)^T gy[n]  (Kc,C,C),  gsum[k] = sum_{n in k} rows of gy[n]  (Kc,C). */
 int wc_bwd_reduce_f32(const float* x, const float* mu, const float* gy, const int32_t* slot,

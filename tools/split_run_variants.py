@@ -1,0 +1,51 @@
+"""Development: times wc_apply_split_f16x2 at the headline site (or N H C from argv) with every library under csrc/build/var/;
+stamp builds (-DWC_SPLIT_STAMPS=1) also print where a wave's time went."""
+import glob, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+child = r'''
+import sys, ctypes, torch
+sys.path.insert(0, %r)
+from wc_gan_amd import _lib
+_lib.LIB_PATH = sys.argv[1]
+from wc_gan_amd import ops
+N, H, C = (int(v) for v in sys.argv[2:5])
+M = N * H * H
+g = torch.Generator(device='cpu'); g.manual_seed(1234)
+x = torch.randn(N, H, H, C, generator=g).cuda(); gamma = (torch.randn(1, C, C, generator=g) / 16).cuda()
+b = torch.zeros(1, C).cuda(); y = torch.empty_like(x)
+s, xtx = ops.stats(x.view(M, C))
+mu, L, W, cs = ops.factor(s, xtx, M, C, 1e-3, 0.99, 1, True, None, None, x.device, want_scale=True)
+xs = ops.split(x)
+A, At, plan = ops.color(W, gamma, xs.scale)
+yref = ops.apply(x, mu, A, b, None, fast=False)
+be = ops.split_bias(A, b, xs, mu)
+lib = _lib.load()
+dbg = torch.zeros(256 * 8 * 8, dtype=torch.int64, device='cuda')
+stamps = "STAMPS" in sys.argv[1]
+if stamps:
+    lib.wc_dev_split_dbg.argtypes = [ctypes.c_void_p]; lib.wc_dev_split_dbg(dbg.data_ptr())
+for _ in range(5): ops.apply_split(xs, None, A, be, None, plan=plan, out=y, folded=True)
+err = ((y - yref).abs().max() / yref.abs().max()).item()
+ts = []
+for rep in range(5):
+    torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): ops.apply_split(xs, None, A, be, None, plan=plan, out=y, folded=True)
+    e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) / 20 * 1e3)
+print("apply us: " + " ".join("%%.1f" %% t for t in sorted(ts)) + "   max err vs exact %%.2e" %% err)
+if stamps:
+    d = dbg.view(256, 8, 8).cpu().double()
+    t0 = d[..., 4].min()
+    print("  timeline (us from the first workgroup's start): last start %%.2f | loop starts %%.2f .. %%.2f | ends %%.2f .. %%.2f" %% (
+        (d[..., 4].max() - t0) / 100, (d[..., 5].min() - t0) / 100, (d[..., 5].max() - t0) / 100, (d[..., 6].min() - t0) / 100, (d[..., 6].max() - t0) / 100))
+    ends = (d[..., 6].amax(dim=1) - t0) / 100
+    print("  workgroup end times, sorted deciles:", " ".join("%%.1f" %% v for v in ends.sort().values[::26].tolist()))
+    w, l, st, tot = d[..., 0], d[..., 1], d[..., 2], d[..., 3]
+    f = lambda t: "mean %%.0f min %%.0f max %%.0f" %% (t.mean(), t.min(), t.max())
+    print("  per wave, whole tile loop (s_memtime ticks): wait+dma-issue", f(w), "| k-loop", f(l), "| stores", f(st), "| total", f(tot))
+    print("  waves 0-3 total", f(tot[:, :4]), "| waves 4-7 total", f(tot[:, 4:]))
+''' % ROOT
+shape = sys.argv[1:4] if len(sys.argv) > 3 else ["128", "32", "256"]
+for lib in sorted(glob.glob(os.path.join(ROOT, "wc_gan_amd", "csrc", "build", "var", "lib_*.so"))):
+    r = subprocess.run([sys.executable, "-c", child, lib] + shape, capture_output=True, text=True, timeout=300)
+    print(os.path.basename(lib), r.stdout.strip() or r.stderr.strip()[-600:], flush=True)

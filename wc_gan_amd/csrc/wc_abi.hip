@@ -230,6 +230,96 @@ int wc_apply_act_f32(const float* x, const float* mu, const float* A, const floa
 }
 
 // ---------------------------------------------------------------------------------------------
+// pre-split activations (ABI 4)
+size_t wc_split_bytes(int64_t M, int C)
+{
+    if (M <= 0 || bad_channels(C)) return 0;
+    return (size_t)M * C * 4;          // two fp16 planes: the bytes of the fp32 tensor
+}
+
+int wc_split_scales_f32(const float* x, int64_t M, int C, float* center, float* scale, int* flag, wc_stream_t stream)
+{
+    if (!x || !center || !scale || !flag) return WC_ERR_NULL;
+    if (M <= 0) return WC_ERR_SHAPE;
+    if (bad_channels(C)) return WC_ERR_CHANNELS;
+    WC_TRY(wc_launch_subsample_mean_scale(x, M, C, center, scale, flag, static_cast<hipStream_t>(stream)));
+    return WC_OK;
+}
+
+int wc_split_f32(const float* x, const float* center, const float* scale, int64_t M, int C, int relu, void* xs, int* flag,
+                 wc_stream_t stream)
+{
+    if (!x || !scale || !xs) return WC_ERR_NULL;
+    if (relu != 0 && relu != 1) return WC_ERR_ARG;
+    if (M <= 0) return WC_ERR_SHAPE;
+    if (bad_channels(C)) return WC_ERR_CHANNELS;
+    WC_TRY(wc_launch_split_rows(x, center, scale, M, C, relu, xs, flag, static_cast<hipStream_t>(stream)));
+    return WC_OK;
+}
+
+int wc_unsplit_f32(const void* xs, const float* center, const float* scale, int64_t M, int C, float* x, wc_stream_t stream)
+{
+    if (!x || !scale || !xs) return WC_ERR_NULL;
+    if (M <= 0) return WC_ERR_SHAPE;
+    if (bad_channels(C)) return WC_ERR_CHANNELS;
+    WC_TRY(wc_launch_unsplit_rows(xs, center, scale, M, C, x, static_cast<hipStream_t>(stream)));
+    return WC_OK;
+}
+
+size_t wc_apply_split_workspace_bytes(int C, int Kc)
+{
+    if (Kc <= 0 || bad_channels(C)) return 0;
+    return slot_bytes((size_t)Kc * C, 4) + wc_fast_affine_workspace(C, Kc);      // bias2 | a plan (when the caller has none)
+}
+
+int wc_split_bias_f32(const float* A, const float* bias, const float* xs_center, const float* mu, int Kc, int C, float* bias_eff,
+                      wc_stream_t stream)
+{
+    if (!A || !bias_eff) return WC_ERR_NULL;
+    if (Kc <= 0) return WC_ERR_SHAPE;
+    if (bad_channels(C)) return WC_ERR_CHANNELS;
+    WC_TRY(wc_launch_split_bias(A, bias, xs_center, mu, Kc, C, bias_eff, static_cast<hipStream_t>(stream)));
+    return WC_OK;
+}
+
+int wc_apply_split_supported(int64_t N, int64_t HW, int C)
+{
+    return (N > 0 && HW > 0 && wc_split_apply_supported(N, HW, C)) ? 1 : 0;
+}
+
+int wc_apply_split_f16x2(const void* xs, const float* xs_center, const float* xs_scale, const float* mu, const float* A,
+                         const float* bias, const int32_t* slot, int64_t N, int64_t HW, int C, int Kc, int relu,
+                         float* y, const void* plan, void* ws, size_t ws_bytes, wc_stream_t stream)
+{
+    if (!xs || !xs_scale || !A || !y || !ws) return WC_ERR_NULL;
+    if (relu != 0 && relu != 1) return WC_ERR_ARG;
+    if (N <= 0 || HW <= 0 || Kc <= 0) return WC_ERR_SHAPE;
+    if (bad_channels(C)) return WC_ERR_CHANNELS;
+    if (!wc_split_apply_supported(N, HW, C)) return WC_ERR_SHAPE;
+    const size_t need = slot_bytes((size_t)Kc * C, 4) + (plan ? 0 : wc_fast_affine_workspace(C, Kc));
+    if (ws_bytes < need) return WC_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Carver cv(ws, ws_bytes);
+    float* bias2 = cv.take<float>((size_t)Kc * C);
+    if (!plan) {
+        void* own = cv.take<char>(wc_fast_affine_workspace(C, Kc));
+        WC_TRY(wc_launch_fast_plan_tables(A, Kc, C, own, st, xs_scale));
+        plan = own;
+    }
+    const float *pscale, *pcol; const void *phi, *plo;
+    wc_fast_plan_parts(plan, C, Kc, &pscale, &pcol, &phi, &plo);
+    // the kernel's additive term is beta + (center - mu) A; a caller that has folded it already (wc_split_bias_f32) passes it
+    // as `bias` with mu = xs_center = NULL, and the call is ONE launch
+    const float* eff = bias;
+    if (xs_center || mu || !bias) {
+        WC_TRY(wc_launch_split_bias(A, bias, xs_center, mu, Kc, C, bias2, st));
+        eff = bias2;
+    }
+    WC_TRY(wc_launch_apply_split(xs, xs_scale, A, Kc, eff, slot, N, HW, C, relu, y, phi, plo, pcol, nullptr, st));
+    return WC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 size_t wc_bwd_reduce_workspace_bytes(int64_t N, int64_t HW, int C, int Kc, int has_slot)
 {
     (void)Kc;

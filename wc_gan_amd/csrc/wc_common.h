@@ -143,6 +143,19 @@ hipError_t wc_launch_channel_scale(const float* in, const float* center, int64_t
 hipError_t wc_launch_channel_scale2(const float* in, const float* center, float* scale, const float* in2, const float* center2,
                                     float* scale2, int64_t M, int C, int* gate, hipStream_t st);
 
+void wc_fast_plan_parts(const void* plan, int C, int Kc, const float** scale, const float** colscale, const void** hi, const void** lo);
+
+// ----- pre-split activations (wc_split.hip) ---------------------------------------------------
+bool wc_split_apply_supported(int64_t N, int64_t HW, int C);
+hipError_t wc_launch_split_rows(const float* x, const float* center, const float* scale, int64_t M, int C, int relu,
+                                void* xs, int* flag, hipStream_t st);
+hipError_t wc_launch_unsplit_rows(const void* xs, const float* center, const float* scale, int64_t M, int C, float* x, hipStream_t st);
+hipError_t wc_launch_split_bias(const float* A, const float* bias, const float* center, const float* mu, int Kc, int C,
+                                float* out, hipStream_t st);
+hipError_t wc_launch_apply_split(const void* xs, const float* xs_scale, const float* A, int Kc, const float* bias2,
+                                 const int32_t* slot, int64_t N, int64_t HW, int C, int relu, float* y,
+                                 const void* plan_hi, const void* plan_lo, const float* plan_colscale, void* dbg, hipStream_t st);
+
 // ----- small-matrix stage (wc_small.hip) -----------------------------------------------------
 
 // K1 tail: shifted fp32 partials -> raw float64 moments

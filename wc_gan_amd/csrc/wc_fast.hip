@@ -1469,6 +1469,13 @@ hipError_t wc_launch_fast_plan_tables2(const float* B0, int Kc0, void* plan0, co
 
 float* wc_fast_plan_scale(void* plan) { return reinterpret_cast<float*>(plan); }
 
+// the parts of a plan, for the kernels of other translation units that read the same tables (wc_split.hip)
+void wc_fast_plan_parts(const void* plan, int C, int Kc, const float** scale, const float** colscale, const void** hi, const void** lo)
+{
+    const PlanView v = plan_view(const_cast<void*>(plan), C, Kc);
+    *scale = v.scale; *colscale = v.colscale; *hi = v.hi; *lo = v.lo;
+}
+
 // The main kernel alone, on a prepared plan.  B is still needed: tiles outside the fp16 range are recomputed from it.
 hipError_t wc_launch_fast_affine_planned(const float* in, const float* center, const float* B, int Kc, bool shared_table,
                                          const float* bias, const float* sub, const int32_t* slot,

@@ -143,6 +143,99 @@ def apply(x, mu, A, bias, slot, out=None, fast=True, plan=None, relu=False):
     return y
 
 
+class SplitTensor:
+    """An activation in the pre-split format of include/wc_hip.h (ABI 4): `planes` (2, M, C) float16 = hi | lo,
+    x ~= center + (hi + lo) / scale.  `shape` is the NHWC shape of the tensor it stands for; `flag` (64,) int32: [0] != 0
+    after a split that had to clamp (scales off by more than three decades)."""
+
+    __slots__ = ("planes", "center", "scale", "flag", "shape")
+
+    def __init__(self, planes, center, scale, flag, shape):
+        self.planes, self.center, self.scale, self.flag, self.shape = planes, center, scale, flag, tuple(shape)
+
+    @property
+    def C(self):
+        return self.shape[-1]
+
+    @property
+    def M(self):
+        return self.planes.shape[1]
+
+
+def split_scales(x):
+    """-> (center (C,), scale (C,), flag (64,) int32 zeroed): sampled per-channel centre and power-of-two scale of x (..., C)."""
+    lib = _lib.load()
+    _need(x, torch.float32, "x")
+    C = x.shape[-1]
+    M = x.numel() // C
+    center = torch.empty(C, dtype=torch.float32, device=x.device)
+    scale = torch.empty(C, dtype=torch.float32, device=x.device)
+    flag = torch.empty(64, dtype=torch.int32, device=x.device)
+    _lib.check(lib.wc_split_scales_f32(_ptr(x), M, C, _ptr(center), _ptr(scale), _ptr(flag), _stream()), "wc_split_scales_f32")
+    return center, scale, flag
+
+
+def split(x, center=None, scale=None, flag=None, relu=False):
+    """x (N, ..., C) float32 -> SplitTensor (scales sampled from x when not given)."""
+    lib = _lib.load()
+    _need(x, torch.float32, "x")
+    C = x.shape[-1]
+    M = x.numel() // C
+    if scale is None:
+        center, scale, flag = split_scales(x)
+    planes = torch.empty(2, M, C, dtype=torch.float16, device=x.device)
+    _lib.check(lib.wc_split_f32(_ptr(x), _ptr(center), _ptr(scale), M, C, 1 if relu else 0, _ptr(planes), _ptr(flag), _stream()),
+               "wc_split_f32")
+    return SplitTensor(planes, center, scale, flag, x.shape)
+
+
+def unsplit(xs):
+    """SplitTensor -> float32 tensor of xs.shape."""
+    lib = _lib.load()
+    x = torch.empty(xs.shape, dtype=torch.float32, device=xs.planes.device)
+    _lib.check(lib.wc_unsplit_f32(_ptr(xs.planes), _ptr(xs.center), _ptr(xs.scale), xs.M, xs.C, _ptr(x), _stream()), "wc_unsplit_f32")
+    return x
+
+
+def apply_split_supported(shape):
+    lib = _lib.load()
+    N, C = shape[0], shape[-1]
+    HW = 1
+    for d in shape[1:-1]:
+        HW *= d
+    return bool(lib.wc_apply_split_supported(N, HW, C))
+
+
+def split_bias(A, bias, xs, mu):
+    """bias_eff (Kc, C) = bias + (xs.center - mu) A: the split apply's additive term, folded once per forward."""
+    lib = _lib.load()
+    Kc, C = A.shape[0], A.shape[-1]
+    out = torch.empty(Kc, C, dtype=torch.float32, device=A.device)
+    _lib.check(lib.wc_split_bias_f32(_ptr(A), _ptr(bias), _ptr(xs.center), _ptr(mu), Kc, C, _ptr(out), _stream()), "wc_split_bias_f32")
+    return out
+
+
+def apply_split(xs, mu, A, bias, slot, plan=None, relu=False, out=None, folded=False):
+    """K3 on a pre-split input: y[n] = (x[n] - mu) A[slot[n]] + bias[slot[n]].  `plan` must come from color(W, gamma,
+    chan_scale=xs.scale) (None: the tables are built inside the call).  folded=True: `bias` is split_bias(...)'s result
+    (mu is ignored) and the call is a single launch."""
+    lib = _lib.load()
+    N, C = xs.shape[0], xs.shape[-1]
+    HW = xs.M // N
+    Kc = A.shape[0]
+    if bias is not None:
+        _need(bias, torch.float32, "bias", 2)
+    if slot is not None:
+        _need(slot, torch.int32, "slot", 1)
+    y = torch.empty(xs.shape, dtype=torch.float32, device=xs.planes.device) if out is None else out
+    ws = _workspace(lib.wc_apply_split_workspace_bytes(C, Kc), y.device)
+    _lib.check(lib.wc_apply_split_f16x2(_ptr(xs.planes), None if folded else _ptr(xs.center), _ptr(xs.scale), None if folded else _ptr(mu),
+                                        _ptr(A), _ptr(bias), _ptr(slot),
+                                        N, HW, C, Kc, 1 if relu else 0, _ptr(y), _ptr(plan), _ptr(ws), ws.numel(), _stream()),
+               "wc_apply_split_f16x2")
+    return y
+
+
 def bwd_reduce(x, mu, gy, slot, Kc, flat=False, want_scales=False, relu_y=None):
     """K4: -> (R (Kc,C,C) f64, gsum (Kc,C) f64); flat=True: views of one buffer, returned third (sync-WC's single all-reduce);
     want_scales=True: the (2C,) per-channel input scales of (x - mu) and gy, returned last, for bwd_apply(scales=...);
