@@ -150,6 +150,15 @@ int wc_split_f32(const float* x, const float* center /*nullable*/, const float* 
 int wc_unsplit_f32(const void* xs, const float* center /*nullable*/, const float* scale, int64_t M, int C, float* x /*out*/,
                    wc_stream_t stream);
 
+/* K1 on a pre-split input: the raw moments of wc_stats_f32 (same outputs, same meaning of `groups`) of the tensor the planes
+ * stand for.  No conversion in the kernel: LDS-DMA staging, transposing LDS reads (ds_read_b64_tr_b16) for the [channel][row]
+ * MFMA operands.  C in {128, 256}, rows per group a multiple of 64 and N*HW >= 16384 (wc_stats_split_supported; WC_ERR_SHAPE
+ * otherwise: convert with wc_unsplit_f32 and call wc_stats_f32).  Replaces the same reference call site as wc_stats_f32. */
+int    wc_stats_split_supported(int64_t M, int C, int groups);
+size_t wc_stats_split_workspace_bytes(int64_t M, int C, int groups);
+int wc_stats_split_f16x2(const void* xs, const float* xs_center, const float* xs_scale, int64_t M, int C, int groups,
+                         double* sum /*[groups,C]*/, double* xtx /*[groups,C,C]*/, void* ws, size_t ws_bytes, wc_stream_t stream);
+
 /* K3 on a pre-split input:  y[n] = (x[n] - mu) A[slot[n]] + bias[slot[n]]  with x given as (xs, xs_center, xs_scale).
  * The staging is pure LDS-DMA into the fp16 image the MFMAs read (no conversion in the kernel).  `plan` = the tables
  * wc_color_f32 builds when it is given chan_scale = xs_scale (NULL: built here, in ws).  C in {128, 256} and N*HW a multiple

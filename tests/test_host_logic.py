@@ -198,6 +198,18 @@ def test_supports_statistic_groups_and_refusals():
     layer = DecorelationNormalization(name='r', renorm=True, channels=32)
     with statistic_groups(2), pytest.raises(RuntimeError):
         layer.transform(torch.zeros(4, 2, 2, 32))
+    # sync-WC: the grouped forward has no collective, so a layer with a process group refuses it (its critic-phase fakes would
+    # be whitened with per-replica statistics and the replicas' moving statistics would drift apart) and the trainer falls
+    # back to separate passes
+    sync = DecorelationNormalization(name='s', channels=32, process_group=object())
+    with statistic_groups(2), pytest.raises(RuntimeError, match="sync-WC"):
+        sync.transform(torch.zeros(4, 2, 2, 32))
+    G_s = make_generator(**CONFIGS['cifar10_uncond']['generator'])
+    for m in G_s.modules():
+        if isinstance(m, DecorelationNormalization):
+            m.process_group = object()
+            m.channels = 256
+    assert not supports_statistic_groups(G_s)
     # the setting is per host thread
     import threading
     seen = []

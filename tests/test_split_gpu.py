@@ -129,3 +129,56 @@ def test_forward_through_split_meets_the_contract(ops, shape, Kc, kind):
     e = rel(y.cpu().numpy(), y_ref)
     print(shape, Kc, kind, e)
     assert e < 1e-4
+
+
+# ---- K1 on the planes (wc_split_xty.hip) ------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape,groups", [((16, 32, 32, 256), 1), ((128, 32, 32, 256), 1), ((32, 32, 32, 128), 1), ((128, 32, 32, 128), 1),
+                                          ((128, 16, 16, 256), 1), ((320, 32, 32, 256), 5), ((320, 16, 16, 256), 5), ((128, 48, 48, 256), 1)])
+def test_stats_split_matches_float64(ops, shape, groups):
+    """Kernel level: the moments of the value the planes hold exactly, in float64 on the host (covariance to 1e-7, as
+    wc_stats_f32's fast path), exact symmetry, and -- end to end -- the covariance of the fp32 input to 1e-6."""
+    from oracle import wc_oracle as o
+    rng = np.random.default_rng(31)
+    C = shape[-1]
+    x = o.synth_activation(rng, shape, "ill").astype(np.float32)
+    xs = ops.split(dev(x))
+    M = xs.M
+    assert ops.stats_split_supported(M, C, groups)
+    s, xtx = ops.stats_split(xs, groups)
+    V = _planes64(xs).reshape(groups, M // groups, C)
+    sn, xn = s.cpu().numpy().reshape(groups, C), xtx.cpu().numpy().reshape(groups, C, C)
+    for g in range(groups):
+        s_ref, xtx_ref, Mg = o.batch_moments(V[g])
+        _, cov_ref = o.moments_to_stats(s_ref, xtx_ref, Mg)
+        _, cov = o.moments_to_stats(sn[g], xn[g], Mg)
+        assert rel(sn[g], s_ref) < 1e-5
+        e = rel(cov, cov_ref)
+        print(shape, groups, g, "cov rel err", e)
+        assert e < 1e-7, e
+        assert np.abs(xn[g] - xn[g].T).max() == 0.0
+        # against the covariance of the fp32 tensor itself: the split's 2^-22 perturbation of x
+        X = x.reshape(groups, M // groups, C)[g].astype(np.float64)
+        s0, x0, _ = o.batch_moments(X)
+        _, cov0 = o.moments_to_stats(s0, x0, Mg)
+        assert rel(cov, cov0) < 1e-6
+
+
+def test_forward_site_on_planes_meets_the_contract(ops):
+    """K1 (planes) -> K2 -> color -> K3 (planes) at the headline site against the oracle's forward of the fp32 input."""
+    from oracle import wc_oracle as o
+    rng = np.random.default_rng(6)
+    shape, Kc = (128, 32, 32, 256), 1
+    C, M = 256, 128 * 32 * 32
+    x = o.synth_activation(rng, shape, "ill").astype(np.float32)
+    G, B = o.synth_coloring(rng, C, Kc)
+    G = G.astype(np.float32); B = B.astype(np.float32)
+    xs = ops.split(dev(x))
+    s, xtx = ops.stats_split(xs)
+    mu, L, W, cs = ops.factor(s, xtx, M, C, 1e-3, 0.99, 1, True, None, None, xs.planes.device, want_scale=True)
+    A, At, plan = ops.color(W, dev(G), xs.scale)
+    be = ops.split_bias(A, dev(B), xs, mu)
+    y = ops.apply_split(xs, None, A, be, None, plan=plan, folded=True)
+    y_ref, _ = o.wc_forward(x, G, B, np.zeros(128, np.int32))
+    e = rel(y.cpu().numpy(), y_ref)
+    print("forward on planes", e)
+    assert e < 1e-4

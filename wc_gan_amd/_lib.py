@@ -55,6 +55,9 @@ SIGNATURES = {
     "wc_split_scales_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wc_split_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "wc_unsplit_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "wc_stats_split_supported": (c_int, [c_int64, c_int, c_int]),
+    "wc_stats_split_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "wc_stats_split_f16x2": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wc_split_bias_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "wc_apply_split_supported": (c_int, [c_int64, c_int64, c_int]),
     "wc_apply_split_workspace_bytes": (c_size_t, [c_int, c_int]),

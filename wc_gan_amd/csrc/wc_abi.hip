@@ -266,6 +266,48 @@ int wc_unsplit_f32(const void* xs, const float* center, const float* scale, int6
     return WC_OK;
 }
 
+// K1 on a pre-split input
+int wc_stats_split_supported(int64_t M, int C, int groups)
+{
+    if (M <= 0 || groups <= 0 || (M % groups) != 0 || bad_channels(C)) return 0;
+    int nsplit, ntypes; int64_t rps;
+    return wc_split_xtx_plan(groups, M / groups, C, groups > 1, &nsplit, &rps, &ntypes) > 0 ? 1 : 0;
+}
+
+size_t wc_stats_split_workspace_bytes(int64_t M, int C, int groups)
+{
+    if (!wc_stats_split_supported(M, C, groups)) return 0;
+    int nsplit, ntypes; int64_t rps;
+    const int nslab = wc_split_xtx_plan(groups, M / groups, C, groups > 1, &nsplit, &rps, &ntypes);
+    return 256 + slot_bytes((size_t)groups * C, 8) + slot_bytes((size_t)nslab * C, 4) + slot_bytes((size_t)nslab * C, 8) +
+           slot_bytes((size_t)nslab * C * C, 8);
+}
+
+int wc_stats_split_f16x2(const void* xs, const float* xs_center, const float* xs_scale, int64_t M, int C, int groups,
+                         double* sum, double* xtx, void* ws, size_t ws_bytes, wc_stream_t stream)
+{
+    if (!xs || !xs_center || !xs_scale || !sum || !xtx || !ws) return WC_ERR_NULL;
+    if (M <= 0 || groups <= 0 || (M % groups) != 0) return WC_ERR_SHAPE;
+    if (bad_channels(C)) return WC_ERR_CHANNELS;
+    if (!wc_stats_split_supported(M, C, groups)) return WC_ERR_SHAPE;
+    if (ws_bytes < wc_stats_split_workspace_bytes(M, C, groups)) return WC_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int per_seg = groups > 1;
+    const int64_t Ns = groups, HWs = M / groups;
+    int nsplit, ntypes; int64_t rps;
+    const int nslab = wc_split_xtx_plan(Ns, HWs, C, per_seg, &nsplit, &rps, &ntypes);
+    Carver cv(ws, ws_bytes);
+    (void)cv.take<int>(64);
+    double* Sp = cv.take<double>((size_t)groups * C);
+    float* colsum = cv.take<float>((size_t)nslab * C);
+    double* dfix = cv.take<double>((size_t)nslab * C);
+    double* P = cv.take<double>((size_t)nslab * C * C);
+    WC_TRY(wc_launch_split_xtx(xs, xs_scale, Ns, HWs, C, per_seg, nsplit, rps, nslab, ntypes, P, colsum, dfix, st));
+    // the planes hold g = (x - center) scale: the tail adds the centre's terms back (it is the "shift" of wc_stats_f32's tail)
+    WC_TRY(wc_launch_stats_finalize(P, colsum, xs_center, nslab / groups, HWs, C, groups, Sp, sum, xtx, dfix, nullptr, st));
+    return WC_OK;
+}
+
 size_t wc_apply_split_workspace_bytes(int C, int Kc)
 {
     if (Kc <= 0 || bad_channels(C)) return 0;

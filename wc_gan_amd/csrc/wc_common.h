@@ -156,6 +156,10 @@ hipError_t wc_launch_apply_split(const void* xs, const float* xs_scale, const fl
                                  const int32_t* slot, int64_t N, int64_t HW, int C, int relu, float* y,
                                  const void* plan_hi, const void* plan_lo, const float* plan_colscale, void* dbg, hipStream_t st);
 
+int wc_split_xtx_plan(int64_t N, int64_t HW, int C, int per_sample, int* nsplit, int64_t* rows_per_slab, int* ntypes);      // wc_split_xty.hip
+hipError_t wc_launch_split_xtx(const void* xs, const float* scale, int64_t N, int64_t HW, int C, int per_sample, int nsplit,
+                               int64_t rows_per_slab, int nslab, int ntypes, double* P, float* colsum, double* dfix, hipStream_t st);
+
 // ----- small-matrix stage (wc_small.hip) -----------------------------------------------------
 
 // K1 tail: shifted fp32 partials -> raw float64 moments

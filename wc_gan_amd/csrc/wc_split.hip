@@ -54,6 +54,9 @@
 #ifndef WC_SPLIT_POLL_SLEEP
 #define WC_SPLIT_POLL_SLEEP 1
 #endif
+#ifndef WC_SPLIT_DEFER
+#define WC_SPLIT_DEFER 0        // 1: a tile's stores ride in the next tile's MFMA gaps; 0: they follow the tile's own loop
+#endif
 #ifndef WC_SPLIT_ABL
 #define WC_SPLIT_ABL 0       // development ablation bits: 1 no stores, 2 no MFMA, 4 linear (unswizzled) DMA source
 #endif
@@ -447,6 +450,15 @@ __global__ __launch_bounds__(512, 1) void apply_split_kernel(SplitApplyArgs a)
             else if (dma) tile_body(t, P0{}, T_{}, F_{}, F_{}, F_{});
             else tile_body(t, P0{}, F_{}, F_{}, F_{}, F_{});
         }
+#if !WC_SPLIT_DEFER
+        // D0, table, D1, D2 | tile 0: D3, S0 | tile 1: D4, S1 | ... : 8, 20, 36 ... 36, 32
+        else if (t == 0) tile_body(t, P8{}, T_{}, T_{}, F_{}, F_{});
+        else if (t == 1) tile_body(t, P20{}, T_{}, F_{}, F_{}, F_{});
+        else if (dma) tile_body(t, P36{}, T_{}, F_{}, F_{}, F_{});
+        else if (t + 2 < n) tile_body(t, P36{}, F_{}, F_{}, F_{}, F_{});
+        else if (t + 1 < n) tile_body(t, P32{}, F_{}, F_{}, F_{}, F_{});
+        else tile_body(t, N_{}, F_{}, F_{}, F_{}, F_{});
+#else
         else if (t == 0) tile_body(t, P8{}, T_{}, T_{}, F_{}, T_{});
         else if (t == 1) tile_body(t, P4{}, T_{}, F_{}, T_{}, T_{});
         else if (t == 2) tile_body(t, P20{}, T_{}, F_{}, T_{}, T_{});
@@ -454,6 +466,7 @@ __global__ __launch_bounds__(512, 1) void apply_split_kernel(SplitApplyArgs a)
         else if (t + 2 < n) tile_body(t, P36{}, F_{}, F_{}, T_{}, T_{});
         else if (t + 1 < n) tile_body(t, P32{}, F_{}, F_{}, T_{}, T_{});
         else tile_body(t, N_{}, F_{}, F_{}, T_{}, F_{});
+#endif
     }
     if (WC_SPLIT_STAMPS && a.dbg && lane == 0) {
         unsigned long long* d = a.dbg + ((int64_t)blockIdx.x * 8 + wave) * 8;

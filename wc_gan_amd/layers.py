@@ -66,6 +66,8 @@ def supports_statistic_groups(module):
         if isinstance(m, DecorelationNormalization):
             if m.renorm or m.decomposition != 'cholesky' or (m.channels is not None and m.channels % 32 != 0):
                 return False
+            if m.process_group is not None:
+                return False                      # sync-WC: the grouped forward has no collective (per-replica statistics only)
             if m.channels is None:
                 return False                      # not built yet: width unknown
         elif isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)) or type(m).__name__ == '_BatchNormNoAffine':
@@ -149,6 +151,12 @@ class DecorelationNormalization(_Lazy):
         if groups > 1 and (C % 32 != 0 or self.decomposition != 'cholesky' or self.renorm):
             raise RuntimeError(f"{self.layer_name}: statistic_groups({groups}) has no grouped form for this layer "
                                "(zca / renorm / a width that is not a multiple of 32): run separate passes")
+        if groups > 1 and self.process_group is not None:
+            # the grouped forward whitens with per-replica moments and updates the moving statistics from the local batch only:
+            # under sync-WC that would silently differ from g_step's all-reduced statistics and let the replicas' moving
+            # statistics drift apart
+            raise RuntimeError(f"{self.layer_name}: statistic_groups({groups}) has no sync-WC form (process_group is set): "
+                               "run separate passes")
         if C % 32 != 0:
             y = self._padded(x, gamma, beta, slot)
             return F.relu(y) if relu else y

@@ -206,6 +206,32 @@ def apply_split_supported(shape):
     return bool(lib.wc_apply_split_supported(N, HW, C))
 
 
+def stats_split_supported(M, C, groups=1):
+    return bool(_lib.load().wc_stats_split_supported(int(M), int(C), int(groups)))
+
+
+def stats_split(xs, groups=1, flat=False):
+    """K1 on a SplitTensor: as stats(x2d, groups, flat) for the tensor the planes stand for."""
+    lib = _lib.load()
+    M, C = xs.M, xs.C
+    dev = xs.planes.device
+    lead = (groups,) if groups > 1 else ()
+    buf = None
+    if flat and groups == 1:
+        buf = torch.empty(C + C * C, dtype=torch.float64, device=dev)
+        s, xtx = buf[:C], buf[C:].view(C, C)
+    else:
+        s = torch.empty(*lead, C, dtype=torch.float64, device=dev)
+        xtx = torch.empty(*lead, C, C, dtype=torch.float64, device=dev)
+    nb = lib.wc_stats_split_workspace_bytes(M, C, groups)
+    if nb == 0:
+        _lib.check(-2, "wc_stats_split_f16x2")
+    ws = _workspace(nb, dev)
+    _lib.check(lib.wc_stats_split_f16x2(_ptr(xs.planes), _ptr(xs.center), _ptr(xs.scale), M, C, groups, _ptr(s), _ptr(xtx),
+                                        _ptr(ws), ws.numel(), _stream()), "wc_stats_split_f16x2")
+    return (s, xtx, buf) if buf is not None else (s, xtx)
+
+
 def split_bias(A, bias, xs, mu):
     """bias_eff (Kc, C) = bias + (xs.center - mu) A: the split apply's additive term, folded once per forward."""
     lib = _lib.load()
