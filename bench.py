@@ -60,6 +60,7 @@ def parse_args(argv=None):
     ap.add_argument("--training-ratio", type=int, default=TRAINING_RATIO)
     ap.add_argument("--sync-wc", action="store_true", help="all-reduce WC statistics across replicas")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-port", action="store_true", help="also time the C-ABI CPU restatement (oracle/wc_cpu.cpp; ~45 s more)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the whole G+D step as one hipGraph.  The default on one GPU: with ~2000 launches per step the "
                          "eager loop is at the edge of host-bound; the eager step is reported next to it")
@@ -125,7 +126,17 @@ def roofline_apply(dev):
     mu, L, W, cs = ops.factor(s, xtx, M, C, 1e-3, 0.99, 1, True, None, None, dev, want_scale=True)
     A, At, plan = ops.color(W, gamma, cs)
     y = torch.empty_like(x)
-    t = time_kernel(lambda: ops.apply(x, mu, A, b, None, out=y, plan=plan))
+    t_f32 = time_kernel(lambda: ops.apply(x, mu, A, b, None, out=y, plan=plan))
+    # Round 3: the same K3 on the PRE-SPLIT input (include/wc_hip.h ABI 4, wc_apply_split_f16x2): the producer hands x over as
+    # fp16 hi/lo planes -- the bytes of the fp32 tensor -- and the kernel's staging is pure LDS-DMA.  The split itself
+    # (ops.split: the stand-in for a producer epilogue) and the table / bias folding are outside the timed launch, as the
+    # statistics and the plan are for the fp32-input kernel above.
+    xs = ops.split(x)
+    A2, At2, plan2 = ops.color(W, gamma, xs.scale)
+    be = ops.split_bias(A2, b, xs, mu)
+    t = time_kernel(lambda: ops.apply_split(xs, None, A2, be, None, plan=plan2, out=y, folded=True))
+    y_f32 = ops.apply(x, mu, A, b, None, plan=plan)
+    split_vs_f32 = float((y - y_f32).abs().max() / y_f32.abs().max())
     alg_bytes = 2 * M * C * 4 + (C * C + C) * 4
     y2 = torch.empty_like(x)
     t_copy = time_kernel(lambda: ops.stream_copy(x, y2))
@@ -133,7 +144,7 @@ def roofline_apply(dev):
     # HBM bytes per launch: NOT measured in this run -- read from the committed PMC passes of the same command
     # (FETCH_SIZE x2 + WRITE_SIZE, collected as MI355X_MICROARCH.md's HBM section prescribes; see the file)
     traffic = src = None
-    for name in ("r2_apply_k3_pmc.json", "r1_apply_k3_pmc.json"):
+    for name in ("r3_apply_k3_pmc.json", "r2_apply_k3_pmc.json", "r1_apply_k3_pmc.json"):
         pmc = os.path.join(ROOT, "profiles", name)
         if os.path.exists(pmc):
             traffic, src = json.load(open(pmc)).get("traffic_bytes_per_launch"), "profiles/" + name
@@ -145,29 +156,51 @@ def roofline_apply(dev):
         A_, _, plan_ = ops.color(W_, gamma, cs_)
         ops.apply(x, mu_, A_, b, None, out=y, plan=plan_)
     t_site = time_kernel(site, iters=10)
+    def site_split():       # the same site on the planes (the producer's split not included: it replaces the producer's fp32 store)
+        s_, xtx_ = ops.stats_split(xs)
+        mu_, _, W_ = ops.factor(s_, xtx_, M, C, 1e-3, 0.99, 1, True, None, None, dev)
+        A_, _, plan_ = ops.color(W_, gamma, xs.scale)
+        be_ = ops.split_bias(A_, b, xs, mu_)
+        ops.apply_split(xs, None, A_, be_, None, plan=plan_, out=y, folded=True)
+    t_site_split = time_kernel(site_split, iters=10)
     # every stage of the site on its own (HIP events, same inputs): the algorithmic bytes of SURVEY section 8d per stage
     gy = torch.randn(N, H, H, C, generator=g).to(dev)
+    y_relu = ops.apply(x, mu, A, b, None, plan=plan, relu=True)
     R, gsum, scales = ops.bwd_reduce(x, mu, gy, None, 1, want_scales=True)
     dg, db, S, gm = ops.bwd_factor(R, gsum, W, L, gamma, A, M, 1e-3, 1, True)
     xb = M * C * 4
     stage = lambda fn, nbytes: (lambda tt: {"us": round(tt * 1e6, 1), "frac_of_peak": round(nbytes / tt / 1e9 / HBM_PEAK_GBS, 3)})(time_kernel(fn, iters=10))
     stages = {
         "K1 wc_stats_f32": stage(lambda: ops.stats(x.view(M, C)), xb),
+        "K1 wc_stats_split_f16x2 (planes)": stage(lambda: ops.stats_split(xs), xb),
         "K2 wc_factor_f64": {"us": round(time_kernel(lambda: ops.factor(s, xtx, M, C, 1e-3, 0.99, 1, True, None, None, dev), iters=10) * 1e6, 1)},
         "color wc_color_f32": {"us": round(time_kernel(lambda: ops.color(W, gamma, cs), iters=10) * 1e6, 1)},
-        "K3 wc_apply_f32": {"us": round(t * 1e6, 1), "frac_of_peak": round(achieved / HBM_PEAK_GBS, 3)},
+        "K3 wc_apply_f32": {"us": round(t_f32 * 1e6, 1), "frac_of_peak": round(alg_bytes / t_f32 / 1e9 / HBM_PEAK_GBS, 3)},
+        "K3 wc_apply_split_f16x2 (planes)": {"us": round(t * 1e6, 1), "frac_of_peak": round(achieved / HBM_PEAK_GBS, 3)},
+        "producer stand-in wc_split_f32": stage(lambda: ops.split(x, xs.center, xs.scale, xs.flag), 2 * xb),
         "K4 wc_bwd_reduce_f32": stage(lambda: ops.bwd_reduce(x, mu, gy, None, 1), 2 * xb),
+        # what the generator runs: every WC site is followed by a ReLU (generator.py:144-151,154), so K4 also reads y and
+        # writes the masked gradient (the un-masked variant under-reported the backward site)
+        "K4 wc_bwd_reduce_relu_f32 (as the generator runs it)": stage(lambda: ops.bwd_reduce(x, mu, gy, None, 1, want_scales=True, relu_y=y_relu), 4 * xb),
         "K5 wc_bwd_factor_f64": {"us": round(time_kernel(lambda: ops.bwd_factor(R, gsum, W, L, gamma, A, M, 1e-3, 1, True), iters=10) * 1e6, 1)},
         "K6 wc_bwd_apply_f32": stage(lambda: ops.bwd_apply(gy, x, mu, At, S, gm, None, scales=scales), 3 * xb),
     }
-    return {"bound": "hbm", "site_stages": stages, "kernel": "affine_ring_kernel<256,false> (wc_apply_f32 with plan, 128x32x32x256 fp32)",
+    copy_gbs = 2 * M * C * 4 / t_copy / 1e9
+    return {"bound": "hbm", "site_stages": stages,
+            "kernel": "apply_split_kernel<256,false> (wc_apply_split_f16x2: K3 on the pre-split planes, 128x32x32x256, output fp32)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_from_committed_profile": src,
             "launch_us": round(t * 1e6, 2), "algorithmic_bytes": alg_bytes,
-            "stream_copy_GBs": round(2 * M * C * 4 / t_copy / 1e9, 1),
-            "frac_of_stream_copy": round(achieved / (2 * M * C * 4 / t_copy / 1e9), 4),
+            "stream_copy_GBs": round(copy_gbs, 1),
+            "frac_of_stream_copy": round(achieved / copy_gbs, 4),
+            "split_vs_fp32_input_rel_diff": split_vs_f32,
+            "fp32_input_kernel": {"kernel": "affine_ring_kernel<256,false> (wc_apply_f32 with plan)", "launch_us": round(t_f32 * 1e6, 2),
+                                  "frac": round(alg_bytes / t_f32 / 1e9 / HBM_PEAK_GBS, 4),
+                                  "frac_of_stream_copy": round(alg_bytes / t_f32 / 1e9 / copy_gbs, 4)},
             "forward_site_us": round(t_site * 1e6, 1),
-            "forward_site_frac_of_peak": round(3 * M * C * 4 / t_site / 1e9 / HBM_PEAK_GBS, 4)}
+            "forward_site_frac_of_peak": round(3 * M * C * 4 / t_site / 1e9 / HBM_PEAK_GBS, 4),
+            "forward_site_on_planes_us": round(t_site_split * 1e6, 1),
+            "forward_site_on_planes_frac_of_peak": round(3 * M * C * 4 / t_site_split / 1e9 / HBM_PEAK_GBS, 4)}
 
 
 def conv_roofline(dev):
@@ -339,6 +372,40 @@ def cpu_port_baseline(ratio, sites, config_name):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+def multi_rank_diagnostics(trainer, eager_step, my_s_per_step, world, group, dev, nsteps):
+    """What the first N > 1 run should say about itself: every rank's own ms per step (min / max over the
+    ranks: a straggler shows), the size of the process group as the backend reports it, and the share of a step spent in the
+    gradient all-reduces -- measured on `nsteps` extra eager steps OUTSIDE the timed region, with events around the
+    collectives (train.AllreduceTimer).  All ranks call this; the numbers are the same on each."""
+    import torch
+    import torch.distributed as dist
+    from wc_gan_amd.train import AllreduceTimer
+    tm = AllreduceTimer()
+    for b in (trainer.g_bucket, trainer.d_bucket):
+        b.timer = tm
+    for _ in range(nsteps):
+        eager_step()
+    if dev is not None:
+        torch.cuda.synchronize()
+    for b in (trainer.g_bucket, trainer.d_bucket):
+        b.timer = None
+    ar_ms = tm.total_ms() / nsteps
+    per_rank = [my_s_per_step * 1e3]
+    ar_all = [ar_ms]
+    seen = 1
+    if group is not None:
+        seen = dist.get_world_size(group)
+        t = torch.tensor([my_s_per_step * 1e3, ar_ms], dtype=torch.float64, device=dev if dev is not None else "cpu")
+        out = [torch.zeros_like(t) for _ in range(seen)]
+        dist.all_gather(out, t, group=group)
+        per_rank = [float(o[0]) for o in out]
+        ar_all = [float(o[1]) for o in out]
+    return {"ranks_seen_by_backend": seen, "ms_per_step_rank_min": round(min(per_rank), 3), "ms_per_step_rank_max": round(max(per_rank), 3),
+            "allreduce_ms_per_step": round(max(ar_all), 3), "allreduce_calls_per_step": tm.calls // max(nsteps, 1),
+            "allreduce_bytes_per_step": int(sum(b.flat.numel() * 4 * n for b, n in ((trainer.d_bucket, trainer.training_ratio), (trainer.g_bucket, 1))
+                                            if b.flat is not None))}
+
+
 def dry_run(args, world, rank):
     """The N-rank path on the CPU: rendezvous over gloo, flat gradient buckets, GanTrainer.step with the all-reduces,
     the cut points capture_segments() would use -- with a tiny model that contains no HIP layer (batch norm + diagonal
@@ -378,6 +445,7 @@ def dry_run(args, world, rank):
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    diag = multi_rank_diagnostics(tr, lambda: tr.step(reals), dt / args.steps, world, group, None, max(1, min(2, args.steps)))
     w = torch.cat([p.detach().reshape(-1) for p in list(G.parameters()) + list(D.parameters())])
     same = True
     orders = [order]
@@ -394,7 +462,8 @@ def dry_run(args, world, rank):
         print(json.dumps({"metric": "images/sec G+D step (dry run: tiny CPU model, not a measurement)", "dry_run": True,
                           "value": round(4.0 * world * args.steps / dt, 2), "unit": "images/sec", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-                          "replicas_identical": bool(same), "allreduce_order": orders, "finite": bool(torch.isfinite(w).all())}),
+                          "replicas_identical": bool(same), "allreduce_order": orders, "finite": bool(torch.isfinite(w).all()),
+                          "config": {"launch": "eager", "launch_fallback": None}, "multi_gpu": diag}),
               flush=True)
     if world > 1:
         dist.barrier()
@@ -468,6 +537,7 @@ def main(argv=None):
     for _ in range(args.warmup):
         step()
     launch_mode = "eager"
+    launch_fallback = None            # why a requested / default graph mode was not used (None: it was)
     in_group = group is not None
     if args.graph and in_group:
         # tried on one GPU with a one-rank group: capturing the RCCL all-reduce aborts the process (SIGABRT inside the
@@ -480,12 +550,14 @@ def main(argv=None):
             replay = trainer.capture_segments(reals, labels)
         except Exception as exc:
             ok = False
-            print(f"[bench] rank {rank}: segment capture failed ({type(exc).__name__}: {exc})", file=sys.stderr)
+            launch_fallback = f"rank {rank}: segment capture failed ({type(exc).__name__}: {str(exc)[:160]})"
+            print(f"[bench] {launch_fallback}", file=sys.stderr)
             torch.cuda.synchronize()
         if all_ok(ok):
             step, launch_mode = replay, "hipgraph-segments"
             step()
         else:
+            launch_fallback = launch_fallback or "segment capture failed on another rank: all ranks run eagerly"
             print("[bench] segment capture did not succeed on every rank: all ranks run eagerly", file=sys.stderr)
     elif args.graph or (world == 1 and not args.eager):
         try:
@@ -493,7 +565,8 @@ def main(argv=None):
             launch_mode = "hipgraph"
             step()
         except Exception as exc:                 # fall back, say so
-            print(f"[bench] graph capture failed ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
+            launch_fallback = f"graph capture failed ({type(exc).__name__}: {str(exc)[:160]})"
+            print(f"[bench] {launch_fallback}; running eagerly", file=sys.stderr)
             torch.cuda.synchronize()
             step = eager_step
     barrier()
@@ -502,22 +575,38 @@ def main(argv=None):
         step()
     barrier()
     dt = time.perf_counter() - t0
+    dt_mine = dt
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    # training_ratio is an upstream-recall default -> also report the step at ratio 1
+    # training_ratio is an upstream-recall default -> also report the step at ratio 1.  Launched the way the
+    # headline step is (round 2 timed it eagerly, where it is host-bound: 3 675 images/sec on the driver's box against
+    # 5 400-5 940 on the builder's)
     dt1 = None
+    launch1 = "eager"
     if args.training_ratio != 1:
         trainer.training_ratio = 1
+        step1 = eager_step
         for _ in range(2):
             eager_step()
+        if launch_mode != "eager":
+            ok1, rep1 = True, None
+            try:
+                rep1 = (trainer.capture_segments if launch_mode == "hipgraph-segments" else trainer.capture)(reals[:1], labels[:1] if labels else None)
+            except Exception as exc:
+                ok1 = False
+                print(f"[bench] rank {rank}: ratio-1 capture failed ({type(exc).__name__}: {exc}); timing it eagerly", file=sys.stderr)
+                torch.cuda.synchronize()
+            if all_ok(ok1):
+                step1, launch1 = rep1, launch_mode
+                step1()
         barrier()
         t1 = time.perf_counter()
         n1 = max(3, args.steps // 2)
         for _ in range(n1):
-            eager_step()
+            step1()
         barrier()
         dt1 = (time.perf_counter() - t1) / n1
         if world > 1:
@@ -536,13 +625,22 @@ def main(argv=None):
         barrier()
         dt_eager = (time.perf_counter() - te) / ne
 
+    # N > 1: what the run says about itself (all ranks take part; outside every timed region).  Rank 0 then spends a few
+    # seconds in roofline_apply() while the others wait in the final barrier: fine under the process group's 10-minute watchdog.
+    diag = None
+    if in_group:
+        diag = multi_rank_diagnostics(trainer, eager_step, dt_mine / args.steps, world, group, dev, 2)
+        diag["launch_agreed"] = launch_mode
+        diag["launch_fallback"] = launch_fallback
     if rank == 0:
         extra = {}
+        if diag is not None:
+            extra["multi_gpu"] = diag
         if dt_eager is not None:
             extra["eager_launch"] = {"value": round(64.0 * world / dt_eager, 2), "unit": "images/sec", "ms_per_step": round(dt_eager * 1e3, 3)}
         if dt1 is not None:
             extra["training_ratio_1"] = {"value": round(64.0 * world / dt1, 2), "unit": "images/sec", "ms_per_step": round(dt1 * 1e3, 3),
-                                         "launch": "eager"}
+                                         "launch": launch1}
         roof = roofline_apply(dev)
         cpu = None
         if world == 1:
@@ -553,10 +651,11 @@ def main(argv=None):
                                      "ms": round(wc_gpu * 1e3, 3)}
             if not args.no_cpu_baseline:
                 cpu = cpu_baseline(args.training_ratio, sites, args.config)
-                try:
-                    extra["cpu_port"] = cpu_port_baseline(args.training_ratio, sites, args.config)
-                except Exception as ex:                       # the port is test infrastructure: its absence is not an error of the bench
-                    extra["cpu_port"] = {"value": None, "kind": "port", "error": repr(ex)[:200]}
+                if args.cpu_port:         # the C-ABI CPU restatement, 4.5 x slower than the torch-CPU leg and ~45 s of wall time: on request
+                    try:
+                        extra["cpu_port"] = cpu_port_baseline(args.training_ratio, sites, args.config)
+                    except Exception as ex:                       # the port is test infrastructure: its absence is not an error of the bench
+                        extra["cpu_port"] = {"value": None, "kind": "port", "error": repr(ex)[:200]}
         out = {
             "metric": "images/sec G+D step, CIFAR-10 ResNet-SN+WC, batch 64" if args.config == "cifar10_uncond"
                       else f"images/sec G+D step, {args.config} ResNet-SN+WC, batch 64",
@@ -567,7 +666,8 @@ def main(argv=None):
             "config": {"workload": f"{WORKLOADS[args.config]}, batch 64/GPU, training_ratio {args.training_ratio}, "
                                    "generator_batch_multiple 2",
                        "name": args.config, "parallelism": f"dp{world}",
-                       "wc_statistics": "sync" if args.sync_wc else "per-replica", "launch": launch_mode},
+                       "wc_statistics": "sync" if args.sync_wc else "per-replica", "launch": launch_mode,
+                       "launch_fallback": launch_fallback},
             "roofline": roof, "cpu_baseline": cpu,
         }
         out.update(extra)

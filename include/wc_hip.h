@@ -192,7 +192,8 @@ int wc_bwd_reduce_scaled_f32(const float* x, const float* mu, const float* gy, c
                              double* R /*[Kc,C,C]*/, double* gsum /*[Kc,C]*/, float* scales_out /*[2C], nullable*/,
                              void* ws, size_t ws_bytes, wc_stream_t stream);
 /* K4 behind a site whose ReLU rode in K3's epilogue (wc_apply_act_f32, relu = 1): the activation's gradient mask
- * gy := gy where y > 0, else 0 (generator.py:144-154 `Activation('relu')` after each norm stack) applied while K4 stages gy,
+ * gy := gy unless y <= 0 (a NaN in y lets the gradient through, as aten::threshold_backward does; generator.py:144-154
+ * `Activation('relu')` after each norm stack) applied while K4 stages gy,
  * instead of an elementwise pass over three tensors in front of it.  relu_y = the site's output y; gy_masked (out, same
  * shape as gy, must not alias it) receives the masked gradient -- what K6 then takes as its gy.  R, gsum, scales_out as in
  * wc_bwd_reduce_scaled_f32, computed from the masked gradient.  relu_y == NULL (then gy_masked must be NULL too) is that
@@ -238,6 +239,10 @@ size_t wc_spectral_norm_workspace_bytes(int rows, int cols);
 /* After a forward call the 32 floats at this byte offset of `ws` hold per-workgroup maxima of |w_sn| (unused entries keep
  * the caller's zeros): wc_conv_weights_f32 takes them as `known_amax` and skips its own sweep over the weight. */
 size_t wc_spectral_norm_amax_offset(int rows, int cols);
+/* The unsigned word at this byte offset of `ws` is the weight's sticky error word: a workgroup whose wait for its peers ran out
+ * (> 0.1 s: the device could not hold the launch's workgroups at once -- CUs held by another process or stream) sets it to 1 and
+ * goes on; that call's outputs are then invalid.  0 after every normal call; never cleared by the library. */
+size_t wc_spectral_norm_error_offset(int rows, int cols);
 int wc_spectral_norm_f32(const float* W, int rows, int cols, float* u, float* v, int iterations, float eps,
                          float* w_sn /*[rows*cols] out*/, float* sigma /*[1] out*/,
                          float* u_used /*[rows] out, nullable*/, float* v_used /*[cols] out, nullable: u, v as used for sigma,

@@ -36,7 +36,10 @@ def load():
     if _LIB is None:
         path = os.path.join(_HERE, "libwc_cpu.so")
         src = os.path.join(_HERE, "wc_cpu.cpp")
-        if not os.path.exists(path) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(path)):
+        alt = os.environ.get("WC_CPU_PORT_LIB")          # another build of the same source (`make -C oracle asan`)
+        if alt:
+            path = alt
+        elif not os.path.exists(path) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(path)):
             build()
         lib = C.CDLL(path)
         for name, (res, args) in _SIGS.items():

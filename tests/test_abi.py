@@ -36,7 +36,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_abi_version_and_error_strings(lib):
     from wc_gan_amd import _lib
-    assert lib.wc_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.wc_abi_version() == _lib.ABI_VERSION == 4
     assert b"multiple of 32" in lib.wc_error_string(-3)
     assert lib.wc_error_string(0) == b"ok"
 
@@ -63,6 +63,26 @@ def test_argument_checks_return_codes_without_touching_the_gpu(lib):
     assert lib.wc_color_f32(one, None, 2, 64, 1, 0, one, None, None, None, None, 0, None) == -2
     assert lib.wc_bwd_reduce_f32(one, None, one, None, 4, 16, 64, 3, one, one, one, 1 << 30, None) == -2
     assert lib.wc_stream_copy_f32(one, one, 6, None) == -2
+
+
+def test_split_entry_points_check_their_arguments(lib):
+    """ABI 4 (pre-split activations): sizes, shape support and rejections, no kernel launched."""
+    one = ctypes.c_void_p(16)
+    assert lib.wc_split_bytes(1024, 256) == 1024 * 256 * 4 and lib.wc_split_bytes(1024, 40) == 0
+    assert lib.wc_apply_split_supported(128, 1024, 256) == 1 and lib.wc_apply_split_supported(128, 16, 128) == 1
+    assert lib.wc_apply_split_supported(128, 1024, 64) == 0 and lib.wc_apply_split_supported(3, 5, 256) == 0
+    assert lib.wc_stats_split_supported(131072, 256, 1) == 1 and lib.wc_stats_split_supported(8192, 256, 1) == 0
+    assert lib.wc_stats_split_supported(327680, 256, 5) == 1 and lib.wc_stats_split_supported(131072, 64, 1) == 0
+    assert lib.wc_stats_split_workspace_bytes(131072, 256, 1) > 36 * 32 * 32 * 8 and lib.wc_stats_split_workspace_bytes(8192, 256, 1) == 0
+    assert lib.wc_apply_split_workspace_bytes(256, 10) > 10 * 256 * 4
+    assert lib.wc_split_f32(None, None, one, 64, 64, 0, one, None, None) == -1
+    assert lib.wc_split_f32(one, None, one, 64, 64, 2, one, None, None) == -5
+    assert lib.wc_split_scales_f32(one, 64, 48, one, one, one, None) == -3
+    assert lib.wc_unsplit_f32(one, None, one, 0, 64, one, None) == -2
+    assert lib.wc_apply_split_f16x2(one, None, one, None, one, None, None, 128, 1024, 64, 1, 0, one, None, one, 1 << 30, None) == -2
+    assert lib.wc_apply_split_f16x2(one, None, one, None, one, None, None, 128, 1024, 256, 1, 0, one, None, one, 16, None) == -4
+    assert lib.wc_stats_split_f16x2(one, one, one, 8192, 256, 1, one, one, one, 1 << 30, None) == -2
+    assert lib.wc_split_bias_f32(None, None, None, None, 1, 64, one, None) == -1
 
 
 def test_host_wrappers_refuse_cpu_tensors():

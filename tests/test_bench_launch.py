@@ -34,6 +34,13 @@ def test_gpus_2_spawns_two_ranks_and_keeps_replicas_consistent():
     assert out["replicas_identical"] and out["finite"]
     # training_ratio critic all-reduces, then the generator's -- the same on both ranks
     assert out["allreduce_order"] == [["d", "d", "g"], ["d", "d", "g"]]
+    # the self-diagnosis of an N > 1 line: group size as the backend sees it, every rank's own step time,
+    # the collectives' share of a step, the agreed launch mode and why a graph mode fell back (None here: eager was asked for)
+    mg = out["multi_gpu"]
+    assert mg["ranks_seen_by_backend"] == 2
+    assert 0 < mg["ms_per_step_rank_min"] <= mg["ms_per_step_rank_max"]
+    assert mg["allreduce_calls_per_step"] == 3 and mg["allreduce_ms_per_step"] > 0 and mg["allreduce_bytes_per_step"] > 0
+    assert out["config"]["launch"] == "eager" and out["config"]["launch_fallback"] is None
 
 
 def test_single_rank_dry_run_needs_no_process_group():

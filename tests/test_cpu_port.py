@@ -85,3 +85,29 @@ def test_cpu_port_error_codes():
     assert lib.wc_stats_f32_cpu(None, 64, 32, 1, p(s), p(t), None, 0, None) == -1           # WC_ERR_NULL
     assert lib.wc_stats_f32_cpu(p(x), 0, 32, 1, p(s), p(t), None, 0, None) == -2            # WC_ERR_SHAPE
     assert lib.wc_stats_f32_cpu(p(x), 64, 32, 1, p(s), p(t), None, 0, None) == 0
+
+
+def test_cpu_port_is_clean_under_asan_and_ubsan():
+    """SURVEY.md section 5 (host-side sanitizer build of the C++ restatement): `make -C oracle asan`, then this file's other
+    tests again in a child process against that library with the ASan runtime preloaded.  Any AddressSanitizer report or
+    UBSan runtime error fails the child (-fno-sanitize-recover=undefined; ASan aborts by default)."""
+    import shutil
+    import subprocess
+    import sys
+    if os.environ.get("WC_CPU_PORT_LIB"):
+        pytest.skip("already inside the sanitizer run")
+    if shutil.which("g++") is None or shutil.which("make") is None:
+        pytest.skip("no host toolchain")
+    oracle_dir = os.path.join(ROOT, "oracle")
+    r = subprocess.run(["make", "-C", oracle_dir, "asan"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    libasan = subprocess.run(["g++", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(libasan) or not os.path.exists(libasan):
+        pytest.skip("libasan.so not found")
+    env = dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", OMP_NUM_THREADS="4",
+               WC_CPU_PORT_LIB=os.path.join(oracle_dir, "libwc_cpu_asan.so"))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, cwd=ROOT, timeout=900)
+    out = r.stdout + r.stderr
+    assert "AddressSanitizer" not in out and "runtime error" not in out, out[-3000:]
+    assert r.returncode == 0, out[-3000:]

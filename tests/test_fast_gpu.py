@@ -156,8 +156,13 @@ def test_bwd_reduce_with_the_relu_mask_in_its_staging(ops, shape, Kc):
     slot = rng.integers(0, Kc, N).astype(np.int32)
     st = dev(slot, torch.int32) if Kc > 1 else None
     R, gsum, gm, scales = ops.bwd_reduce(dev(x), dev(mu), dev(gy), st, Kc, want_scales=True, relu_y=dev(y))
-    g_ref = np.where(y > 0, gy, np.float32(0))
+    # NaN in y lets the gradient through on every path (the in-kernel mask at C = 256, the elementwise pass elsewhere) -- what
+    # aten::threshold_backward does (the three implementations used to disagree there)
+    g_ref = np.where(~(y <= 0), gy, np.float32(0))
     assert np.array_equal(gm.cpu().numpy(), g_ref)
+    assert gm[1, 2, 3, 4].item() == gy[1, 2, 3, 4]
+    tb = torch.ops.aten.threshold_backward(dev(gy), dev(y), 0.0)
+    assert torch.equal(tb, gm)
     R2, gsum2 = ops.bwd_reduce(dev(x), dev(mu), dev(g_ref), st, Kc)
     f = x.astype(np.float64).reshape(N, -1, C) - mu.astype(np.float64)
     g = g_ref.astype(np.float64).reshape(N, -1, C)

@@ -238,3 +238,30 @@ def test_one_power_iteration_per_forward_on_every_layer_path():
         layer.forward_relu(x)
         ref.conv.normalized_weight()
         assert torch.equal(layer.conv.sn_u, ref.conv.sn_u)
+
+
+@pytest.mark.gpu
+def test_error_word_stays_clear_and_batches_split_by_residency():
+    """the meeting of a weight's workgroups is a bounded wait that sets a sticky error word instead of hanging; a
+    normal run (per layer, and the whole Tiny-ImageNet-sized critic in batched launches that are cut to what the device
+    holds at once) leaves every word 0 and gives the per-layer results."""
+    from wc_gan_amd import _lib, ops
+    lib = _lib.load()
+    torch.manual_seed(7)
+    shapes = [(1024, 9216)] * 6 + [(512, 4608), (128, 27), (256, 1152)] * 4       # > 768 workgroups of up to ~42 KB LDS in one call
+    ws_, us, vs, wss = [], [], [], []
+    for r, c in shapes:
+        ws_.append(torch.randn(r, c, device='cuda') / c ** 0.5)
+        us.append(torch.randn(r, device='cuda')); vs.append(torch.randn(c, device='cuda'))
+        wss.append(ops.spectral_norm_workspace(r, c, 'cuda'))
+    us2, vs2 = [u.clone() for u in us], [v.clone() for v in vs]
+    wss2 = [ops.spectral_norm_workspace(r, c, 'cuda') for r, c in shapes]
+    outs = ops.spectral_norm_batched(ws_, us, vs, wss, 1)
+    for i, (r, c) in enumerate(shapes):
+        w1, s1 = ops.spectral_norm(ws_[i], us2[i], vs2[i], 1, wss2[i])
+        assert torch.equal(outs[i][0], w1) and torch.equal(outs[i][1], s1)
+        off = lib.wc_spectral_norm_error_offset(r, c)
+        assert off + 32 == wss[i].numel()
+        for buf in (wss[i], wss2[i]):
+            assert int(buf[off:off + 4].view(torch.int32)[0]) == 0
+            assert int(buf[-16:].view(torch.int32).abs().sum()) == 0          # the meeting words are left zero

@@ -598,6 +598,13 @@ size_t wc_spectral_norm_amax_offset(int rows, int cols)
     return wc_sn_amax_offset(rows, cols);
 }
 
+size_t wc_spectral_norm_error_offset(int rows, int cols)
+{
+    if (rows <= 0 || cols <= 0) return 0;
+    return wc_sn_error_offset(rows, cols);
+}
+
+
 int wc_spectral_norm_f32(const float* W, int rows, int cols, float* u, float* v, int iterations, float eps,
                          float* w_sn, float* sigma, float* u_used, float* v_used,
                          void* ws, size_t ws_bytes, wc_stream_t stream)

@@ -101,6 +101,7 @@ hipError_t wc_launch_spectral_norm_bwd_batched(const WcSnBwdItem* items, int cou
 size_t wc_sn_lds_bytes(int R, int K);
 size_t wc_sn_workspace_bytes(int R, int K);
 size_t wc_sn_amax_offset(int R, int K);
+size_t wc_sn_error_offset(int R, int K);
 hipError_t wc_launch_spectral_norm(const float* W, int R, int K, float* u, float* v, int iterations, float eps,
                                    float* w_sn, float* sigma, float* u_used, float* v_used, void* ws, hipStream_t st);
 hipError_t wc_launch_spectral_norm_bwd(const float* g, const float* w_sn, const float* u, const float* v, const float* sigma,

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
 #pragma unroll
             for (int p = 0; p < 8; ++p)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) xr[p][j] = yr[RELU ? p : 0][j] > 0.f ? xr[p][j] : 0.f;
+                for (int j = 0; j < 4; ++j) xr[p][j] = !(yr[RELU ? p : 0][j] <= 0.f) ? xr[p][j] : 0.f;      // (NaN in y: the gradient passes, as in relu_mask_kernel and aten::threshold_backward)
             if (qi == 0) {                  // each half of Y's columns is written by one type
                 float* dst = a.Yout + (r0 + (int64_t)st_of_data * R + rgrp * 8) * C + cbase + 4 * c4;
 #pragma unroll

@@ -548,7 +548,7 @@ __global__ __launch_bounds__(256) void relu_mask_kernel(const f32x4* __restrict_
         const f32x4 g = gy[i], v = y[i];
         f32x4 o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = v[j] > 0.f ? g[j] : 0.f;
+        for (int j = 0; j < 4; ++j) o[j] = !(v[j] <= 0.f) ? g[j] : 0.f;      // NaN in y lets the gradient through, as aten::threshold_backward does
         out[i] = o;
     }
 }

@@ -52,8 +52,14 @@ __device__ __forceinline__ void put(float* p, float x)
 __device__ __forceinline__ float get(const float* p)
 { return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
 
-// all workgroups of the launch (co-resident: at most SN_MAXWG of them) meet here for the `phase`-th time
-__device__ __forceinline__ void grid_meet(unsigned* sync, int nwg, int phase)
+// all workgroups of the launch (co-resident: at most SN_MAXWG of them) meet here for the `phase`-th time.
+// The wait is BOUNDED: the peers of a weight are dispatched in block order, so a resident workgroup only ever
+// waits for peers that the dispatcher starts as soon as earlier blocks leave -- but if CUs are held by something that does
+// not leave (another process, a kernel on a second stream that spins itself) the meeting would otherwise hang the device.
+// After ~2^21 polls (> 0.1 s) the waiter gives up, sets the weight's sticky error word (the last word of its scratch:
+// wc_spectral_norm_error_offset) and goes on: the results of this weight are then garbage, the flag says so, nothing hangs.
+constexpr unsigned SN_MEET_POLLS = 1u << 21;
+__device__ __forceinline__ void grid_meet(unsigned* sync, int nwg, int phase, unsigned* err)
 {
     if (nwg == 1) { __syncthreads(); return; }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave: my write-through stores have landed
@@ -61,7 +67,11 @@ __device__ __forceinline__ void grid_meet(unsigned* sync, int nwg, int phase)
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned target = (unsigned)(phase + 1) * (unsigned)nwg;
-        while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+        unsigned polls = 0;
+        while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (++polls > SN_MEET_POLLS) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
     }
     __syncthreads();
 }
@@ -121,7 +131,7 @@ __device__ __forceinline__ void sn_forward_body(const SnArgs& a, const int b)
                 __syncthreads();
             }
         }
-        grid_meet(a.sync, nwg, phase++);
+        grid_meet(a.sync, nwg, phase++, a.sync - 4);
         float nrm = 0.f;
         for (int j = tid; j < K; j += SN_THREADS) { const float tv = get(a.t + j); vs[j] = tv; nrm = fmaf(tv, tv, nrm); }
         nrm = block_sum(nrm, red);
@@ -129,7 +139,7 @@ __device__ __forceinline__ void sn_forward_body(const SnArgs& a, const int b)
         for (int j = tid; j < K; j += SN_THREADS) vs[j] *= inv_v;
         __syncthreads();
         rows_times_v();
-        grid_meet(a.sync, nwg, phase++);
+        grid_meet(a.sync, nwg, phase++, a.sync - 4);
         float n2 = 0.f;
         for (int r = tid; r < R; r += SN_THREADS) { const float sv = get(a.s + r); us[r] = sv; n2 = fmaf(sv, sv, n2); }
         n2 = block_sum(n2, red);
@@ -137,12 +147,12 @@ __device__ __forceinline__ void sn_forward_body(const SnArgs& a, const int b)
         for (int r = tid; r < R; r += SN_THREADS) us[r] *= inv_u;
         __syncthreads();
         sig_norm = n2 * inv_u;                       // u^T (W v) with u = (W v) / max(|W v|, eps)
-        if (it + 1 < a.iterations) grid_meet(a.sync, nwg, phase++);      // a.t / a.s are rewritten by the next round
+        if (it + 1 < a.iterations) grid_meet(a.sync, nwg, phase++, a.sync - 4);      // a.t / a.s are rewritten by the next round
     }
     float sigma = sig_norm;
     if (a.iterations == 0) {
         rows_times_v();
-        grid_meet(a.sync, nwg, phase++);
+        grid_meet(a.sync, nwg, phase++, a.sync - 4);
         float d = 0.f;
         for (int r = tid; r < R; r += SN_THREADS) d = fmaf(us[r], get(a.s + r), d);
         sigma = block_sum(d, red);
@@ -201,7 +211,7 @@ __device__ __forceinline__ void sn_backward_body(const SnBwdArgs& a, const int b
         for (int64_t e = e0 + tid; e < e1; e += SN_THREADS) p = fmaf(a.g[e], a.w_sn[e], p);
         p = block_sum(p, red);
         if (tid == 0) put(a.partial + b, p);
-        grid_meet(a.sync, nwg, 0);
+        grid_meet(a.sync, nwg, 0, a.sync - 6);      // (the backward's words are the forward's + 2)
         for (int q = 0; q < nwg; ++q) c += get(a.partial + q);   // same order in every workgroup
     }
     const float inv = 1.0f / a.sigma[0];
@@ -258,7 +268,9 @@ int sn_workgroups(int R, int K)
 
 size_t wc_sn_lds_bytes(int R, int K) { return (size_t)(R + K + SN_THREADS / 64 + SN_THREADS) * sizeof(float); }
 // scratch: t[K] | s[R] | partial[SN_MAXWG] | amax[SN_MAXWG] | sync[4] (the sync words must be zero before the first launch; every launch leaves them zero)
-size_t wc_sn_workspace_bytes(int R, int K) { return ((size_t)(R + K + 2 * SN_MAXWG) * sizeof(float) + 15) / 16 * 16 + 16; }
+// ... | 16 bytes whose first word is the sticky error word of grid_meet | 16 bytes of meeting words (forward [0..1], backward [2..3])
+size_t wc_sn_workspace_bytes(int R, int K) { return ((size_t)(R + K + 2 * SN_MAXWG) * sizeof(float) + 15) / 16 * 16 + 32; }
+size_t wc_sn_error_offset(int R, int K) { return wc_sn_workspace_bytes(R, K) - 32; }
 size_t wc_sn_amax_offset(int R, int K) { return (size_t)(R + K + SN_MAXWG) * sizeof(float); }
 
 hipError_t wc_launch_spectral_norm(const float* W, int R, int K, float* u, float* v, int iterations, float eps,
@@ -287,11 +299,40 @@ hipError_t wc_launch_spectral_norm_bwd(const float* g, const float* w_sn, const 
     return hipGetLastError();
 }
 
+// How many workgroups of `kernel` (SN_THREADS threads, `lds` bytes) the device holds at once: a batched launch never asks for
+// more (16 items x 128 workgroups of 42 KB could not all be resident, and forward progress then rested on
+// in-order dispatch alone).  0 = unknown: no limit is applied.
+template <typename K>
+static int sn_resident_capacity(K kernel, size_t lds)
+{
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, SN_THREADS, lds) != hipSuccess) return 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return per_cu * cus;
+}
+
 hipError_t wc_launch_spectral_norm_batched(const WcSnItem* items, int count, int iterations, float eps, hipStream_t st)
 {
-    for (int c0 = 0; c0 < count; c0 += SN_MAXITEMS) {
+    size_t lds_all = 0;
+    for (int i = 0; i < count; ++i) { const size_t l = wc_sn_lds_bytes(items[i].rows, items[i].cols); if (l > lds_all) lds_all = l; }
+    static size_t cap_lds = ~(size_t)0; static int cap = 0;
+    if (cap_lds != lds_all) {
+        if (lds_all > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sn_forward_batched_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_all);
+            if (e != hipSuccess) return e;
+        }
+        cap = sn_resident_capacity(sn_forward_batched_kernel, lds_all); cap_lds = lds_all;
+    }
+    for (int c0 = 0; c0 < count;) {
         SnBatch q = {};
-        q.count = count - c0 < SN_MAXITEMS ? count - c0 : SN_MAXITEMS;
+        int take = 0, total = 0;
+        while (c0 + take < count && take < SN_MAXITEMS) {        // as many items as are resident together (at least one)
+            const int nw = sn_workgroups(items[c0 + take].rows, items[c0 + take].cols);
+            if (take > 0 && cap > 0 && total + nw > cap) break;
+            total += nw; ++take;
+        }
+        q.count = take;
         size_t lds = 0;
         int blocks = 0;
         for (int i = 0; i < q.count; ++i) {
@@ -312,15 +353,24 @@ hipError_t wc_launch_spectral_norm_batched(const WcSnItem* items, int count, int
             if (e != hipSuccess) return e;
         }
         hipLaunchKernelGGL(sn_forward_batched_kernel, dim3(blocks), dim3(SN_THREADS), lds, st, q);
+        c0 += take;
     }
     return hipGetLastError();
 }
 
 hipError_t wc_launch_spectral_norm_bwd_batched(const WcSnBwdItem* items, int count, int fully_diff, hipStream_t st)
 {
-    for (int c0 = 0; c0 < count; c0 += SN_MAXITEMS) {
+    static int cap = -1;
+    if (cap < 0) cap = sn_resident_capacity(sn_backward_batched_kernel, 0);
+    for (int c0 = 0; c0 < count;) {
         SnBwdBatch q = {};
-        q.count = count - c0 < SN_MAXITEMS ? count - c0 : SN_MAXITEMS;
+        int take = 0, total = 0;
+        while (c0 + take < count && take < SN_MAXITEMS) {
+            const int nw = sn_workgroups(items[c0 + take].rows, items[c0 + take].cols);
+            if (take > 0 && cap > 0 && total + nw > cap) break;
+            total += nw; ++take;
+        }
+        q.count = take;
         int blocks = 0;
         for (int i = 0; i < q.count; ++i) {
             const WcSnBwdItem& it = items[c0 + i];
@@ -333,6 +383,7 @@ hipError_t wc_launch_spectral_norm_bwd_batched(const WcSnBwdItem* items, int cou
         }
         q.first[q.count] = blocks;
         hipLaunchKernelGGL(sn_backward_batched_kernel, dim3(blocks), dim3(SN_THREADS), 0, st, q);
+        c0 += take;
     }
     return hipGetLastError();
 }

@@ -57,8 +57,46 @@ class FlatGradBucket:
 
     def allreduce_mean(self):
         if (self.world > 1 or _FORCE_COLLECTIVES) and self.flat is not None:
+            tm = self.timer
+            if tm is not None:
+                tm.begin(self.flat)
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            if tm is not None:
+                tm.end(self.flat)
             self.flat.mul_(1.0 / self.world)
+
+    timer = None          # an AllreduceTimer while bench.py measures the collectives' share of a step (diagnostics only)
+
+
+class AllreduceTimer:
+    """Time spent in the gradient all-reduces, for the N > 1 diagnostics of bench.py: HIP events on the launching stream
+    around each collective (the NCCL/RCCL call makes that stream wait for its result), wall clock on the CPU (gloo)."""
+
+    def __init__(self):
+        self.pairs, self.cpu_s, self.calls = [], 0.0, 0
+
+    def begin(self, t):
+        self.calls += 1
+        if t.is_cuda:
+            e0 = torch.cuda.Event(enable_timing=True); e0.record()
+            self._e0 = e0
+        else:
+            import time
+            self._t0 = time.perf_counter()
+
+    def end(self, t):
+        if t.is_cuda:
+            e1 = torch.cuda.Event(enable_timing=True); e1.record()
+            self.pairs.append((self._e0, e1))
+        else:
+            import time
+            self.cpu_s += time.perf_counter() - self._t0
+
+    def total_ms(self):
+        if self.pairs:
+            torch.cuda.synchronize()
+            return sum(a.elapsed_time(b) for a, b in self.pairs)
+        return self.cpu_s * 1e3
 
 
 def broadcast_state(module, src=0, group=None):
