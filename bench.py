@@ -165,7 +165,8 @@ def roofline_apply(dev):
     t_site_split = time_kernel(site_split, iters=10)
     # every stage of the site on its own (HIP events, same inputs): the algorithmic bytes of SURVEY section 8d per stage
     gy = torch.randn(N, H, H, C, generator=g).to(dev)
-    y_relu = ops.apply(x, mu, A, b, None, plan=plan, relu=True)
+    y_relu, relu_bits = ops.apply(x, mu, A, b, None, plan=plan, relu=True, want_mask=True)
+    t_k3_mask = time_kernel(lambda: ops.apply(x, mu, A, b, None, out=y, plan=plan, relu=True, want_mask=True), iters=10)
     R, gsum, scales = ops.bwd_reduce(x, mu, gy, None, 1, want_scales=True)
     dg, db, S, gm = ops.bwd_factor(R, gsum, W, L, gamma, A, M, 1e-3, 1, True)
     xb = M * C * 4
@@ -181,7 +182,12 @@ def roofline_apply(dev):
         "K4 wc_bwd_reduce_f32": stage(lambda: ops.bwd_reduce(x, mu, gy, None, 1), 2 * xb),
         # what the generator runs: every WC site is followed by a ReLU (generator.py:144-151,154), so K4 also reads y and
         # writes the masked gradient (the un-masked variant under-reported the backward site)
-        "K4 wc_bwd_reduce_relu_f32 (as the generator runs it)": stage(lambda: ops.bwd_reduce(x, mu, gy, None, 1, want_scales=True, relu_y=y_relu), 4 * xb),
+        # round 3: the mask travels as ONE BIT per element, written by K3's epilogue (wc_apply_mask_f32) and read by K4
+        # (wc_bwd_reduce_mask_f32): x, gy in, masked gy out + 1/32 of a tensor -- this is what the layer runs now; the fp32-y
+        # form of round 2 beside it
+        "K3 wc_apply_mask_f32 (ReLU + bit mask, as the generator runs it)": {"us": round(t_k3_mask * 1e6, 1)},
+        "K4 wc_bwd_reduce_mask_f32 (as the generator runs it)": stage(lambda: ops.bwd_reduce(x, mu, gy, None, 1, want_scales=True, relu_mask=relu_bits), 3 * xb),
+        "K4 wc_bwd_reduce_relu_f32 (round 2: mask from y in fp32)": stage(lambda: ops.bwd_reduce(x, mu, gy, None, 1, want_scales=True, relu_y=y_relu), 4 * xb),
         "K5 wc_bwd_factor_f64": {"us": round(time_kernel(lambda: ops.bwd_factor(R, gsum, W, L, gamma, A, M, 1e-3, 1, True), iters=10) * 1e6, 1)},
         "K6 wc_bwd_apply_f32": stage(lambda: ops.bwd_apply(gy, x, mu, At, S, gm, None, scales=scales), 3 * xb),
     }

@@ -175,6 +175,21 @@ int wc_apply_split_f16x2(const void* xs, const float* xs_center /*nullable*/, co
                          const int32_t* slot, int64_t N, int64_t HW, int C, int Kc, int relu,
                          float* y, const void* plan /*nullable*/, void* ws, size_t ws_bytes, wc_stream_t stream);
 
+/* K3 + ReLU + the ReLU's gradient mask as ONE BIT per element (ABI 4).  As wc_apply_act_f32 with relu = 1, and
+ * relu_mask (wc_relu_mask_bytes(N*HW, C) bytes; N*HW a multiple of 32) receives, for every 32-row block t and channel c, the word
+ * mask[t * C + c] whose bit b says "y[32 t + b][c] passed the ReLU" (y > 0, or NaN).  The planned fast kernel writes the words
+ * from its epilogue (32 vector instructions and one 128-byte store per 32 x 32 outputs); every other path takes one pass over
+ * y.  The backward then needs neither y nor a masked copy of the gradient to know the mask: wc_bwd_reduce_mask_f32.
+ * (generator.py:144-151, 154: `Activation('relu')` behind every norm stack.) */
+size_t wc_relu_mask_bytes(int64_t M, int C);
+/* out = gy where the mask's bit is set, else 0 (the elementwise form of the ReLU gradient; wc_bwd_reduce_mask_f32 does the same
+ * while it stages gy).  M a multiple of 32, C a multiple of 32 in [32, 1024]. */
+int wc_relu_mask_apply_f32(const float* gy, const void* relu_mask, int64_t M, int C, float* out, wc_stream_t stream);
+int wc_apply_mask_f32(const float* x, const float* mu, const float* A, const float* bias,
+                      const int32_t* slot, int64_t N, int64_t HW, int C, int Kc,
+                      float* y, void* relu_mask /*out*/, const void* plan /*from wc_color_f32, nullable*/,
+                      void* ws, size_t ws_bytes, wc_stream_t stream);
+
 /* K4: R[k] = sum_{n: slot[n]=k} (x[n]-mu)^T gy[n]  (Kc,C,C),  gsum[k] = sum_{n in k} rows of gy[n]  (Kc,C). */
 int wc_bwd_reduce_f32(const float* x, const float* mu, const float* gy, const int32_t* slot,
                       int64_t N, int64_t HW, int C, int Kc,
@@ -201,6 +216,13 @@ int wc_bwd_reduce_scaled_f32(const float* x, const float* mu, const float* gy, c
 int wc_bwd_reduce_relu_f32(const float* x, const float* mu, const float* gy, const float* relu_y /*nullable*/, const int32_t* slot,
                            int64_t N, int64_t HW, int C, int Kc,
                            double* R /*[Kc,C,C]*/, double* gsum /*[Kc,C]*/, float* gy_masked /*[N*HW*C] out, nullable*/,
+                           float* scales_out /*[2C], nullable*/, void* ws, size_t ws_bytes, wc_stream_t stream);
+/* The same with the mask in wc_apply_mask_f32's one-bit form: K4 reads x, gy and 1/32 of a tensor where wc_bwd_reduce_relu_f32
+ * reads three tensors (the quadrant kernel at C = 256 masks while it stages: one 16-byte load of mask words per thread and
+ * 64-row stage; other shapes take one elementwise pass inside the call).  gy_masked as above (required). */
+int wc_bwd_reduce_mask_f32(const float* x, const float* mu, const float* gy, const void* relu_mask, const int32_t* slot,
+                           int64_t N, int64_t HW, int C, int Kc,
+                           double* R /*[Kc,C,C]*/, double* gsum /*[Kc,C]*/, float* gy_masked /*[N*HW*C] out*/,
                            float* scales_out /*[2C], nullable*/, void* ws, size_t ws_bytes, wc_stream_t stream);
 int wc_bwd_apply_scaled_f32(const float* gy, const float* x, const float* mu, const float* At,
                             const float* S, const float* gmean, const int32_t* slot,

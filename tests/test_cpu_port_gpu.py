@@ -16,7 +16,8 @@ def dev(a, dtype=torch.float32):
     return torch.tensor(np.ascontiguousarray(a), dtype=dtype, device="cuda")
 
 
-@pytest.mark.parametrize("shape,Kc", [((16, 16, 16, 128), 1), ((24, 8, 8, 64), 4), ((32, 32, 32, 256), 1)])
+@pytest.mark.parametrize("shape,Kc", [((16, 16, 16, 128), 1), ((24, 8, 8, 64), 4), ((32, 32, 32, 256), 1),
+                                      ((128, 32, 32, 256), 1), ((128, 16, 16, 128), 10)])      # + the headline site and a conditional one at full size
 def test_hip_stages_match_their_cpu_twins(shape, Kc):
     from oracle import cpu_port as cp
     from oracle import wc_oracle as o
@@ -67,3 +68,35 @@ def test_hip_stages_match_their_cpu_twins(shape, Kc):
     dx_c = cp.bwd_apply(gy, x, mu_c, At_c, S_c, gm_c, slot)
     dx_g = ops.bwd_apply(dev(gy), dev(x), dev(mu_c), dev(At_c), dev(S_c), dev(gm_c), st)
     assert rel(dx_g.cpu().numpy(), dx_c) < 3e-5
+
+
+def test_grouped_hip_stages_match_their_cpu_twins():
+    """The critic-phase form (five statistic groups in one call) of K1 / K2 / color / group bias / K3 against the `_cpu` twins."""
+    from oracle import cpu_port as cp
+    from oracle import wc_oracle as o
+    from wc_gan_amd import ops
+    rng = np.random.default_rng(19)
+    shape, groups, Kc = (320, 16, 16, 256), 5, 1
+    N, C = shape[0], shape[-1]
+    M = int(np.prod(shape[:-1])); Mg = M // groups
+    x = o.synth_activation(rng, shape, "ill").astype(np.float32)
+    G, B = o.synth_coloring(rng, C, Kc)
+    G = G.astype(np.float32); B = B.astype(np.float32)
+    s_c, xtx_c = cp.stats(x.reshape(M, C), groups)
+    s_g, xtx_g = ops.stats(dev(x).view(M, C), groups)
+    for g in range(groups):
+        _, cov_c = o.moments_to_stats(s_c[g], xtx_c[g], Mg)
+        _, cov_g = o.moments_to_stats(s_g[g].cpu().numpy(), xtx_g[g].cpu().numpy(), Mg)
+        assert rel(cov_g, cov_c) < 1e-7
+    mu_g, L_g, W_g, cs_g = ops.factor(dev(s_c, torch.float64), dev(xtx_c, torch.float64), Mg, C, 1e-3, 0.99, 1, True, None, None,
+                                      "cuda", want_scale=True, groups=groups)
+    A_g, At_g, plan = ops.color(W_g, dev(G), cs_g, groups)
+    center, bias = ops.group_bias(mu_g.view(groups, C), A_g, dev(B), groups, Kc)
+    slot = (torch.arange(N, device="cuda", dtype=torch.int32) // (N // groups)).contiguous()
+    y_g = ops.apply(dev(x), center, A_g, bias, slot, plan=plan)
+    for g in range(groups):          # each group against the single-group CPU pipeline on its own rows
+        xg = x[g * (N // groups):(g + 1) * (N // groups)]
+        mu_c, L_c, W_c, _ = cp.factor(s_c[g], xtx_c[g], Mg, C)
+        A_c, _ = cp.color(W_c, G)
+        y_c = cp.apply(xg, mu_c, A_c, B, None)
+        assert rel(y_g[g * (N // groups):(g + 1) * (N // groups)].cpu().numpy(), y_c) < 5e-5

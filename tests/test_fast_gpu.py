@@ -281,3 +281,65 @@ def test_fused_relu_keeps_nan(ops, shape):
         assert bool(torch.isnan(y[..., 7]).all())
         rest = torch.cat([y[..., :7], y[..., 8:]], dim=-1)
         assert not bool(torch.isnan(rest).any()) and float(rest.min()) >= 0.0
+
+
+# ---- the ReLU's gradient mask as one bit per element (wc_apply_mask_f32 / wc_bwd_reduce_mask_f32) -------------------------------
+def _mask_ref(y):
+    """(M/32, C) words: bit b of word (t, c) = y[32 t + b, c] passed (> 0, or NaN)"""
+    M, C = y.shape
+    keep = ~(y <= 0)
+    w = (keep.reshape(M // 32, 32, C).astype(np.uint64) << np.arange(32, dtype=np.uint64)[None, :, None]).sum(1)
+    return w.astype(np.uint32)
+
+
+@pytest.mark.parametrize("shape,Kc", [((128, 32, 32, 256), 1), ((16, 32, 32, 256), 1), ((64, 16, 16, 128), 5), ((128, 4, 4, 256), 1),
+                                      ((12, 8, 4, 96), 1), ((17, 8, 8, 64), 3)])
+def test_apply_leaves_the_relu_bit_mask(ops, shape, Kc):
+    """Every path of K3 (planned ring kernel, its per-row redo for straddling slots, the f32-MFMA kernel for widths the fast
+    path does not take) gives the same y as wc_apply_act_f32 and the mask that y implies, bit for bit -- NaN and +-0 included."""
+    rng = np.random.default_rng(51)
+    N, C = shape[0], shape[-1]
+    M = int(np.prod(shape[:-1]))
+    x = rng.standard_normal(shape).astype(np.float32)
+    x[0, 0, 0, 3] = np.nan                       # a NaN row: NaN in every output of that row -> its bits are set
+    mu = (0.1 * rng.standard_normal(C)).astype(np.float32)
+    A = (rng.standard_normal((Kc, C, C)) / np.sqrt(C)).astype(np.float32)
+    A[:, :, 5] = 0.0                             # an all-zero output column with zero bias: exact +0 outputs -> bits clear
+    b = rng.standard_normal((Kc, C)).astype(np.float32); b[:, 5] = 0.0
+    slot = rng.integers(0, Kc, N).astype(np.int32)
+    st = dev(slot, torch.int32) if Kc > 1 else None
+    s_, xtx_ = ops.stats(dev(np.nan_to_num(x)).view(M, C))
+    _, _, W, cs = ops.factor(s_, xtx_, M, C, 1e-3, 0.99, 1, True, None, None, "cuda", want_scale=True)
+    for plan in (ops.color(W, dev(A), cs)[2] if C in (32, 64, 128, 256) else None, None):
+        y_ref = ops.apply(dev(x), dev(mu), dev(A), dev(b), st, plan=plan, relu=True)
+        y, mask = ops.apply(dev(x), dev(mu), dev(A), dev(b), st, plan=plan, relu=True, want_mask=True)
+        yn = y.cpu().numpy().reshape(M, C)
+        assert np.array_equal(yn, y_ref.cpu().numpy().reshape(M, C), equal_nan=True)
+        assert np.array_equal(mask.cpu().numpy().view(np.uint32), _mask_ref(yn))
+        if not np.isnan(yn[1:, 5]).any():
+            assert (yn[1:, 5] == 0).all()
+    # the elementwise consumer of the bits
+    gy = rng.standard_normal(shape).astype(np.float32)
+    out = ops.relu_mask_bits(dev(gy), mask)
+    assert np.array_equal(out.cpu().numpy().reshape(M, C), np.where(~(yn <= 0), gy.reshape(M, C), np.float32(0)))
+
+
+@pytest.mark.parametrize("shape,Kc", [((32, 32, 32, 256), 1), ((32, 32, 32, 256), 4), ((64, 16, 16, 128), 1), ((128, 32, 32, 256), 1)])
+def test_bwd_reduce_with_the_bit_mask(ops, shape, Kc):
+    """wc_bwd_reduce_mask_f32 == wc_bwd_reduce_relu_f32 given the y the mask came from: R, gsum, scales and the masked gradient
+    bit for bit (same products in the same order; the quadrant kernel at C = 256 reads one mask word per column and 32 rows)."""
+    rng = np.random.default_rng(52)
+    N, C = shape[0], shape[-1]
+    M = int(np.prod(shape[:-1]))
+    x = (rng.standard_normal(shape) * np.exp(rng.uniform(-1, 1, C)) + 0.3).astype(np.float32)
+    gy = (rng.standard_normal(shape) * 1e-2).astype(np.float32)
+    y = rng.standard_normal(shape).astype(np.float32)
+    y[0, 0, 0, :8] = 0.0; y[0, 0, 1, :8] = -0.0; y[1, 2, 3, 4] = np.nan
+    mu = x.reshape(-1, C).mean(0).astype(np.float32)
+    slot = rng.integers(0, Kc, N).astype(np.int32)
+    st = dev(slot, torch.int32) if Kc > 1 else None
+    mask = dev(_mask_ref(y.reshape(M, C)).view(np.int32), torch.int32)
+    R1, g1, gm1, sc1 = ops.bwd_reduce(dev(x), dev(mu), dev(gy), st, Kc, want_scales=True, relu_y=dev(y))
+    R2, g2, gm2, sc2 = ops.bwd_reduce(dev(x), dev(mu), dev(gy), st, Kc, want_scales=True, relu_mask=mask)
+    assert torch.equal(gm1, gm2) and torch.equal(sc1, sc2)
+    assert torch.equal(R1, R2) and torch.equal(g1, g2)

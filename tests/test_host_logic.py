@@ -127,6 +127,7 @@ def test_flat_grad_bucket_views_track_backward():
 
 
 def test_keras_named_checkpoint_roundtrip(tmp_path):
+    """N4: EVERY tensor of the generator under its Keras layer name and in Keras' layout (run.py:79-83 loads by name)."""
     from wc_gan_amd.checkpoint import keras_named_state, load_keras_named, save_keras_named
     G = make_generator(**CIFAR10_COND['generator'])
     st = keras_named_state(G)
@@ -135,15 +136,56 @@ def test_keras_named_checkpoint_roundtrip(tmp_path):
     assert st['Generator.BN.Final_repart/kernel:0'].shape == (1, 1, 128, 128)
     assert st['Generator.0.bn1_repart_c/kernel:0'].shape == (10, 128, 128)
     assert st['Generator.0.bn1_repart_u/bias:0'].shape == (128,)
+    # the dense layer (generator.py:127, Keras' automatic name), the block convolutions (generator.py:145) and the last
+    # convolution (generator.py:154-155), kernels in Keras' (kh, kw, Cin, Cout) / (in, out) layouts
+    assert st['dense_1/kernel:0'].shape == (128, 4 * 4 * 128) and st['dense_1/bias:0'].shape == (4 * 4 * 128,)
+    assert st['Generator.0.conv1/kernel:0'].shape == (3, 3, 128, 128) and st['Generator.2.shortcut/kernel:0'].shape == (1, 1, 128, 128)
+    assert st['Generator.Final/kernel:0'].shape == (3, 3, 128, 3) and st['Generator.Final/bias:0'].shape == (3,)
+    w = G.blocks[1].conv2.conv.weight.detach().numpy()                       # torch (Cout, Cin, kh, kw)
+    assert np.array_equal(st['Generator.1.conv2/kernel:0'], np.transpose(w, (2, 3, 1, 0)))
+    assert np.array_equal(st['dense_1/kernel:0'], G.dense.weight.detach().numpy().T)
+    # every parameter and every persistent buffer of the generator is covered
+    n_tensors = len(list(G.parameters())) + sum(1 for n, _ in G.named_buffers() if 'moving_' in n)
+    assert len(st) == n_tensors
     p = str(tmp_path / "g.npz")
     save_keras_named(G, p)
+    torch.manual_seed(123)
     G2 = make_generator(**CIFAR10_COND['generator'])
+    assert not np.array_equal(keras_named_state(G2)['Generator.0.conv1/kernel:0'], st['Generator.0.conv1/kernel:0'])
     loaded = load_keras_named(G2, p)
     assert len(loaded) == len(st)
     for k, v in keras_named_state(G2).items():
         assert np.array_equal(v, st[k])
+    assert G2.blocks[0].conv1.conv.weight.is_contiguous(memory_format=torch.channels_last)       # strides kept
     with pytest.raises(KeyError):
         load_keras_named(G2, {k: v for k, v in list(st.items())[:-1]})
+    with pytest.raises(ValueError):
+        bad = dict(st); bad['Generator.Final/kernel:0'] = bad['Generator.Final/kernel:0'][:, :, :, :2]
+        load_keras_named(G2, bad)
+    # spectrally normalised generator (generator.py:104-113): u under the layer's name, this build's v optional on load
+    Gs = make_generator(block_sizes=(32,), resamples=("UP",), first_block_shape=(4, 4, 32), block_norm='d', block_after_norm='uconv',
+                        last_norm='d', last_after_norm='uconv', spectral=True)
+    ss = keras_named_state(Gs)
+    assert ss['sn_dense_1/u:0'].shape == (1, 4 * 4 * 32) and ss['Generator.0.conv1/u:0'].shape == (1, 32)
+    Gs2 = make_generator(block_sizes=(32,), resamples=("UP",), first_block_shape=(4, 4, 32), block_norm='d', block_after_norm='uconv',
+                         last_norm='d', last_after_norm='uconv', spectral=True)
+    load_keras_named(Gs2, {k: v for k, v in ss.items() if not k.endswith('/v:0')})                    # an upstream file has no v
+    assert torch.equal(Gs2.blocks[0].conv1.conv.sn_u, Gs.blocks[0].conv1.conv.sn_u)
+
+
+def test_h5_converter_round_trip_when_h5py_is_available(tmp_path):
+    """tools/h5_to_npz.py (runs wherever h5py exists; skipped here when it does not)."""
+    pytest.importorskip("h5py")
+    import importlib.util, os
+    from wc_gan_amd.checkpoint import keras_named_state, save_keras_named
+    spec = importlib.util.spec_from_file_location("h5_to_npz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "h5_to_npz.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    G = make_generator(**CIFAR10_COND['generator'])
+    a, h, b = str(tmp_path / "a.npz"), str(tmp_path / "g.h5"), str(tmp_path / "b.npz")
+    save_keras_named(G, a)
+    mod.npz_to_h5(a, h); mod.h5_to_npz(h, b)
+    sa, sb = dict(np.load(a)), dict(np.load(b))
+    assert sorted(sa) == sorted(sb) and all(np.array_equal(sa[k], sb[k]) for k in sa)
 
 
 def test_all_four_gpu_configs_and_their_site_lists():

@@ -8,7 +8,12 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 N, H, C = (int(v) for v in sys.argv[2:5]) if len(sys.argv) > 4 else (128, 32, 256)
 M = N * H * H
 g = torch.Generator(device='cpu'); g.manual_seed(1234)
-x = torch.randn(N, H, H, C, generator=g).cuda(); gamma = (torch.randn(1, C, C, generator=g) / 16).cuda()
+if os.environ.get("ILL"):      # the SURVEY section 8d kernel-bench input (cond ~ 1e6), as bench.py's roofline uses it
+    z = torch.randn(M, C, generator=g)
+    mix = torch.randn(C, C, generator=g) / C ** 0.5 + 0.3 * (torch.randn(C, 8, generator=g) @ torch.randn(8, C, generator=g)) / 8 ** 0.5
+    x = (z @ mix + 0.2).view(N, H, H, C).cuda(); gamma = (torch.randn(1, C, C, generator=g) / C ** 0.5).cuda()
+else:
+    x = torch.randn(N, H, H, C, generator=g).cuda(); gamma = (torch.randn(1, C, C, generator=g) / 16).cuda()
 b = torch.zeros(1, C).cuda(); y = torch.empty_like(x); y2 = torch.empty_like(x)
 s, xtx = ops.stats(x.view(M, C))
 mu, L, W, cs = ops.factor(s, xtx, M, C, 1e-3, 0.99, 1, True, None, None, x.device, want_scale=True)
@@ -48,6 +53,21 @@ for r in range(rounds):
     res["copy"].append(timed(lambda: ops.stream_copy(x, y2)))
     res["base_zero_input"].append(timed(lambda: run(libs["base"], zp)))
     res["k3_fp32"].append(timed(lambda: ops.apply(x, mu, A1, b, None, out=y2, plan=plan1)))
+# the same kernels launched ONE AT A TIME behind another kernel (a stream copy of the same tensors), events around the single
+# launch: what a launch costs inside a layer's flow, without the overlap of one launch's tail with the next one's head
+def single(fn, n=30):
+    out = []
+    for _ in range(n):
+        ops.stream_copy(x, y2)
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        out.append(e0.elapsed_time(e1) * 1e3)
+    out.sort(); return out
+print("single launches behind a copy (min / median / max us):")
+for name, l in libs.items():
+    v = single(lambda: run(l)); print("  %-38s %.1f %.1f %.1f" % (name, v[0], v[len(v) // 2], v[-1]))
+v = single(lambda: ops.apply(x, mu, A1, b, None, out=y2, plan=plan1)); print("  %-38s %.1f %.1f %.1f" % ("k3_fp32", v[0], v[len(v) // 2], v[-1]))
+v = single(lambda: ops.stream_copy(x, y)); print("  %-38s %.1f %.1f %.1f" % ("copy", v[0], v[len(v) // 2], v[-1]))
 cp = sorted(res["copy"])[len(res["copy"]) // 2]
 for k, v in res.items():
     v = sorted(v)

@@ -229,6 +229,40 @@ int wc_apply_act_f32(const float* x, const float* mu, const float* A, const floa
     return WC_OK;
 }
 
+// K3 + ReLU + the ReLU's one-bit gradient mask (ABI 4)
+size_t wc_relu_mask_bytes(int64_t M, int C)
+{
+    if (M <= 0 || (M % 32) != 0 || bad_channels(C)) return 0;
+    return (size_t)(M / 32) * C * 4;
+}
+
+int wc_relu_mask_apply_f32(const float* gy, const void* relu_mask, int64_t M, int C, float* out, wc_stream_t stream)
+{
+    if (!gy || !relu_mask || !out) return WC_ERR_NULL;
+    if (M <= 0 || (M % 32) != 0) return WC_ERR_SHAPE;
+    if (bad_channels(C)) return WC_ERR_CHANNELS;
+    WC_TRY(wc_launch_relu_mask_bits(gy, static_cast<const unsigned*>(relu_mask), out, M, C, static_cast<hipStream_t>(stream)));
+    return WC_OK;
+}
+
+int wc_apply_mask_f32(const float* x, const float* mu, const float* A, const float* bias, const int32_t* slot,
+                      int64_t N, int64_t HW, int C, int Kc, float* y, void* relu_mask, const void* plan,
+                      void* ws, size_t ws_bytes, wc_stream_t stream)
+{
+    if (!relu_mask) return WC_ERR_NULL;
+    if (N <= 0 || HW <= 0 || ((N * HW) % 32) != 0) return WC_ERR_SHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    unsigned* mask = static_cast<unsigned*>(relu_mask);
+    if (x && A && y && !bad_channels(C) && Kc > 0 && plan && wc_fast_affine_writes_mask(N, HW, C)) {      // the ring kernel writes the bits from its epilogue
+        WC_TRY(wc_launch_fast_affine_planned(x, mu, A, Kc, false, bias, nullptr, slot, N, HW, C, 2, y, plan, st, mask));
+        return WC_OK;
+    }
+    const int rc = wc_apply_act_f32(x, mu, A, bias, slot, N, HW, C, Kc, 1, y, plan, ws, ws_bytes, stream);
+    if (rc != WC_OK) return rc;
+    WC_TRY(wc_launch_mask_from_y(y, N * HW, C, mask, st));          // every other path: one pass over y
+    return WC_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // pre-split activations (ABI 4)
 size_t wc_split_bytes(int64_t M, int C)
@@ -384,13 +418,14 @@ int wc_bwd_reduce_scaled_f32(const float* x, const float* mu, const float* gy, c
     return wc_bwd_reduce_relu_f32(x, mu, gy, nullptr, slot, N, HW, C, Kc, R, gsum, nullptr, scales_out, ws, ws_bytes, stream);
 }
 
-int wc_bwd_reduce_relu_f32(const float* x, const float* mu, const float* gy, const float* relu_y, const int32_t* slot,
-                           int64_t N, int64_t HW, int C, int Kc, double* R, double* gsum, float* gy_masked, float* scales_out,
-                           void* ws, size_t ws_bytes, wc_stream_t stream)
+static int bwd_reduce_masked(const float* x, const float* mu, const float* gy, const float* relu_y, const unsigned* relu_mask,
+                             const int32_t* slot, int64_t N, int64_t HW, int C, int Kc, double* R, double* gsum, float* gy_masked,
+                             float* scales_out, void* ws, size_t ws_bytes, wc_stream_t stream)
 {
-    if ((relu_y != nullptr) != (gy_masked != nullptr)) return WC_ERR_NULL;
+    const bool masked = relu_y || relu_mask;
     if (!x || !gy || !R || !gsum || !ws) return WC_ERR_NULL;
     if (N <= 0 || HW <= 0 || Kc <= 0 || (!slot && Kc != 1)) return WC_ERR_SHAPE;
+    if (relu_mask && ((N * HW) % 32) != 0) return WC_ERR_SHAPE;
     if (bad_channels(C)) return WC_ERR_CHANNELS;
     if (ws_bytes < wc_bwd_reduce_workspace_bytes(N, HW, C, Kc, slot != nullptr)) return WC_ERR_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -408,9 +443,11 @@ int wc_bwd_reduce_relu_f32(const float* x, const float* mu, const float* gy, con
     a.X = x; a.Y = gy; a.cx = mu; a.cy = nullptr; a.N = Ns; a.HW = HWs;
     a.per_sample = per_sample; a.nsplit = p.nsplit; a.rows_per_slab = p.rps; a.C = C; a.sym = 0; a.P = P; a.colsum = colsum;
     // the ReLU mask: inside the staging of the quadrant kernel (C = 256 on the fast path), else one elementwise pass in front
-    const bool mask_in_kernel = relu_y && p.fast && C == 256;
-    if (relu_y && !mask_in_kernel) {
-        WC_TRY(wc_launch_relu_mask(gy, relu_y, gy_masked, N * HW * C, st));
+    const bool mask_in_kernel = masked && p.fast && C == 256;
+    if (masked && !gy_masked) return WC_ERR_NULL;
+    if (masked && !mask_in_kernel) {
+        if (relu_mask) WC_TRY(wc_launch_relu_mask_bits(gy, relu_mask, gy_masked, N * HW, C, st));
+        else WC_TRY(wc_launch_relu_mask(gy, relu_y, gy_masked, N * HW * C, st));
         gy = gy_masked; a.Y = gy_masked;
     }
     if (!p.fast && scales_out) WC_TRY(wc_launch_channel_scale2(x, mu, sx, gy, nullptr, sy, N * HW, C, gate, st));   // asked for: sampled anyway
@@ -418,13 +455,31 @@ int wc_bwd_reduce_relu_f32(const float* x, const float* mu, const float* gy, con
         // (masked in the kernel: the scales are sampled from the unmasked gy -- a superset of the masked values' range)
         WC_TRY(wc_launch_channel_scale2(x, mu, sx, gy, nullptr, sy, N * HW, C, gate, st));      // both scales, gate := 0
         WC_TRY(wc_launch_fast_xty(x, gy, mu, nullptr, sx, sy, Ns, HWs, C, per_sample, p.nsplit, p.rps, p.nslab, p.ntypes,
-                                  P, colsum, nullptr, gate, st, mask_in_kernel ? relu_y : nullptr, mask_in_kernel ? gy_masked : nullptr));
+                                  P, colsum, nullptr, gate, st, mask_in_kernel ? relu_y : nullptr, mask_in_kernel ? gy_masked : nullptr,
+                                  mask_in_kernel ? relu_mask : nullptr));
         a.gate = gate;
         if (mask_in_kernel) a.Y = gy_masked;          // the gated exact redo reads what the fast kernel wrote
     }
     WC_TRY(wc_launch_xty(a, p.nslab, st));
     WC_TRY(wc_launch_bwd_combine(P, colsum, slot, N, p.nsplit, per_sample, C, Kc, R, gsum, st));
     return WC_OK;
+}
+
+int wc_bwd_reduce_relu_f32(const float* x, const float* mu, const float* gy, const float* relu_y, const int32_t* slot,
+                           int64_t N, int64_t HW, int C, int Kc, double* R, double* gsum, float* gy_masked, float* scales_out,
+                           void* ws, size_t ws_bytes, wc_stream_t stream)
+{
+    if ((relu_y != nullptr) != (gy_masked != nullptr)) return WC_ERR_NULL;
+    return bwd_reduce_masked(x, mu, gy, relu_y, nullptr, slot, N, HW, C, Kc, R, gsum, gy_masked, scales_out, ws, ws_bytes, stream);
+}
+
+int wc_bwd_reduce_mask_f32(const float* x, const float* mu, const float* gy, const void* relu_mask, const int32_t* slot,
+                           int64_t N, int64_t HW, int C, int Kc, double* R, double* gsum, float* gy_masked, float* scales_out,
+                           void* ws, size_t ws_bytes, wc_stream_t stream)
+{
+    if (!relu_mask || !gy_masked) return WC_ERR_NULL;
+    return bwd_reduce_masked(x, mu, gy, nullptr, static_cast<const unsigned*>(relu_mask), slot, N, HW, C, Kc, R, gsum, gy_masked,
+                             scales_out, ws, ws_bytes, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

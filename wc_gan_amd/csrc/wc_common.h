@@ -127,7 +127,8 @@ hipError_t wc_launch_fast_xty(const float* X, const float* Y, const float* cx, c
                               const float* sx, const float* sy, int64_t N, int64_t HW, int C,
                               int per_sample, int nsplit, int64_t rows_per_slab, int nslab, int ntypes,
                               double* P, float* colsum, double* dfix /*[nslab][C], covariance only, nullable*/, int* gate, hipStream_t st,
-                              const float* yrelu = nullptr, float* yout = nullptr);      // yrelu (C = 256, two operands): Y masked by yrelu > 0, written to yout
+                              const float* yrelu = nullptr, float* yout = nullptr,       // yrelu (C = 256, two operands): Y masked by yrelu > 0, written to yout
+                              const unsigned* ymask = nullptr);                          // ... or by K3's bit mask ([M/32][C] words)
 hipError_t wc_launch_fast_plan_tables(const float* B, int Kc, int C, void* plan, hipStream_t st, const float* scale = nullptr);
 bool wc_bwd_apply_onepass_supported(int64_t N, int64_t HW, int C);
 hipError_t wc_launch_bwd_apply_onepass(const float* gy, const float* x, const float* mu, const float* At, int Kc, const float* S,
@@ -139,7 +140,10 @@ float* wc_fast_plan_scale(void* plan);
 hipError_t wc_launch_fast_affine_planned(const float* in, const float* center, const float* B, int Kc, bool shared_table,
                                          const float* bias, const float* sub, const int32_t* slot,
                                          int64_t N, int64_t HW, int C, int accumulate, float* out,
-                                         const void* plan, hipStream_t st);
+                                         const void* plan, hipStream_t st, unsigned* relu_mask = nullptr);      // relu_mask: see wc_fast_affine_writes_mask
+bool wc_fast_affine_writes_mask(int64_t N, int64_t HW, int C);      // the planned ring kernel leaves the ReLU's bit mask itself (else: wc_launch_mask_from_y)
+hipError_t wc_launch_mask_from_y(const float* y, int64_t M, int C, unsigned* mask, hipStream_t st);
+hipError_t wc_launch_relu_mask_bits(const float* gy, const unsigned* mask, float* out, int64_t M, int C, hipStream_t st);
 hipError_t wc_launch_channel_scale(const float* in, const float* center, int64_t M, int C, float* scale, hipStream_t st);
 hipError_t wc_launch_channel_scale2(const float* in, const float* center, float* scale, const float* in2, const float* center2,
                                     float* scale2, int64_t M, int C, int* gate, hipStream_t st);

@@ -181,6 +181,7 @@ struct FastArgs {
     int accumulate;
     int mixed;                                                       // slots given and HW % tile != 0: a tile may straddle samples of different slots
     int relu;                                                        // epilogue: out = max(out, 0) (NaN stays NaN)
+    unsigned* maskout;                                               // ring kernel, relu != 0: the activation's 1-bit mask, [M/32][C] words (bit b of word (t, c) = out[32 t + b][c] != 0); nullable
     const float* Bf; int64_t bf_stride;                             // the fp32 table [slot][k][n] for the exact path
     float* out;
     int ntiles, tiles_per_wg;
@@ -505,7 +506,9 @@ __global__ __launch_bounds__(512, 2) void affine_f16x3_kernel(FastArgs a)
 #define WC_AHEAD 1      // k-steps between a fragment's ds_read and its MFMAs (2 measured no faster, costs 8 VGPRs)
 #endif
 
-template <int C, bool HAS_SLOT>
+// MASK: the epilogue also leaves the ReLU's one-bit gradient mask (a.maskout; relu is then on).  A template parameter, not a
+// branch: as a third epilogue inside one kernel it cost the plain form 7 VGPRs and 32 bytes of scratch.
+template <int C, bool HAS_SLOT, bool MASK = false>
 __global__ __launch_bounds__(512, 1) void affine_ring_kernel(FastArgs a)
 {
     constexpr int TR = 8192 / C;              // rows per tile (32 KiB of fp32)
@@ -889,8 +892,10 @@ __global__ __launch_bounds__(512, 1) void affine_ring_kernel(FastArgs a)
         // One scalar branch per tile, not one per value (the flag is a kernel argument: tested inside the loop it cut the epilogue
         // into eight basic blocks).  ReLU as !(v <= 0) ? v : 0 -- one v_cmp_nle + one v_cndmask, NaN stays NaN -- instead of the
         // four instructions of (v > 0 || isnan(v)).
-        auto leave = [&](auto RL_) __attribute__((always_inline)) {
+        auto leave = [&](auto RL_, auto MK_) __attribute__((always_inline)) {
             constexpr bool RL = decltype(RL_)::value;       // the ReLU that follows every WC site rides in the epilogue
+            constexpr bool MK = decltype(MK_)::value;       // ... and leaves its gradient mask behind as ONE BIT per element
+            unsigned bits = 0;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int rh = i >> 2, r = i & 3;
@@ -902,6 +907,13 @@ __global__ __launch_bounds__(512, 1) void affine_ring_kernel(FastArgs a)
                 // (inline asm: with __builtin_amdgcn_permlane16_swap hipcc 7.0 stored the FIRST result twice here -- the second
                 // definition of the instruction got lost; s_nop: the operands were just written by VALU instructions)
                 asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(v0), "+v"(v1));
+                if (MK) {
+                    // after the ReLU a value is +0 or passes (positive, or NaN): "not zero" is one v_min_u32 on its bits.  v0 is
+                    // row 16 rh + r (+ 8 in lanes 32-63) of the wave's 32, v1 four rows below; column l31
+                    const unsigned b0 = __builtin_bit_cast(unsigned, v0), b1 = __builtin_bit_cast(unsigned, v1);
+                    bits |= (b0 < 1u ? b0 : 1u) << (16 * rh + r);
+                    bits |= (b1 < 1u ? b1 : 1u) << (16 * rh + r + 4);
+                }
 #if WC_NT_STORE
                 __builtin_nontemporal_store(v0, &po[(16 * rh + r) * C]);
                 __builtin_nontemporal_store(v1, &po[(16 * rh + r + 4) * C]);
@@ -910,8 +922,21 @@ __global__ __launch_bounds__(512, 1) void affine_ring_kernel(FastArgs a)
                 po[(16 * rh + r + 4) * C] = v1;      // rows 4 + r and 12 + r
 #endif
             }
+            if (MK) {
+                // lanes l and l + 32 hold the two halves of column l31's 32 row bits (rows +0..7, +16..23 | +8..15, +24..31)
+                unsigned own = bits, other = bits;
+                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(own), "+v"(other));      // own[32..63] <-> other[0..31]: lanes 0-31 now hold their partner's bits in `other`
+                // SGPR base + lane offset (asm: as a 64-bit VGPR address the pointer was spilled and came back behind an
+                // s_waitcnt vmcnt(0) once per tile -- the whole DMA ring drained).  One more store per tile than the header's
+                // count of 16: a hand-counted wait only gets more conservative by it.
+                const unsigned* pm = a.maskout + ((int64_t)tile_of(t) * (TR / 32) + rg) * C;      // wave-uniform
+                const unsigned moff = (unsigned)(out_lane & (C - 1)) * 4u, word = own | (other << 8);
+                if (lh == 0) asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" :: "v"(moff), "v"(word), "s"(pm) : "memory");
+            }
         };
-        if (a.relu) leave(std::true_type{}); else leave(std::false_type{});
+        if (MASK) leave(std::true_type{}, std::true_type{});
+        else if (a.relu) leave(std::true_type{}, std::false_type{});
+        else leave(std::false_type{}, std::false_type{});
 #else
         if (a.relu) {       // the ReLU that follows every WC site rides in the epilogue
 #pragma unroll
@@ -1005,7 +1030,16 @@ __global__ __launch_bounds__(512, 1) void affine_ring_kernel(FastArgs a)
                 const float* xrow = xin + row * C;
                 float accf = 0.f;
                 for (int k = 0; k < C; ++k) accf = fmaf(xrow[k] - (a.center ? a.center[k] : 0.f), Bf[(int64_t)k * C], accf);
-                { const float v = accf + add; out_tile[row * C + ecol] = a.relu ? (v > 0.f ? v : (v == v ? 0.f : v)) : v; }
+                {
+                    const float v = accf + add;
+                    const float o = (MASK || a.relu) ? (!(v <= 0.f) ? v : 0.f) : v;
+                    out_tile[row * C + ecol] = o;
+                    if (MASK) {       // the redone element's mask bit (rare path: atomics on the word it shares with 31 rows)
+                        unsigned* pm = a.maskout + ((r0 + row) >> 5) * C + ecol;
+                        const unsigned bit = 1u << ((r0 + row) & 31);
+                        if (__builtin_bit_cast(unsigned, o) != 0u) atomicOr(pm, bit); else atomicAnd(pm, ~bit);
+                    }
+                }
             }
         }
     }
@@ -1336,18 +1370,20 @@ hipError_t launch_affine_ring(const FastArgs& a, hipStream_t st)
     int nwg = b.ntiles < 256 ? b.ntiles : 256;
     b.tiles_per_wg = (b.ntiles + nwg - 1) / nwg;
     nwg = (b.ntiles + b.tiles_per_wg - 1) / b.tiles_per_wg;
-#define WC_LAUNCH_RING(SLOT_)                                                                                          \
+#define WC_LAUNCH_RING(SLOT_, MASK_)                                                                                   \
     do {                                                                                                                \
         static bool attr_set = false;                                                                                   \
         if (!attr_set) {                                                                                                \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(affine_ring_kernel<C, SLOT_>),             \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(affine_ring_kernel<C, SLOT_, MASK_>),      \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
             if (e != hipSuccess) return e;                                                                              \
             attr_set = true;                                                                                            \
         }                                                                                                               \
-        hipLaunchKernelGGL((affine_ring_kernel<C, SLOT_>), dim3(nwg), dim3(512), lds, st, b);                           \
+        hipLaunchKernelGGL((affine_ring_kernel<C, SLOT_, MASK_>), dim3(nwg), dim3(512), lds, st, b);                    \
     } while (0)
-    if (b.slot != nullptr) WC_LAUNCH_RING(true); else WC_LAUNCH_RING(false);
+    const bool mask = WC_MFMA16 && b.maskout != nullptr && b.relu;
+    if (b.slot != nullptr) { if (mask) WC_LAUNCH_RING(true, true); else WC_LAUNCH_RING(true, false); }
+    else { if (mask) WC_LAUNCH_RING(false, true); else WC_LAUNCH_RING(false, false); }
 #undef WC_LAUNCH_RING
     return hipGetLastError();
 }
@@ -1406,6 +1442,12 @@ bool wc_fast_affine_supported(int64_t N, int64_t HW, int C, bool has_slot)
     if (has_slot && !use_ring() && (HW % BM) != 0) return false;
     if ((M % BM) != 0) return false;                         // whole tiles only (keeps the kernel free of masked accesses)
     return true;
+}
+
+// does wc_launch_fast_affine_planned(relu, relu_mask) write the mask itself?  (the planned ring kernel on the 16x16x32 shape)
+bool wc_fast_affine_writes_mask(int64_t N, int64_t HW, int C)
+{
+    return WC_MFMA16 && use_ring() && wc_fast_affine_supported(N, HW, C, false) && ((N * HW) % (8192 / C)) == 0;
 }
 
 size_t wc_fast_affine_workspace(int C, int Kc)
@@ -1480,13 +1522,14 @@ void wc_fast_plan_parts(const void* plan, int C, int Kc, const float** scale, co
 hipError_t wc_launch_fast_affine_planned(const float* in, const float* center, const float* B, int Kc, bool shared_table,
                                          const float* bias, const float* sub, const int32_t* slot,
                                          int64_t N, int64_t HW, int C, int accumulate, float* out,
-                                         const void* plan, hipStream_t st)
+                                         const void* plan, hipStream_t st, unsigned* relu_mask)
 {
     const PlanView v = plan_view(const_cast<void*>(plan), C, Kc);
     FastArgs a = {};
     a.in = in; a.center = center; a.scale = v.scale; a.Bhi = v.hi; a.Blo = v.lo; a.colscale = v.colscale;
     a.slot_stride = shared_table ? 0 : (int64_t)C * C;
     a.bias = bias; a.sub = sub; a.slot = shared_table ? nullptr : slot; a.M = N * HW; a.HW = HW;
+    a.maskout = relu_mask;
     a.accumulate = accumulate & 1; a.relu = (accumulate >> 1) & 1; a.Bf = B; a.bf_stride = shared_table ? 0 : (int64_t)C * C; a.out = out; a.dbg = v.dbg;
     // the ring kernel takes any HW: tiles are cut from the M rows, and tiles that straddle samples of different slots
     // are redone with per-row tables at the end of the launch (rare shapes; none of the shipped recipes)

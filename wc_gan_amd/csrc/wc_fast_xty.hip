@@ -60,13 +60,17 @@ struct FastXtyArgs {
     double* dfix;                          // [nslab][C], covariance only: the diagonal, sum_m g_i[m]^2 on the VALU (see stage_write)
     int* flag;
     const float* Yrelu; float* Yout;       // RELU form (two operands, quadrant scheme): Y := Y where Yrelu > 0 else 0, written to Yout
+    const unsigned* Ymask;                 // RELU == 2: the same mask as ONE BIT per element, [M/32][C] words (wc_apply_mask_f32)
 };
 
 // RELU (K4 behind a site whose ReLU rode in K3's epilogue): the gradient mask gy := gy where y > 0
 // is applied to the Y operand as it is staged -- the Y threads load the matching rows of y beside those of gy (32 more
 // registers: the quadrant form has them) and the types of quadrant row 0 write the masked rows out for K6 -- instead of a
 // separate elementwise pass over three tensors in front of K4.
-template <int C, bool TWO, bool RELU = false>
+// RELU: 0 none; 1 the site's output y in fp32 (8 x 16 bytes per Y thread and stage); 2 the bit mask K3 left (ONE 16-byte load of
+// the thread's four columns' words per stage: the stage's 64 rows are two 32-row mask blocks, the thread's 8 rows one byte of a
+// word -- K4 then reads x, gy and 1/32 of a tensor instead of three tensors)
+template <int C, bool TWO, int RELU = 0>
 __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
 {
     static_assert(!RELU || xty_quad<C, TWO>(), "the masked form exists for the quadrant scheme only");
@@ -177,16 +181,23 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
     }
 
     f32x4 xr[8];
-    f32x4 yr[RELU ? 8 : 1];
+    f32x4 yr[RELU == 1 ? 8 : 1];
+    uint4 ym = {0u, 0u, 0u, 0u};
     const bool y_wave = RELU && __builtin_amdgcn_readfirstlane(op) != 0;       // waves 4-7 stage Y (wave-uniform: a scalar branch)
     auto stage_load = [&](int st) {
         const int64_t off = (r0 + (int64_t)st * R + rgrp * 8) * C + cbase + 4 * c4;
         const float* base = src + off;
 #pragma unroll
         for (int p = 0; p < 8; ++p) xr[p] = ldg4(base + p * C);
-        if (RELU && y_wave) {
+        if (RELU == 1 && y_wave) {
 #pragma unroll
-            for (int p = 0; p < 8; ++p) yr[RELU ? p : 0] = ldg4(a.Yrelu + off + p * C);
+            for (int p = 0; p < 8; ++p) yr[RELU == 1 ? p : 0] = ldg4(a.Yrelu + off + p * C);
+        }
+        if (RELU == 2 && y_wave) {      // rows row0 .. row0 + 7 (row0 a multiple of 8): byte (row0 % 32) / 8 of the 32-row block's words
+            const int64_t row0 = r0 + (int64_t)st * R + rgrp * 8;
+            ym = *reinterpret_cast<const uint4*>(a.Ymask + (row0 >> 5) * C + cbase + 4 * c4);
+            const int sh = (int)(row0 & 31);
+            ym.x >>= sh; ym.y >>= sh; ym.z >>= sh; ym.w >>= sh;
         }
     };
     // The staging is what bounds this kernel: 16 (K1) to 22 (K4) vector instructions per MFMA before this trim (rocprofv3
@@ -214,11 +225,23 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
         char* img = smem + buf * (NOP * 2 * IMG);
         f32x4 g[8];
         if (RELU && y_wave) {
+            if (RELU == 2) {
+                const unsigned mw[4] = {ym.x, ym.y, ym.z, ym.w};
+#pragma unroll
+                for (int p = 0; p < 8; ++p)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {       // v_bfe_i32 sign-extends the row's bit to 0 / ~0: two vector instructions per element, as the compare form
+                        const unsigned keep = (unsigned)__builtin_amdgcn_sbfe((int)mw[j], p, 1);
+                        const float e = xr[p][j];        // (a scalar copy: __builtin_bit_cast applied to the vector ELEMENT took element 0 for every j -- hipcc 7.0)
+                        xr[p][j] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, e) & keep);
+                    }
+            } else {
 #pragma unroll
             for (int p = 0; p < 8; ++p)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) xr[p][j] = !(yr[RELU ? p : 0][j] <= 0.f) ? xr[p][j] : 0.f;      // (NaN in y: the gradient passes, as in relu_mask_kernel and aten::threshold_backward)
-            if (qi == 0) {                  // each half of Y's columns is written by one type
+                for (int j = 0; j < 4; ++j) xr[p][j] = !(yr[RELU == 1 ? p : 0][j] <= 0.f) ? xr[p][j] : 0.f;      // (NaN in y: the gradient passes, as in relu_mask_kernel and aten::threshold_backward)
+            }
+            if (qi == 0 && a.Yout) {        // each half of Y's columns is written by one type (nullable: a K6 that masks for itself)
                 float* dst = a.Yout + (r0 + (int64_t)st_of_data * R + rgrp * 8) * C + cbase + 4 * c4;
 #pragma unroll
                 for (int p = 0; p < 8; ++p) *reinterpret_cast<f32x4*>(dst + p * C) = xr[p];
@@ -422,7 +445,7 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
 template <int C, bool TWO>
 constexpr int stage_rows() { return xty_quad<C, TWO>() ? 64 : (TWO ? (512 / (C / 4)) * 4 : (512 / (C / 4)) * 8); }
 
-template <int C, bool TWO, bool RELU = false>
+template <int C, bool TWO, int RELU = 0>
 hipError_t launch_xty_fast(const FastXtyArgs& a, hipStream_t st)
 {
     constexpr int R = stage_rows<C, TWO>();
@@ -487,10 +510,10 @@ hipError_t wc_launch_fast_xty(const float* X, const float* Y, const float* cx, c
                               const float* sx, const float* sy, int64_t N, int64_t HW, int C,
                               int per_sample, int nsplit, int64_t rows_per_slab, int nslab, int ntypes,
                               double* P, float* colsum, double* dfix, int* gate, hipStream_t st,
-                              const float* yrelu, float* yout)
+                              const float* yrelu, float* yout, const unsigned* ymask)
 {
     FastXtyArgs a = {};
-    a.Yrelu = yrelu; a.Yout = yout;
+    a.Yrelu = yrelu; a.Yout = yout; a.Ymask = ymask;
     a.dfix = (Y == X) ? dfix : nullptr;
     a.X = X; a.Y = Y; a.cx = cx; a.cy = cy; a.sx = sx; a.sy = sy; a.N = N; a.HW = HW;
     a.per_sample = per_sample; a.nsplit = nsplit; a.rows_per_slab = rows_per_slab; a.nslab = nslab; a.ntypes = ntypes;
@@ -500,7 +523,8 @@ hipError_t wc_launch_fast_xty(const float* X, const float* Y, const float* cx, c
         case 32: return two ? launch_xty_fast<32, true>(a, st) : launch_xty_fast<32, false>(a, st);
         case 64: return two ? launch_xty_fast<64, true>(a, st) : launch_xty_fast<64, false>(a, st);
         case 128: return two ? launch_xty_fast<128, true>(a, st) : launch_xty_fast<128, false>(a, st);
-        case 256: return two ? (yrelu ? launch_xty_fast<256, true, true>(a, st) : launch_xty_fast<256, true>(a, st)) : launch_xty_fast<256, false>(a, st);
+        case 256: return two ? (ymask ? launch_xty_fast<256, true, 2>(a, st) : yrelu ? launch_xty_fast<256, true, 1>(a, st) : launch_xty_fast<256, true>(a, st))
+                             : launch_xty_fast<256, false>(a, st);
     }
     return hipErrorInvalidValue;
 }

@@ -553,6 +553,41 @@ __global__ __launch_bounds__(256) void relu_mask_kernel(const f32x4* __restrict_
     }
 }
 
+// The same gradient mask from the ONE-BIT form K3 leaves behind (wc_apply_mask_f32): mask[(m / 32) * C + c] bit m % 32 = "the
+// activation passed".  One thread = 4 channels of a row: one 16-byte load of the four columns' words instead of 16 bytes of y.
+__global__ __launch_bounds__(256) void relu_mask_bits_kernel(const f32x4* __restrict__ gy, const unsigned* __restrict__ mask,
+                                                             f32x4* __restrict__ out, int64_t n4, int C4)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const int64_t m = i / C4;
+        const int c4 = (int)(i - m * C4);
+        const uint4 w = *reinterpret_cast<const uint4*>(mask + ((m >> 5) * C4 + c4) * 4);
+        const int b = (int)(m & 31);
+        const f32x4 g = gy[i];
+        f32x4 o;
+        o[0] = (w.x >> b) & 1u ? g[0] : 0.f; o[1] = (w.y >> b) & 1u ? g[1] : 0.f;
+        o[2] = (w.z >> b) & 1u ? g[2] : 0.f; o[3] = (w.w >> b) & 1u ? g[3] : 0.f;
+        out[i] = o;
+    }
+}
+
+// the bit mask of an activation that exists in fp32 (the K3 paths that do not write it themselves): one thread per
+// (32-row block, column); 32 coalesced loads a row apart
+__global__ __launch_bounds__(256) void mask_from_y_kernel(const float* __restrict__ y, int64_t blocks, int C, unsigned* __restrict__ mask)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, n = blocks * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t t = i / C;
+        const int c = (int)(i - t * C);
+        const float* p = y + (t * 32) * C + c;
+        unsigned w = 0;
+#pragma unroll 8
+        for (int b = 0; b < 32; ++b) w |= (!(p[(int64_t)b * C] <= 0.f) ? 1u : 0u) << b;
+        mask[i] = w;
+    }
+}
+
 __global__ __launch_bounds__(256) void stream_copy_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, int64_t n4)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -649,6 +684,22 @@ hipError_t wc_launch_relu_mask(const float* gy, const float* y, float* out, int6
 {
     hipLaunchKernelGGL(relu_mask_kernel, dim3(2048), dim3(256), 0, st, reinterpret_cast<const f32x4*>(gy),
                        reinterpret_cast<const f32x4*>(y), reinterpret_cast<f32x4*>(out), n / 4);
+    return hipGetLastError();
+}
+
+hipError_t wc_launch_relu_mask_bits(const float* gy, const unsigned* mask, float* out, int64_t M, int C, hipStream_t st)
+{
+    hipLaunchKernelGGL(relu_mask_bits_kernel, dim3(2048), dim3(256), 0, st, reinterpret_cast<const f32x4*>(gy), mask,
+                       reinterpret_cast<f32x4*>(out), M * C / 4, C / 4);
+    return hipGetLastError();
+}
+
+hipError_t wc_launch_mask_from_y(const float* y, int64_t M, int C, unsigned* mask, hipStream_t st)
+{
+    const int64_t n = (M / 32) * C;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(mask_from_y_kernel, dim3((unsigned)blocks), dim3(256), 0, st, y, M / 32, C, mask);
     return hipGetLastError();
 }
 

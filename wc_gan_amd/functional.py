@@ -54,11 +54,18 @@ class WhitenColorFunction(torch.autograd.Function):
         g = gamma.contiguous() if gamma is not None else None
         b = beta.contiguous() if beta is not None else None
         A, At, plan = ops.color(W, g, chan_scale)      # plan: the apply's fp16 tables, so K3 is one launch
-        y = ops.apply(x, mu, A, b, slot, plan=plan, relu=relu)      # relu: folded into K3's epilogue (row N2)
+        # relu: folded into K3's epilogue (row N2).  Its gradient mask is kept as ONE BIT per element (K3 writes it): the
+        # backward neither re-reads y (K4: 134 MB at the headline site) nor keeps y alive for it
+        bits = bool(relu) and M_local % 32 == 0
+        if bits:
+            y, mask = ops.apply(x, mu, A, b, slot, plan=plan, relu=True, want_mask=True)
+        else:
+            y, mask = ops.apply(x, mu, A, b, slot, plan=plan, relu=relu), None
         ctx.save_for_backward(x, mu, L, W, A, At, g if g is not None else torch.empty(0, device=dev),
                               slot if slot is not None else torch.empty(0, dtype=torch.int32, device=dev),
-                              y if relu else torch.empty(0, device=dev))
+                              mask if bits else (y if relu else torch.empty(0, device=dev)))
         ctx.relu = bool(relu)
+        ctx.mask_bits = bits
         ctx.has_gamma = g is not None
         ctx.has_beta = b is not None
         ctx.has_slot = slot is not None
@@ -80,20 +87,25 @@ class WhitenColorFunction(torch.autograd.Function):
         want_b = ctx.has_beta and need_b
         reduce_runs = want_g or want_b or stats_path
         if ctx.relu and not reduce_runs:  # the fused activation's gradient: the mask in front of the unchanged backward
-            gy = torch.ops.aten.threshold_backward(gy, y, 0.0)      # gy where y > 0, else 0: ONE elementwise pass (where(y > 0, ...) took three launches)
+            if ctx.mask_bits:
+                gy = ops.relu_mask_bits(gy, y)
+            else:
+                gy = torch.ops.aten.threshold_backward(gy, y, 0.0)      # gy where y > 0, else 0: ONE elementwise pass (where(y > 0, ...) took three launches)
         scales = None          # K4 samples the fp16 scales of (x - mu) and gy; K6 reuses them (three launches instead of six)
         if reduce_runs:
             share = bool(stats_path)
-            ry = y if ctx.relu else None  # K4 applies the mask while it stages gy and hands the masked gradient on (no pass of its own)
+            # K4 applies the mask while it stages gy and hands the masked gradient on (no pass of its own)
+            ry = y if (ctx.relu and not ctx.mask_bits) else None
+            rm = y if (ctx.relu and ctx.mask_bits) else None          # (the saved tensor is the bit mask then)
             if ctx.group is None:
-                out = ops.bwd_reduce(x, mu, gy, slot, Kc, want_scales=share, relu_y=ry)
+                out = ops.bwd_reduce(x, mu, gy, slot, Kc, want_scales=share, relu_y=ry, relu_mask=rm)
                 R, gsum = out[0], out[1]
             else:
-                out = ops.bwd_reduce(x, mu, gy, slot, Kc, flat=True, want_scales=share, relu_y=ry)
+                out = ops.bwd_reduce(x, mu, gy, slot, Kc, flat=True, want_scales=share, relu_y=ry, relu_mask=rm)
                 R, gsum, rbuf = out[0], out[1], out[2]
             if share:
                 scales = out[-1]
-            if ry is not None:
+            if ry is not None or rm is not None:
                 gy = out[-2] if share else out[-1]
             if ctx.group is None:
                 dgamma, dbeta, S, gmean = ops.bwd_factor(R, gsum, W, L, g, A, ctx.M, ctx.eps, ctx.ddof, stats_path,

@@ -123,9 +123,11 @@ def group_bias(mu, A, beta, groups, Kc, per_group=False):
     return center, bias
 
 
-def apply(x, mu, A, bias, slot, out=None, fast=True, plan=None, relu=False):
+def apply(x, mu, A, bias, slot, out=None, fast=True, plan=None, relu=False, want_mask=False):
     """K3: y[n] = (x[n] - mu) A[slot[n]] + bias[slot[n]];  x is (N, ..., C) with C contiguous.
-    relu=True folds the ReLU that follows the site into the epilogue (wc_apply_act_f32)."""
+    relu=True folds the ReLU that follows the site into the epilogue (wc_apply_act_f32).
+    want_mask=True (with relu, N*HW % 32 == 0): -> (y, mask), mask the ReLU's one-bit gradient mask (int32 (M/32, C),
+    wc_apply_mask_f32) for bwd_reduce(relu_mask=...)."""
     lib = _lib.load()
     _need(x, torch.float32, "x")
     N, C = x.shape[0], x.shape[-1]
@@ -137,6 +139,14 @@ def apply(x, mu, A, bias, slot, out=None, fast=True, plan=None, relu=False):
         _need(slot, torch.int32, "slot", 1)
     y = torch.empty_like(x) if out is None else out
     ws = _workspace(lib.wc_apply_workspace_bytes(N, HW, C, Kc), x.device) if (fast and plan is None) else None
+    if want_mask:
+        if not relu or (N * HW) % 32 != 0:
+            raise ValueError("want_mask needs relu=True and a row count that is a multiple of 32")
+        mask = torch.empty((N * HW) // 32, C, dtype=torch.int32, device=x.device)
+        _lib.check(lib.wc_apply_mask_f32(_ptr(x), _ptr(mu), _ptr(A), _ptr(bias), _ptr(slot), N, HW, C, Kc, _ptr(y), _ptr(mask),
+                                         _ptr(plan) if fast else None, _ptr(ws), ws.numel() if ws is not None else 0, _stream()),
+                   "wc_apply_mask_f32")
+        return y, mask
     _lib.check(lib.wc_apply_act_f32(_ptr(x), _ptr(mu), _ptr(A), _ptr(bias), _ptr(slot), N, HW, C, Kc, 1 if relu else 0,
                                     _ptr(y), _ptr(plan) if fast else None, _ptr(ws), ws.numel() if ws is not None else 0,
                                     _stream()), "wc_apply_act_f32")
@@ -262,7 +272,7 @@ def apply_split(xs, mu, A, bias, slot, plan=None, relu=False, out=None, folded=F
     return y
 
 
-def bwd_reduce(x, mu, gy, slot, Kc, flat=False, want_scales=False, relu_y=None):
+def bwd_reduce(x, mu, gy, slot, Kc, flat=False, want_scales=False, relu_y=None, relu_mask=None):
     """K4: -> (R (Kc,C,C) f64, gsum (Kc,C) f64); flat=True: views of one buffer, returned third (sync-WC's single all-reduce);
     want_scales=True: the (2C,) per-channel input scales of (x - mu) and gy, returned last, for bwd_apply(scales=...);
     relu_y: the site's output y when its ReLU rode in K3 -- gy is masked (gy where y > 0) while it is staged, and the masked
@@ -282,6 +292,14 @@ def bwd_reduce(x, mu, gy, slot, Kc, flat=False, want_scales=False, relu_y=None):
     ws = _workspace(lib.wc_bwd_reduce_workspace_bytes(N, HW, C, Kc, int(slot is not None)), x.device)
     scales = torch.empty(2 * C, dtype=torch.float32, device=x.device) if want_scales else None
     gm = None
+    if relu_mask is not None:         # the mask in apply(..., want_mask=True)'s one-bit form: same outputs as relu_y
+        _need(relu_mask, torch.int32, "relu_mask", 2)
+        gm = torch.empty_like(gy)
+        _lib.check(lib.wc_bwd_reduce_mask_f32(_ptr(x), _ptr(mu), _ptr(gy), _ptr(relu_mask), _ptr(slot), N, HW, C, Kc, _ptr(R), _ptr(gsum),
+                                              _ptr(gm), _ptr(scales), _ptr(ws), ws.numel(), _stream()), "wc_bwd_reduce_mask_f32")
+        out = (R, gsum, buf) if buf is not None else (R, gsum)
+        out = out + (gm,)
+        return out + (scales,) if want_scales else out
     if relu_y is not None:
         _need(relu_y, torch.float32, "relu_y")
         gm = torch.empty_like(gy)
@@ -291,6 +309,18 @@ def bwd_reduce(x, mu, gy, slot, Kc, flat=False, want_scales=False, relu_y=None):
     if gm is not None:
         out = out + (gm,)
     return out + (scales,) if want_scales else out
+
+
+def relu_mask_bits(gy, mask):
+    """gy where the one-bit mask says the activation passed, else 0 (the elementwise form; K4 does the same while it stages)."""
+    lib = _lib.load()
+    _need(gy, torch.float32, "gy")
+    C = gy.shape[-1]
+    M = gy.numel() // C
+    out = torch.empty_like(gy)
+    # (no dedicated entry point: the masked copy is what wc_bwd_reduce_mask_f32 writes; here via the same kernel)
+    _lib.check(lib.wc_relu_mask_apply_f32(_ptr(gy), _ptr(mask), M, C, _ptr(out), _stream()), "wc_relu_mask_apply_f32")
+    return out
 
 
 def bwd_factor(R, gsum, W, L, gamma, A, M, eps, ddof, training, want_dgamma=True, want_dbeta=True):
