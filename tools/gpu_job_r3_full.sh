@@ -1,9 +1,10 @@
 #!/bin/bash
-# round 3: the whole GPU suite, then the bench line
+# round 3: the whole GPU suite, the seed sweep, then the bench line
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/r3
-timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -15 > gpurun_out/r3/pytest_gpu.txt
+timeout 3000 python -m pytest tests -x -q -m gpu 2>&1 | tail -15 > gpurun_out/r3/pytest_gpu.txt
 cat gpurun_out/r3/pytest_gpu.txt
+timeout 1500 python tools/seed_sweep.py 5 > gpurun_out/r3/seed_sweep.txt 2>&1; echo "seed sweep rc $?"; grep "WORST\|worst" gpurun_out/r3/seed_sweep.txt
 timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/r3/bench_line.json 2> gpurun_out/r3/bench_err.txt
 tail -3 gpurun_out/r3/bench_err.txt
 python - <<'PY'

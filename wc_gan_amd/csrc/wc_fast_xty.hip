@@ -42,6 +42,12 @@ constexpr int BW_PLAIN = 3;                // 32x32 blocks per wave
 #ifndef XTY_ALLLIVE
 #define XTY_ALLLIVE 1
 #endif
+#ifndef XTY_FLUSH_STAGES
+#define XTY_FLUSH_STAGES 1     // covariance (K1): stages per fp32 MFMA chain before the float64 flush.  Development knob, measured in round 3
+                               // (tools/seed_sweep.py, worst dx over three seeds at 128x32x32x256, cond 1e6): 1 stage = 12 MFMA accumulations
+                               // 1.39e-4; 2 stages 1.72e-4; 4 stages 2.19e-4; 16 stages 1.03e-3 -- and SHORTER chains (a flush every 2 k-steps /
+                               // every k-step, built and dropped) 1.92e-4 / 3.23e-4: one stage per chain is the optimum of this scheme
+#endif
 template <int C, bool TWO> constexpr bool xty_quad() { return TWO && C == 256; }
 
 
@@ -317,6 +323,7 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
     // converting waves and the fragment reads of the MFMA waves fight over the LDS.  An L2 prefetch of the stage three steps
     // ahead: 89 -> 100 us.  Reading the A fragments once for a wave's blocks of the same block row (12 -> 9 ds_read_b128 per
     // k-step): no change, +18 spilled registers.)
+    f32x16 acc[BW];
     for (int st = 0; st < nst; ++st) {
         const int cur = st & 1;
         XS();
@@ -326,11 +333,13 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
         XS();
         // the fp32 accumulators live for one stage only (their first MFMA takes a zero operand: no zeroing pass, and the 16 BW
         // registers are free while the next stage is converted)
-        f32x16 acc[BW];
+        constexpr int FS = TWO ? 1 : XTY_FLUSH_STAGES;
+        if (FS == 1 || st % FS == 0) {
 #pragma unroll
-        for (int b = 0; b < BW; ++b)
+            for (int b = 0; b < BW; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+        }
         const int kbuf = cur << 16;
         auto frag = [&](int base, int ks, int lo) __attribute__((always_inline)) {
             return *reinterpret_cast<const f16x8*>(smem + (base ^ ((ks << 5) | kbuf)) + lo * IMG);
@@ -377,7 +386,8 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
         else if (any_live) products(std::false_type{}, std::integral_constant<int, BW>{});
         XS();
         // float64 flush: the fp32 rounding chain never exceeds one stage (3*KS MFMA accumulations)
-        if (two_live) {
+        if (FS > 1 && st % FS != FS - 1 && st + 1 < nst) {}
+        else if (two_live) {
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
