@@ -190,6 +190,30 @@ int wc_apply_mask_f32(const float* x, const float* mu, const float* A, const flo
                       float* y, void* relu_mask /*out*/, const void* plan /*from wc_color_f32, nullable*/,
                       void* ws, size_t ws_bytes, wc_stream_t stream);
 
+/* K3 -> convolution hand-off (ABI 4).  Every WC site of the generator is followed by
+ * ReLU and a convolution (generator.py:144-151), and this build's convolution (wc_conv_f16x3) reads its input as two fp16 planes
+ * hi | lo of s * y with ONE power-of-two scale s: wc_apply_planes_f32 is wc_apply_act_f32 whose output leaves in that form -- no
+ * fp32 y, and no wc_conv_split_f32 (one pass for max |y|, one to split) in front of the convolution.
+ *   planes  (out) 2 * N*HW*C fp16: hi plane, then lo plane;  y ~= (hi + lo) / oscale[0]
+ *   oscale  float[wc_apply_planes_scale_floats()], the scale record: wc_out_scale_f32 fills its input part from the coloring
+ *           parameters alone, no pass over data (a whitened activation has unit covariance, so channel c of table k has standard
+ *           deviation |Gamma_k[:, c]|: [1] = K as an int, [2 + k] = max_c (|beta_k[c]| + 16 |Gamma_k[:, c]|), K <= 1024; the
+ *           kernel puts the largest bound into [2^13, 2^14), the convolution's own target for max |y|).  A caller with a better
+ *           bound writes [1] = 1 (int) and [2] = the bound.  [0] (out) = the scale the planes were written with -- the device
+ *           scalar wc_conv_f16x3 takes.  The rest is scratch (per-workgroup maxima).
+ *   Two launches of the same kernel: the pass, and a gated one that leaves at once unless an element of s * y left fp16's range
+ *   (beyond ~64 sigma), in which case it redoes the pass with the scale the measured maximum asks for.  No host synchronisation.
+ *   relu_mask (nullable, relu = 1): as in wc_apply_mask_f32.  plan: required (wc_color_f32).
+ * wc_apply_planes_supported: C in {128, 256}, N*HW a multiple of 8192/C rows and of 32; otherwise WC_ERR_SHAPE -- call
+ * wc_apply_act_f32 and let the convolution split its input. */
+int    wc_apply_planes_supported(int64_t N, int64_t HW, int C);
+size_t wc_apply_planes_scale_floats(void);
+int    wc_out_scale_f32(const float* gamma /*[K,C,C], nullable = identity*/, const float* beta /*[K,C], nullable*/, int K, int C,
+                        float* oscale, wc_stream_t stream);
+int    wc_apply_planes_f32(const float* x, const float* mu, const float* A, const float* bias, const int32_t* slot,
+                           int64_t N, int64_t HW, int C, int Kc, int relu, void* planes /*out*/, float* oscale,
+                           void* relu_mask /*out, nullable*/, const void* plan, wc_stream_t stream);
+
 /* K4: R[k] = sum_{n: slot[n]=k} (x[n]-mu)^T gy[n]  (Kc,C,C),  gsum[k] = sum_{n in k} rows of gy[n]  (Kc,C). */
 int wc_bwd_reduce_f32(const float* x, const float* mu, const float* gy, const int32_t* slot,
                       int64_t N, int64_t HW, int C, int Kc,

@@ -1,0 +1,197 @@
+"""GPU tests of the K3 -> convolution hand-off: the site's apply kernel writes the
+next convolution's fp16 operand planes itself (wc_apply_planes_f32) -- against the float64 oracle, against the fp32 form of K3
+followed by the convolution's own split, and through the layers (forward and every gradient of site + convolution)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import wc_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a, dtype=torch.float32):
+    return torch.tensor(np.ascontiguousarray(a), dtype=dtype, device="cuda")
+
+
+def _site(shape, Kc, seed, cond="well"):
+    rng = np.random.default_rng(seed)
+    N, C = shape[0], shape[-1]
+    x = o.synth_activation(rng, shape, cond).astype(np.float32)
+    G, B = o.synth_coloring(rng, C, Kc)
+    slot = rng.integers(0, Kc, N).astype(np.int32) if Kc > 1 else None
+    return x, G.astype(np.float32), B.astype(np.float32), slot
+
+
+def _stages(x, G, B, slot):
+    from wc_gan_amd import ops
+    C = x.shape[-1]
+    M = x.numel() // C
+    s, xtx = ops.stats(x.view(M, C))
+    mu, L, W, cs = ops.factor(s, xtx, M, C, 1e-3, 0.99, 1, True, None, None, x.device, want_scale=True)
+    A, At, plan = ops.color(W, G, cs)
+    return mu, A, plan
+
+
+@pytest.mark.parametrize("shape,Kc", [((128, 32, 32, 256), 1), ((128, 16, 16, 256), 10), ((128, 8, 8, 256), 1), ((64, 16, 16, 128), 3),
+                                      ((16, 8, 8, 256), 1)])
+def test_planes_equal_the_fp32_output_and_its_mask(shape, Kc):
+    """(hi + lo) / scale == K3's fp32 ReLU'd output to 2^-20 of max |y| (two fp16 planes carry 22 bits), the 1-bit ReLU masks of
+    the two forms are equal, and against the float64 oracle the planes meet the path's 1e-4."""
+    from wc_gan_amd import ops
+    x, G, B, slot = _site(shape, Kc, 11)
+    xd, Gd, Bd = dev(x), dev(G), dev(B)
+    sd = dev(slot, torch.int32) if slot is not None else None
+    mu, A, plan = _stages(xd, Gd, Bd, sd)
+    y, mask = ops.apply(xd, mu, A, Bd, sd, plan=plan, relu=True, want_mask=True)
+    rec = ops.out_scale(Gd, Bd, shape[-1], xd.device)
+    planes, rec, pmask = ops.apply_planes(xd, mu, A, Bd, sd, plan, rec, relu=True, want_mask=True)
+    torch.cuda.synchronize()
+    s = float(rec[0])
+    assert s > 0 and np.log2(s) == int(np.log2(s))                       # a power of two
+    assert float(planes.float().abs().max()) < 60000.0                   # inside fp16's range
+    back = (planes[0].double() + planes[1].double()) / s
+    ymax = float(y.abs().max())
+    assert float((back - y.double()).abs().max()) <= ymax * 2.0 ** -20
+    assert torch.equal(mask, pmask)
+    ref = np.maximum(o.wc_forward(x.astype(np.float64), G.astype(np.float64), B.astype(np.float64), slot)[0], 0.0)
+    err = float(np.abs(back.cpu().numpy() - ref).max() / np.abs(ref).max())
+    assert err < 1e-4, err
+
+
+def test_the_gate_redoes_the_pass_when_the_predicted_scale_overflows():
+    """A caller's bound that is far too small (scale far too large): s * y leaves fp16's range, the gated second launch sees it in the
+    per-workgroup maxima and rewrites the planes with the scale the measured maximum asks for -- no host round trip."""
+    from wc_gan_amd import ops
+    shape, Kc = (128, 16, 16, 256), 1
+    x, G, B, slot = _site(shape, Kc, 12)
+    xd, Gd, Bd = dev(x), dev(G), dev(B)
+    mu, A, plan = _stages(xd, Gd, Bd, None)
+    y = ops.apply(xd, mu, A, Bd, None, plan=plan, relu=True)
+    rec = ops.out_scale(Gd, Bd, 256, xd.device)
+    good = ops.apply_planes(xd, mu, A, Bd, None, plan, rec.clone(), relu=True)
+    rec[1] = torch.tensor([1], dtype=torch.int32, device="cuda").view(torch.float32)[0]       # one bound ...
+    rec[2] = 1e-3                                                                             # ... a thousand times too small
+    planes, rec = ops.apply_planes(xd, mu, A, Bd, None, plan, rec, relu=True)
+    torch.cuda.synchronize()
+    ymax = float(y.abs().max())
+    s = float(rec[0])
+    assert 2.0 ** 13 <= s * ymax < 2.0 ** 14 * 1.0001            # the convolution's own target range for max |y|
+    assert bool(torch.isfinite(planes.float()).all())
+    back = (planes[0].double() + planes[1].double()) / s
+    assert float((back - y.double()).abs().max()) <= ymax * 2.0 ** -20
+    back_good = (good[0][0].double() + good[0][1].double()) / float(good[1][0])
+    assert float((back - back_good).abs().max()) <= ymax * 2.0 ** -20
+
+
+def _wc_conv_pair(C, Cout, kind, conditional, seed):
+    from wc_gan_amd.generator import Conv2D, create_norm
+    torch.manual_seed(seed)
+    norm = create_norm('d', 'ucconv' if conditional else 'uconv', number_of_classes=10)
+    site = norm(axis=-1, name='t.bn', channels=C).cuda()
+    conv = Conv2D(C, Cout, (3, 3), name='t.conv').cuda()
+    return site, conv
+
+
+@pytest.mark.parametrize("shape,Cout,kind,conditional", [((128, 16, 16, 256), 256, 'same', False), ((128, 8, 8, 256), 256, 'up3', False),
+                                                         ((64, 16, 16, 128), 128, 'same', True), ((128, 32, 32, 256), 256, 'same', False)])
+def test_site_then_conv_is_the_same_with_and_without_the_handoff(shape, Cout, kind, conditional):
+    """relu(WC(x)) -> conv through the layers: with the hand-off (K3 writes the planes) and without (fp32 y, absmax + split inside
+    the convolution) the output, dx, the coloring gradients and the convolution's weight gradients agree to 1e-6 of their
+    maxima (`K3 -> conv == K3; split; conv`)."""
+    import wc_gan_amd.generator as gen
+    C = shape[-1]
+    site, conv = _wc_conv_pair(C, Cout, kind, conditional, 5)
+    rng = np.random.default_rng(9)
+    x0 = dev(o.synth_activation(rng, shape, "well").astype(np.float32))
+    cls = torch.randint(0, 10, (shape[0], 1), device='cuda', dtype=torch.int32) if conditional else None
+    with torch.no_grad():
+        site(x0, cls)       # builds the lazy parameters
+    state = [t.detach().clone() for t in list(site.buffers())]
+    gy = None
+    results = []
+    for handoff in (True, False):
+        for t, s0 in zip(site.buffers(), state):
+            t.data.copy_(s0)
+        gen.HANDOFF = handoff
+        try:
+            x = x0.clone().requires_grad_(True)
+            h = gen._norm_relu(site, x, cls, conv, kind)
+            assert (getattr(h, '_wc_planes', None) is not None) == handoff
+            y = conv.forward_upsampled(h) if kind == 'up3' else conv(h)
+            if gy is None:
+                gy = torch.randn_like(y)
+            params = [p for p in list(site.parameters()) + list(conv.parameters())]
+            grads = torch.autograd.grad(y, [x] + params, gy)
+            results.append([y.detach()] + [g.detach() for g in grads])
+        finally:
+            gen.HANDOFF = True
+    for a, b in zip(*results):
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 1e-6 * scale + 1e-30, (tuple(a.shape), float((a - b).abs().max()) / scale)
+
+
+def test_generator_images_and_gradients_with_and_without_the_handoff():
+    """The whole CIFAR-10 generator, training mode: images and every parameter gradient with the hand-off on equal those with it
+    off to 2e-5 of their maxima (five sites hand over; the two routes round the planes' scale differently, nothing else)."""
+    import wc_gan_amd.generator as gen
+    from wc_gan_amd.generator import make_generator
+    from wc_gan_amd.train import CIFAR10_UNCOND
+    torch.manual_seed(3)
+    G = make_generator(**CIFAR10_UNCOND['generator']).cuda().train()
+    z = torch.randn(128, 128, device='cuda')
+    with torch.no_grad():
+        G(z)
+    state = {k: v.detach().clone() for k, v in G.state_dict().items()}
+    out = []
+    for handoff in (True, False):
+        G.load_state_dict(state)
+        gen.HANDOFF = handoff
+        try:
+            img = G(z)
+            loss = (img * torch.linspace(-1, 1, img.numel(), device='cuda').view_as(img)).sum()
+            params = [p for p in G.parameters() if p.requires_grad]
+            grads = torch.autograd.grad(loss, params)
+            out.append([img.detach()] + [g.detach() for g in grads])
+        finally:
+            gen.HANDOFF = True
+    worst = 0.0
+    for a, b in zip(*out):
+        worst = max(worst, float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30))
+    assert worst < 2e-5, worst
+
+
+def test_grouped_and_eval_paths_hand_over_too():
+    """The forward-only paths (statistic_groups: the generator passes inside the critic updates; eval mode: scorer.py) return a handle
+    whose planes equal the plain tensor of the same call."""
+    from wc_gan_amd.functional import EvalPlan, whiten_color_eval_cached, whiten_color_grouped
+    shape, Kc, groups = (160, 8, 8, 256), 4, 5
+    x, G, B, slot = _site(shape, Kc, 13)
+    xd, Gd, Bd, sd = dev(x), dev(G), dev(B), dev(slot, torch.int32)
+    for run in ("grouped", "eval"):
+        outs = []
+        for planes in (False, True):
+            mm = torch.zeros(256, 1, device="cuda"); mc = torch.eye(256, device="cuda")
+            with torch.no_grad():
+                if run == "grouped":
+                    y = whiten_color_grouped(xd, groups, Gd, Bd, sd, mm, mc, relu=True, planes=planes)
+                else:
+                    y = whiten_color_eval_cached(xd, EvalPlan(), Gd, Bd, sd, mm, mc, relu=True, planes=planes)
+            outs.append(y)
+        plain, handle = outs
+        hi, lo, rec = handle._wc_planes
+        assert bool(torch.isnan(handle.flatten()[0]))            # no data behind the handle itself
+        back = (hi.double() + lo.double()) / float(rec[0])
+        assert float((back - plain.double()).abs().max()) <= float(plain.abs().max()) * 2.0 ** -20
+
+
+def test_a_handle_that_reaches_a_convolution_without_a_planes_path_fails_loudly():
+    from wc_gan_amd import _lib
+    from wc_gan_amd import conv as fast_conv
+    from wc_gan_amd.functional import whiten_color
+    x = torch.randn(16, 8, 8, 256, device='cuda')
+    h = whiten_color(x, relu=True, planes=True)
+    assert getattr(h, '_wc_planes', None) is not None
+    w = torch.randn(96, 256, 3, 3, device='cuda')            # 96 output channels: not a shape the kernel takes
+    with pytest.raises(_lib.WcHipError):
+        fast_conv.fast_conv_or_none(h, w, None, 'same')

@@ -98,7 +98,8 @@ def _supported(g):
 
 def supported(x, w, kind):
     """Does the kernel take this call?  (channels multiples of 128, N*H*W of the virtual grid a multiple of 128)"""
-    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous() and w.dtype == torch.float32):
+    handed = getattr(x, '_wc_planes', None) is not None       # a K3 handle: the data is in the planes it carries
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and (handed or x.is_contiguous()) and w.dtype == torch.float32):
         return False
     p = _plan(kind, x, w)
     return bool(p) and p.ok
@@ -270,11 +271,24 @@ def weight_gradient(x_planes, g_planes, geom, w, k_axis, n_axis, nbytes=None, co
     return dw
 
 
+def takes_planes(shape, wshape, kind):
+    """Would fast_conv_or_none take an input of this NHWC shape as planes handed over by K3 (functional.whiten_color(planes=True))?
+    Shapes only -- the caller asks before it runs the site."""
+    class _S:
+        pass
+    xs, ws = _S(), _S()
+    xs.shape, ws.shape = tuple(shape), tuple(wshape)
+    p = _plan(kind, xs, ws)
+    return bool(p) and p.ok
+
+
 class _FastConv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, kind, plan, relu_input=False):
+    def forward(ctx, x, w, bias, kind, plan, relu_input=False, handed=None):
         gf, kf, nf = plan.fwd
-        planes = split_planes(x, relu=relu_input)   # relu_input: the layer is conv(relu(x)); the ReLU happens in the split
+        # handed: x is a K3 handle and these are its planes (already ReLU'd and split by K3's epilogue: no pass here)
+        # relu_input: the layer is conv(relu(x)); the ReLU happens in the split
+        planes = handed if handed is not None else split_planes(x, relu=relu_input)
         if ctx.needs_input_grad[0]:                 # the data gradient will want its image too: both in one launch
             img, ctx.bwd_image = weight_image_pair(w, plan.fwd, plan.bwd)
         else:
@@ -308,13 +322,20 @@ class _FastConv(torch.autograd.Function):
                 dw = weight_gradient((xh, xl, xs), g_planes, gf, w, kf, nf, nbytes=plan.wrw_ws)
         if want_db and not fused_db:
             db = gy.sum((0, 1, 2))
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
 def fast_conv_or_none(x, w, bias=None, kind='same', relu_input=False):
     """fast_conv when the kernel takes the call, else None (the caller's other path).  relu_input: conv(relu(x))."""
+    handed = getattr(x, '_wc_planes', None)
     if not supported(x, w, kind):
+        if handed is not None:
+            raise _lib.WcHipError(f"fast_conv: a K3 handle reached a convolution that cannot take planes {tuple(x.shape)} x {tuple(w.shape)} ({kind})")
         return None
+    if handed is not None:
+        if relu_input:
+            raise ValueError("a K3 handle is already ReLU'd")
+        return _FastConv.apply(x, w, bias, kind, _plan(kind, x, w), False, handed)
     return _FastConv.apply(x, w, bias, kind, _plan(kind, x, w), relu_input)
 
 

@@ -263,6 +263,38 @@ int wc_apply_mask_f32(const float* x, const float* mu, const float* A, const flo
     return WC_OK;
 }
 
+// K3 -> convolution hand-off (ABI 4): the site's output as the next convolution's operand
+int wc_apply_planes_supported(int64_t N, int64_t HW, int C)
+{
+    return (N > 0 && HW > 0 && !bad_channels(C) && wc_fast_affine_writes_planes(N, HW, C)) ? 1 : 0;
+}
+
+size_t wc_apply_planes_scale_floats(void) { return 2 + 2 * 1024; }
+
+int wc_out_scale_f32(const float* gamma, const float* beta, int K, int C, float* oscale, wc_stream_t stream)
+{
+    if (!oscale) return WC_ERR_NULL;
+    if (K <= 0 || K > 1024) return WC_ERR_ARG;
+    if (bad_channels(C)) return WC_ERR_CHANNELS;
+    WC_TRY(wc_launch_out_scale(gamma, beta, K, C, oscale, static_cast<hipStream_t>(stream)));
+    return WC_OK;
+}
+
+int wc_apply_planes_f32(const float* x, const float* mu, const float* A, const float* bias, const int32_t* slot,
+                        int64_t N, int64_t HW, int C, int Kc, int relu, void* planes, float* oscale, void* relu_mask,
+                        const void* plan, wc_stream_t stream)
+{
+    if (!x || !A || !planes || !oscale || !plan) return WC_ERR_NULL;
+    if (relu != 0 && relu != 1) return WC_ERR_ARG;
+    if (relu_mask && !relu) return WC_ERR_ARG;
+    if (N <= 0 || HW <= 0 || Kc <= 0) return WC_ERR_SHAPE;
+    if (bad_channels(C)) return WC_ERR_CHANNELS;
+    if (!wc_fast_affine_writes_planes(N, HW, C)) return WC_ERR_SHAPE;
+    WC_TRY(wc_launch_fast_affine_planned(x, mu, A, Kc, false, bias, nullptr, slot, N, HW, C, relu ? 2 : 0, nullptr, plan,
+                                         static_cast<hipStream_t>(stream), static_cast<unsigned*>(relu_mask), planes, oscale));
+    return WC_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // pre-split activations (ABI 4)
 size_t wc_split_bytes(int64_t M, int C)

@@ -140,7 +140,10 @@ float* wc_fast_plan_scale(void* plan);
 hipError_t wc_launch_fast_affine_planned(const float* in, const float* center, const float* B, int Kc, bool shared_table,
                                          const float* bias, const float* sub, const int32_t* slot,
                                          int64_t N, int64_t HW, int C, int accumulate, float* out,
-                                         const void* plan, hipStream_t st, unsigned* relu_mask = nullptr);      // relu_mask: see wc_fast_affine_writes_mask
+                                         const void* plan, hipStream_t st, unsigned* relu_mask = nullptr,      // relu_mask: see wc_fast_affine_writes_mask
+                                         void* planes = nullptr, float* oscale = nullptr);                    // planes: see wc_fast_affine_writes_planes
+bool wc_fast_affine_writes_planes(int64_t N, int64_t HW, int C);     // the planned ring kernel can leave its output as the next convolution's fp16 planes
+hipError_t wc_launch_out_scale(const float* gamma, const float* beta, int K, int C, float* oscale, hipStream_t st);   // predicted output scale -> oscale[1]
 bool wc_fast_affine_writes_mask(int64_t N, int64_t HW, int C);      // the planned ring kernel leaves the ReLU's bit mask itself (else: wc_launch_mask_from_y)
 hipError_t wc_launch_mask_from_y(const float* y, int64_t M, int C, unsigned* mask, hipStream_t st);
 hipError_t wc_launch_relu_mask_bits(const float* gy, const unsigned* mask, float* out, int64_t M, int C, hipStream_t st);

@@ -41,6 +41,9 @@
 #endif
 #define WC_STAMP(i) do { if (WC_STAMPS && stamp_on) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ts[i] = t_; } } while (0)
 #ifndef WC_NO_PIPE
+#ifndef WC_NT_STORE_PL
+#define WC_NT_STORE_PL 1   // planes form of the ring kernel: nontemporal stores of the 64-byte pieces
+#endif
 #define WC_NO_PIPE 0   // development: 1 leaves the ring kernel's k-loop to hipcc's own schedule
 #endif
 #ifndef WC_ABL
@@ -60,6 +63,7 @@ __device__ __forceinline__ unsigned pk_rne(float a, float b)
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
 }
 
+constexpr int kPlaneBounds = 1024;             // planes form: per-table bounds (and per-workgroup maxima) in the scale record
 constexpr float kF16Guard = 60000.0f;          // |scaled element| above this -> the tile takes the exact path
 
 __device__ __forceinline__ f32x4 ld4f(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -184,6 +188,12 @@ struct FastArgs {
     unsigned* maskout;                                               // ring kernel, relu != 0: the activation's 1-bit mask, [M/32][C] words (bit b of word (t, c) = out[32 t + b][c] != 0); nullable
     const float* Bf; int64_t bf_stride;                             // the fp32 table [slot][k][n] for the exact path
     float* out;
+    // ring kernel, planes form (PL): the output leaves as the NEXT CONVOLUTION's operand (csrc/wc_conv.hip: fp16 planes hi | lo
+    // of s * out with ONE power-of-two scale s) instead of fp32.  oscale[1..] = the bounds the predicted scale follows from (wc_launch_out_scale), oscale[0] =
+    // the scale the planes were written with (what the convolution reads); oamax[wg] = max |s * out| seen by a workgroup.  gate
+    // (second launch): the first launch's oamax -- every workgroup folds them and leaves at once unless the prediction overflowed
+    // fp16, in which case the whole pass is redone with the scale the maximum asks for.
+    _Float16* phi; _Float16* plo; float* oscale; float* oamax; const float* gate; int ngate;
     int ntiles, tiles_per_wg;
     unsigned long long* dbg;      // WC_STAMPS builds only: s_memtime stamps of one steady-state tile
 };
@@ -508,7 +518,8 @@ __global__ __launch_bounds__(512, 2) void affine_f16x3_kernel(FastArgs a)
 
 // MASK: the epilogue also leaves the ReLU's one-bit gradient mask (a.maskout; relu is then on).  A template parameter, not a
 // branch: as a third epilogue inside one kernel it cost the plain form 7 VGPRs and 32 bytes of scratch.
-template <int C, bool HAS_SLOT, bool MASK = false>
+// PL: the output leaves as the next convolution's fp16 planes (FastArgs::phi ...).
+template <int C, bool HAS_SLOT, bool MASK = false, bool PL = false>
 __global__ __launch_bounds__(512, 1) void affine_ring_kernel(FastArgs a)
 {
     constexpr int TR = 8192 / C;              // rows per tile (32 KiB of fp32)
@@ -544,7 +555,29 @@ __global__ __launch_bounds__(512, 1) void affine_ring_kernel(FastArgs a)
         t_first = blockIdx.x; t_stride = gridDim.x;
         n = (a.ntiles - t_first + t_stride - 1) / t_stride;
     }
-    if (n <= 0) return;
+    float os = 1.f, omax = 0.f;      // PL: output scale; running max |scaled output|
+    if (PL) {
+        {       // the predicted scale: fold the per-table bounds of wc_launch_out_scale
+            const int nb = __builtin_bit_cast(int, a.oscale[1]);
+            float bnd = 0.f;
+            for (int i = lane; i < nb; i += 64) bnd = __builtin_fmaxf(bnd, a.oscale[2 + i]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) bnd = __builtin_fmaxf(bnd, __shfl_xor(bnd, o));
+            int e = 0;
+            if (bnd > 0.f && bnd < 3.0e38f) { (void)frexpf(bnd, &e); os = ldexpf(1.f, 14 - e); }
+        }
+        if (a.gate) {       // second launch: nothing to do unless the first one's planes overflowed
+            float am = 0.f;
+            for (int i = lane; i < a.ngate; i += 64) am = __builtin_fmaxf(am, a.gate[i]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) am = __builtin_fmaxf(am, __shfl_xor(am, o));
+            if (!(am > kF16Guard)) return;
+            int e = 0;
+            if (am < 3.0e38f) { (void)frexpf(am, &e); os = ldexpf(os, 14 - e); } else os = 1.f;
+        }
+        if (blockIdx.x == 0 && tid == 0) a.oscale[0] = os;
+    }
+    if (n <= 0) { if (PL && a.oamax && tid == 0) a.oamax[blockIdx.x] = 0.f; return; }
     auto tile_of = [&](int i) { return t_first + i * t_stride; };
     auto swz = [](int row) -> int {
         if (PAD) return 0;
@@ -657,6 +690,10 @@ __global__ __launch_bounds__(512, 1) void affine_ring_kernel(FastArgs a)
     auto finish_b = [&]() {
 #pragma unroll
         for (int h = 0; h < NCH; ++h) addv[h] = (a.bias_on ? addv_b[h] : 0.f) - (a.sub_on ? addv_s[h] : 0.f);
+        if (PL) {           // the planes hold os * out: the scale rides in the two per-column constants
+#pragma unroll
+            for (int h = 0; h < NCH; ++h) { cscale[h] *= os; addv[h] *= os; }
+        }
     };
 
     // prologue: chunks 0..6 requested, then the B' table (KS*2 + <= 3 loads per lane, in flight while tile 0 is
@@ -695,6 +732,10 @@ __global__ __launch_bounds__(512, 1) void affine_ring_kernel(FastArgs a)
     // D register r of block (rh, ch): row 16 rh + 4 lq + r, column 16 ch + l15; after the epilogue's v_permlane16_swap a
     // lane stores rows 16 rh + 8 lh + {0, 4} + r of column l31
     const int out_lane = (rbase + 8 * lh) * C + cg * 32 + l31;
+    // planes form: a lane pair exchanges its packed halves (DPP quad_perm [1,0,3,2]) so that the EVEN lane holds row +0's columns
+    // (l31, l31 + 1) and the ODD lane row +4's columns (l31 - 1, l31): one dword per lane and plane, 64-byte pieces of a row
+    const int pl_lane = (rbase + 8 * lh + 4 * (l31 & 1)) * C + cg * 32 + (l31 & ~1);
+    const unsigned pl_sel = (l31 & 1) ? 0x03020706u : 0x05040100u;       // v_perm_b32(neighbour, own, sel)
 #else
     const int sw = swz(rbase + l31);
     const int rd_off = (rbase + l31) * PITCH;
@@ -884,6 +925,8 @@ __global__ __launch_bounds__(512, 1) void affine_ring_kernel(FastArgs a)
         WC_STAMP(3);
         // this wave's 32 x 32 block leaves now: its SIMD partner is half a tile away, in the middle of its MFMAs
         float* po = a.out + (int64_t)tile_of(t) * (TR * C) + out_lane;
+        _Float16* pph = nullptr; _Float16* ppl = nullptr;
+        if (PL) { pph = a.phi + (int64_t)tile_of(t) * (TR * C) + pl_lane; ppl = a.plo + (int64_t)tile_of(t) * (TR * C) + pl_lane; }
         unsigned long long s0_ = 0;
         if (WC_STAMPS) s0_ = __builtin_amdgcn_s_memrealtime();
 #if WC_MFMA16
@@ -913,6 +956,26 @@ __global__ __launch_bounds__(512, 1) void affine_ring_kernel(FastArgs a)
                     const unsigned b0 = __builtin_bit_cast(unsigned, v0), b1 = __builtin_bit_cast(unsigned, v1);
                     bits |= (b0 < 1u ? b0 : 1u) << (16 * rh + r);
                     bits |= (b1 < 1u ? b1 : 1u) << (16 * rh + r + 4);
+                }
+                if constexpr (PL) {
+                    omax = __builtin_fmaxf(omax, __builtin_fmaxf(fabsf(v0), fabsf(v1)));
+                    const unsigned H = pk_rne(v0, v1);
+                    float r0, r1;
+                    asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(H), "v"(v0));
+                    asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(H), "v"(v1));
+                    const unsigned L = pk_rne(r0, r1);
+                    const unsigned Hn = (unsigned)__builtin_amdgcn_update_dpp(0, (int)H, 0xB1, 0xF, 0xF, false);
+                    const unsigned Ln = (unsigned)__builtin_amdgcn_update_dpp(0, (int)L, 0xB1, 0xF, 0xF, false);
+                    const unsigned oh = __builtin_amdgcn_perm(Hn, H, pl_sel), ol = __builtin_amdgcn_perm(Ln, L, pl_sel);
+                    unsigned* qh = reinterpret_cast<unsigned*>(pph + (16 * rh + r) * C);
+                    unsigned* ql = reinterpret_cast<unsigned*>(ppl + (16 * rh + r) * C);
+#if WC_NT_STORE_PL
+                    __builtin_nontemporal_store(oh, qh);
+                    __builtin_nontemporal_store(ol, ql);
+#else
+                    *qh = oh; *ql = ol;
+#endif
+                    continue;
                 }
 #if WC_NT_STORE
                 __builtin_nontemporal_store(v0, &po[(16 * rh + r) * C]);
@@ -1033,7 +1096,13 @@ __global__ __launch_bounds__(512, 1) void affine_ring_kernel(FastArgs a)
                 {
                     const float v = accf + add;
                     const float o = (MASK || a.relu) ? (!(v <= 0.f) ? v : 0.f) : v;
-                    out_tile[row * C + ecol] = o;
+                    if (PL) {
+                        const float so = o * os;
+                        const _Float16 h = (_Float16)so;
+                        a.phi[(r0 + row) * C + ecol] = h;
+                        a.plo[(r0 + row) * C + ecol] = (_Float16)(so - (float)h);
+                        omax = __builtin_fmaxf(omax, fabsf(so));
+                    } else out_tile[row * C + ecol] = o;
                     if (MASK) {       // the redone element's mask bit (rare path: atomics on the word it shares with 31 rows)
                         unsigned* pm = a.maskout + ((r0 + row) >> 5) * C + ecol;
                         const unsigned bit = 1u << ((r0 + row) & 31);
@@ -1041,6 +1110,17 @@ __global__ __launch_bounds__(512, 1) void affine_ring_kernel(FastArgs a)
                     }
                 }
             }
+        }
+    }
+    if (PL && a.oamax) {        // this workgroup's max |scaled output| (one partial per workgroup: deterministic, nothing to clear)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) omax = __builtin_fmaxf(omax, __shfl_xor(omax, o));
+        if (lane == 0) cnt[4 + wave] = __builtin_bit_cast(int, omax);
+        __syncthreads();
+        if (tid == 0) {
+            float m = 0.f;
+            for (int w = 0; w < 8; ++w) m = __builtin_fmaxf(m, __builtin_bit_cast(float, (int)cnt[4 + w]));
+            a.oamax[blockIdx.x] = m;
         }
     }
 }
@@ -1370,20 +1450,34 @@ hipError_t launch_affine_ring(const FastArgs& a, hipStream_t st)
     int nwg = b.ntiles < 256 ? b.ntiles : 256;
     b.tiles_per_wg = (b.ntiles + nwg - 1) / nwg;
     nwg = (b.ntiles + b.tiles_per_wg - 1) / b.tiles_per_wg;
-#define WC_LAUNCH_RING(SLOT_, MASK_)                                                                                   \
+#define WC_LAUNCH_RING(SLOT_, MASK_, PL_)                                                                                \
     do {                                                                                                                \
         static bool attr_set = false;                                                                                   \
         if (!attr_set) {                                                                                                \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(affine_ring_kernel<C, SLOT_, MASK_>),      \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(affine_ring_kernel<C, SLOT_, MASK_, PL_>), \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
             if (e != hipSuccess) return e;                                                                              \
             attr_set = true;                                                                                            \
         }                                                                                                               \
-        hipLaunchKernelGGL((affine_ring_kernel<C, SLOT_, MASK_>), dim3(nwg), dim3(512), lds, st, b);                    \
+        hipLaunchKernelGGL((affine_ring_kernel<C, SLOT_, MASK_, PL_>), dim3(nwg), dim3(512), lds, st, b);               \
     } while (0)
     const bool mask = WC_MFMA16 && b.maskout != nullptr && b.relu;
-    if (b.slot != nullptr) { if (mask) WC_LAUNCH_RING(true, true); else WC_LAUNCH_RING(true, false); }
-    else { if (mask) WC_LAUNCH_RING(false, true); else WC_LAUNCH_RING(false, false); }
+    if (b.phi != nullptr) {
+        // planes form (C = 128 | 256): the pass itself, then the same kernel behind the gate (leaves at once unless the predicted
+        // scale overflowed).  oscale: see wc_launch_out_scale
+        if (!WC_MFMA16 || (C != 128 && C != 256) || nwg > 1024) return hipErrorInvalidValue;
+        if constexpr (WC_MFMA16 && (C == 128 || C == 256)) {
+            b.oamax = b.oscale + 2 + kPlaneBounds; b.gate = nullptr; b.ngate = nwg;
+            for (int pass = 0; pass < 2; ++pass) {
+                if (b.slot != nullptr) { if (mask) WC_LAUNCH_RING(true, true, true); else WC_LAUNCH_RING(true, false, true); }
+                else { if (mask) WC_LAUNCH_RING(false, true, true); else WC_LAUNCH_RING(false, false, true); }
+                b.gate = b.oscale + 2 + kPlaneBounds; b.oamax = nullptr;
+            }
+        }
+        return hipGetLastError();
+    }
+    if (b.slot != nullptr) { if (mask) WC_LAUNCH_RING(true, true, false); else WC_LAUNCH_RING(true, false, false); }
+    else { if (mask) WC_LAUNCH_RING(false, true, false); else WC_LAUNCH_RING(false, false, false); }
 #undef WC_LAUNCH_RING
     return hipGetLastError();
 }
@@ -1448,6 +1542,46 @@ bool wc_fast_affine_supported(int64_t N, int64_t HW, int C, bool has_slot)
 bool wc_fast_affine_writes_mask(int64_t N, int64_t HW, int C)
 {
     return WC_MFMA16 && use_ring() && wc_fast_affine_supported(N, HW, C, false) && ((N * HW) % (8192 / C)) == 0;
+}
+
+// ... and can it leave the output as the next convolution's planes (wc_launch_fast_affine_planned(planes, oscale))?
+bool wc_fast_affine_writes_planes(int64_t N, int64_t HW, int C)
+{
+    return (C == 128 || C == 256) && wc_fast_affine_writes_mask(N, HW, C) && (N * HW) / (8192 / C) <= 1024 * 1024;
+}
+
+// Predicted output scale of a site (device scalar, no pass over data): the whitened activation has unit covariance, so output
+// channel c of y = xhat Gamma_k + beta_k has standard deviation |Gamma_k[:, c]|; the scale puts max_c,k (|beta| + 16 sigma) into
+// [2^13, 2^14) -- the convolution's own target range for max |y| (csrc/wc_conv.hip, scale_of) -- which leaves fp16 a factor of
+// 4 to 8 of headroom above a 16-sigma element.  Elements beyond that are caught by the kernel's own maximum (the gate).
+// Record layout (floats): [0] scale used (out) | [1] K as an int | [2, 2 + 1024) per-table bounds | [2 + 1024, 2 + 2048) the apply
+// kernel's per-workgroup maxima.  One workgroup per table writes its bound; the apply kernel folds them (<= 16 L2 hits per lane).
+__global__ __launch_bounds__(256) void out_scale_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, int K, int C,
+                                                        float* __restrict__ oscale)
+{
+    __shared__ float red[4];
+    const int k = blockIdx.x;
+    float m = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) {              // column c of table k: the rows are read coalesced
+        float ss = gamma ? 0.f : 1.f;
+        if (gamma) for (int r = 0; r < C; ++r) { const float g = gamma[((int64_t)k * C + r) * C + c]; ss = fmaf(g, g, ss); }
+        m = fmaxf(m, 16.f * sqrtf(ss) + (beta ? fabsf(beta[(int64_t)k * C + c]) : 0.f));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        oscale[2 + k] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));          // this table's bound; the apply kernel folds them
+        if (k == 0) oscale[1] = __builtin_bit_cast(float, K);
+    }
+}
+
+hipError_t wc_launch_out_scale(const float* gamma, const float* beta, int K, int C, float* oscale, hipStream_t st)
+{
+    if (K < 1 || K > kPlaneBounds) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(out_scale_kernel, dim3(K), dim3(256), 0, st, gamma, beta, K, C, oscale);
+    return hipGetLastError();
 }
 
 size_t wc_fast_affine_workspace(int C, int Kc)
@@ -1522,10 +1656,14 @@ void wc_fast_plan_parts(const void* plan, int C, int Kc, const float** scale, co
 hipError_t wc_launch_fast_affine_planned(const float* in, const float* center, const float* B, int Kc, bool shared_table,
                                          const float* bias, const float* sub, const int32_t* slot,
                                          int64_t N, int64_t HW, int C, int accumulate, float* out,
-                                         const void* plan, hipStream_t st, unsigned* relu_mask)
+                                         const void* plan, hipStream_t st, unsigned* relu_mask, void* planes, float* oscale)
 {
     const PlanView v = plan_view(const_cast<void*>(plan), C, Kc);
     FastArgs a = {};
+    if (planes) {       // the output as the next convolution's fp16 planes (hi | lo, N*HW*C halves each)
+        if (!oscale || !wc_fast_affine_writes_planes(N, HW, C) || (accumulate & 1)) return hipErrorInvalidValue;
+        a.phi = static_cast<_Float16*>(planes); a.plo = a.phi + N * HW * C; a.oscale = oscale;
+    }
     a.in = in; a.center = center; a.scale = v.scale; a.Bhi = v.hi; a.Blo = v.lo; a.colscale = v.colscale;
     a.slot_stride = shared_table ? 0 : (int64_t)C * C;
     a.bias = bias; a.sub = sub; a.slot = shared_table ? nullptr : slot; a.M = N * HW; a.HW = HW;

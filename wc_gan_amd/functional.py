@@ -29,8 +29,10 @@ def _allreduce_(tensors, group):
 
 class WhitenColorFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, slot, moving_mean, moving_cov, training, eps, momentum, ddof, process_group, relu=False):
+    def forward(ctx, x, gamma, beta, slot, moving_mean, moving_cov, training, eps, momentum, ddof, process_group, relu=False,
+                planes_box=None):
         # x: (N, ..., C) float32 contiguous (NHWC); gamma (Kc,C,C)|None; beta (Kc,C)|None; slot int32 (N,)|None
+        # planes_box: a list -> the output leaves as the next convolution's fp16 planes (conv_handoff below); the box receives them
         C = x.shape[-1]
         M_local = x.numel() // C
         x = x.contiguous()
@@ -57,7 +59,10 @@ class WhitenColorFunction(torch.autograd.Function):
         # relu: folded into K3's epilogue (row N2).  Its gradient mask is kept as ONE BIT per element (K3 writes it): the
         # backward neither re-reads y (K4: 134 MB at the headline site) nor keeps y alive for it
         bits = bool(relu) and M_local % 32 == 0
-        if bits:
+        if planes_box is not None:
+            y = _apply_planes(x, mu, A, b, slot, plan, g, relu, bits, planes_box)
+            mask = planes_box[0][2]
+        elif bits:
             y, mask = ops.apply(x, mu, A, b, slot, plan=plan, relu=True, want_mask=True)
         else:
             y, mask = ops.apply(x, mu, A, b, slot, plan=plan, relu=relu), None
@@ -122,7 +127,45 @@ class WhitenColorFunction(torch.autograd.Function):
                                                     want_dgamma=False, want_dbeta=False)
         if need_x:
             dx = ops.bwd_apply(gy, x, mu, At, S, gmean, slot, scales=scales)
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------
+# K3 -> convolution hand-off: the site's output as the next convolution's operand
+# ---------------------------------------------------------------------------------------------
+_NAN = {}
+
+
+def _nan_handle(shape, dev):
+    """The tensor that stands for y in the autograd graph when y itself leaves as fp16 planes: the right shape and dtype, no
+    memory (one NaN element, stride 0) -- anything that reads it as data fails loudly instead of computing on zeros."""
+    t = _NAN.get(str(dev))
+    if t is None:
+        t = torch.full((1,), float('nan'), dtype=torch.float32, device=dev)
+        if not (t.is_cuda and torch.cuda.is_current_stream_capturing()):
+            _NAN[str(dev)] = t
+    return t.expand(tuple(shape))
+
+
+def conv_handoff_supported(shape, relu, Ktables=1):
+    """May a site of this NHWC output shape hand its output to the next convolution as planes? (relu'd sites only: that is what
+    every convolution behind a WC site reads, generator.py:144-151)"""
+    return bool(relu) and Ktables <= 1024 and ops.apply_planes_supported(tuple(shape))
+
+
+def _apply_planes(x, mu, A, b, slot, plan, gamma, relu, want_mask, box, beta=False):
+    # beta: the coloring's own bias where `b` is an effective one (grouped batches: b also carries the groups' mean offsets)
+    rec = ops.out_scale(gamma, b if beta is False else beta, x.shape[-1], x.device)
+    out = ops.apply_planes(x, mu, A, b, slot, plan, rec, relu=relu, want_mask=want_mask)
+    box.append((out[0], out[1], out[2] if want_mask else None))
+    return _nan_handle(x.shape, x.device)
+
+
+def attach_planes(handle, box):
+    """handle._wc_planes = (hi, lo, scale record): what conv.fast_conv_or_none looks for on its input."""
+    both, rec, _ = box[0]
+    handle._wc_planes = (both[0], both[1], rec)
+    return handle
 
 
 _SLOT_BASE = {}
@@ -143,7 +186,7 @@ def _group_slot_base(N, groups, Kc, dev):
 
 
 def whiten_color_grouped(x, groups, gamma=None, beta=None, slot=None, moving_mean=None, moving_cov=None,
-                         eps=1e-3, momentum=0.99, ddof=1, relu=False, per_sample=False):
+                         eps=1e-3, momentum=0.99, ddof=1, relu=False, per_sample=False, planes=False):
     """Training-mode forward of `groups` INDEPENDENT batches stacked along N (no autograd): each run of N/groups
     samples is whitened with its own batch statistics, exactly as `groups` separate calls would be, but the
     covariance / Cholesky / inverse problems of the groups are solved side by side in one set of launches.
@@ -163,20 +206,27 @@ def whiten_color_grouped(x, groups, gamma=None, beta=None, slot=None, moving_mea
     _touched(moving_mean, moving_cov)
     g = gamma.detach().contiguous() if gamma is not None else None
     b = beta.detach().contiguous() if beta is not None else None
+    def finish(center, A, bias, slots, plan):
+        # (the predicted scale follows from the coloring tables as given: every group's whitened batch has unit covariance)
+        if planes and conv_handoff_supported(x.shape, relu, 1 if g is None else g.shape[0]):
+            box = []
+            return attach_planes(_apply_planes(x, center, A, bias, slots, plan, g, relu, False, box, beta=b), box)
+        return ops.apply(x, center, A, bias, slots, plan=plan, relu=relu)
+
     if per_sample:
         if g is None or g.shape[0] != N:
             raise ValueError("per_sample needs one coloring table per sample")
         Kc = N // groups
         A, At, plan = ops.color(W, g, cs, groups, per_group=True)
         center, bias = ops.group_bias(mu.view(groups, C), A, b, groups, Kc, per_group=True)
-        return ops.apply(x, center, A, bias, _group_slot_base(N, N, 1, dev), plan=plan, relu=relu)
+        return finish(center, A, bias, _group_slot_base(N, N, 1, dev), plan)
     Kc = 1 if g is None else g.shape[0]
     A, At, plan = ops.color(W, g, cs, groups)
     center, bias = ops.group_bias(mu.view(groups, C), A, b, groups, Kc)
     full_slot = _group_slot_base(N, groups, Kc, dev)
     if slot is not None:
         full_slot = (full_slot + slot.view(-1)).to(torch.int32).contiguous()
-    return ops.apply(x, center, A, bias, full_slot, plan=plan, relu=relu)
+    return finish(center, A, bias, full_slot, plan)
 
 
 def _touched(*tensors):
@@ -214,18 +264,31 @@ class EvalPlan:
 
 
 def whiten_color_eval_cached(x, cache, gamma=None, beta=None, slot=None, moving_mean=None, moving_cov=None, eps=1e-3,
-                             gamma_key=None, relu=False):
+                             gamma_key=None, relu=False, planes=False):
     """Inference forward (no autograd) through an EvalPlan: one K3 launch per call once the plan is warm."""
     C = x.shape[-1]
     mu, A, At, plan = cache.get(C, gamma, moving_mean, moving_cov, eps, x.device, gamma_key)
     b = beta.detach().contiguous() if beta is not None else None
-    return ops.apply(x.detach().contiguous(), mu, A, b, slot, plan=plan, relu=relu)
+    x = x.detach().contiguous()
+    if planes and conv_handoff_supported(x.shape, relu, A.shape[0]):
+        box = []
+        g = gamma.detach().contiguous() if gamma is not None else None
+        return attach_planes(_apply_planes(x, mu, A, b, slot, plan, g, relu, False, box), box)
+    return ops.apply(x, mu, A, b, slot, plan=plan, relu=relu)
 
 
 def whiten_color(x, gamma=None, beta=None, slot=None, moving_mean=None, moving_cov=None, training=True,
-                 eps=1e-3, momentum=0.99, ddof=1, process_group=None, relu=False):
+                 eps=1e-3, momentum=0.99, ddof=1, process_group=None, relu=False, planes=False):
     """y = coloring(whitening(x)) (relu=True: max(y, 0) from the same kernel).  x: (N, H, W, C) float32 on the GPU,
-    C % 32 == 0 (see layers for padding)."""
+    C % 32 == 0 (see layers for padding).  planes=True (relu'd sites whose consumer is conv.fast_conv): where K3 can, the
+    result is a HANDLE -- a NaN tensor of y's shape without memory that carries the autograd edge -- with the output itself
+    attached as the convolution's fp16 planes (handle._wc_planes); else the plain tensor."""
+    Kt = 1 if gamma is None else gamma.shape[0]
+    if planes and conv_handoff_supported(x.shape, relu, Kt):
+        box = []
+        h = WhitenColorFunction.apply(x, gamma, beta, slot, moving_mean, moving_cov, bool(training),
+                                      float(eps), float(momentum), int(ddof), process_group, True, box)
+        return attach_planes(h, box)
     return WhitenColorFunction.apply(x, gamma, beta, slot, moving_mean, moving_cov, bool(training),
                                      float(eps), float(momentum), int(ddof), process_group, bool(relu))
 

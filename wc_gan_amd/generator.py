@@ -30,6 +30,9 @@ from .layers import (CenterScale, ConditionalCenterScale, ConditionalConv11, Con
 
 # the block convolutions on the split-fp16 MFMA kernel where it takes the shape (WC_FAST_CONV=0: MIOpen everywhere)
 FAST_CONV = os.environ.get('WC_FAST_CONV', '1') != '0'
+# a WC site whose only reader is such a convolution writes that convolution's fp16 operand planes from its apply kernel
+# (WC_HANDOFF=0: fp32 out of the site, absmax + split in front of the convolution)
+HANDOFF = os.environ.get('WC_HANDOFF', '1') != '0'
 
 NORMS = ['n', 'b', 'd', 'dr']
 AFTER_NORMS = ['ucs', 'ccs', 'uccs', 'uconv', 'fconv', 'ufconv', 'cconv', 'ucconv', 'ccsuconv', 'n']
@@ -101,6 +104,15 @@ class Conv2D(nn.Module):
     def _weight(self):
         conv = self.conv
         return conv.normalized_weight() if hasattr(conv, 'normalized_weight') else conv.weight
+
+    def takes_planes(self, shape, kind='same'):
+        """Will forward / forward_upsampled read an input of this shape as planes handed over by the WC site in front of it?"""
+        c = self.conv
+        if not (FAST_CONV and HANDOFF) or (c.out_channels <= 4 and not hasattr(c, 'normalized_weight')):
+            return False
+        if kind == 'up3' and tuple(c.weight.shape[2:]) != (3, 3):
+            return False
+        return c.weight.dtype == torch.float32 and fast_conv_mod.takes_planes(shape, c.weight.shape, kind)
 
     def forward_relu(self, x):
         """conv(relu(x)): on the fast path the ReLU happens while the activation is split (one kernel and one pass less)"""
@@ -255,11 +267,14 @@ def create_norm(norm, after_norm, cls=None, number_of_classes=None, filters_emb=
 # ---------------------------------------------------------------------------------------------
 # generator
 # ---------------------------------------------------------------------------------------------
-def _norm_relu(norm, x, cls):
-    """relu(norm(x, cls)) (generator.py:144-151, 154); the fused WC stack takes the activation into its apply kernel."""
+def _norm_relu(norm, x, cls, consumer=None, kind='same'):
+    """relu(norm(x, cls)) (generator.py:144-151, 154); the fused WC stack takes the activation into its apply kernel.
+    consumer: the Conv2D that reads the result (and nothing else does) -- where it can, the site's apply kernel then writes that
+    convolution's fp16 operand planes directly (no fp32 tensor, no absmax + split passes in front of the convolution)."""
     from .layers import WhiteningColoring
     if isinstance(norm, WhiteningColoring):
-        return norm(x, cls, relu=True)
+        planes = consumer is not None and x.is_cuda and consumer.takes_planes(x.shape, kind)
+        return norm(x, cls, relu=True, planes=planes)
     return F.relu(norm(x, cls))
 
 
@@ -275,7 +290,8 @@ class ResBlockUp(nn.Module):
         self.shortcut = conv_layer(in_ch, nfilters, (1, 1), name=name + '.shortcut')
 
     def forward(self, x, cls):
-        h = _norm_relu(self.bn1, x, cls)
+        up = self.resample == 'UP' and x.shape[1] * x.shape[2] >= 64
+        h = _norm_relu(self.bn1, x, cls, self.conv1 if (up or self.resample != 'UP') else None, 'up3' if up else 'same')
         # the 1x1 shortcut commutes with nearest-neighbour upsampling (every output pixel is the same per-pixel affine
         # map of its source pixel): it runs at the input resolution, a quarter of the work, and is added per 2x2 patch below
         s = self.shortcut(x)
@@ -286,7 +302,7 @@ class ResBlockUp(nn.Module):
             h = self.conv1.forward_upsampled(h) if h.shape[1] * h.shape[2] >= 64 else self.conv1(upsample2x(h))
         else:
             h = self.conv1(h)
-        h = _norm_relu(self.bn2, h, cls)
+        h = _norm_relu(self.bn2, h, cls, self.conv2)
         h = self.conv2(h)
         if self.resample == 'UP':
             # h + upsample2x(s) without the upsampled tensor: every 2x2 output patch adds its one source pixel

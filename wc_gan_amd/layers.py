@@ -141,10 +141,12 @@ class DecorelationNormalization(_Lazy):
             self.register_buffer('_pad_cov', torch.eye(Cp, device=device), persistent=False)
             self.register_buffer('_pad_eye', torch.eye(Cp, device=device), persistent=False)
 
-    def transform(self, x, gamma=None, beta=None, slot=None, gamma_key=None, relu=False, per_sample=False):
+    def transform(self, x, gamma=None, beta=None, slot=None, gamma_key=None, relu=False, per_sample=False, planes=False):
         """Whitening fused with an optional coloring table (gamma (Kc,C,C), beta (Kc,C), slot (N,)); relu=True also
         folds the ReLU that follows the site into the apply kernel where that path has it (else applied after).
-        per_sample: the table holds one entry per sample (slot = arange(N)); only the grouped path needs to know."""
+        per_sample: the table holds one entry per sample (slot = arange(N)); only the grouped path needs to know.
+        planes: the caller is conv.fast_conv and takes the output as its fp16 planes (functional.whiten_color) where K3 can
+        leave it so; the other paths return the plain tensor."""
         self._ensure(x)
         C = self.channels
         groups = _stat_groups() if self.training else 1
@@ -170,17 +172,17 @@ class DecorelationNormalization(_Lazy):
             if torch.is_grad_enabled() and (x.requires_grad or (gamma is not None and gamma.requires_grad)):
                 raise RuntimeError("statistic_groups() is a forward-only path: wrap the call in torch.no_grad()")
             return WF.whiten_color_grouped(x, groups, gamma, beta, slot, self.moving_mean, self.moving_cov,
-                                           self.epsilon, self.momentum, 1, relu=relu, per_sample=per_sample)
+                                           self.epsilon, self.momentum, 1, relu=relu, per_sample=per_sample, planes=planes)
         if not self.training and not torch.is_grad_enabled():
             # inference (scorer.py:60,72): moving statistics are constants -> cached factorisation, one K3 launch
             if not hasattr(self, '_eval_plan'):
                 self._eval_plan = WF.EvalPlan()
             return WF.whiten_color_eval_cached(x, self._eval_plan, gamma, beta, slot, self.moving_mean, self.moving_cov,
-                                               self.epsilon, gamma_key, relu=relu)
+                                               self.epsilon, gamma_key, relu=relu, planes=planes)
         if self.renorm and self.training:
             gamma = self._renorm_gamma(x, gamma)
         return WF.whiten_color(x, gamma, beta, slot, self.moving_mean, self.moving_cov, self.training,
-                               self.epsilon, self.momentum, 1, self.process_group, relu=relu)
+                               self.epsilon, self.momentum, 1, self.process_group, relu=relu, planes=planes)
 
     def _renorm_gamma(self, x, gamma):
         # W_eff = L_mov^-1 . stop_grad(L_batch) . L_batch^-1 (row a4): the batch factor carries the gradient,
@@ -386,7 +388,7 @@ class WhiteningColoring(nn.Module):
             beta = beta.expand(gamma.shape[0], -1)
         return gamma, beta, slot, per_sample
 
-    def forward(self, x, cls=None, relu=False):
+    def forward(self, x, cls=None, relu=False, planes=False):
         if isinstance(x, (list, tuple)):
             x, cls = x
         gamma, beta, slot, per_sample = self.coloring_table(x, cls)
@@ -396,4 +398,4 @@ class WhiteningColoring(nn.Module):
             beta = beta.contiguous()
         # identity of the coloring weights (for the eval-mode plan cache); per-sample tables depend on cls -> no key
         key = None if per_sample else (_state.replays,) + tuple((p.data_ptr(), p._version) for p in self.parameters())
-        return self.npart.transform(x, gamma, beta, slot, gamma_key=key, relu=relu, per_sample=per_sample)
+        return self.npart.transform(x, gamma, beta, slot, gamma_key=key, relu=relu, per_sample=per_sample, planes=planes)

@@ -153,6 +153,50 @@ def apply(x, mu, A, bias, slot, out=None, fast=True, plan=None, relu=False, want
     return y
 
 
+def apply_planes_supported(shape):
+    """Can K3 leave the output of a site of this NHWC shape as the next convolution's planes (apply_planes)?"""
+    N, C = shape[0], shape[-1]
+    HW = 1
+    for d in shape[1:-1]:
+        HW *= d
+    return bool(_lib.load().wc_apply_planes_supported(N, HW, C))
+
+
+def out_scale(gamma, beta, C, device):
+    """-> the (2 + 1024,) float32 scale record of apply_planes with the predicted scale in [1] (wc_out_scale_f32: from the
+    coloring parameters alone -- gamma (K, C, C) | None, beta (K, C) | None -- no pass over data)."""
+    lib = _lib.load()
+    rec = torch.empty(lib.wc_apply_planes_scale_floats(), dtype=torch.float32, device=device)
+    K = gamma.shape[0] if gamma is not None else (beta.shape[0] if beta is not None else 1)
+    if gamma is not None:
+        _need(gamma, torch.float32, "gamma", 3)
+    if beta is not None:
+        _need(beta, torch.float32, "beta", 2)
+        if beta.shape[0] != K:
+            raise ValueError("gamma and beta disagree about the number of tables")
+    _lib.check(lib.wc_out_scale_f32(_ptr(gamma), _ptr(beta), K, C, _ptr(rec), _stream()), "wc_out_scale_f32")
+    return rec
+
+
+def apply_planes(x, mu, A, bias, slot, plan, oscale, relu=True, want_mask=False):
+    """K3 whose output leaves as the next convolution's operand (wc_apply_planes_f32): -> (planes (2, *x.shape) float16 = hi | lo,
+    oscale) [, mask]; y ~= (hi + lo) / oscale[0].  oscale: the record out_scale() made."""
+    lib = _lib.load()
+    _need(x, torch.float32, "x")
+    N, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (N * C)
+    Kc = A.shape[0]
+    if bias is not None:
+        _need(bias, torch.float32, "bias", 2)
+    if slot is not None:
+        _need(slot, torch.int32, "slot", 1)
+    planes = torch.empty((2,) + tuple(x.shape), dtype=torch.float16, device=x.device)
+    mask = torch.empty((N * HW) // 32, C, dtype=torch.int32, device=x.device) if want_mask else None
+    _lib.check(lib.wc_apply_planes_f32(_ptr(x), _ptr(mu), _ptr(A), _ptr(bias), _ptr(slot), N, HW, C, Kc, 1 if relu else 0,
+                                       _ptr(planes), _ptr(oscale), _ptr(mask), _ptr(plan), _stream()), "wc_apply_planes_f32")
+    return (planes, oscale, mask) if want_mask else (planes, oscale)
+
+
 class SplitTensor:
     """An activation in the pre-split format of include/wc_hip.h (ABI 4): `planes` (2, M, C) float16 = hi | lo,
     x ~= center + (hi + lo) / scale.  `shape` is the NHWC shape of the tensor it stands for; `flag` (64,) int32: [0] != 0
