@@ -95,15 +95,32 @@ def launch_ranks(args, argv):
     return subprocess.run(cmd, env=env).returncode
 
 
-def time_kernel(fn, iters=20, warm=3):
+def time_kernel(fn, iters=20, warm=3, graph=False):
+    """Average duration of one fn() on the GPU between two HIP events on the launching stream.
+    graph=False: `iters` calls issued from Python (the launches are separated by whatever the host needs per call -- the form
+    rounds 1 and 2 used, and the one whose per-kernel average the rocprofv3 kernel trace of the same loop reproduces).
+    graph=True: the same calls recorded into ONE hipGraph and replayed -- launches truly back to back.  The two differ for
+    the streaming kernels (round 3): a K3 that starts the moment the previous K3 retires runs beside
+    that launch's write-back (134 MB of dirty lines still on their way to HBM) and takes 55-61 us instead of 47-50."""
     import torch
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
+    g = None
+    if graph:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(iters):
+                fn()
+        g.replay()                        # once untimed: the first replay uploads the graph
+        torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()                       # torch's current stream == the stream the C ABI launches on
-    for _ in range(iters):
-        fn()
+    if g is not None:
+        g.replay()
+    else:
+        for _ in range(iters):
+            fn()
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e-3
@@ -134,7 +151,11 @@ def roofline_apply(dev):
     xs = ops.split(x)
     A2, At2, plan2 = ops.color(W, gamma, xs.scale)
     be = ops.split_bias(A2, b, xs, mu)
-    t = time_kernel(lambda: ops.apply_split(xs, None, A2, be, None, plan=plan2, out=y, folded=True))
+    ws_split = ops.apply_split_workspace(C, 1, dev)        # (allocated once: with a torch.empty per call the Python loop, not the kernel, set the pace -- 54 us against 47.0 in the kernel trace)
+    k3_split = lambda: ops.apply_split(xs, None, A2, be, None, plan=plan2, out=y, folded=True, ws=ws_split)
+    k3_f32 = lambda: ops.apply(x, mu, A, b, None, out=y, plan=plan)
+    t = time_kernel(k3_split)
+    t_b2b = {"split": time_kernel(k3_split, graph=True), "f32": time_kernel(k3_f32, graph=True)}
     y_f32 = ops.apply(x, mu, A, b, None, plan=plan)
     split_vs_f32 = float((y - y_f32).abs().max() / y_f32.abs().max())
     alg_bytes = 2 * M * C * 4 + (C * C + C) * 4
@@ -166,6 +187,8 @@ def roofline_apply(dev):
     # every stage of the site on its own (HIP events, same inputs): the algorithmic bytes of SURVEY section 8d per stage
     gy = torch.randn(N, H, H, C, generator=g).to(dev)
     y_relu, relu_bits = ops.apply(x, mu, A, b, None, plan=plan, relu=True, want_mask=True)
+    from wc_gan_amd import conv as fconv
+    orec = ops.out_scale(gamma, b, C, dev)
     t_k3_mask = time_kernel(lambda: ops.apply(x, mu, A, b, None, out=y, plan=plan, relu=True, want_mask=True), iters=10)
     R, gsum, scales = ops.bwd_reduce(x, mu, gy, None, 1, want_scales=True)
     dg, db, S, gm = ops.bwd_factor(R, gsum, W, L, gamma, A, M, 1e-3, 1, True)
@@ -185,7 +208,13 @@ def roofline_apply(dev):
         # round 3: the mask travels as ONE BIT per element, written by K3's epilogue (wc_apply_mask_f32) and read by K4
         # (wc_bwd_reduce_mask_f32): x, gy in, masked gy out + 1/32 of a tensor -- this is what the layer runs now; the fp32-y
         # form of round 2 beside it
-        "K3 wc_apply_mask_f32 (ReLU + bit mask, as the generator runs it)": {"us": round(t_k3_mask * 1e6, 1)},
+        "K3 wc_apply_mask_f32 (ReLU + bit mask: sites whose reader is not a block convolution)": {"us": round(t_k3_mask * 1e6, 1)},
+        # ... and where the site's only reader is a block convolution (5 of the 7 generator sites), K3 writes that convolution's
+        # fp16 operand planes itself (wc_apply_planes_f32: the pass + the gated launch), which is what the convolution's own
+        # absmax + split passes over an fp32 y would have produced
+        "K3 wc_apply_planes_f32 (ReLU + bit mask + the next convolution's planes, two launches: as the generator runs it)":
+            {"us": round(time_kernel(lambda: ops.apply_planes(x, mu, A, b, None, plan, orec, relu=True, want_mask=True), iters=10) * 1e6, 1)},
+        "  replaces: wc_conv_split_f32 of y (absmax + split, two launches)": {"us": round(time_kernel(lambda: fconv.split_planes(y_relu), iters=10) * 1e6, 1)},
         "K4 wc_bwd_reduce_mask_f32 (as the generator runs it)": stage(lambda: ops.bwd_reduce(x, mu, gy, None, 1, want_scales=True, relu_mask=relu_bits), 3 * xb),
         "K4 wc_bwd_reduce_relu_f32 (round 2: mask from y in fp32)": stage(lambda: ops.bwd_reduce(x, mu, gy, None, 1, want_scales=True, relu_y=y_relu), 4 * xb),
         "K5 wc_bwd_factor_f64": {"us": round(time_kernel(lambda: ops.bwd_factor(R, gsum, W, L, gamma, A, M, 1e-3, 1, True), iters=10) * 1e6, 1)},
@@ -205,10 +234,13 @@ def roofline_apply(dev):
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_from_committed_profile": src,
             "launch_us": round(tb * 1e6, 2), "algorithmic_bytes": alg_bytes,
+            "timing": "HIP events around 20 launches issued from Python on the launching stream (k3_kernels.*.back_to_back_us: the same 20 launches replayed as one hipGraph)",
             "stream_copy_GBs": round(copy_gbs, 1),
             "frac_of_stream_copy": round(achieved / copy_gbs, 4),
             "k3_kernels": {k: {"launch_us": round(v * 1e6, 2), "frac": round(alg_bytes / v / 1e9 / HBM_PEAK_GBS, 4),
-                               "frac_of_stream_copy": round(alg_bytes / v / 1e9 / copy_gbs, 4)} for k, v in k3.items()},
+                               "frac_of_stream_copy": round(alg_bytes / v / 1e9 / copy_gbs, 4),
+                               "back_to_back_us": round(t_b2b["split" if k.startswith("apply_split") else "f32"] * 1e6, 2)}
+                           for k, v in k3.items()},
             "split_vs_fp32_input_rel_diff": split_vs_f32,
             "forward_site_us": round(t_site * 1e6, 1),
             "forward_site_frac_of_peak": round(3 * M * C * 4 / t_site / 1e9 / HBM_PEAK_GBS, 4),

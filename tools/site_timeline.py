@@ -1,5 +1,6 @@
-"""One WC site through the layer path (functional.whiten_color with autograd, ReLU epilogue, and the grouped critic-phase
-form): run under rocprofv3 --kernel-trace; tools/site_timeline_print.py lists the launches of the last call of each."""
+"""One WC site through the layer path (functional.whiten_color with autograd, ReLU epilogue; the grouped critic-phase form; and the
+K3 -> convolution hand-off form, whose forward writes the next convolution's planes): run under rocprofv3 --kernel-trace;
+tools/site_timeline_print.py lists the launches of the last call of each."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from wc_gan_amd import functional as F
@@ -14,4 +15,10 @@ torch.cuda.synchronize()
 xg = torch.randn(320, 32, 32, C, device='cuda')
 with torch.no_grad():
     for _ in range(6): F.whiten_color_grouped(xg, 5, gamma.detach(), beta.detach(), None, mm, mc, relu=True)
+torch.cuda.synchronize()
+x2 = torch.randn(128, 32, 32, C, device='cuda', requires_grad=True)
+for _ in range(6):
+    h = F.whiten_color(x2, gamma, beta, None, mm, mc, True, relu=True, planes=True)
+    assert getattr(h, '_wc_planes', None) is not None
+    h.backward(gy)
 torch.cuda.synchronize()

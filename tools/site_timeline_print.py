@@ -8,5 +8,7 @@ def show(i0, i1, title):
     for r in rows[i0:i1]:
         print('  %-70s start %7.1f dur %6.1f' % (r['Kernel_Name'][:68], (int(r['Start_Timestamp']) - t0) / 1e3, (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3))
     print('  total %.1f us, %d launches' % ((int(rows[i1]['Start_Timestamp']) - t0) / 1e3, i1 - i0))
-show(idx[4], idx[5], 'forward + backward, 128x32x32x256, ReLU epilogue')
-show(idx[-2], idx[-1], 'grouped forward (5 groups), 320x32x32x256')
+show(idx[4], idx[5], 'forward + backward, 128x32x32x256, ReLU epilogue (1-bit mask)')
+show(idx[10], idx[11], 'grouped forward (5 groups), 320x32x32x256')
+if len(idx) >= 18:
+    show(idx[16], idx[17], 'forward + backward with the K3 -> convolution hand-off (planes out, gated second launch), 128x32x32x256')

@@ -42,7 +42,7 @@
 #define WC_STAMP(i) do { if (WC_STAMPS && stamp_on) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ts[i] = t_; } } while (0)
 #ifndef WC_NO_PIPE
 #ifndef WC_NT_STORE_PL
-#define WC_NT_STORE_PL 1   // planes form of the ring kernel: nontemporal stores of the 64-byte pieces
+#define WC_NT_STORE_PL 0   // planes form of the ring kernel: nontemporal stores of its 64-byte pieces (a wave owns 32 columns = 64 bytes of an fp16 row).  Measured and left off: they leave the chip un-merged -- HBM writes 170 MB per launch for 138 MB of planes + mask (WRITE_SIZE), 61 us against the fp32 form's 50, 80 us in the layer's flow; plain stores let the L2 put the two halves of a line together
 #endif
 #define WC_NO_PIPE 0   // development: 1 leaves the ring kernel's k-loop to hipcc's own schedule
 #endif
@@ -1556,23 +1556,46 @@ bool wc_fast_affine_writes_planes(int64_t N, int64_t HW, int C)
 // 4 to 8 of headroom above a 16-sigma element.  Elements beyond that are caught by the kernel's own maximum (the gate).
 // Record layout (floats): [0] scale used (out) | [1] K as an int | [2, 2 + 1024) per-table bounds | [2 + 1024, 2 + 2048) the apply
 // kernel's per-workgroup maxima.  One workgroup per table writes its bound; the apply kernel folds them (<= 16 L2 hits per lane).
-__global__ __launch_bounds__(256) void out_scale_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, int K, int C,
-                                                        float* __restrict__ oscale)
+__global__ __launch_bounds__(1024) void out_scale_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, int K, int C,
+                                                         float* __restrict__ oscale)
 {
-    __shared__ float red[4];
+    // one workgroup per table; thread = (column c, row group q of 1024 / CW): the rows of a group are read coalesced across
+    // the columns, four independent loads in flight per thread (as one dependent chain of C loads the launch took 26 us)
+    __shared__ float part[1024];
     const int k = blockIdx.x;
+    const int CW = C < 1024 ? (C < 256 ? C : 256) : 1024;     // columns handled side by side (a multiple of 32)
+    const int Q = 1024 / CW, cl = threadIdx.x % CW, q = threadIdx.x / CW;
     float m = 0.f;
-    for (int c = threadIdx.x; c < C; c += 256) {              // column c of table k: the rows are read coalesced
-        float ss = gamma ? 0.f : 1.f;
-        if (gamma) for (int r = 0; r < C; ++r) { const float g = gamma[((int64_t)k * C + r) * C + c]; ss = fmaf(g, g, ss); }
-        m = fmaxf(m, 16.f * sqrtf(ss) + (beta ? fabsf(beta[(int64_t)k * C + c]) : 0.f));
+    for (int c0 = 0; c0 < C; c0 += CW) {
+        const int c = c0 + cl;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (gamma && c < C && q < Q) {
+            const float* g = gamma + (int64_t)k * C * C + c;
+            int r = q;
+            for (; r + 3 * Q < C; r += 4 * Q) {
+                const float a0 = g[(int64_t)r * C], a1 = g[(int64_t)(r + Q) * C], a2 = g[(int64_t)(r + 2 * Q) * C], a3 = g[(int64_t)(r + 3 * Q) * C];
+                s0 = fmaf(a0, a0, s0); s1 = fmaf(a1, a1, s1); s2 = fmaf(a2, a2, s2); s3 = fmaf(a3, a3, s3);
+            }
+            for (; r < C; r += Q) { const float a0 = g[(int64_t)r * C]; s0 = fmaf(a0, a0, s0); }
+        }
+        part[threadIdx.x] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (q == 0 && c < C) {
+            float ss = gamma ? 0.f : 1.f;
+            if (gamma) for (int j = 0; j < Q; ++j) ss += part[j * CW + cl];
+            m = fmaxf(m, 16.f * sqrtf(ss) + (beta ? fabsf(beta[(int64_t)k * C + c]) : 0.f));
+        }
+        __syncthreads();
     }
+    // (only threads of row group 0 hold a bound; the rest contribute 0)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
-        oscale[2 + k] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));          // this table's bound; the apply kernel folds them
+        float b = 0.f;
+        for (int w = 0; w < 16; ++w) b = fmaxf(b, part[w]);
+        oscale[2 + k] = b;          // this table's bound; the apply kernel folds them
         if (k == 0) oscale[1] = __builtin_bit_cast(float, K);
     }
 }
@@ -1580,7 +1603,7 @@ __global__ __launch_bounds__(256) void out_scale_kernel(const float* __restrict_
 hipError_t wc_launch_out_scale(const float* gamma, const float* beta, int K, int C, float* oscale, hipStream_t st)
 {
     if (K < 1 || K > kPlaneBounds) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(out_scale_kernel, dim3(K), dim3(256), 0, st, gamma, beta, K, C, oscale);
+    hipLaunchKernelGGL(out_scale_kernel, dim3(K), dim3(1024), 0, st, gamma, beta, K, C, oscale);
     return hipGetLastError();
 }
 

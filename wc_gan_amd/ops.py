@@ -295,7 +295,12 @@ def split_bias(A, bias, xs, mu):
     return out
 
 
-def apply_split(xs, mu, A, bias, slot, plan=None, relu=False, out=None, folded=False):
+def apply_split_workspace(C, Kc, device):
+    """The scratch apply_split needs (pass it as ws= to keep a hot loop free of allocations)."""
+    return _workspace(_lib.load().wc_apply_split_workspace_bytes(C, Kc), device)
+
+
+def apply_split(xs, mu, A, bias, slot, plan=None, relu=False, out=None, folded=False, ws=None):
     """K3 on a pre-split input: y[n] = (x[n] - mu) A[slot[n]] + bias[slot[n]].  `plan` must come from color(W, gamma,
     chan_scale=xs.scale) (None: the tables are built inside the call).  folded=True: `bias` is split_bias(...)'s result
     (mu is ignored) and the call is a single launch."""
@@ -308,7 +313,8 @@ def apply_split(xs, mu, A, bias, slot, plan=None, relu=False, out=None, folded=F
     if slot is not None:
         _need(slot, torch.int32, "slot", 1)
     y = torch.empty(xs.shape, dtype=torch.float32, device=xs.planes.device) if out is None else out
-    ws = _workspace(lib.wc_apply_split_workspace_bytes(C, Kc), y.device)
+    if ws is None:
+        ws = _workspace(lib.wc_apply_split_workspace_bytes(C, Kc), y.device)
     _lib.check(lib.wc_apply_split_f16x2(_ptr(xs.planes), None if folded else _ptr(xs.center), _ptr(xs.scale), None if folded else _ptr(mu),
                                         _ptr(A), _ptr(bias), _ptr(slot),
                                         N, HW, C, Kc, 1 if relu else 0, _ptr(y), _ptr(plan), _ptr(ws), ws.numel(), _stream()),
