@@ -60,6 +60,17 @@ typedef void* wc_stream_t;        /* hipStream_t */
 int         wc_abi_version(void);
 const char* wc_error_string(int code);
 
+/* K1 + K2 in one call (ABI 4): wc_stats_f32 followed by wc_factor_f64(training = 1) for the caller that does not need the moments
+ * themselves -- per-replica statistics, the reference's behaviour (sync-WC all-reduces (sum, xtx) between the two and keeps the
+ * separate entries).  Same arguments and results as that pair; the K1 tail's slab reduction and the K2 head's bookkeeping run as ONE
+ * launch (bit-identical mu, L, W, chan_scale and moving statistics: the same float64 expressions in the same order), sum / xtx are
+ * never stored.  M = all rows (groups * rows per group).  DecorelationNormalization.call, generator.py:24. */
+size_t wc_whiten_workspace_bytes(int64_t M, int C, int groups);
+int    wc_whiten_f32(const float* x, int64_t M, int C, int groups, double eps, double momentum, int ddof,
+                     float* moving_mean /*[C] in/out, nullable*/, float* moving_cov /*[C,C] in/out, nullable*/,
+                     float* mu /*[groups,C]*/, float* chan_scale /*[C], nullable*/, double* L /*[groups,C,C]*/, double* W /*[groups,C,C]*/,
+                     void* ws, size_t ws_bytes, wc_stream_t stream);
+
 /* Bytes of scratch each stage needs for the given problem (16-byte aligned carve inside). */
 size_t wc_stats_workspace_bytes(int64_t M, int C, int groups);
 size_t wc_factor_workspace_bytes(int C, int groups);

@@ -343,3 +343,25 @@ def test_bwd_reduce_with_the_bit_mask(ops, shape, Kc):
     R2, g2, gm2, sc2 = ops.bwd_reduce(dev(x), dev(mu), dev(gy), st, Kc, want_scales=True, relu_mask=mask)
     assert torch.equal(gm1, gm2) and torch.equal(sc1, sc2)
     assert torch.equal(R1, R2) and torch.equal(g1, g2)
+
+
+@pytest.mark.parametrize("shape,groups", [((128, 32, 32, 256), 1), ((320, 16, 16, 256), 5), ((64, 8, 8, 128), 1), ((40, 8, 8, 64), 5),
+                                          ((16, 8, 8, 256), 1), ((12, 6, 6, 96), 3)])
+def test_whiten_is_stats_then_factor_bit_for_bit(shape, groups):
+    """wc_whiten_f32 (K1 + K2 as one call: the K1 tail's slab reduction and the K2 head's bookkeeping in ONE launch, the moments never
+    stored) returns exactly what wc_stats_f32 followed by wc_factor_f64 returns -- mu, L, W, chan_scale and both moving statistics,
+    over several statistic groups too (their moving-statistics updates are applied one after the other)."""
+    from oracle import wc_oracle as o
+    from wc_gan_amd import ops
+    rng = np.random.default_rng(41)
+    C = shape[-1]
+    x = dev(o.synth_activation(rng, shape, "ill").astype(np.float32))
+    M = x.numel() // C
+    mm1 = torch.randn(C, device="cuda") * 0.1; mc1 = torch.eye(C, device="cuda") * 1.5
+    mm2, mc2 = mm1.clone(), mc1.clone()
+    s, xtx = ops.stats(x.view(M, C), groups)
+    mu1, L1, W1, cs1 = ops.factor(s, xtx, M // groups, C, 1e-3, 0.99, 1, True, mm1, mc1, x.device, want_scale=True, groups=groups)
+    mu2, L2, W2, cs2 = ops.whiten(x.view(M, C), 1e-3, 0.99, 1, mm2, mc2, groups)
+    torch.cuda.synchronize()
+    for a, b in ((mu1, mu2), (torch.tril(L1), torch.tril(L2)), (W1, W2), (cs1, cs2), (mm1, mm2), (mc1, mc2)):
+        assert torch.equal(a, b)

@@ -48,6 +48,9 @@ SIGNATURES = {
     "wc_relu_mask_apply_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "wc_apply_mask_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wc_whiten_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "wc_whiten_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_double, c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                              c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wc_apply_planes_supported": (c_int, [c_int64, c_int64, c_int]),
     "wc_apply_planes_scale_floats": (c_size_t, []),
     "wc_out_scale_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),

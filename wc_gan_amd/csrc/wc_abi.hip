@@ -59,7 +59,7 @@ size_t wc_stats_workspace_bytes(int64_t M, int C, int groups)
 {
     if (M <= 0 || groups <= 0 || (M % groups) != 0 || bad_channels(C)) return 0;
     const XtyPlan p = plan_xty(groups, M / groups, C, groups > 1, 1);
-    return 256 + 2 * slot_bytes(C, 4) + slot_bytes((size_t)groups * C, 8) + slot_bytes((size_t)p.nslab * C, 4) + slot_bytes((size_t)p.nslab * C, 8) +
+    return 256 + 2 * slot_bytes(C, 4) + slot_bytes((size_t)2 * groups * C, 8) + slot_bytes((size_t)p.nslab * C, 4) + slot_bytes((size_t)p.nslab * C, 8) +
            slot_bytes((size_t)p.nslab * C * C, 8);
 }
 
@@ -79,7 +79,7 @@ int wc_stats_f32(const float* x, int64_t M, int C, int groups, double* sum, doub
     int* gate = cv.take<int>(64);
     float* shift = cv.take<float>(C);
     float* scale = cv.take<float>(C);
-    double* Sp = cv.take<double>((size_t)groups * C);
+    double* Sp = cv.take<double>((size_t)2 * groups * C);        // column sums | the diagonal's slab sums (bias compensation)
     float* colsum = cv.take<float>((size_t)p.nslab * C);
     double* dfix = cv.take<double>((size_t)p.nslab * C);
     double* P = cv.take<double>((size_t)p.nslab * C * C);
@@ -96,7 +96,63 @@ int wc_stats_f32(const float* x, int64_t M, int C, int groups, double* sum, doub
     }
     WC_TRY(wc_launch_xty(a, p.nslab, st));
     WC_TRY(wc_launch_stats_finalize(P, colsum, shift, p.nslab / groups, HWs, C, groups, Sp, sum, xtx,
-                                    p.fast ? dfix : nullptr, p.fast ? gate : nullptr, st));
+                                    p.fast ? dfix : nullptr, p.fast ? gate : nullptr, st, p.fast ? wc_fast_xty_offdiag_bias() : 0.0));
+    return WC_OK;
+}
+
+// K1 + K2 as one call (training mode, per-replica statistics): the moments never leave the workspace
+size_t wc_whiten_workspace_bytes(int64_t M, int C, int groups)
+{
+    const size_t a = wc_stats_workspace_bytes(M, C, groups);
+    if (a == 0) return 0;
+    return a + slot_bytes((size_t)groups * C, 8) + slot_bytes((size_t)groups * C * C, 8);
+}
+
+int wc_whiten_f32(const float* x, int64_t M, int C, int groups, double eps, double momentum, int ddof,
+                  float* moving_mean, float* moving_cov, float* mu, float* chan_scale, double* L, double* W,
+                  void* ws, size_t ws_bytes, wc_stream_t stream)
+{
+    if (!x || !mu || !L || !W || !ws) return WC_ERR_NULL;
+    if ((moving_mean == nullptr) != (moving_cov == nullptr)) return WC_ERR_NULL;
+    if (M <= 0 || groups <= 0 || (M % groups) != 0 || M / groups <= ddof) return WC_ERR_SHAPE;
+    if (bad_channels(C)) return WC_ERR_CHANNELS;
+    if (!(eps > 0.0) || eps >= 1.0 || momentum < 0.0 || momentum > 1.0 || ddof < 0 || ddof > 1) return WC_ERR_ARG;
+    if (ws_bytes < wc_whiten_workspace_bytes(M, C, groups)) return WC_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int per_seg = groups > 1;
+    const int64_t Ns = groups, HWs = M / groups;
+    const XtyPlan p = plan_xty(Ns, HWs, C, per_seg, 1);
+    Carver cv(ws, ws_bytes);
+    int* gate = cv.take<int>(64);
+    float* shift = cv.take<float>(C);
+    float* scale = cv.take<float>(C);
+    double* Sp = cv.take<double>((size_t)2 * groups * C);        // column sums | the diagonal's slab sums (bias compensation)
+    float* colsum = cv.take<float>((size_t)p.nslab * C);
+    double* dfix = cv.take<double>((size_t)p.nslab * C);
+    double* P = cv.take<double>((size_t)p.nslab * C * C);
+    double* sum_scratch = cv.take<double>((size_t)groups * C);
+    double* tmp = cv.take<double>((size_t)groups * C * C);
+
+    if (p.fast) WC_TRY(wc_launch_subsample_mean_scale(x, M, C, shift, scale, gate, st));
+    else WC_TRY(wc_launch_subsample_mean(x, M, C, shift, st));
+    WcXtyArgs a = {};
+    a.X = x; a.Y = x; a.cx = shift; a.cy = shift; a.N = Ns; a.HW = HWs; a.per_sample = per_seg; a.nsplit = p.nsplit;
+    a.rows_per_slab = p.rps; a.C = C; a.sym = 1; a.P = P; a.colsum = colsum;
+    if (p.fast) {
+        WC_TRY(wc_launch_fast_xty(x, x, shift, shift, scale, scale, Ns, HWs, C, per_seg, p.nsplit, p.rps, p.nslab, p.ntypes,
+                                  P, colsum, dfix, gate, st));
+        a.gate = gate;
+    }
+    WC_TRY(wc_launch_xty(a, p.nslab, st));
+    WC_TRY(wc_launch_stats_prepare(P, colsum, shift, p.nslab / groups, HWs, C, groups, Sp, sum_scratch, p.fast ? dfix : nullptr,
+                                   p.fast ? gate : nullptr, eps, momentum, ddof, moving_mean, moving_cov, mu, chan_scale, L, st, tmp,
+                                   p.fast ? wc_fast_xty_offdiag_bias() : 0.0));
+    if (wc_factor_is_fused(C)) {
+        WC_TRY(wc_launch_factor_fused(L, W, tmp, C, groups, st));
+        return WC_OK;
+    }
+    WC_TRY(wc_launch_cholesky(L, C, groups, st));
+    WC_TRY(wc_launch_tri_inverse(L, W, tmp, C, groups, st));
     return WC_OK;
 }
 
@@ -345,7 +401,7 @@ size_t wc_stats_split_workspace_bytes(int64_t M, int C, int groups)
     if (!wc_stats_split_supported(M, C, groups)) return 0;
     int nsplit, ntypes; int64_t rps;
     const int nslab = wc_split_xtx_plan(groups, M / groups, C, groups > 1, &nsplit, &rps, &ntypes);
-    return 256 + slot_bytes((size_t)groups * C, 8) + slot_bytes((size_t)nslab * C, 4) + slot_bytes((size_t)nslab * C, 8) +
+    return 256 + slot_bytes((size_t)2 * groups * C, 8) + slot_bytes((size_t)nslab * C, 4) + slot_bytes((size_t)nslab * C, 8) +
            slot_bytes((size_t)nslab * C * C, 8);
 }
 
@@ -364,7 +420,7 @@ int wc_stats_split_f16x2(const void* xs, const float* xs_center, const float* xs
     const int nslab = wc_split_xtx_plan(Ns, HWs, C, per_seg, &nsplit, &rps, &ntypes);
     Carver cv(ws, ws_bytes);
     (void)cv.take<int>(64);
-    double* Sp = cv.take<double>((size_t)groups * C);
+    double* Sp = cv.take<double>((size_t)2 * groups * C);        // column sums | the diagonal's slab sums (bias compensation)
     float* colsum = cv.take<float>((size_t)nslab * C);
     double* dfix = cv.take<double>((size_t)nslab * C);
     double* P = cv.take<double>((size_t)nslab * C * C);

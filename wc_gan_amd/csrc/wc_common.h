@@ -174,11 +174,17 @@ hipError_t wc_launch_split_xtx(const void* xs, const float* scale, int64_t N, in
 hipError_t wc_launch_stats_finalize(const double* P, const float* colsum, const float* shift, int nslab,
                                     int64_t M, int C, int groups, double* Sp /*[groups*C] scratch*/, double* sum, double* xtx,
                                     const double* dfix /*[groups*nslab][C] the fast path's VALU diagonal, nullable*/,
-                                    const int* gate /*dfix is void when *gate != 0 (the exact redo ran)*/, hipStream_t st);
+                                    const int* gate /*dfix is void when *gate != 0 (the exact redo ran)*/, hipStream_t st,
+                                    double kappa = 0.0 /*off-diagonal bias compensation of the kernel that wrote P (wc_fast_xty_offdiag_bias); Sp then holds 2*groups*C doubles*/);
+double wc_fast_xty_offdiag_bias(void);       // kappa of xty_f16x3_kernel's covariance partials (wc_fast_xty.hip)
 // K4 tail: per-slab partials -> per-slot float64 R, gsum
 hipError_t wc_launch_bwd_combine(const double* P, const float* colsum, const int32_t* slot, int64_t N, int nsplit,
                                  int per_sample, int C, int Kc, double* R, double* gsum, hipStream_t st);
 
+hipError_t wc_launch_stats_prepare(const double* P, const float* colsum, const float* shift, int nslab, int64_t M, int C, int groups,
+                                   double* Sp, double* sum_scratch, const double* dfix, const int* gate, double eps, double momentum,
+                                   int ddof, float* moving_mean, float* moving_cov, float* mu, float* chan_scale, double* T,
+                                   hipStream_t st, double* tmp, double kappa = 0.0);      // K1 tail + K2 head in two launches (wc_whiten_f32)
 hipError_t wc_launch_factor_prepare(const double* sum, const double* xtx, int64_t M, int C, double eps, double momentum,
                                     int ddof, int training, int groups, float* moving_mean, float* moving_cov, float* mu,
                                     float* chan_scale, double* T, hipStream_t st, double* tmp = nullptr);

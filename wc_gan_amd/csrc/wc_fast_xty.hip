@@ -50,6 +50,19 @@ constexpr int BW_PLAIN = 3;                // 32x32 blocks per wave
 #endif
 template <int C, bool TWO> constexpr bool xty_quad() { return TWO && C == 256; }
 
+// The off-diagonal sums of the covariance kernel come out of the matrix pipe LOW by a nearly constant 8-10 e-10 of sqrt(S_ii S_jj)
+// (S = the centred sums of squares): v_mfma_f32_*_f16's accumulation is not correctly rounded, and with the
+// diagonal taken from exact VALU sums the off-diagonal bias is a rank-one perturbation -kappa s s^T that the whitening amplifies
+// by cond(Sigma) -- 1.39e-4 in dx on one seed of five at 128x32x32x256, 3e-5 once the mean bias is taken out (tools/k1_err_structure.py).
+// Measured with tools/k1_bias_survey.py (mean over i != j of (Sigma_gpu - Sigma_f64)_ij / sqrt(Sigma_ii Sigma_jj)):
+//   cond-1e6 inputs, M = 32768 ... 524288, C = 128 | 256, channel scales over 4 decades   -9.7e-10 ... -1.00e-9
+//   independent gaussian -8.3e-10 (C = 128: -6.2e-10), + mean 3: -8.2e-10, heavy tails -9.4e-10, rank-4 + noise -1.12e-9,
+//   uniform(-1, 1) -5.9e-10, C = 64 gaussian -5.8e-10
+// The compensation adds kappa sqrt(S_ii S_jj) back to every off-diagonal sum (stats_xtx_kernel): with kappa in the middle of that
+// range the residual bias is <= 1/3 of the uncompensated one for every input above.  It belongs to THIS kernel's accumulation
+// scheme (three products into one fp32 accumulator, 12 accumulations per chain, XTY_FLUSH_STAGES 1): re-measure when that changes.
+constexpr double kXtyOffdiagBias = 8.5e-10;
+
 
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
@@ -537,4 +550,10 @@ hipError_t wc_launch_fast_xty(const float* X, const float* Y, const float* cx, c
                              : launch_xty_fast<256, false>(a, st);
     }
     return hipErrorInvalidValue;
+}
+
+double wc_fast_xty_offdiag_bias(void)
+{
+    static const char* off = getenv("WC_K1_NO_BIAS_COMP");       // development: the uncompensated sums (tools/k1_bias_survey.py)
+    return off ? 0.0 : kXtyOffdiagBias;
 }

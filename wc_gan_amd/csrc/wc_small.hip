@@ -25,9 +25,12 @@ __device__ __forceinline__ double readlane64(double v, int l)
 // K1 tail
 // ---------------------------------------------------------------------------------------------
 // 16 slab groups x 64 channels per block; partial sums meet in LDS (fixed order: deterministic)
+// dfix / Dp (nullable): the fast path's per-slab VALU diagonal -> Dp[c] = the centred sum of squares of channel c, which the
+// off-diagonal elements' bias compensation scales with (stats_xtx_kernel)
 __global__ __launch_bounds__(1024) void stats_colsum_kernel(const float* __restrict__ colsum, const float* __restrict__ shift,
                                                             int nslab, int64_t M, int C, double* __restrict__ Sp,
-                                                            double* __restrict__ sum)
+                                                            double* __restrict__ sum, const double* __restrict__ dfix = nullptr,
+                                                            double* __restrict__ Dp = nullptr)
 {
     __shared__ double red[16][64];
     // statistic group = blockIdx.y: its nslab partial slabs, its Sp / sum rows (shift is common to all groups)
@@ -45,6 +48,21 @@ __global__ __launch_bounds__(1024) void stats_colsum_kernel(const float* __restr
         for (int p = 0; p < 16; ++p) t += red[p][threadIdx.x];
         Sp[c] = t;
         sum[c] = t + (double)M * (double)shift[c];
+    }
+    if (dfix && Dp) {
+        __syncthreads();
+        dfix += (int64_t)blockIdx.y * nslab * C; Dp += (int64_t)blockIdx.y * C;
+        double d = 0.0;
+        if (c < C)
+            for (int z = part; z < nslab; z += 16) d += dfix[(int64_t)z * C + c];
+        red[part][threadIdx.x & 63] = d;
+        __syncthreads();
+        if (threadIdx.x < 64 && c < C) {
+            double t = 0.0;
+#pragma unroll
+            for (int p = 0; p < 16; ++p) t += red[p][threadIdx.x];
+            Dp[c] = t;
+        }
     }
 }
 
@@ -83,7 +101,8 @@ constexpr int SX_PARTS = 8;
 __global__ __launch_bounds__(64 * SX_PARTS) void stats_xtx_kernel(const double* __restrict__ P, const float* __restrict__ shift,
                                                                   const double* __restrict__ Sp, int nslab, int64_t M, int C,
                                                                   double* __restrict__ xtx, const double* __restrict__ dfix,
-                                                                  const int* __restrict__ gate)
+                                                                  const int* __restrict__ gate, double kappa = 0.0,
+                                                                  const double* __restrict__ Dp = nullptr)
 {
     __shared__ double red[SX_PARTS][64];
     const int j = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -92,6 +111,7 @@ __global__ __launch_bounds__(64 * SX_PARTS) void stats_xtx_kernel(const double* 
     if (blockIdx.x * 64 + 63 < i) return;          // whole block below the diagonal
     const int64_t CC = (int64_t)C * C;
     P += (int64_t)blockIdx.z * nslab * CC; Sp += (int64_t)blockIdx.z * C; xtx += (int64_t)blockIdx.z * CC;   // group
+    if (Dp) Dp += (int64_t)blockIdx.z * C;
     double g = 0.0;
     if (j < C && j >= i) {
         // the fast reduction's diagonal comes from its VALU sums of squares, not from the matrix pipe (wc_fast_xty.hip:
@@ -107,10 +127,81 @@ __global__ __launch_bounds__(64 * SX_PARTS) void stats_xtx_kernel(const double* 
         g = 0.0;
 #pragma unroll
         for (int q = 0; q < SX_PARTS; ++q) g += red[q][threadIdx.x];
+        // the matrix pipe's accumulation bias on the off-diagonal sums (wc_fast_xty.hip, kXtyOffdiagBias), taken out again
+        if (j != i && Dp && kappa != 0.0 && dfix && !(gate && *gate != 0)) g += kappa * sqrt(Dp[i] * Dp[j]);
         const double si = shift[i], sj = shift[j];
         const double v = g + si * Sp[j] + Sp[i] * sj + (double)M * si * sj;
         xtx[(int64_t)i * C + j] = v;
         if (j != i) xtx[(int64_t)j * C + i] = v;   // mirrored by the same thread: exact symmetry
+    }
+}
+
+// K1 tail + K2 head in ONE launch, for the caller that wants the factorisation and not the moments (wc_whiten_f32: training mode,
+// per-replica statistics -- the reference's behaviour): stats_xtx_kernel's slab reduction and
+// factor_prepare_kernel's bookkeeping by the same thread, element by element the SAME float64 expressions in the same order
+// (tests compare the two routes for equality).  The statistic groups are walked by every workgroup in turn (their
+// moving-statistics updates are applied one after the other, as `groups` separate calls would); xtx and sum are never stored.
+__global__ __launch_bounds__(64 * SX_PARTS) void stats_xtx_prepare_kernel(const double* __restrict__ P, const float* __restrict__ shift,
+                                                                          const double* __restrict__ Sp, int nslab, int64_t M, int C,
+                                                                          const double* __restrict__ dfix, const int* __restrict__ gate,
+                                                                          double kappa, const double* __restrict__ Dp,
+                                                                          int groups, double eps, double momentum, int ddof,
+                                                                          float* __restrict__ moving_mean, float* __restrict__ moving_cov,
+                                                                          float* __restrict__ mu, float* __restrict__ chan_scale,
+                                                                          double* __restrict__ T, int lower_only,
+                                                                          unsigned* __restrict__ rows, int nrows)
+{
+    __shared__ double red[SX_PARTS][64];
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int part = threadIdx.x >> 6;
+    const int i = blockIdx.y;
+    if (i == 0 && part == 0 && j < nrows) rows[j] = 0u;       // the row-block counters of the fused factor launch
+    if (blockIdx.x * 64 + 63 < i) return;                     // whole block below the diagonal (its elements are mirrored from above)
+    const int64_t CC = (int64_t)C * C;
+    const bool live = j < C && j >= i;
+    const bool exact_diag = dfix && !(gate && *gate != 0);
+    const int64_t e = (int64_t)i * C + j, et = (int64_t)j * C + i;
+    const double invM = 1.0 / (double)M;
+    double tmax = 0.0;
+    for (int g = 0; g < groups; ++g) {
+        double acc = 0.0;
+        if (live) {
+            const bool diag = j == i && exact_diag;
+            const double* p = diag ? dfix + (int64_t)g * nslab * C + i : P + (int64_t)g * nslab * CC + e;
+            acc = strided_sum(p, diag ? (int64_t)C : CC, part, SX_PARTS, nslab);
+        }
+        red[part][threadIdx.x & 63] = acc;
+        __syncthreads();
+        if (threadIdx.x < 64 && live) {
+            acc = 0.0;
+#pragma unroll
+            for (int q = 0; q < SX_PARTS; ++q) acc += red[q][threadIdx.x];
+            if (j != i && Dp && kappa != 0.0 && exact_diag) acc += kappa * sqrt(Dp[(int64_t)g * C + i] * Dp[(int64_t)g * C + j]);
+            const double* spg = Sp + (int64_t)g * C;
+            const double si = shift[i], sj = shift[j];
+            const double v = acc + si * spg[j] + spg[i] * sj + (double)M * si * sj;              // xtx[i][j] (= xtx[j][i])
+            const double sum_i = spg[i] + (double)M * si, sum_j = spg[j] + (double)M * sj;       // sum[i], sum[j]
+            const double sig = (0.5 * (v + v) - sum_i * sum_j * invM) / (double)(M - ddof);
+            if (moving_cov) {
+                moving_cov[e] = (float)(momentum * (double)moving_cov[e] + (1.0 - momentum) * sig);
+                if (j != i) moving_cov[et] = (float)(momentum * (double)moving_cov[et] + (1.0 - momentum) * sig);
+            }
+            if (i == 0) {
+                const double m = sum_j * invM;
+                mu[(int64_t)g * C + j] = (float)m;
+                if (moving_mean) moving_mean[j] = (float)(momentum * (double)moving_mean[j] + (1.0 - momentum) * m);
+            }
+            const double t = (1.0 - eps) * sig + (i == j ? eps : 0.0);
+            T[g * CC + e] = (lower_only && (j >> 4) > (i >> 4)) ? 0.0 : t;
+            if (j != i) T[g * CC + et] = t;
+            tmax = t > tmax ? t : tmax;
+        }
+        __syncthreads();
+    }
+    if (chan_scale && threadIdx.x < 64 && live && i == j) {
+        int ex;
+        frexp(sqrt(tmax), &ex);
+        chan_scale[j] = (float)ldexp(1.0, 3 - ex);
     }
 }
 
@@ -1358,11 +1449,14 @@ __global__ void f64_to_f32_kernel(const double* __restrict__ src, float* __restr
 
 hipError_t wc_launch_stats_finalize(const double* P, const float* colsum, const float* shift, int nslab,
                                     int64_t M, int C, int groups, double* Sp, double* sum, double* xtx,
-                                    const double* dfix, const int* gate, hipStream_t st)
+                                    const double* dfix, const int* gate, hipStream_t st, double kappa)
 {
-    // nslab and M are PER GROUP; group g owns slabs [g*nslab, (g+1)*nslab)
-    hipLaunchKernelGGL(stats_colsum_kernel, dim3((C + 63) / 64, groups), dim3(1024), 0, st, colsum, shift, nslab, M, C, Sp, sum);
-    hipLaunchKernelGGL(stats_xtx_kernel, dim3((C + 63) / 64, C, groups), dim3(64 * SX_PARTS), 0, st, P, shift, (const double*)Sp, nslab, M, C, xtx, dfix, gate);
+    // nslab and M are PER GROUP; group g owns slabs [g*nslab, (g+1)*nslab).  Sp holds 2*groups*C doubles: the column sums, then
+    // (kappa != 0) the diagonal's slab sums Dp
+    double* Dp = (dfix && kappa != 0.0) ? Sp + (size_t)groups * C : nullptr;
+    hipLaunchKernelGGL(stats_colsum_kernel, dim3((C + 63) / 64, groups), dim3(1024), 0, st, colsum, shift, nslab, M, C, Sp, sum, dfix, Dp);
+    hipLaunchKernelGGL(stats_xtx_kernel, dim3((C + 63) / 64, C, groups), dim3(64 * SX_PARTS), 0, st, P, shift, (const double*)Sp, nslab, M, C, xtx, dfix, gate,
+                       kappa, (const double*)Dp);
     return hipGetLastError();
 }
 
@@ -1404,6 +1498,23 @@ hipError_t wc_launch_factor_prepare(const double* sum, const double* xtx, int64_
     if (rows && 16 * groups > 128) return hipErrorInvalidValue;
     hipLaunchKernelGGL(factor_prepare_kernel, dim3((C + 127) / 128, C), dim3(128), 0, st,
                        sum, xtx, M, C, eps, momentum, ddof, training, groups, moving_mean, moving_cov, mu, chan_scale, T,
+                       use_fused_factor(C) ? 1 : 0, rows, rows ? 16 * groups : 0);
+    return hipGetLastError();
+}
+
+// K1 tail and K2 head together (wc_whiten_f32): the column sums, then ONE launch for slab reduction + moments -> T, mu,
+// moving statistics, chan_scale.  nslab and M are PER GROUP; `tmp` as in wc_launch_factor_prepare; sum_scratch [groups*C].
+hipError_t wc_launch_stats_prepare(const double* P, const float* colsum, const float* shift, int nslab, int64_t M, int C, int groups,
+                                   double* Sp, double* sum_scratch, const double* dfix, const int* gate, double eps, double momentum,
+                                   int ddof, float* moving_mean, float* moving_cov, float* mu, float* chan_scale, double* T,
+                                   hipStream_t st, double* tmp, double kappa)
+{
+    unsigned* rows = (tmp && factor_one_launch(C, groups)) ? reinterpret_cast<unsigned*>(tmp + (size_t)groups * C * 16) : nullptr;
+    if (rows && 16 * groups > 128) return hipErrorInvalidValue;
+    double* Dp = (dfix && kappa != 0.0) ? Sp + (size_t)groups * C : nullptr;       // Sp holds 2*groups*C doubles
+    hipLaunchKernelGGL(stats_colsum_kernel, dim3((C + 63) / 64, groups), dim3(1024), 0, st, colsum, shift, nslab, M, C, Sp, sum_scratch, dfix, Dp);
+    hipLaunchKernelGGL(stats_xtx_prepare_kernel, dim3((C + 63) / 64, C), dim3(64 * SX_PARTS), 0, st, P, shift, (const double*)Sp, nslab, M, C,
+                       dfix, gate, kappa, (const double*)Dp, groups, eps, momentum, ddof, moving_mean, moving_cov, mu, chan_scale, T,
                        use_fused_factor(C) ? 1 : 0, rows, rows ? 16 * groups : 0);
     return hipGetLastError();
 }

@@ -86,6 +86,31 @@ def factor(s, xtx, M, C, eps, momentum, ddof, training, moving_mean, moving_cov,
     return mu, L, W
 
 
+def whiten(x2d, eps, momentum, ddof, moving_mean, moving_cov, groups=1):
+    """K1 + K2 as one call (wc_whiten_f32; training mode, per-replica statistics): x2d (M, C) float32 -> (mu, L, W, chan_scale)
+    exactly as factor(*stats(x2d, groups), M / groups, ..., training=True, want_scale=True, groups=groups) returns them, with one
+    launch less and without the moments leaving the workspace.  Updates the moving statistics in place when given."""
+    lib = _lib.load()
+    _need(x2d, torch.float32, "x", 2)
+    M, C = x2d.shape
+    dev = x2d.device
+    lead = (groups,) if groups > 1 else ()
+    mu = torch.empty(*lead, C, dtype=torch.float32, device=dev)
+    chan_scale = torch.empty(C, dtype=torch.float32, device=dev)
+    L = torch.empty(*lead, C, C, dtype=torch.float64, device=dev)
+    W = torch.empty(*lead, C, C, dtype=torch.float64, device=dev)
+    if moving_mean is not None:
+        _need(moving_mean, torch.float32, "moving_mean")
+        _need(moving_cov, torch.float32, "moving_cov", 2)
+    nb = lib.wc_whiten_workspace_bytes(M, C, groups)
+    if nb == 0:
+        _lib.check(-3 if M % groups == 0 else -2, "wc_whiten_f32")
+    ws = _workspace(nb, dev)
+    _lib.check(lib.wc_whiten_f32(_ptr(x2d), M, C, groups, float(eps), float(momentum), int(ddof), _ptr(moving_mean), _ptr(moving_cov),
+                                 _ptr(mu), _ptr(chan_scale), _ptr(L), _ptr(W), _ptr(ws), ws.numel(), _stream()), "wc_whiten_f32")
+    return mu, L, W, chan_scale
+
+
 def color(W, gamma, chan_scale=None, groups=1, per_group=False):
     """A_k = W^T Gamma_k and At_k = A_k^T.  gamma (Kc, C, C) float32 or None (whitening only).
     With chan_scale also returns the apply plan (opaque uint8 tensor) -> (A, At, plan).
