@@ -5,10 +5,16 @@ import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import wc_oracle as o
 from wc_gan_amd import ops
+SPLIT = "--split" in sys.argv          # the K1 on pre-split planes (wc_stats_split_f16x2) instead of the fp32-input kernel
 def case(name, x):
     M, C = x.shape
     xd = x.cuda()
-    s, xtx = ops.stats(xd)
+    if SPLIT:
+        if not ops.stats_split_supported(M, C):
+            return
+        s, xtx = ops.stats_split(ops.split(xd.view(M // 1024, 32, 32, C)))
+    else:
+        s, xtx = ops.stats(xd)
     X = xd.double()
     s_ref = X.sum(0); xtx_ref = X.t() @ X
     cov = lambda s_, x_: (x_ - torch.outer(s_, s_) / M) / (M - 1)

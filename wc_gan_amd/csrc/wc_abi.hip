@@ -426,7 +426,9 @@ int wc_stats_split_f16x2(const void* xs, const float* xs_center, const float* xs
     double* P = cv.take<double>((size_t)nslab * C * C);
     WC_TRY(wc_launch_split_xtx(xs, xs_scale, Ns, HWs, C, per_seg, nsplit, rps, nslab, ntypes, P, colsum, dfix, st));
     // the planes hold g = (x - center) scale: the tail adds the centre's terms back (it is the "shift" of wc_stats_f32's tail)
-    WC_TRY(wc_launch_stats_finalize(P, colsum, xs_center, nslab / groups, HWs, C, groups, Sp, sum, xtx, dfix, nullptr, st));
+    // (the planes kernel's off-diagonal bias measures the same as the fp32-input kernel's: tools/k1_bias_survey.py --split)
+    WC_TRY(wc_launch_stats_finalize(P, colsum, xs_center, nslab / groups, HWs, C, groups, Sp, sum, xtx, dfix, nullptr, st,
+                                    wc_fast_xty_offdiag_bias()));
     return WC_OK;
 }
 
