@@ -156,6 +156,28 @@ def roofline_apply(dev):
     k3_f32 = lambda: ops.apply(x, mu, A, b, None, out=y, plan=plan)
     t = time_kernel(k3_split)
     t_b2b = {"split": time_kernel(k3_split, graph=True), "f32": time_kernel(k3_f32, graph=True)}
+    # ... and each kernel IN THE LAYER'S FLOW ("isolated AND in the layer's flow"): the site's own K1 -> K2 -> color
+    # in front of every launch, HIP events around that one launch (the events' own ~1-2 us included), 20 times
+    def in_flow(front, k3_launch):
+        ev = []
+        for _ in range(23):
+            front()
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(); k3_launch(); e1.record()
+            ev.append((e0, e1))
+        torch.cuda.synchronize()
+        ts = [a.elapsed_time(b) for a, b in ev[3:]]
+        return sum(ts) / len(ts) * 1e-3
+    def front_f32():
+        s_, xtx_ = ops.stats(x.view(M, C))
+        mu_, _, W_, cs_ = ops.factor(s_, xtx_, M, C, 1e-3, 0.99, 1, True, None, None, dev, want_scale=True)
+        ops.color(W_, gamma, cs_)
+    def front_split():
+        s_, xtx_ = ops.stats_split(xs)
+        mu_, _, W_ = ops.factor(s_, xtx_, M, C, 1e-3, 0.99, 1, True, None, None, dev)
+        A_, _, _ = ops.color(W_, gamma, xs.scale)
+        ops.split_bias(A_, b, xs, mu_)
+    t_flow = {"split": in_flow(front_split, k3_split), "f32": in_flow(front_f32, k3_f32)}
     y_f32 = ops.apply(x, mu, A, b, None, plan=plan)
     split_vs_f32 = float((y - y_f32).abs().max() / y_f32.abs().max())
     alg_bytes = 2 * M * C * 4 + (C * C + C) * 4
@@ -234,12 +256,14 @@ def roofline_apply(dev):
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_from_committed_profile": src,
             "launch_us": round(tb * 1e6, 2), "algorithmic_bytes": alg_bytes,
-            "timing": "HIP events around 20 launches issued from Python on the launching stream (k3_kernels.*.back_to_back_us: the same 20 launches replayed as one hipGraph)",
+            "timing": "launch_us: HIP events around 20 launches issued from Python on the launching stream; k3_kernels.*.back_to_back_us: the same 20 launches replayed as one hipGraph; in_flow_us: events around single launches behind the site's own K1 -> K2 -> color",
             "stream_copy_GBs": round(copy_gbs, 1),
             "frac_of_stream_copy": round(achieved / copy_gbs, 4),
             "k3_kernels": {k: {"launch_us": round(v * 1e6, 2), "frac": round(alg_bytes / v / 1e9 / HBM_PEAK_GBS, 4),
                                "frac_of_stream_copy": round(alg_bytes / v / 1e9 / copy_gbs, 4),
-                               "back_to_back_us": round(t_b2b["split" if k.startswith("apply_split") else "f32"] * 1e6, 2)}
+                               "back_to_back_us": round(t_b2b["split" if k.startswith("apply_split") else "f32"] * 1e6, 2),
+                               "in_flow_us": round(t_flow["split" if k.startswith("apply_split") else "f32"] * 1e6, 2),
+                               "in_flow_frac_of_stream_copy": round(alg_bytes / t_flow["split" if k.startswith("apply_split") else "f32"] / 1e9 / copy_gbs, 4)}
                            for k, v in k3.items()},
             "split_vs_fp32_input_rel_diff": split_vs_f32,
             "forward_site_us": round(t_site * 1e6, 1),

@@ -643,3 +643,38 @@ def test_checkpoint_round_trip_reproduces_eval_images_bit_for_bit(tmp_path):
     with torch.no_grad():
         img2 = G2(z, cls)
     assert torch.isfinite(img2).all() and torch.equal(img2, img)
+
+
+@pytest.mark.gpu
+def test_layers_through_the_registered_operator_give_the_same_generator():
+    """the layers can run the fused site through torch.ops.wc.whiten_color (layers.USE_TORCH_OPS / WC_TORCH_OPS=1)
+    instead of the ctypes wrappers: same images, same parameter gradients (the operator route has no hand-off and keeps y for the
+    ReLU mask, so sums are ordered differently downstream: 2e-5 of the maxima), same moving statistics."""
+    import wc_gan_amd.layers as layers
+    from wc_gan_amd.generator import make_generator
+    from wc_gan_amd.train import CIFAR10_UNCOND
+    torch.manual_seed(4)
+    G = make_generator(**CIFAR10_UNCOND['generator']).cuda().train()
+    z = torch.randn(64, 128, device='cuda')
+    with torch.no_grad():
+        G(z)
+    state = {k: v.detach().clone() for k, v in G.state_dict().items()}
+    out, stats = [], []
+    for route in (False, True):
+        G.load_state_dict(state)
+        layers.USE_TORCH_OPS = route
+        try:
+            img = G(z)
+            loss = (img * torch.linspace(-1, 1, img.numel(), device='cuda').view_as(img)).sum()
+            params = [p for p in G.parameters() if p.requires_grad]
+            out.append([img.detach()] + [g.detach() for g in torch.autograd.grad(loss, params)])
+            stats.append([b.detach().clone() for n, b in G.named_buffers() if 'moving' in n])
+        finally:
+            layers.USE_TORCH_OPS = False
+    # (gradients that are zero in exact arithmetic -- the bias of a convolution in front of a WC site: the site removes the mean --
+    # are rounding noise of size 3e-4 on either route, beside gradients of size 600: those are bounded by 1e-6 of the largest gradient)
+    top = max(float(b.abs().max()) for b in out[1][1:])
+    for a, b in zip(*out):
+        assert float((a - b).abs().max()) <= max(2e-5 * float(b.abs().max()), 1e-6 * top)
+    for a, b in zip(*stats):
+        assert float((a - b).abs().max()) <= 1e-6 * max(float(b.abs().max()), 1e-30)

@@ -33,14 +33,20 @@ __global__ __launch_bounds__(1024) void stats_colsum_kernel(const float* __restr
                                                             double* __restrict__ Dp = nullptr)
 {
     __shared__ double red[16][64];
+    __shared__ double redd[16][64];
     // statistic group = blockIdx.y: its nslab partial slabs, its Sp / sum rows (shift is common to all groups)
     colsum += (int64_t)blockIdx.y * nslab * C; Sp += (int64_t)blockIdx.y * C; sum += (int64_t)blockIdx.y * C;
+    const bool diag = dfix && Dp;
+    if (diag) { dfix += (int64_t)blockIdx.y * nslab * C; Dp += (int64_t)blockIdx.y * C; }
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int part = threadIdx.x >> 6;
-    double s = 0.0;
-    if (c < C)
+    double s = 0.0, d = 0.0;
+    if (c < C) {
         for (int z = part; z < nslab; z += 16) s += (double)colsum[(int64_t)z * C + c];
+        if (diag) for (int z = part; z < nslab; z += 16) d += dfix[(int64_t)z * C + c];      // (both loops' loads are in flight together)
+    }
     red[part][threadIdx.x & 63] = s;
+    if (diag) redd[part][threadIdx.x & 63] = d;
     __syncthreads();
     if (threadIdx.x < 64 && c < C) {
         double t = 0.0;
@@ -48,21 +54,11 @@ __global__ __launch_bounds__(1024) void stats_colsum_kernel(const float* __restr
         for (int p = 0; p < 16; ++p) t += red[p][threadIdx.x];
         Sp[c] = t;
         sum[c] = t + (double)M * (double)shift[c];
-    }
-    if (dfix && Dp) {
-        __syncthreads();
-        dfix += (int64_t)blockIdx.y * nslab * C; Dp += (int64_t)blockIdx.y * C;
-        double d = 0.0;
-        if (c < C)
-            for (int z = part; z < nslab; z += 16) d += dfix[(int64_t)z * C + c];
-        red[part][threadIdx.x & 63] = d;
-        __syncthreads();
-        if (threadIdx.x < 64 && c < C) {
-            double t = 0.0;
+    } else if (diag && threadIdx.x >= 64 && threadIdx.x < 128 && c < C) {
+        double t = 0.0;
 #pragma unroll
-            for (int p = 0; p < 16; ++p) t += red[p][threadIdx.x];
-            Dp[c] = t;
-        }
+        for (int p = 0; p < 16; ++p) t += redd[p][threadIdx.x - 64];
+        Dp[c] = t;
     }
 }
 

@@ -12,7 +12,12 @@ from __future__ import annotations
 import torch
 import torch.distributed as dist
 
+import os
+
 from . import _state, ops
+
+# K1 + K2 through the one-call entry wc_whiten_f32 (one launch less; identical results).  WC_WHITEN=0: the two separate calls.
+USE_WHITEN = os.environ.get('WC_WHITEN', '1') != '0'
 
 
 def _allreduce_(tensors, group):
@@ -39,17 +44,19 @@ class WhitenColorFunction(torch.autograd.Function):
         dev = x.device
         M = M_local
         mm = moving_mean.view(-1) if moving_mean is not None else None
-        if training and process_group is None:
+        if training and process_group is None and USE_WHITEN:
             # per-replica statistics (the reference's behaviour): K1 and K2 as one call -- the moments never leave the workspace
             # and the K1 tail / K2 head run as one launch (wc_whiten_f32; identical results to the two calls below)
             mu, L, W, chan_scale = ops.whiten(x.view(M_local, C), eps, momentum, ddof, mm, moving_cov)
         else:
-            if training:
+            if training and process_group is not None:
                 # sync-WC: the additive moments of all replicas, ONE collective on the buffer K1 wrote them into (no pack /
                 # unpack launches); every replica holds the same number of rows (fixed per-GPU batch): no host sync for the count
                 s, xtx, buf = ops.stats(x.view(M_local, C), flat=True)
                 dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=process_group)
                 M = M_local * dist.get_world_size(process_group)
+            elif training:
+                s, xtx = ops.stats(x.view(M_local, C))
             else:
                 s = xtx = None
             mu, L, W, chan_scale = ops.factor(s, xtx, M, C, eps, momentum, ddof, training, mm, moving_cov, dev, want_scale=True)
@@ -203,7 +210,11 @@ def whiten_color_grouped(x, groups, gamma=None, beta=None, slot=None, moving_mea
     Mg = M // groups
     dev = x.device
     mm = moving_mean.view(-1) if moving_mean is not None else None
-    mu, L, W, cs = ops.whiten(x.view(M, C), eps, momentum, ddof, mm, moving_cov, groups)      # K1 + K2 (wc_whiten_f32)
+    if USE_WHITEN:
+        mu, L, W, cs = ops.whiten(x.view(M, C), eps, momentum, ddof, mm, moving_cov, groups)      # K1 + K2 (wc_whiten_f32)
+    else:
+        s, xtx = ops.stats(x.view(M, C), groups)
+        mu, L, W, cs = ops.factor(s, xtx, Mg, C, eps, momentum, ddof, True, mm, moving_cov, dev, want_scale=True, groups=groups)
     _touched(moving_mean, moving_cov)
     g = gamma.detach().contiguous() if gamma is not None else None
     b = beta.detach().contiguous() if beta is not None else None

@@ -21,6 +21,8 @@ and runs them as ONE statistics pass, one small float64 stage and ONE affine pas
 """
 from __future__ import annotations
 
+import os
+
 import math
 import threading
 
@@ -38,6 +40,11 @@ _TLS = threading.local()          # per host thread: two trainers on two threads
 def _stat_groups():
     return getattr(_TLS, 'groups', 1)
 
+
+# WC_TORCH_OPS=1 (or layers.USE_TORCH_OPS = True): the layers call the fused site through torch.ops.wc.whiten_color instead of
+# the ctypes wrappers.  Off by default: a Python custom op costs tens of microseconds of dispatch per call (the eager step
+# makes ~300 such calls); inside a captured hipGraph both routes replay the same launches.
+USE_TORCH_OPS = os.environ.get('WC_TORCH_OPS', '0') == '1'
 
 class statistic_groups:
     """Context: WC layers treat the batch as `n` independent, equally sized batches stacked along N, each whitened
@@ -181,6 +188,12 @@ class DecorelationNormalization(_Lazy):
                                                self.epsilon, gamma_key, relu=relu, planes=planes)
         if self.renorm and self.training:
             gamma = self._renorm_gamma(x, gamma)
+        if USE_TORCH_OPS and self.process_group is None:
+            # the same site through the registered operator torch.ops.wc.whiten_color (torch_ops.py: schema, fake kernel,
+            # autograd formula on the op) -- what torch.compile / FX tooling see; no hand-off, no bit mask on this route
+            from . import torch_ops
+            return torch_ops.whiten_color_site(x, gamma, beta, slot, self.moving_mean, self.moving_cov, self.training,
+                                               self.epsilon, self.momentum, 1, relu)
         return WF.whiten_color(x, gamma, beta, slot, self.moving_mean, self.moving_cov, self.training,
                                self.epsilon, self.momentum, 1, self.process_group, relu=relu, planes=planes)
 
