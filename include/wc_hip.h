@@ -66,6 +66,13 @@ const char* wc_error_string(int code);
  * launch (bit-identical mu, L, W, chan_scale and moving statistics: the same float64 expressions in the same order), sum / xtx are
  * never stored.  M = all rows (groups * rows per group).  DecorelationNormalization.call, generator.py:24. */
 size_t wc_whiten_workspace_bytes(int64_t M, int C, int groups);
+/* Error words of K2's one-launch form (128 <= C <= 256: the inverse's workgroups wait, with a bounded spin, for the factorising
+ * workgroup of the same launch): byte offset into the workspace given to wc_factor_f64 / wc_whiten_f32 of `groups` uint32 words, 64
+ * bytes apart, that are 0 after a clean call and 1 when a wait ran out (W then also holds a NaN).  Read them back behind the
+ * call (stream order) when the GPU is shared or time-sliced; WC_K2_TWO_LAUNCH=1 selects the form without such a wait.  0: no such
+ * launch for this shape. */
+size_t wc_factor_error_offset(int C, int groups);
+size_t wc_whiten_error_offset(int64_t M, int C, int groups);
 int    wc_whiten_f32(const float* x, int64_t M, int C, int groups, double eps, double momentum, int ddof,
                      float* moving_mean /*[C] in/out, nullable*/, float* moving_cov /*[C,C] in/out, nullable*/,
                      float* mu /*[groups,C]*/, float* chan_scale /*[C], nullable*/, double* L /*[groups,C,C]*/, double* W /*[groups,C,C]*/,

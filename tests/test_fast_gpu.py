@@ -365,3 +365,23 @@ def test_whiten_is_stats_then_factor_bit_for_bit(shape, groups):
     torch.cuda.synchronize()
     for a, b in ((mu1, mu2), (torch.tril(L1), torch.tril(L2)), (W1, W2), (cs1, cs2), (mm1, mm2), (mc1, mc2)):
         assert torch.equal(a, b)
+
+
+def test_k2_error_words_are_clear_after_a_clean_call():
+    """ADVICE r2: the one-launch K2 leaves a sticky error word per statistic group when its bounded wait runs out (and poisons W);
+    wc_factor_error_offset / wc_whiten_error_offset say where.  With WC_CHECK_K2 the wrappers read them back: clean calls pass."""
+    from oracle import wc_oracle as o
+    from wc_gan_amd import _lib, ops
+    lib = _lib.load()
+    assert lib.wc_factor_error_offset(256, 5) == 5 * 256 * 16 * 8 + 4
+    assert lib.wc_factor_error_offset(64, 1) == 0                       # two launches at this width: no wait, nothing to check
+    x = dev(o.synth_activation(np.random.default_rng(3), (40, 8, 8, 256), "ill").astype(np.float32))
+    prev = ops.CHECK_K2
+    ops.CHECK_K2 = True
+    try:
+        mu, L, W, cs = ops.whiten(x.view(-1, 256), 1e-3, 0.99, 1, None, None, 5)
+        s, xtx = ops.stats(x.view(-1, 256), 5)
+        mu2, L2, W2 = ops.factor(s, xtx, 512, 256, 1e-3, 0.99, 1, True, None, None, x.device, groups=5)
+    finally:
+        ops.CHECK_K2 = prev
+    assert bool(torch.isfinite(W).all()) and torch.equal(W, W2)

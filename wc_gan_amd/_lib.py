@@ -49,6 +49,8 @@ SIGNATURES = {
     "wc_apply_mask_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wc_whiten_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "wc_factor_error_offset": (c_size_t, [c_int, c_int]),
+    "wc_whiten_error_offset": (c_size_t, [c_int64, c_int, c_int]),
     "wc_whiten_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_double, c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wc_apply_planes_supported": (c_int, [c_int64, c_int64, c_int]),

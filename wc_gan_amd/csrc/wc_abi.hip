@@ -163,6 +163,23 @@ size_t wc_factor_workspace_bytes(int C, int groups)
     return slot_bytes((size_t)groups * C * C, 8);
 }
 
+// K2 in one launch (128 <= C <= 256): the inverse's workgroups wait for the factorising one with a bounded spin; a wait that ran
+// out poisons W with a NaN and sets word [16 g + 1] of the row-block counters (group g) -- `groups` words 64 bytes apart from the
+// returned byte offset into the call's workspace, zero after a clean call.  0: this shape has no such launch (nothing to check).
+size_t wc_factor_error_offset(int C, int groups)
+{
+    if (bad_channels(C) || groups <= 0 || !wc_factor_is_fused(C) || C < 128 || C > 256) return 0;
+    return (size_t)groups * C * 16 * 8 + 4;
+}
+
+size_t wc_whiten_error_offset(int64_t M, int C, int groups)
+{
+    const size_t in_tmp = wc_factor_error_offset(C, groups);
+    const size_t a = wc_stats_workspace_bytes(M, C, groups);
+    if (in_tmp == 0 || a == 0) return 0;
+    return a + slot_bytes((size_t)groups * C, 8) + in_tmp;           // tmp is the last block of wc_whiten_f32's workspace
+}
+
 int wc_factor_f64(const double* sum, const double* xtx, int64_t M, int C, int groups, double eps, double momentum, int ddof,
                   int training, float* moving_mean, float* moving_cov, float* mu, float* chan_scale, double* L, double* W,
                   void* ws, size_t ws_bytes, wc_stream_t stream)

@@ -813,7 +813,12 @@ __device__ __forceinline__ void tri_inverse_role(const double* __restrict__ L, c
     // a wait that ran out means the factorising workgroup never got there (it cannot happen while the launch is resident as a
     // whole); fail loudly: NaN on this workgroup's first diagonal entry poisons every table built from W
     __syncthreads();
-    if (flag && avail[1] != 0u && tid == 0) W[(int64_t)(16 * wg) * C + 16 * wg] = __builtin_nan("");
+    if (flag && avail[1] != 0u && tid == 0) {
+        W[(int64_t)(16 * wg) * C + 16 * wg] = __builtin_nan("");
+        // ... and a sticky error word the host can read: the matrix's row-block counter is rows[16 g], the word behind
+        // it is free and zeroed by the same prepare launch -- wc_factor_error_offset / wc_whiten_error_offset say where it is
+        atomicOr(const_cast<unsigned*>(flag) + 1, 1u);
+    }
 }
 
 __global__ __launch_bounds__(1024) void tri_inverse_split_kernel(const double* __restrict__ L, const double* __restrict__ Linv,

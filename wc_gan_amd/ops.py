@@ -12,6 +12,8 @@ from __future__ import annotations
 
 import ctypes
 
+import os
+
 import torch
 
 from . import _lib
@@ -81,6 +83,8 @@ def factor(s, xtx, M, C, eps, momentum, ddof, training, moving_mean, moving_cov,
     _lib.check(lib.wc_factor_f64(_ptr(s), _ptr(xtx), int(M), C, groups, float(eps), float(momentum), int(ddof), int(bool(training)),
                                  _ptr(moving_mean), _ptr(moving_cov), _ptr(mu), _ptr(chan_scale), _ptr(L), _ptr(W),
                                  _ptr(ws), ws.numel(), _stream()), "wc_factor_f64")
+    if CHECK_K2:
+        _check_k2(ws, lib.wc_factor_error_offset(C, groups), groups, "wc_factor_f64")
     if want_scale:
         return mu, L, W, chan_scale
     return mu, L, W
@@ -108,7 +112,23 @@ def whiten(x2d, eps, momentum, ddof, moving_mean, moving_cov, groups=1):
     ws = _workspace(nb, dev)
     _lib.check(lib.wc_whiten_f32(_ptr(x2d), M, C, groups, float(eps), float(momentum), int(ddof), _ptr(moving_mean), _ptr(moving_cov),
                                  _ptr(mu), _ptr(chan_scale), _ptr(L), _ptr(W), _ptr(ws), ws.numel(), _stream()), "wc_whiten_f32")
+    if CHECK_K2:
+        _check_k2(ws, lib.wc_whiten_error_offset(M, C, groups), groups, "wc_whiten_f32")
     return mu, L, W, chan_scale
+
+
+# WC_CHECK_K2=1: read K2's error words back after every call (a host synchronisation per site: for shared / time-sliced GPUs and for
+# debugging -- not under graph capture).  The one-launch K2 waits, with a bounded spin, for a workgroup of its own launch.
+CHECK_K2 = os.environ.get("WC_CHECK_K2", "0") == "1"
+
+
+def _check_k2(ws, offset, groups, what):
+    if offset == 0:
+        return
+    words = ws[offset:offset + 64 * groups].view(torch.int32)[::16]
+    if bool((words != 0).any()):
+        raise _lib.WcHipError(f"{what}: the inverse's wait for the factorisation ran out (W holds a NaN); "
+                              "rerun with WC_K2_TWO_LAUNCH=1 on a shared GPU")
 
 
 def color(W, gamma, chan_scale=None, groups=1, per_group=False):
