@@ -266,6 +266,21 @@ int wc_bwd_reduce_mask_f32(const float* x, const float* mu, const float* gy, con
                            int64_t N, int64_t HW, int C, int Kc,
                            double* R /*[Kc,C,C]*/, double* gsum /*[Kc,C]*/, float* gy_masked /*[N*HW*C] out*/,
                            float* scales_out /*[2C], nullable*/, void* ws, size_t ws_bytes, wc_stream_t stream);
+
+/* The ReLU'd backward with NO masked copy of the gradient in between (ABI 4): K4 applies the one-bit mask while it stages gy and
+ * writes nothing back (wc_bwd_reduce_bits_f32: x, gy and M*C/8 bytes of mask in, R / gsum / scales out), K6 applies the same bits
+ * while it converts gy (wc_bwd_apply_bits_f32: gy here is the gradient BEFORE the ReLU, as K4 received it).  The backward site then
+ * moves 5.03 M*C*4 bytes instead of 7 (fp32 y, masked copy) -- VERDICT r2 item 3.  Only where both kernels carry the mask in their
+ * staging (wc_bwd_bits_supported: C = 256, the fast reduction and the one-pass K6, N*HW a multiple of 32; `scales` required);
+ * elsewhere WC_ERR_SHAPE: use wc_bwd_reduce_mask_f32 (which writes the masked gradient) + wc_bwd_apply_scaled_f32.
+ * Arguments otherwise as in wc_bwd_reduce_scaled_f32 / wc_bwd_apply_scaled_f32.  generator.py:144-151, 154. */
+int wc_bwd_bits_supported(int64_t N, int64_t HW, int C, int has_slot);
+int wc_bwd_reduce_bits_f32(const float* x, const float* mu, const float* gy, const void* relu_mask, const int32_t* slot,
+                           int64_t N, int64_t HW, int C, int Kc, double* R /*[Kc,C,C]*/, double* gsum /*[Kc,C]*/,
+                           float* scales_out /*[2C]*/, void* ws, size_t ws_bytes, wc_stream_t stream);
+int wc_bwd_apply_bits_f32(const float* gy, const void* relu_mask, const float* x, const float* mu, const float* At, const float* S,
+                          const float* gmean, const int32_t* slot, int64_t N, int64_t HW, int C, int Kc,
+                          const float* scales /*[2C] from wc_bwd_reduce_bits_f32*/, float* dx, void* ws, size_t ws_bytes, wc_stream_t stream);
 int wc_bwd_apply_scaled_f32(const float* gy, const float* x, const float* mu, const float* At,
                             const float* S, const float* gmean, const int32_t* slot,
                             int64_t N, int64_t HW, int C, int Kc, const float* scales /*[2C], nullable*/, float* dx,

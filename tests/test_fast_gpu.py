@@ -385,3 +385,64 @@ def test_k2_error_words_are_clear_after_a_clean_call():
     finally:
         ops.CHECK_K2 = prev
     assert bool(torch.isfinite(W).all()) and torch.equal(W, W2)
+
+
+@pytest.mark.parametrize("shape,Kc", [((128, 32, 32, 256), 1), ((128, 16, 16, 256), 10), ((128, 12, 12, 256), 7), ((72, 16, 16, 256), 1),
+                                      ((136, 12, 12, 256), 1), ((136, 12, 12, 256), 5), ((320, 8, 8, 256), 1)])
+def test_relu_backward_without_a_masked_copy_equals_the_one_with(shape, Kc):
+    """VERDICT r2 item 3, second half: K4 applies the one-bit mask in its staging and writes NO masked gradient
+    (wc_bwd_reduce_bits_f32), K6 applies the same bits while it converts gy (wc_bwd_apply_bits_f32).  R, gsum and the scales are
+    bit-identical to the route that writes the copy, dx equal to 1e-6 of its maximum (K6 converts gy*bit instead of the stored
+    product: the same numbers), for plain and per-class tables, uneven tile counts per workgroup pair (9 and 10) and tiles that
+    straddle samples of different slots."""
+    from oracle import wc_oracle as o
+    from wc_gan_amd import ops
+    rng = np.random.default_rng(5)
+    N, C = shape[0], shape[-1]
+    x = dev(o.synth_activation(rng, shape, "ill").astype(np.float32))
+    gy = dev(rng.standard_normal(shape).astype(np.float32))
+    G, B = o.synth_coloring(rng, C, Kc)
+    Gd, Bd = dev(G.astype(np.float32)), dev(B.astype(np.float32))
+    slot = dev(rng.integers(0, Kc, N).astype(np.int32), torch.int32) if Kc > 1 else None
+    M = x.numel() // C
+    if not ops.bwd_bits_supported(shape, slot is not None):
+        assert shape not in ((128, 32, 32, 256), (128, 16, 16, 256))          # the generator's own sites must be on this route
+        pytest.skip("no bits-only route for this shape (the per-sample reduction takes another kernel): the copy is written")
+    mu, L, W, cs = ops.whiten(x.view(M, C), 1e-3, 0.99, 1, None, None)
+    A, At, plan = ops.color(W, Gd, cs)
+    y, mask = ops.apply(x, mu, A, Bd, slot, plan=plan, relu=True, want_mask=True)
+    R1, g1, gm, sc1 = ops.bwd_reduce(x, mu, gy, slot, Kc, want_scales=True, relu_mask=mask)
+    R2, g2, sc2 = ops.bwd_reduce(x, mu, gy, slot, Kc, want_scales=True, relu_mask=mask, write_masked=False)
+    assert torch.equal(R1, R2) and torch.equal(g1, g2) and torch.equal(sc1, sc2)
+    _, _, S, gmean = ops.bwd_factor(R1, g1, W, L, Gd, A, M, 1e-3, 1, True)
+    dx1 = ops.bwd_apply(gm, x, mu, At, S, gmean, slot, scales=sc1)
+    dx2 = ops.bwd_apply(gy, x, mu, At, S, gmean, slot, scales=sc2, relu_mask=mask)
+    torch.cuda.synchronize()
+    assert float((dx1 - dx2).abs().max()) <= 1e-6 * float(dx1.abs().max())
+
+
+def test_relu_backward_bits_route_redoes_out_of_range_tiles_exactly():
+    """An element of gy far outside the sampled fp16 range: both kernels take their exact path for that tile -- K4's gated redo
+    masks while it loads, K6's row-wise redo masks per element -- and the two routes still agree."""
+    from oracle import wc_oracle as o
+    from wc_gan_amd import ops
+    rng = np.random.default_rng(6)
+    shape = (96, 16, 16, 256); C = 256
+    assert ops.bwd_bits_supported(shape, False)
+    x = dev(o.synth_activation(rng, shape, "ill").astype(np.float32))
+    gy = rng.standard_normal(shape).astype(np.float32)
+    gy[5, 3, 3, 17] = 3e7; gy[9, 1, 2, 200] = -2e7; gy[77, 15, 15, 0] = 1e7
+    gy = dev(gy)
+    M = x.numel() // C
+    mu, L, W, cs = ops.whiten(x.view(M, C), 1e-3, 0.99, 1, None, None)
+    A, At, plan = ops.color(W, None, cs)
+    y, mask = ops.apply(x, mu, A, None, None, plan=plan, relu=True, want_mask=True)
+    R1, g1, gm, sc1 = ops.bwd_reduce(x, mu, gy, None, 1, want_scales=True, relu_mask=mask)
+    R2, g2, sc2 = ops.bwd_reduce(x, mu, gy, None, 1, want_scales=True, relu_mask=mask, write_masked=False)
+    assert float((R1 - R2).abs().max()) <= 1e-9 * float(R1.abs().max()) and float((g1 - g2).abs().max()) <= 1e-9 * float(g1.abs().max())
+    _, _, S, gmean = ops.bwd_factor(R1, g1, W, L, None, A, M, 1e-3, 1, True)
+    dx1 = ops.bwd_apply(gm, x, mu, At, S, gmean, None, scales=sc1)
+    dx2 = ops.bwd_apply(gy, x, mu, At, S, gmean, None, scales=sc2, relu_mask=mask)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(dx2).all())
+    assert float((dx1 - dx2).abs().max()) <= 1e-6 * float(dx1.abs().max())

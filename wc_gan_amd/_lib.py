@@ -60,6 +60,11 @@ SIGNATURES = {
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wc_bwd_reduce_mask_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wc_bwd_bits_supported": (c_int, [c_int64, c_int64, c_int, c_int]),
+    "wc_bwd_reduce_bits_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wc_bwd_apply_bits_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wc_bwd_apply_scaled_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wc_bwd_factor_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64,

@@ -551,7 +551,11 @@ static int bwd_reduce_masked(const float* x, const float* mu, const float* gy, c
     a.per_sample = per_sample; a.nsplit = p.nsplit; a.rows_per_slab = p.rps; a.C = C; a.sym = 0; a.P = P; a.colsum = colsum;
     // the ReLU mask: inside the staging of the quadrant kernel (C = 256 on the fast path), else one elementwise pass in front
     const bool mask_in_kernel = masked && p.fast && C == 256;
-    if (masked && !gy_masked) return WC_ERR_NULL;
+    // gy_masked == NULL with the bit mask: the masked gradient is not written at all (wc_bwd_reduce_bits_f32: K6 applies the bits
+    // itself) -- only where the mask rides in the kernel's staging; the gated exact redo then masks while it loads
+    const bool nowrite = relu_mask && !gy_masked;
+    if (nowrite && !mask_in_kernel) return WC_ERR_SHAPE;
+    if (masked && !gy_masked && !nowrite) return WC_ERR_NULL;
     if (masked && !mask_in_kernel) {
         if (relu_mask) WC_TRY(wc_launch_relu_mask_bits(gy, relu_mask, gy_masked, N * HW, C, st));
         else WC_TRY(wc_launch_relu_mask(gy, relu_y, gy_masked, N * HW * C, st));
@@ -565,7 +569,8 @@ static int bwd_reduce_masked(const float* x, const float* mu, const float* gy, c
                                   P, colsum, nullptr, gate, st, mask_in_kernel ? relu_y : nullptr, mask_in_kernel ? gy_masked : nullptr,
                                   mask_in_kernel ? relu_mask : nullptr));
         a.gate = gate;
-        if (mask_in_kernel) a.Y = gy_masked;          // the gated exact redo reads what the fast kernel wrote
+        if (mask_in_kernel && !nowrite) a.Y = gy_masked;          // the gated exact redo reads what the fast kernel wrote
+        if (nowrite) a.ymask = relu_mask;                         // ... or masks gy itself
     }
     WC_TRY(wc_launch_xty(a, p.nslab, st));
     WC_TRY(wc_launch_bwd_combine(P, colsum, slot, N, p.nsplit, per_sample, C, Kc, R, gsum, st));
@@ -586,6 +591,27 @@ int wc_bwd_reduce_mask_f32(const float* x, const float* mu, const float* gy, con
 {
     if (!relu_mask || !gy_masked) return WC_ERR_NULL;
     return bwd_reduce_masked(x, mu, gy, nullptr, static_cast<const unsigned*>(relu_mask), slot, N, HW, C, Kc, R, gsum, gy_masked,
+                             scales_out, ws, ws_bytes, stream);
+}
+
+// K4 / K6 behind a ReLU'd site with the mask as bits and NO masked copy of the gradient in between (ABI 4): K4 applies the bits
+// while it stages gy and writes nothing back, K6 applies them again while it converts gy.  Only where both kernels have the mask in
+// their staging: C = 256 on the fast paths (wc_bwd_bits_supported); elsewhere wc_bwd_reduce_mask_f32 + wc_bwd_apply_scaled_f32.
+int wc_bwd_bits_supported(int64_t N, int64_t HW, int C, int has_slot)
+{
+    if (N <= 0 || HW <= 0 || C != 256 || ((N * HW) % 32) != 0) return 0;
+    const int per_sample = has_slot != 0;
+    const XtyPlan p = plan_xty(per_sample ? N : 1, per_sample ? HW : N * HW, C, per_sample, 0);
+    return (p.fast && wc_fast_affine_supported(N, HW, C, has_slot != 0) && wc_bwd_apply_onepass_supported(N, HW, C)) ? 1 : 0;
+}
+
+int wc_bwd_reduce_bits_f32(const float* x, const float* mu, const float* gy, const void* relu_mask, const int32_t* slot,
+                           int64_t N, int64_t HW, int C, int Kc, double* R, double* gsum, float* scales_out,
+                           void* ws, size_t ws_bytes, wc_stream_t stream)
+{
+    if (!relu_mask || !scales_out) return WC_ERR_NULL;
+    if (!wc_bwd_bits_supported(N, HW, C, slot != nullptr)) return WC_ERR_SHAPE;
+    return bwd_reduce_masked(x, mu, gy, nullptr, static_cast<const unsigned*>(relu_mask), slot, N, HW, C, Kc, R, gsum, nullptr,
                              scales_out, ws, ws_bytes, stream);
 }
 
@@ -697,9 +723,30 @@ int wc_bwd_apply_f32(const float* gy, const float* x, const float* mu, const flo
     return wc_bwd_apply_scaled_f32(gy, x, mu, At, S, gmean, slot, N, HW, C, Kc, nullptr, dx, ws, ws_bytes, stream);
 }
 
+static int bwd_apply_impl(const float* gy, const float* x, const float* mu, const float* At, const float* S,
+                          const float* gmean, const int32_t* slot, int64_t N, int64_t HW, int C, int Kc,
+                          const float* scales, float* dx, void* ws, size_t ws_bytes, wc_stream_t stream, const unsigned* relu_mask);
+
 int wc_bwd_apply_scaled_f32(const float* gy, const float* x, const float* mu, const float* At, const float* S,
                             const float* gmean, const int32_t* slot, int64_t N, int64_t HW, int C, int Kc,
                             const float* scales, float* dx, void* ws, size_t ws_bytes, wc_stream_t stream)
+{
+    return bwd_apply_impl(gy, x, mu, At, S, gmean, slot, N, HW, C, Kc, scales, dx, ws, ws_bytes, stream, nullptr);
+}
+
+int wc_bwd_apply_bits_f32(const float* gy, const void* relu_mask, const float* x, const float* mu, const float* At, const float* S,
+                          const float* gmean, const int32_t* slot, int64_t N, int64_t HW, int C, int Kc,
+                          const float* scales, float* dx, void* ws, size_t ws_bytes, wc_stream_t stream)
+{
+    if (!relu_mask || !scales || !S || !mu || !x) return WC_ERR_NULL;
+    if (!wc_bwd_bits_supported(N, HW, C, slot != nullptr)) return WC_ERR_SHAPE;
+    if (!ws || ws_bytes < wc_fast_affine_workspace(C, Kc) + wc_fast_affine_workspace(C, 1)) return WC_ERR_WORKSPACE;
+    return bwd_apply_impl(gy, x, mu, At, S, gmean, slot, N, HW, C, Kc, scales, dx, ws, ws_bytes, stream, static_cast<const unsigned*>(relu_mask));
+}
+
+static int bwd_apply_impl(const float* gy, const float* x, const float* mu, const float* At, const float* S,
+                          const float* gmean, const int32_t* slot, int64_t N, int64_t HW, int C, int Kc,
+                          const float* scales, float* dx, void* ws, size_t ws_bytes, wc_stream_t stream, const unsigned* relu_mask)
 {
     if (!gy || !At || !dx) return WC_ERR_NULL;
     if (S && !x) return WC_ERR_NULL;
@@ -722,13 +769,15 @@ int wc_bwd_apply_scaled_f32(const float* gy, const float* x, const float* mu, co
         void* plan1 = static_cast<char*>(ws) + wc_fast_affine_workspace(C, Kc);
         WC_TRY(wc_launch_fast_plan_tables2(At, Kc, plan0, scales + C, S, 1, plan1, scales, C, st));
         if (mu && wc_bwd_apply_onepass_supported(N, HW, C)) {       // C = 256: one pass over K = 512 (wc_fast.hip)
-            WC_TRY(wc_launch_bwd_apply_onepass(gy, x, mu, At, Kc, S, gmean, slot, N, HW, scales, dx, plan0, plan1, st));
+            WC_TRY(wc_launch_bwd_apply_onepass(gy, x, mu, At, Kc, S, gmean, slot, N, HW, scales, dx, plan0, plan1, st, relu_mask));
             return WC_OK;
         }
+        if (relu_mask) return WC_ERR_SHAPE;
         WC_TRY(wc_launch_fast_affine_planned(gy, nullptr, At, Kc, false, nullptr, gmean, slot, N, HW, C, 0, dx, plan0, st));
         WC_TRY(wc_launch_fast_affine_planned(x, mu, S, 1, true, nullptr, nullptr, nullptr, N, HW, C, 1, dx, plan1, st));
         return WC_OK;
     }
+    if (relu_mask) return WC_ERR_SHAPE;          // (only the one-pass kernel applies the bits)
     if (fast) {
         // two passes over dx (the B' fragments of both streams do not fit one wave's registers at C = 256):
         //   dx  = gy At[slot] - gmean ;   dx += (x - mu) S

@@ -84,6 +84,7 @@ struct WcXtyArgs {
     double* P;                           // [nslab][C][C] float64 partials
     float* colsum;                       // [nslab][C]
     const int* gate;                     // optional: run only when *gate != 0 (exact redo of a fast-path call)
+    const unsigned* ymask;               // optional: Y is a gradient in front of a ReLU whose one-bit mask this is (wc_apply_mask_f32 layout): applied while Y is loaded
 };
 int  wc_xty_plan(int64_t N, int64_t HW, int C, int per_sample, int sym, int* nsplit, int64_t* rows_per_slab);  // returns nslab
 hipError_t wc_launch_xty(const WcXtyArgs& a, int nslab, hipStream_t st);
@@ -133,7 +134,8 @@ hipError_t wc_launch_fast_plan_tables(const float* B, int Kc, int C, void* plan,
 bool wc_bwd_apply_onepass_supported(int64_t N, int64_t HW, int C);
 hipError_t wc_launch_bwd_apply_onepass(const float* gy, const float* x, const float* mu, const float* At, int Kc, const float* S,
                                        const float* gmean, const int32_t* slot, int64_t N, int64_t HW, const float* scales /*[2C]: x | gy*/,
-                                       float* dx, const void* plan0, const void* plan1, hipStream_t st);
+                                       float* dx, const void* plan0, const void* plan1, hipStream_t st,
+                                       const unsigned* relu_mask = nullptr /*gy is the gradient before the site's ReLU: masked while it is converted*/);
 hipError_t wc_launch_fast_plan_tables2(const float* B0, int Kc0, void* plan0, const float* scale0,
                                        const float* B1, int Kc1, void* plan1, const float* scale1, int C, hipStream_t st);
 float* wc_fast_plan_scale(void* plan);

@@ -63,6 +63,7 @@ __device__ __forceinline__ unsigned pk_rne(float a, float b)
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
 }
 
+typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
 constexpr int kPlaneBounds = 1024;             // planes form: per-table bounds (and per-workgroup maxima) in the scale record
 constexpr float kF16Guard = 60000.0f;          // |scaled element| above this -> the tile takes the exact path
 
@@ -1151,9 +1152,18 @@ struct OnePassArgs {
     const float* Bf0; int64_t bf0_stride; const float* Bf1;   // the fp32 tables, for the exact redo
     float* out;
     int ntiles, tiles_per_pair, mixed;
+    const unsigned* gmask;        // MK kernels: the ReLU's one-bit mask of the site (wc_apply_mask_f32 layout); gy is masked while it is converted
 };
 
-template <bool HAS_SLOT>
+// MK: gy is the gradient BEFORE the site's ReLU and a.gmask the activation's one-bit mask: the bits are applied while the gy chunks
+// are converted (K4 then has no masked copy to write).  A tile's 16 rows sit in one 32-row block of the mask =
+// 1 KiB of words, the same for all eight waves: it travels by LDS-DMA into one of two shared 1-KiB buffers behind the counters,
+// each wave bringing in 128 bytes of it TWO tiles ahead; a wave's piece has landed before its arrive(0) of that tile (one counted
+// wait), so the existing "converted" counter also says "the next tile's mask block is complete", and the buffer is rewritten only
+// after every wave has passed the next tile's wait on that counter.  (A register-destination load was tried first: as inline asm
+// its results land asynchronously in registers hipcc may have moved meanwhile -- a memory fault at 128x32x32x256 and one wrong row
+// pair in 500 launches at 128x16x16x256; as a plain load hipcc waits for it with the DMAs' counter.)
+template <bool HAS_SLOT, bool MK = false>
 __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
 {
     constexpr int C = 256, TR = 16, K2 = 2 * C;
@@ -1206,8 +1216,35 @@ __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
     auto craw_read = [&](int slot, int lane_) {
         craw = *reinterpret_cast<const f32x4*>(ring + wave * RAWW + slot * 1024 + lane_ * 16);
     };
-    auto cv_scale = [&](int p) {
-        if (p & 2) cg4 = craw * scl_x + ncs_x; else cg4 = craw * scl_g;
+    // the mask words of this lane's four channels for the tile being converted (MK), and the bit of row 2w of that tile
+    // MK: the mask block of tile tl -> shared buffer tl & 1; this wave's 128 bytes (lanes 0-7)
+    char* const mbuf = smem + 3 * FBUF + 8 * RAWW + 64;
+    const unsigned mb_w = (unsigned)(size_t)((__attribute__((address_space(3))) char*)(mbuf + wave * 128));
+    auto mask_dma = [&](int tl) {
+        if (lane < 8) {
+            const char* g = reinterpret_cast<const char*>(a.gmask + (int64_t)(tile_of(tl) >> 1) * C) + wave * 128 + lane * 16;
+            const unsigned l = __builtin_amdgcn_readfirstlane(mb_w + (tl & 1) * 1024);
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(g), "s"(l) : "memory");
+        }
+    };
+    auto cv_scale = [&](int p, int tl) {
+        if (p & 2) cg4 = craw * scl_x + ncs_x;
+        else {
+            cg4 = craw * scl_g;
+            if (MK) {
+                const u32x4_ m = *reinterpret_cast<const u32x4_*>(mbuf + (tl & 1) * 1024 + lane * 16);     // this lane's four channels' words
+                const int bit = __builtin_amdgcn_readfirstlane(((tile_of(tl) & 1) << 4) + 2 * wave + (p & 1));
+                // (elements copied to scalars first: __builtin_bit_cast on an ext-vector element read element 0 for every j, hipcc 7.0)
+                const float e0 = cg4[0], e1 = cg4[1], e2 = cg4[2], e3 = cg4[3];
+                const unsigned w0 = m[0], w1 = m[1], w2 = m[2], w3 = m[3];
+                cg4[0] = __builtin_bit_cast(float, __builtin_bit_cast(int, e0) & __builtin_amdgcn_sbfe((int)w0, bit, 1));
+                cg4[1] = __builtin_bit_cast(float, __builtin_bit_cast(int, e1) & __builtin_amdgcn_sbfe((int)w1, bit, 1));
+                cg4[2] = __builtin_bit_cast(float, __builtin_bit_cast(int, e2) & __builtin_amdgcn_sbfe((int)w2, bit, 1));
+                cg4[3] = __builtin_bit_cast(float, __builtin_bit_cast(int, e3) & __builtin_amdgcn_sbfe((int)w3, bit, 1));
+            }
+        }
         gmax = __builtin_fmaxf(__builtin_fmaxf(gmax, fabsf(cg4[0])), fabsf(cg4[1]));
         gmax = __builtin_fmaxf(__builtin_fmaxf(gmax, fabsf(cg4[2])), fabsf(cg4[3]));
     };
@@ -1273,6 +1310,12 @@ __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
         subv = a.sub[a.sub_on ? col : 0];
     };
 
+    if (MK) {       // the blocks of tiles 0 and 1: every wave's pieces have landed before anyone converts (barrier: once per launch)
+        mask_dma(0);
+        if (n > 1) mask_dma(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
 #pragma unroll
     for (int i = 0; i < NSLOT; ++i) if (i / 4 < n) dma_chunk(i / 4, i % 4, i, lane);
     load_b1();
@@ -1283,7 +1326,7 @@ __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
         if (n >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(TBL + 6) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         craw_read(p, lane);
-        cv_scale(p);
+        cv_scale(p, 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the slot has been read out
         if ((p + NSLOT) / 4 < n) dma_chunk((p + NSLOT) / 4, (p + NSLOT) % 4, p, lane);
         cv_hi(); cv_lo(); cv_write(0, p, woff0);
@@ -1301,14 +1344,18 @@ __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
     int fcur = 0;
     using T_ = std::integral_constant<bool, true>;
     using F_ = std::integral_constant<bool, false>;
-    auto tile_body = [&](int t, auto conv_tag, auto wm_tag) {
+    auto tile_body = [&](int t, auto conv_tag, auto wm_tag, auto par_tag) {
         constexpr bool CONV_ = decltype(conv_tag)::value;
         constexpr int WM_ = decltype(wm_tag)::value;
+        (void)par_tag;
         const int fnext = fcur == 2 ? 0 : fcur + 1;
         int lane_t = lane, woff_t = woff0, rd_t = rd_off;
         asm volatile("" : "+v"(lane_t), "+v"(woff_t), "+v"(rd_t));
-        wait_for(0, 8 * (t + 1));
+        wait_for(0, 8 * (t + 1));          // (MK: also "tile t + 1's mask block is complete", and every wave is done with tile t's)
         if (CONV_) wait_for(1, 8 * (t - 1));
+        // MK: this wave's piece of the block of tile t + 2 (converted during the next tile) into the buffer tile t's block has just left.
+        // One more DMA per tile than the waits below count: they only get more conservative by it
+        if (MK && CONV_ && t + 2 < n) mask_dma(t + 2);
         int rs[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p) { const int v = rslot + p; rs[p] = v >= NSLOT ? v - NSLOT : v; }
@@ -1335,7 +1382,7 @@ __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
         auto cstep = [&](int j) {
             const int p = j / 5, st = j % 5;
             if (st == 0) {
-                cv_scale(p);
+                cv_scale(p, t + 1);
                 if (p == 0) { if (WC_FENCE_DEP) asm volatile("" :: "v"(cg4[0]) : "memory"); else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }   // chunk 0's ds_read was issued a few instructions ago: it must have RETURNED before the DMA that refills its slot may issue -- with the read only issued, a DMA served from L2 overtook it (one-pass K6, the pair's second workgroup: one corrupted row in ~1e5 tiles)
                 const int tl = t + 1 + (p + NSLOT) / 4;
                 if (tl < n) dma_chunk(tl, (p + NSLOT) % 4, rs[p], lane_t);
@@ -1364,7 +1411,14 @@ __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
                     for (int j = 0; j < 21; ++j) {
                         if ((j * H) / 21 != g) continue;
                         if (j < 20) cstep(j);
-                        else { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); arrive(0); }
+                        else {
+                            // MK: this tile's mask DMA (issued at its start) must have landed before the arrival that publishes it:
+                            // behind it sit this tile's DMAs -- 4 in steady state, 1 at n - 3, none issued at n - 2
+                            if (MK && (WM_ == 1 || WM_ == 2)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                            else if (MK && WM_ == 3) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                            else if (MK && WM_ == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); arrive(0);
+                        }
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -1395,15 +1449,18 @@ __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
             if (slot != cur_slot) { load_b0(slot); __builtin_amdgcn_s_waitcnt(0x0F70); }
         }
     };
+    auto tile_any = [&](int t, auto par_tag) {
+        if (t == 0) { if (t + 3 < n) tile_body(t, T_{}, W1{}, par_tag); else tile_body(t, T_{}, W0{}, par_tag); }
+        else if (t + 3 < n) tile_body(t, T_{}, W2{}, par_tag);
+        else if (t + 3 == n) tile_body(t, T_{}, W3{}, par_tag);
+        else tile_body(t, T_{}, W4{}, par_tag);
+    };
     for (int t = 0; t + 1 < n; ++t) {
         pick_table(t);
-        if (t == 0) { if (t + 3 < n) tile_body(t, T_{}, W1{}); else tile_body(t, T_{}, W0{}); }
-        else if (t + 3 < n) tile_body(t, T_{}, W2{});
-        else if (t + 3 == n) tile_body(t, T_{}, W3{});
-        else tile_body(t, T_{}, W4{});
+        tile_any(t, W0{});
     }
     pick_table(n - 1);
-    tile_body(n - 1, F_{}, W0{});
+    tile_body(n - 1, F_{}, W0{}, W0{});
 
     // Exact redo (rare), as in affine_ring_kernel: the workgroup's tiles again in fp32 from global memory when anything it
     // staged was outside the fp16 range; tiles that straddle samples of different slots per row.  Same thread, same element.
@@ -1429,6 +1486,11 @@ __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
                 const float* gr = a.gy + row * C;
                 const float* xr = a.x + row * C;
                 float accf = 0.f;
+                if (MK) {
+                    const unsigned* mr = a.gmask + (row >> 5) * C;
+                    const int bit = (int)(row & 31);
+                    for (int k = 0; k < C; ++k) accf = fmaf(((mr[k] >> bit) & 1u) ? gr[k] : 0.f, B0[(int64_t)k * C], accf);
+                } else
                 for (int k = 0; k < C; ++k) accf = fmaf(gr[k], B0[(int64_t)k * C], accf);
                 for (int k = 0; k < C; ++k) accf = fmaf(xr[k] - a.mu[k], B1[(int64_t)k * C], accf);
                 a.out[row * C + col] = accf - (a.sub_on ? a.sub[col] : 0.f);
@@ -1721,7 +1783,7 @@ bool wc_bwd_apply_onepass_supported(int64_t N, int64_t HW, int C)
 
 hipError_t wc_launch_bwd_apply_onepass(const float* gy, const float* x, const float* mu, const float* At, int Kc, const float* S,
                                        const float* gmean, const int32_t* slot, int64_t N, int64_t HW, const float* scales,
-                                       float* dx, const void* plan0, const void* plan1, hipStream_t st)
+                                       float* dx, const void* plan0, const void* plan1, hipStream_t st, const unsigned* relu_mask)
 {
     constexpr int C = 256, TR = 16;
     const PlanView v0 = plan_view(const_cast<void*>(plan0), C, Kc), v1 = plan_view(const_cast<void*>(plan1), C, 1);
@@ -1731,25 +1793,28 @@ hipError_t wc_launch_bwd_apply_onepass(const float* gy, const float* x, const fl
     a.hi1 = v1.hi; a.lo1 = v1.lo; a.cs1 = v1.colscale;
     a.sub_on = gmean != nullptr; a.sub = gmean ? gmean : scales;
     a.slot = slot; a.HW = HW; a.Bf0 = At; a.bf0_stride = (int64_t)C * C; a.Bf1 = S; a.out = dx;
+    a.gmask = relu_mask;
+    if (relu_mask && ((N * HW) % 32) != 0) return hipErrorInvalidValue;
     a.ntiles = (int)(N * HW / TR);
     a.mixed = (slot != nullptr && (HW % TR) != 0) ? 1 : 0;
     int pairs = a.ntiles < 128 ? a.ntiles : 128;
     const int groups16 = (pairs + 7) / 8;                 // block ids come in groups of 16: 8 pairs x 2 column halves
     pairs = groups16 * 8;
     a.tiles_per_pair = (a.ntiles + pairs - 1) / pairs;
-    constexpr size_t lds = 3 * 2 * (size_t)(TR * (2 * C * 2 + 32)) + 8 * 7 * 1024 + 64;
-#define WC_LAUNCH_ONEPASS(SLOT_)                                                                                       \
+    const size_t lds = 3 * 2 * (size_t)(TR * (2 * C * 2 + 32)) + 8 * 7 * 1024 + 64 + (relu_mask ? 2048 : 0);      // + the two shared mask blocks
+#define WC_LAUNCH_ONEPASS(SLOT_, MK_)                                                                                  \
     do {                                                                                                                \
         static bool attr_set = false;                                                                                   \
         if (!attr_set) {                                                                                                \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(onepass_ring_kernel<SLOT_>),               \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(onepass_ring_kernel<SLOT_, MK_>),          \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
             if (e != hipSuccess) return e;                                                                              \
             attr_set = true;                                                                                            \
         }                                                                                                               \
-        hipLaunchKernelGGL((onepass_ring_kernel<SLOT_>), dim3(groups16 * 16), dim3(512), lds, st, a);                   \
+        hipLaunchKernelGGL((onepass_ring_kernel<SLOT_, MK_>), dim3(groups16 * 16), dim3(512), lds, st, a);              \
     } while (0)
-    if (slot) WC_LAUNCH_ONEPASS(true); else WC_LAUNCH_ONEPASS(false);
+    if (relu_mask) { if (slot) WC_LAUNCH_ONEPASS(true, true); else WC_LAUNCH_ONEPASS(false, true); }
+    else { if (slot) WC_LAUNCH_ONEPASS(true, false); else WC_LAUNCH_ONEPASS(false, false); }
 #undef WC_LAUNCH_ONEPASS
     return hipGetLastError();
 }

@@ -225,7 +225,16 @@ __global__ __launch_bounds__(256) void xty_kernel(WcXtyArgs a, int ntiles, int n
             const int64_t m = m0 + rbase + 8 * p;
             const bool ok = m < r1;
             xv[p] = (ok && vi) ? ld4(a.X + m * C + ci) - cx : zero4;
-            if (!diag) yv[p] = (ok && vj) ? ld4(a.Y + m * C + cj) - cy : zero4;
+            if (!diag) {
+                yv[p] = (ok && vj) ? ld4(a.Y + m * C + cj) : zero4;
+                if (a.ymask && ok && vj) {       // the ReLU's bit mask of row m, columns cj .. cj + 3
+                    const uint4 w = *reinterpret_cast<const uint4*>(a.ymask + (m >> 5) * C + cj);
+                    const int b = (int)(m & 31);
+                    yv[p][0] = (w.x >> b) & 1u ? yv[p][0] : 0.f; yv[p][1] = (w.y >> b) & 1u ? yv[p][1] : 0.f;
+                    yv[p][2] = (w.z >> b) & 1u ? yv[p][2] : 0.f; yv[p][3] = (w.w >> b) & 1u ? yv[p][3] : 0.f;
+                }
+                if (ok && vj) yv[p] -= cy;
+            }
         }
     };
 

@@ -18,6 +18,8 @@ from . import _state, ops
 
 # K1 + K2 through the one-call entry wc_whiten_f32 (one launch less; identical results).  WC_WHITEN=0: the two separate calls.
 USE_WHITEN = os.environ.get('WC_WHITEN', '1') != '0'
+# the ReLU'd backward without a masked copy of the gradient (K4 and K6 both apply the bit mask; WC_BWD_BITS=0: K4 writes the copy)
+USE_BWD_BITS = os.environ.get('WC_BWD_BITS', '1') != '0'
 
 
 def _allreduce_(tensors, group):
@@ -106,20 +108,25 @@ class WhitenColorFunction(torch.autograd.Function):
             else:
                 gy = torch.ops.aten.threshold_backward(gy, y, 0.0)      # gy where y > 0, else 0: ONE elementwise pass (where(y > 0, ...) took three launches)
         scales = None          # K4 samples the fp16 scales of (x - mu) and gy; K6 reuses them (three launches instead of six)
+        k6_mask = None
         if reduce_runs:
             share = bool(stats_path)
             # K4 applies the mask while it stages gy and hands the masked gradient on (no pass of its own)
             ry = y if (ctx.relu and not ctx.mask_bits) else None
             rm = y if (ctx.relu and ctx.mask_bits) else None          # (the saved tensor is the bit mask then)
+            # with the bits and a K6 that masks for itself (C = 256 fast paths) K4 writes no masked copy of the gradient at all
+            bits_only = rm is not None and share and need_x and USE_BWD_BITS and ops.bwd_bits_supported(x.shape, slot is not None)
             if ctx.group is None:
-                out = ops.bwd_reduce(x, mu, gy, slot, Kc, want_scales=share, relu_y=ry, relu_mask=rm)
+                out = ops.bwd_reduce(x, mu, gy, slot, Kc, want_scales=share, relu_y=ry, relu_mask=rm, write_masked=not bits_only)
                 R, gsum = out[0], out[1]
             else:
-                out = ops.bwd_reduce(x, mu, gy, slot, Kc, flat=True, want_scales=share, relu_y=ry, relu_mask=rm)
+                out = ops.bwd_reduce(x, mu, gy, slot, Kc, flat=True, want_scales=share, relu_y=ry, relu_mask=rm, write_masked=not bits_only)
                 R, gsum, rbuf = out[0], out[1], out[2]
             if share:
                 scales = out[-1]
-            if ry is not None or rm is not None:
+            if bits_only:
+                k6_mask = rm
+            elif ry is not None or rm is not None:
                 gy = out[-2] if share else out[-1]
             if ctx.group is None:
                 dgamma, dbeta, S, gmean = ops.bwd_factor(R, gsum, W, L, g, A, ctx.M, ctx.eps, ctx.ddof, stats_path,
@@ -135,7 +142,7 @@ class WhitenColorFunction(torch.autograd.Function):
                     _, _, S, gmean = ops.bwd_factor(R, gsum, W, L, g, A, ctx.M, ctx.eps, ctx.ddof, True,
                                                     want_dgamma=False, want_dbeta=False)
         if need_x:
-            dx = ops.bwd_apply(gy, x, mu, At, S, gmean, slot, scales=scales)
+            dx = ops.bwd_apply(gy, x, mu, At, S, gmean, slot, scales=scales, relu_mask=k6_mask)
         return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
 

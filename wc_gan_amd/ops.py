@@ -367,7 +367,17 @@ def apply_split(xs, mu, A, bias, slot, plan=None, relu=False, out=None, folded=F
     return y
 
 
-def bwd_reduce(x, mu, gy, slot, Kc, flat=False, want_scales=False, relu_y=None, relu_mask=None):
+def bwd_bits_supported(shape, has_slot):
+    """Can the ReLU'd backward of a site of this NHWC shape run without a masked copy of the gradient (bwd_reduce(..., relu_mask=,
+    write_masked=False) + bwd_apply(..., relu_mask=))?"""
+    N, C = shape[0], shape[-1]
+    HW = 1
+    for d in shape[1:-1]:
+        HW *= d
+    return bool(_lib.load().wc_bwd_bits_supported(N, HW, C, int(bool(has_slot))))
+
+
+def bwd_reduce(x, mu, gy, slot, Kc, flat=False, want_scales=False, relu_y=None, relu_mask=None, write_masked=True):
     """K4: -> (R (Kc,C,C) f64, gsum (Kc,C) f64); flat=True: views of one buffer, returned third (sync-WC's single all-reduce);
     want_scales=True: the (2C,) per-channel input scales of (x - mu) and gy, returned last, for bwd_apply(scales=...);
     relu_y: the site's output y when its ReLU rode in K3 -- gy is masked (gy where y > 0) while it is staged, and the masked
@@ -387,6 +397,15 @@ def bwd_reduce(x, mu, gy, slot, Kc, flat=False, want_scales=False, relu_y=None, 
     ws = _workspace(lib.wc_bwd_reduce_workspace_bytes(N, HW, C, Kc, int(slot is not None)), x.device)
     scales = torch.empty(2 * C, dtype=torch.float32, device=x.device) if want_scales else None
     gm = None
+    if relu_mask is not None and not write_masked:
+        # K4 with the bits and NO masked copy (wc_bwd_reduce_bits_f32): -> (R, gsum[, buf], scales); bwd_apply(relu_mask=) masks for itself
+        _need(relu_mask, torch.int32, "relu_mask", 2)
+        if scales is None:
+            scales = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+        _lib.check(lib.wc_bwd_reduce_bits_f32(_ptr(x), _ptr(mu), _ptr(gy), _ptr(relu_mask), _ptr(slot), N, HW, C, Kc, _ptr(R), _ptr(gsum),
+                                              _ptr(scales), _ptr(ws), ws.numel(), _stream()), "wc_bwd_reduce_bits_f32")
+        out = (R, gsum, buf) if buf is not None else (R, gsum)
+        return out + (scales,)
     if relu_mask is not None:         # the mask in apply(..., want_mask=True)'s one-bit form: same outputs as relu_y
         _need(relu_mask, torch.int32, "relu_mask", 2)
         gm = torch.empty_like(gy)
@@ -434,9 +453,10 @@ def bwd_factor(R, gsum, W, L, gamma, A, M, eps, ddof, training, want_dgamma=True
     return dgamma, dbeta, S, gmean
 
 
-def bwd_apply(gy, x, mu, At, S, gmean, slot, fast=True, scales=None):
+def bwd_apply(gy, x, mu, At, S, gmean, slot, fast=True, scales=None, relu_mask=None):
     """K6: dx[n] = gy[n] At[slot[n]] + (x[n]-mu) S - gmean.  scales: the (2C,) input scales bwd_reduce(..., want_scales=True)
-    returned for the same x, mu, gy (three launches instead of six)."""
+    returned for the same x, mu, gy (three launches instead of six).  relu_mask: gy is the gradient BEFORE the site's ReLU and
+    this its one-bit mask -- applied while gy is converted (wc_bwd_apply_bits_f32; bwd_bits_supported shapes, scales required)."""
     lib = _lib.load()
     _need(gy, torch.float32, "gy")
     N, C = gy.shape[0], gy.shape[-1]
@@ -444,6 +464,12 @@ def bwd_apply(gy, x, mu, At, S, gmean, slot, fast=True, scales=None):
     Kc = At.shape[0]
     dx = torch.empty_like(gy)
     ws = _workspace(lib.wc_bwd_apply_workspace_bytes(N, HW, C, Kc), gy.device) if fast else None
+    if relu_mask is not None:
+        _need(relu_mask, torch.int32, "relu_mask", 2)
+        _lib.check(lib.wc_bwd_apply_bits_f32(_ptr(gy), _ptr(relu_mask), _ptr(x), _ptr(mu), _ptr(At), _ptr(S), _ptr(gmean), _ptr(slot),
+                                             N, HW, C, Kc, _ptr(scales), _ptr(dx), _ptr(ws), ws.numel() if ws is not None else 0,
+                                             _stream()), "wc_bwd_apply_bits_f32")
+        return dx
     _lib.check(lib.wc_bwd_apply_scaled_f32(_ptr(gy), _ptr(x), _ptr(mu), _ptr(At), _ptr(S), _ptr(gmean), _ptr(slot),
                                            N, HW, C, Kc, _ptr(scales), _ptr(dx), _ptr(ws), ws.numel() if ws is not None else 0,
                                            _stream()), "wc_bwd_apply_scaled_f32")
