@@ -237,7 +237,11 @@ def roofline_apply(dev):
         "K3 wc_apply_planes_f32 (ReLU + bit mask + the next convolution's planes, two launches: as the generator runs it)":
             {"us": round(time_kernel(lambda: ops.apply_planes(x, mu, A, b, None, plan, orec, relu=True, want_mask=True), iters=10) * 1e6, 1)},
         "  replaces: wc_conv_split_f32 of y (absmax + split, two launches)": {"us": round(time_kernel(lambda: fconv.split_planes(y_relu), iters=10) * 1e6, 1)},
-        "K4 wc_bwd_reduce_mask_f32 (as the generator runs it)": stage(lambda: ops.bwd_reduce(x, mu, gy, None, 1, want_scales=True, relu_mask=relu_bits), 3 * xb),
+        "K4 wc_bwd_reduce_bits_f32 (bit mask in, no masked copy out: as the generator runs it)":
+            stage(lambda: ops.bwd_reduce(x, mu, gy, None, 1, want_scales=True, relu_mask=relu_bits, write_masked=False), 2 * xb + xb // 32),
+        "K6 wc_bwd_apply_bits_f32 (applies the same bits to gy: as the generator runs it)":
+            stage(lambda: ops.bwd_apply(gy, x, mu, At, S, gm, None, scales=scales, relu_mask=relu_bits), 3 * xb + xb // 32),
+        "K4 wc_bwd_reduce_mask_f32 (writes the masked copy: shapes without the bits route)": stage(lambda: ops.bwd_reduce(x, mu, gy, None, 1, want_scales=True, relu_mask=relu_bits), 3 * xb),
         "K4 wc_bwd_reduce_relu_f32 (round 2: mask from y in fp32)": stage(lambda: ops.bwd_reduce(x, mu, gy, None, 1, want_scales=True, relu_y=y_relu), 4 * xb),
         "K5 wc_bwd_factor_f64": {"us": round(time_kernel(lambda: ops.bwd_factor(R, gsum, W, L, gamma, A, M, 1e-3, 1, True), iters=10) * 1e6, 1)},
         "K6 wc_bwd_apply_f32": stage(lambda: ops.bwd_apply(gy, x, mu, At, S, gm, None, scales=scales), 3 * xb),
