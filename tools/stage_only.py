@@ -1,7 +1,7 @@
 """Runs ONE stage of the WC path n times at the headline site 128x32x32x256 on the SURVEY section 8d kernel-bench input: the target
 of the round-3 rocprofv3 --kernel-trace / --pmc passes (tools/gpu_job_pmc_mode.sh <mode> <tag>; one kernel per run, so that what
 the previous launch left in the 256-MiB memory-side cache is the same tensor every time, as in bench.py's timing loops).
-usage: stage_only.py <n> <mode>;  mode = k3 | k3split | k3planes | k3mask | k1 | k1split | k4 | k4mask | k6"""
+usage: stage_only.py <n> <mode>;  mode = k3 | k3split | k3planes | k3mask | k1 | k1split | k4 | k4mask | k4bits | k6 | k6bits"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from wc_gan_amd import ops
@@ -23,11 +23,11 @@ if mode in ("k3split", "k1split"):
     xs = ops.split(x)
     A2, At2, plan2 = ops.color(W, gamma, xs.scale)
     be = ops.split_bias(A2, b, xs, mu)
-if mode in ("k4mask", "k3mask"):
+if mode in ("k4mask", "k3mask", "k4bits", "k6bits"):
     _, mask = ops.apply(x, mu, A, b, None, plan=plan, relu=True, want_mask=True, out=y)
 if mode == "k3planes":
     rec = ops.out_scale(gamma, b, C, x.device)
-if mode == "k6":
+if mode in ("k6", "k6bits"):
     R, gsum, scales = ops.bwd_reduce(x, mu, gy, None, 1, want_scales=True)
     _, _, S, gm = ops.bwd_factor(R, gsum, W, L, gamma, A, M, 1e-3, 1, True)
 run = {
@@ -39,7 +39,9 @@ run = {
     "k1split": lambda: ops.stats_split(xs),
     "k4": lambda: ops.bwd_reduce(x, mu, gy, None, 1),
     "k4mask": lambda: ops.bwd_reduce(x, mu, gy, None, 1, relu_mask=mask),
+    "k4bits": lambda: ops.bwd_reduce(x, mu, gy, None, 1, want_scales=True, relu_mask=mask, write_masked=False),
     "k6": lambda: ops.bwd_apply(gy, x, mu, At, S, gm, None, scales=scales),
+    "k6bits": lambda: ops.bwd_apply(gy, x, mu, At, S, gm, None, scales=scales, relu_mask=mask),
 }[mode]
 torch.cuda.synchronize()
 for _ in range(n):

@@ -1157,9 +1157,9 @@ struct OnePassArgs {
 
 // MK: gy is the gradient BEFORE the site's ReLU and a.gmask the activation's one-bit mask: the bits are applied while the gy chunks
 // are converted (K4 then has no masked copy to write).  A tile's 16 rows sit in one 32-row block of the mask =
-// 1 KiB of words, the same for all eight waves: it travels by LDS-DMA into one of two shared 1-KiB buffers behind the counters,
-// each wave bringing in 128 bytes of it TWO tiles ahead; a wave's piece has landed before its arrive(0) of that tile (one counted
-// wait), so the existing "converted" counter also says "the next tile's mask block is complete", and the buffer is rewritten only
+// 1 KiB of words, the same for all eight waves: it travels by LDS-DMA into one of three shared 1-KiB buffers behind the counters,
+// each wave bringing in 128 bytes of it THREE tiles ahead; a wave's piece has landed before its arrive(0) of the following tile (one
+// counted wait on a DMA a tile and a half old), so the existing "converted" counter also says "the next tile's mask block is complete", and the buffer is rewritten only
 // after every wave has passed the next tile's wait on that counter.  (A register-destination load was tried first: as inline asm
 // its results land asynchronously in registers hipcc may have moved meanwhile -- a memory fault at 128x32x32x256 and one wrong row
 // pair in 500 launches at 128x16x16x256; as a plain load hipcc waits for it with the DMAs' counter.)
@@ -1223,18 +1223,20 @@ __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
     auto mask_dma = [&](int tl) {
         if (lane < 8) {
             const char* g = reinterpret_cast<const char*>(a.gmask + (int64_t)(tile_of(tl) >> 1) * C) + wave * 128 + lane * 16;
-            const unsigned l = __builtin_amdgcn_readfirstlane(mb_w + (tl & 1) * 1024);
+            const unsigned l = __builtin_amdgcn_readfirstlane(mb_w + (tl % 3) * 1024);
             unsigned keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(g), "s"(l) : "memory");
         }
     };
+    u32x4_ mkw = {0u, 0u, 0u, 0u};          // MK: this lane's four channels' mask words of the tile being converted (read once per tile)
+    auto mask_words = [&](int tl) { mkw = *reinterpret_cast<const u32x4_*>(mbuf + (tl % 3) * 1024 + lane * 16); };
     auto cv_scale = [&](int p, int tl) {
         if (p & 2) cg4 = craw * scl_x + ncs_x;
         else {
             cg4 = craw * scl_g;
             if (MK) {
-                const u32x4_ m = *reinterpret_cast<const u32x4_*>(mbuf + (tl & 1) * 1024 + lane * 16);     // this lane's four channels' words
+                const u32x4_ m = mkw;
                 const int bit = __builtin_amdgcn_readfirstlane(((tile_of(tl) & 1) << 4) + 2 * wave + (p & 1));
                 // (elements copied to scalars first: __builtin_bit_cast on an ext-vector element read element 0 for every j, hipcc 7.0)
                 const float e0 = cg4[0], e1 = cg4[1], e2 = cg4[2], e3 = cg4[3];
@@ -1310,11 +1312,10 @@ __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
         subv = a.sub[a.sub_on ? col : 0];
     };
 
-    if (MK) {       // the blocks of tiles 0 and 1: every wave's pieces have landed before anyone converts (barrier: once per launch)
-        mask_dma(0);
+    if (MK) {       // the blocks of tiles 0, 1 and 2: older than every DMA below, landed at the first chunk's wait; the barrier there
+        mask_dma(0);    // makes all eight waves' pieces visible before anyone converts (once per launch)
         if (n > 1) mask_dma(1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (n > 2) mask_dma(2);
     }
 #pragma unroll
     for (int i = 0; i < NSLOT; ++i) if (i / 4 < n) dma_chunk(i / 4, i % 4, i, lane);
@@ -1325,6 +1326,7 @@ __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
     for (int p = 0; p < 4; ++p) {
         if (n >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(TBL + 6) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (MK && p == 0) { __syncthreads(); mask_words(0); }
         craw_read(p, lane);
         cv_scale(p, 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the slot has been read out
@@ -1353,9 +1355,10 @@ __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
         asm volatile("" : "+v"(lane_t), "+v"(woff_t), "+v"(rd_t));
         wait_for(0, 8 * (t + 1));          // (MK: also "tile t + 1's mask block is complete", and every wave is done with tile t's)
         if (CONV_) wait_for(1, 8 * (t - 1));
-        // MK: this wave's piece of the block of tile t + 2 (converted during the next tile) into the buffer tile t's block has just left.
-        // One more DMA per tile than the waits below count: they only get more conservative by it
-        if (MK && CONV_ && t + 2 < n) mask_dma(t + 2);
+        // MK: this wave's piece of the block of tile t + 3 into the buffer tile t's block has just left (three buffers: the piece is
+        // waited for at the NEXT tile's arrival, by when it is a tile and a half old).  One more DMA per tile than the waits below
+        // count: they only get more conservative by it
+        if (MK && CONV_) { if (t + 3 < n) mask_dma(t + 3); mask_words(t + 1); }
         int rs[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p) { const int v = rslot + p; rs[p] = v >= NSLOT ? v - NSLOT : v; }
@@ -1412,10 +1415,11 @@ __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
                         if ((j * H) / 21 != g) continue;
                         if (j < 20) cstep(j);
                         else {
-                            // MK: this tile's mask DMA (issued at its start) must have landed before the arrival that publishes it:
-                            // behind it sit this tile's DMAs -- 4 in steady state, 1 at n - 3, none issued at n - 2
-                            if (MK && (WM_ == 1 || WM_ == 2)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                            else if (MK && WM_ == 3) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                            // MK: the mask DMA of the PREVIOUS tile's start (the block of tile t + 2) must have landed before this arrival,
+                            // which publishes it: behind it sit that tile's 4 DMAs and 4 stores, this tile's mask DMA and its 4 DMAs (one
+                            // DMA and no mask DMA at n - 3); tile 0 publishes what the prologue loaded
+                            if (MK && (WM_ == 1 || WM_ == 2)) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+                            else if (MK && WM_ == 3) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
                             else if (MK && WM_ == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); arrive(0);
                         }
@@ -1801,7 +1805,7 @@ hipError_t wc_launch_bwd_apply_onepass(const float* gy, const float* x, const fl
     const int groups16 = (pairs + 7) / 8;                 // block ids come in groups of 16: 8 pairs x 2 column halves
     pairs = groups16 * 8;
     a.tiles_per_pair = (a.ntiles + pairs - 1) / pairs;
-    const size_t lds = 3 * 2 * (size_t)(TR * (2 * C * 2 + 32)) + 8 * 7 * 1024 + 64 + (relu_mask ? 2048 : 0);      // + the two shared mask blocks
+    const size_t lds = 3 * 2 * (size_t)(TR * (2 * C * 2 + 32)) + 8 * 7 * 1024 + 64 + (relu_mask ? 3072 : 0);      // + the three shared mask blocks
 #define WC_LAUNCH_ONEPASS(SLOT_, MK_)                                                                                  \
     do {                                                                                                                \
         static bool attr_set = false;                                                                                   \
