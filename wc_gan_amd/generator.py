@@ -267,6 +267,19 @@ def create_norm(norm, after_norm, cls=None, number_of_classes=None, filters_emb=
 # ---------------------------------------------------------------------------------------------
 # generator
 # ---------------------------------------------------------------------------------------------
+# WC_OVERLAP_SHORTCUT=0: the block's shortcut convolution on the main stream also in forward-only passes
+OVERLAP_SHORTCUT = os.environ.get('WC_OVERLAP_SHORTCUT', '1') != '0'
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    key = str(device)
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 def _norm_relu(norm, x, cls, consumer=None, kind='same'):
     """relu(norm(x, cls)) (generator.py:144-151, 154); the fused WC stack takes the activation into its apply kernel.
     consumer: the Conv2D that reads the result (and nothing else does) -- where it can, the site's apply kernel then writes that
@@ -294,7 +307,17 @@ class ResBlockUp(nn.Module):
         h = _norm_relu(self.bn1, x, cls, self.conv1 if (up or self.resample != 'UP') else None, 'up3' if up else 'same')
         # the 1x1 shortcut commutes with nearest-neighbour upsampling (every output pixel is the same per-pixel affine
         # map of its source pixel): it runs at the input resolution, a quarter of the work, and is added per 2x2 patch below
-        s = self.shortcut(x)
+        side = None
+        if OVERLAP_SHORTCUT and x.is_cuda and not torch.is_grad_enabled():
+            # forward-only passes (the generator passes inside the critic updates): the shortcut needs x only, so it runs on a
+            # second stream beside the site's narrow stage (K2: a handful of workgroups for 70-80 us) and the block's convolutions
+            main = torch.cuda.current_stream()
+            side = _side_stream(x.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                s = self.shortcut(x)
+        else:
+            s = self.shortcut(x)
         if self.resample == 'UP':
             # from 8x8 inputs on, upsample + 3x3 as one 4x4 stride-2 transposed convolution is faster than MIOpen on
             # the 4x tensor (measured forward+backward at N = 128: 3.91 -> 2.02 ms from 16x16, 1.06 -> 0.72 from 8x8,
@@ -304,6 +327,9 @@ class ResBlockUp(nn.Module):
             h = self.conv1(h)
         h = _norm_relu(self.bn2, h, cls, self.conv2)
         h = self.conv2(h)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+            s.record_stream(torch.cuda.current_stream())
         if self.resample == 'UP':
             # h + upsample2x(s) without the upsampled tensor: every 2x2 output patch adds its one source pixel
             N, H, W, C = s.shape
