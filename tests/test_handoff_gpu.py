@@ -34,7 +34,7 @@ def _stages(x, G, B, slot):
 
 
 @pytest.mark.parametrize("shape,Kc", [((128, 32, 32, 256), 1), ((128, 16, 16, 256), 10), ((128, 8, 8, 256), 1), ((64, 16, 16, 128), 3),
-                                      ((16, 8, 8, 256), 1)])
+                                      ((16, 8, 8, 256), 1), ((128, 12, 12, 256), 7)])       # (the last: tiles that straddle samples of different slots: redone per row)
 def test_planes_equal_the_fp32_output_and_its_mask(shape, Kc):
     """(hi + lo) / scale == K3's fp32 ReLU'd output to 2^-20 of max |y| (two fp16 planes carry 22 bits), the 1-bit ReLU masks of
     the two forms are equal, and against the float64 oracle the planes meet the path's 1e-4."""
