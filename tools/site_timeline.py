@@ -22,3 +22,15 @@ for _ in range(6):
     assert getattr(h, '_wc_planes', None) is not None
     h.backward(gy)
 torch.cuda.synchronize()
+# the same K3 (ReLU + bit mask) in a loop of its own, under the same profiler: the "isolated" figure beside the in-flow one above
+from wc_gan_amd import ops
+M = 128 * 32 * 32
+with torch.no_grad():
+    xd = x.detach()
+    mu_, L_, W_, cs_ = ops.whiten(xd.view(M, C), 1e-3, 0.99, 1, None, None)
+    A_, At_, plan_ = ops.color(W_, gamma.detach(), cs_)
+    yb = torch.empty_like(xd)
+    torch.cuda.synchronize()
+    for _ in range(20):
+        ops.apply(xd, mu_, A_, beta.detach(), None, out=yb, plan=plan_, relu=True, want_mask=True)
+torch.cuda.synchronize()

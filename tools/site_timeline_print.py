@@ -12,3 +12,8 @@ show(idx[4], idx[5], 'forward + backward, 128x32x32x256, ReLU epilogue (1-bit ma
 show(idx[10], idx[11], 'grouped forward (5 groups), 320x32x32x256')
 if len(idx) >= 18:
     show(idx[16], idx[17], 'forward + backward with the K3 -> convolution hand-off (planes out, gated second launch), 128x32x32x256')
+k3 = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in rows if 'affine_ring_kernel<256, false, true, false>' in r['Kernel_Name']]
+if len(k3) >= 26:
+    flow, loop = k3[:6], k3[-20:]
+    print('K3 (ReLU + bit mask) under this profiler: in the layer\'s flow %.1f us (6 launches: %s); in a loop of its own %.1f us (20 launches, min %.1f max %.1f)'
+          % (sum(flow) / len(flow), ' '.join('%.1f' % v for v in flow), sum(loop) / len(loop), min(loop), max(loop)))
