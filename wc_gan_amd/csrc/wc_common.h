@@ -109,7 +109,7 @@ hipError_t wc_launch_spectral_norm_bwd(const float* g, const float* w_sn, const 
                                        int R, int K, int fully_diff, float* dW, void* ws, hipStream_t st);
 
 // ----- fast split-fp16 affine (wc_fast.hip) ---------------------------------------------------
-constexpr int64_t WC_FAST_MIN_ROWS = 16384;     // reductions (K1/K4): below this the exact float64-MFMA kernel runs (development: WC_XTY_MIN_ROWS)
+constexpr int64_t WC_FAST_MIN_ROWS = 20480;     // reductions (K1/K4): below this the exact float64-MFMA kernel runs (development: WC_XTY_MIN_ROWS)
 // apply (K3/K6): below this the f32-MFMA kernel runs.  1024 since round 2: with the plan built by wc_color_f32 the split-fp16
 // apply is ONE launch whatever the size -- 8 against 35-43 us at the 4x4 / 8x8 sites of the generator (M = 2048..8192)
 constexpr int64_t WC_AFFINE_MIN_ROWS = 1024;

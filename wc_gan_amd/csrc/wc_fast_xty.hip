@@ -506,7 +506,9 @@ int wc_fast_xty_plan(int64_t N, int64_t HW, int C, int per_sample, int two, int*
 {
     if (!(C == 32 || C == 64 || C == 128 || C == 256)) return 0;
     const int64_t M = N * HW;
-    if (M < wc_fast_xty_min_rows()) return 0;
+    // K1 (the covariance: the whole error budget of dx at cond 1e6) stays on the exact kernel up to WC_FAST_MIN_ROWS; K4's R
+    // (6e-7 of that budget) takes the fast kernel from 16384 rows on as before
+    if (M < (two ? (wc_fast_xty_min_rows() < 16384 ? wc_fast_xty_min_rows() : 16384) : wc_fast_xty_min_rows())) return 0;
     const int R = xty_stage_rows(C, two != 0);
     const int64_t seg = per_sample ? HW : M;                  // rows of one segment (slabs never cross segments)
     if (seg % R != 0) return 0;

@@ -21,7 +21,7 @@ constexpr int BN = 128;      // tile cols
 constexpr int BK = 32;       // depth per LDS chunk
 constexpr int AS_LD = BM + 1;   // transposed x tile [k][row]; +1 makes the 4-way-k scatter write conflict-free
 constexpr int BS_LD = BN;
-constexpr int64_t WC_EXACT_ROWS = 16384;   // M at or below this: exact float64-MFMA reductions
+constexpr int64_t WC_EXACT_ROWS = 20479;   // M at or below this: exact float64-MFMA reductions (round 3: was 16384; 128x12x12 = 18432 rows, the STL-10 generator-update site, read dx 7.9e-5 on the split-fp16 kernel and has the least averaging of the sites above the old threshold)
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
