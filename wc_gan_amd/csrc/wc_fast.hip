@@ -1346,10 +1346,9 @@ __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
     int fcur = 0;
     using T_ = std::integral_constant<bool, true>;
     using F_ = std::integral_constant<bool, false>;
-    auto tile_body = [&](int t, auto conv_tag, auto wm_tag, auto par_tag) {
+    auto tile_body = [&](int t, auto conv_tag, auto wm_tag) {
         constexpr bool CONV_ = decltype(conv_tag)::value;
         constexpr int WM_ = decltype(wm_tag)::value;
-        (void)par_tag;
         const int fnext = fcur == 2 ? 0 : fcur + 1;
         int lane_t = lane, woff_t = woff0, rd_t = rd_off;
         asm volatile("" : "+v"(lane_t), "+v"(woff_t), "+v"(rd_t));
@@ -1453,18 +1452,15 @@ __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
             if (slot != cur_slot) { load_b0(slot); __builtin_amdgcn_s_waitcnt(0x0F70); }
         }
     };
-    auto tile_any = [&](int t, auto par_tag) {
-        if (t == 0) { if (t + 3 < n) tile_body(t, T_{}, W1{}, par_tag); else tile_body(t, T_{}, W0{}, par_tag); }
-        else if (t + 3 < n) tile_body(t, T_{}, W2{}, par_tag);
-        else if (t + 3 == n) tile_body(t, T_{}, W3{}, par_tag);
-        else tile_body(t, T_{}, W4{}, par_tag);
-    };
     for (int t = 0; t + 1 < n; ++t) {
         pick_table(t);
-        tile_any(t, W0{});
+        if (t == 0) { if (t + 3 < n) tile_body(t, T_{}, W1{}); else tile_body(t, T_{}, W0{}); }
+        else if (t + 3 < n) tile_body(t, T_{}, W2{});
+        else if (t + 3 == n) tile_body(t, T_{}, W3{});
+        else tile_body(t, T_{}, W4{});
     }
     pick_table(n - 1);
-    tile_body(n - 1, F_{}, W0{}, W0{});
+    tile_body(n - 1, F_{}, W0{});
 
     // Exact redo (rare), as in affine_ring_kernel: the workgroup's tiles again in fp32 from global memory when anything it
     // staged was outside the fp16 range; tiles that straddle samples of different slots per row.  Same thread, same element.
