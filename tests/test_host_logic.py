@@ -171,6 +171,49 @@ def test_keras_named_checkpoint_roundtrip(tmp_path):
                          last_norm='d', last_after_norm='uconv', spectral=True)
     load_keras_named(Gs2, {k: v for k, v in ss.items() if not k.endswith('/v:0')})                    # an upstream file has no v
     assert torch.equal(Gs2.blocks[0].conv1.conv.sn_u, Gs.blocks[0].conv1.conv.sn_u)
+    # ... so v is rebuilt from the LOADED weight and u (the random-init v would give a wrong sigma in eval mode, where
+    # the op runs no iteration and takes sigma = u^T W v as stored): v = normalize(W^T u), sigma as the source model's
+    for a, b in ((Gs2.blocks[0].conv1.conv, Gs.blocks[0].conv1.conv), (Gs2.dense, Gs.dense)):
+        wm = a._as_matrix(a.weight.detach())
+        assert torch.allclose(a.sn_v, torch.nn.functional.normalize(wm.t().mv(a.sn_u), dim=0), atol=1e-6)
+        sig = lambda m: float(m.sn_u @ m._as_matrix(m.weight.detach()) @ m.sn_v)
+        # (one half-step of the power iteration further than the source's stored v: equal at convergence, 2e-3 apart after the
+        # constructor's 15 warm-up steps; the random-init v this replaces gave sigma ~ 0.1 of it)
+        assert abs(sig(a) - sig(b)) < 1e-2 * abs(sig(b)) and sig(a) >= sig(b) * (1 - 1e-6)
+
+
+def test_keras_named_checkpoint_covers_embedding_batchnorm_and_any_dense_index():
+    """`Generator.emb` (concat_cls, generator.py:120-121 / run.py:175) and the moving statistics of norm == 'b'
+    (generator.py:22) travel too; a tensor that no entry names raises instead of being dropped; `dense_N` loads for any N."""
+    from wc_gan_amd.checkpoint import keras_named_state, load_keras_named
+    kw = dict(block_sizes=(32,), resamples=("UP",), first_block_shape=(4, 4, 32), number_of_classes=7, concat_cls=True,
+              block_norm='b', block_after_norm='ucs', last_norm='d', last_after_norm='uconv', gan_type='AC_GAN')
+    G = make_generator(**kw)
+    z, cls = torch.randn(4, 128), torch.randint(0, 7, (4, 1))
+    # the BatchNorm layers build on their first call (Keras-style): before it there is nothing to save for them
+    st0 = keras_named_state(G)
+    assert 'embedding_1/embeddings:0' in st0 and st0['embedding_1/embeddings:0'].shape == (7, 32)
+    for blk in G.blocks:                                     # build the lazily created BatchNorm state without running HIP layers
+        for bn in (blk.bn1, blk.bn2):
+            bn.norm_layer(torch.randn(2, 4, 4, 32))
+    st = keras_named_state(G)
+    assert st['Generator.0.bn1_npart/moving_variance:0'].shape == (32,) and 'Generator.0.bn2_npart/moving_mean:0' in st
+    torch.manual_seed(5)
+    G2 = make_generator(**kw)
+    for blk in G2.blocks:
+        for bn in (blk.bn1, blk.bn2):
+            bn.norm_layer(torch.randn(2, 4, 4, 32) * 3 + 1)
+    renamed = {k.replace('dense_1/', 'dense_7/').replace('embedding_1/', 'embedding_3/'): v for k, v in st.items()}
+    load_keras_named(G2, renamed)                            # Keras' automatic names count per process: any index loads
+    for k, v in keras_named_state(G2).items():
+        assert np.array_equal(v, st[k]), k
+    assert torch.equal(G2.emb.weight, G.emb.weight)
+    # a weight the walk does not know: loud, both ways
+    G2.extra = torch.nn.Parameter(torch.zeros(3))
+    with pytest.raises(NotImplementedError):
+        keras_named_state(G2)
+    with pytest.raises(NotImplementedError):
+        load_keras_named(G2, st)
 
 
 def test_h5_converter_round_trip_when_h5py_is_available(tmp_path):

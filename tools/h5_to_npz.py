@@ -3,7 +3,12 @@ wc_gan_amd.checkpoint.load_keras_named() reads -- and back.  h5py is imported la
 run wherever an upstream `generator.h5` lives.
 
     python tools/h5_to_npz.py generator.h5 generator.npz        # upstream -> this build
-    python tools/h5_to_npz.py generator.npz generator.h5        # this build -> upstream
+    python tools/h5_to_npz.py generator.npz generator.h5        # this build -> upstream, for `load_weights(path, by_name=True)`
+
+The npz -> h5 direction writes the layers in this build's module order, which is NOT Keras' `model.layers` order: the reference's
+positional `generator.load_weights(path)` (run.py:79, by_name=False) would mis-assign same-shaped layers, so such a file must be
+loaded with `by_name=True`.  This build's extra tensors (the right power-iteration vector `/v:0`, which upstream's SN layers do
+not have) are left out of the h5 so that the per-layer weight counts match upstream's.
 
 A Keras weights file: root attribute `layer_names`; one group per layer with attribute `weight_names` (entries such as
 `Generator.0.conv1/kernel:0`) and one dataset per weight under that path.  The .npz holds the same arrays under the same
@@ -13,6 +18,9 @@ A Keras weights file: root attribute `layer_names`; one group per layer with att
 import sys
 
 import numpy as np
+
+
+EXTRA_SUFFIXES = ("/v:0",)      # wc_gan_amd.checkpoint.OPTIONAL_SUFFIXES: tensors upstream's layers do not hold
 
 
 def h5_to_npz(src, dst):
@@ -32,7 +40,7 @@ def h5_to_npz(src, dst):
 
 def npz_to_h5(src, dst):
     import h5py
-    state = dict(np.load(src))
+    state = {k: v for k, v in dict(np.load(src)).items() if not k.endswith(EXTRA_SUFFIXES)}
     layers = {}
     for k in state:
         layers.setdefault(k.split("/")[0], []).append(k)
