@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define WC_ABI_VERSION 4
+#define WC_ABI_VERSION 5
 
 #define WC_OK                 0
 #define WC_ERR_NULL          -1   /* a required pointer is NULL                     */
@@ -192,6 +192,59 @@ int wc_apply_split_f16x2(const void* xs, const float* xs_center /*nullable*/, co
                          const float* mu /*nullable*/, const float* A, const float* bias /*nullable*/,
                          const int32_t* slot, int64_t N, int64_t HW, int C, int Kc, int relu,
                          float* y, const void* plan /*nullable*/, void* ws, size_t ws_bytes, wc_stream_t stream);
+
+/* ---- The residual add as the producer of pre-split activations (ABI 5, additive; SURVEY.md section 8f row N2: "residual Add
+ * feeding K1") ---------------------------------------------------------------------------------------------------------------
+ * reference generator.py:142-146: every `resblock(...)` ends in the Add of its convolution path h and its shortcut s, and the sum
+ * is what the next block's first norm stack and Generator.BN.Final (generator.py:154) read.  With up = 1 the shortcut is given
+ * BEFORE the nearest-neighbour upsample (a 1x1 convolution commutes with it) and every 2x2 output patch adds its source pixel:
+ *     out[n][y][x][c] = h[n][y][x][c] + s[n][y >> up][x >> up][c]      h (N, H, W, C), s (N, H >> up, W >> up, C) or NULL (= 0)
+ * wc_resadd_f32 writes the fp32 sum.  wc_resadd_split_f32 writes the sum in the pre-split format above instead (xs, center,
+ * scale, flag: exactly what wc_split_scales_f32 + wc_split_f32 make of the fp32 sum -- the same <= 256 sampled rows, the same
+ * centre and scales) in ONE pass over h and s behind one small sampling launch, so that K1 / K3 of the next site
+ * (wc_whiten_split_f16x2, wc_apply_split_ex_f16x2) and the next block's shortcut convolution (wc_fold_channel_scale_f32 +
+ * wc_conv_f16x3 on the same planes) read it without a conversion; x32 (nullable) also receives the fp32 sum, for a reader without
+ * a planes path.  C in {128, 256} (wc_resadd_split_supported), N*H*W < 2^31.
+ * wc_patch_sum_f32: the gradient of the up = 1 form with respect to s: out[n][y][x] = the sum of g over the 2x2 patch. */
+int wc_resadd_split_supported(int64_t N, int64_t H, int64_t W, int C);
+int wc_resadd_f32(const float* h, const float* s /*nullable*/, int64_t N, int64_t H, int64_t W, int C, int up, float* out,
+                  wc_stream_t stream);
+int wc_resadd_split_f32(const float* h, const float* s /*nullable*/, int64_t N, int64_t H, int64_t W, int C, int up,
+                        void* xs /*out: 2*N*H*W*C halves*/, float* center /*[C] out*/, float* scale /*[C] out*/,
+                        int* flag /*[64] out: [0] = 1 when an element saturated*/, float* x32 /*out, nullable*/, wc_stream_t stream);
+int wc_patch_sum_f32(const float* g /*(N, 2 Hs, 2 Ws, C)*/, int64_t N, int64_t Hs, int64_t Ws, int C, float* out /*(N, Hs, Ws, C)*/,
+                     wc_stream_t stream);
+/* A 1x1 convolution (the block's shortcut, generator.py:142-146) on a pre-split input: with x[c] = center[c] + g[c] / scale[c],
+ *     sum_c x[c] w[o][c] + b[o] = sum_c g[c] wf[o][c] + bf[o],   wf[o][c] = w[o][c] / scale[c],  bf[o] = b[o] + <center, w[o]>
+ * so wc_conv_f16x3 runs on the planes themselves (x scale 1) with the folded weight and bias; its weight gradient D (of wf, from
+ * wc_conv_wrw_bias_f16x3 on the same planes) and bias gradient db unfold to dW[o][c] = D[o][c] / scale[c] + center[c] db[o].
+ * w / wf / D / dW: element (o, c) at o * stride_o + c * stride_c. */
+int wc_fold_channel_scale_f32(const float* w, int64_t stride_o, int64_t stride_c, int Cout, int Cin, const float* bias /*nullable*/,
+                              const float* scale, const float* center, float* wf /*out*/, float* bf /*[Cout] out*/, wc_stream_t stream);
+int wc_unfold_channel_scale_f32(const float* D, const float* db, int64_t stride_o, int64_t stride_c, int Cout, int Cin,
+                                const float* scale, const float* center, float* dW /*out*/, wc_stream_t stream);
+
+/* K1 + K2 on a pre-split input in one call (ABI 5): wc_stats_split_f16x2 + wc_factor_f64(training = 1) as wc_whiten_f32 is for the
+ * fp32 input -- same results as that pair, the K1 tail and the K2 head as one launch, the moments never stored.  No chan_scale
+ * output: the apply's input scales are the planes' own (pass xs_scale to wc_color_f32).  DecorelationNormalization.call,
+ * generator.py:24. */
+size_t wc_whiten_split_workspace_bytes(int64_t M, int C, int groups);
+size_t wc_whiten_split_error_offset(int64_t M, int C, int groups);
+int    wc_whiten_split_f16x2(const void* xs, const float* xs_center, const float* xs_scale, int64_t M, int C, int groups,
+                             double eps, double momentum, int ddof, float* moving_mean /*nullable*/, float* moving_cov /*nullable*/,
+                             float* mu /*[groups,C]*/, double* L /*[groups,C,C]*/, double* W /*[groups,C,C]*/,
+                             void* ws, size_t ws_bytes, wc_stream_t stream);
+
+/* K3 on a pre-split input with the epilogues the generator's sites use (ABI 5): as wc_apply_split_f16x2, and
+ *   relu_mask (nullable; relu = 1, N*HW a multiple of 32): the ReLU's one-bit gradient mask, as wc_apply_mask_f32 leaves it;
+ *   planes + oscale instead of y (exactly one of y / planes is given): the output as the next convolution's fp16 planes,
+ *   oscale the record wc_out_scale_f32 filled -- the protocol of wc_apply_planes_f32 (two launches: the pass and its gate).
+ * Replaces the same reference call site as wc_apply_f32 (generator.py:83-87) + Activation('relu') (generator.py:144-151, 154). */
+int wc_apply_split_ex_f16x2(const void* xs, const float* xs_center /*nullable*/, const float* xs_scale,
+                            const float* mu /*nullable*/, const float* A, const float* bias /*nullable*/,
+                            const int32_t* slot, int64_t N, int64_t HW, int C, int Kc, int relu,
+                            float* y /*nullable*/, void* relu_mask /*out, nullable*/, void* planes /*out, nullable*/, float* oscale,
+                            const void* plan /*nullable*/, void* ws, size_t ws_bytes, wc_stream_t stream);
 
 /* K3 + ReLU + the ReLU's gradient mask as ONE BIT per element (ABI 4).  As wc_apply_act_f32 with relu = 1, and
  * relu_mask (wc_relu_mask_bytes(N*HW, C) bytes; N*HW a multiple of 32) receives, for every 32-row block t and channel c, the word

@@ -36,7 +36,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_abi_version_and_error_strings(lib):
     from wc_gan_amd import _lib
-    assert lib.wc_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.wc_abi_version() == _lib.ABI_VERSION == 5
     assert b"multiple of 32" in lib.wc_error_string(-3)
     assert lib.wc_error_string(0) == b"ok"
 
@@ -83,6 +83,34 @@ def test_split_entry_points_check_their_arguments(lib):
     assert lib.wc_apply_split_f16x2(one, None, one, None, one, None, None, 128, 1024, 256, 1, 0, one, None, one, 16, None) == -4
     assert lib.wc_stats_split_f16x2(one, one, one, 8192, 256, 1, one, one, one, 1 << 30, None) == -2
     assert lib.wc_split_bias_f32(None, None, None, None, 1, 64, one, None) == -1
+
+
+def test_producer_entry_points_check_their_arguments(lib):
+    """ABI 5 (the residual add as the producer of pre-split planes; K1 + K2 and the K3 epilogues on planes): no kernel launched."""
+    one = ctypes.c_void_p(16)
+    assert lib.wc_resadd_split_supported(128, 32, 32, 256) == 1 and lib.wc_resadd_split_supported(128, 32, 32, 64) == 0
+    assert lib.wc_resadd_f32(None, None, 4, 8, 8, 64, 0, one, None) == -1
+    assert lib.wc_resadd_f32(one, one, 4, 7, 8, 64, 1, one, None) == -2             # up: even output planes only
+    assert lib.wc_resadd_f32(one, one, 4, 8, 8, 40, 0, one, None) == -3
+    assert lib.wc_resadd_f32(one, one, 4, 8, 8, 64, 2, one, None) == -5
+    assert lib.wc_resadd_split_f32(one, one, 4, 8, 8, 64, 0, one, one, one, one, None, None) == -2      # planes: C = 128 | 256
+    assert lib.wc_resadd_split_f32(one, one, 4, 8, 8, 128, 0, None, one, one, one, None, None) == -1
+    assert lib.wc_patch_sum_f32(None, 4, 4, 4, 64, one, None) == -1 and lib.wc_patch_sum_f32(one, 4, 0, 4, 64, one, None) == -2
+    assert lib.wc_fold_channel_scale_f32(one, 256, 1, 256, 256, None, None, one, one, one, None) == -1
+    assert lib.wc_unfold_channel_scale_f32(one, one, 256, 1, 0, 256, one, one, one, None) == -2
+    assert lib.wc_whiten_split_workspace_bytes(131072, 256, 1) > lib.wc_stats_split_workspace_bytes(131072, 256, 1) > 0
+    assert lib.wc_whiten_split_workspace_bytes(8192, 256, 1) == 0
+    assert lib.wc_whiten_split_error_offset(131072, 256, 1) > 0 and lib.wc_whiten_split_error_offset(131072, 64, 1) == 0
+    args = (one, one, one, 131072, 256, 1, 1e-3, 0.99, 1, None, None, one, one, one, one, 1 << 30, None)
+    assert lib.wc_whiten_split_f16x2(*args[:6], 0.0, *args[7:]) == -5
+    assert lib.wc_whiten_split_f16x2(one, one, one, 8192, 256, 1, 1e-3, 0.99, 1, None, None, one, one, one, one, 1 << 30, None) == -2
+    assert lib.wc_whiten_split_f16x2(*args[:15], 16, None) == -4
+    ex = lambda y, mask, planes, osc, relu=1, hw=1024: lib.wc_apply_split_ex_f16x2(one, None, one, None, one, None, None, 128, hw, 256, 1, relu,
+                                                                                    y, mask, planes, osc, None, one, 1 << 30, None)
+    assert ex(None, None, None, None) == -1 and ex(one, None, one, one) == -1          # exactly one destination
+    assert ex(None, None, one, None) == -1                                              # planes need their scale record
+    assert ex(one, one, None, None, relu=0) == -5                                       # a mask belongs to a ReLU
+    assert lib.wc_apply_split_ex_f16x2(one, None, one, None, one, None, None, 3, 5, 256, 1, 1, one, one, None, None, None, one, 1 << 30, None) == -2
 
 
 def test_host_wrappers_refuse_cpu_tensors():

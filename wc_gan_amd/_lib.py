@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwc_hip.so")
 
 WC_OK = 0
-ABI_VERSION = 4          # WC_ABI_VERSION of include/wc_hip.h
+ABI_VERSION = 5          # WC_ABI_VERSION of include/wc_hip.h
 ERRORS = {-1: "WC_ERR_NULL", -2: "WC_ERR_SHAPE", -3: "WC_ERR_CHANNELS", -4: "WC_ERR_WORKSPACE", -5: "WC_ERR_ARG"}
 
 # name -> (restype, argtypes); mirrors include/wc_hip.h one to one
@@ -84,6 +84,19 @@ SIGNATURES = {
     "wc_apply_split_workspace_bytes": (c_size_t, [c_int, c_int]),
     "wc_apply_split_f16x2": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                      c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wc_apply_split_ex_f16x2": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                        c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wc_whiten_split_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "wc_whiten_split_error_offset": (c_size_t, [c_int64, c_int, c_int]),
+    "wc_whiten_split_f16x2": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_double, c_double, c_int, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wc_resadd_split_supported": (c_int, [c_int64, c_int64, c_int64, c_int]),
+    "wc_resadd_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "wc_resadd_split_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p]),
+    "wc_patch_sum_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p]),
+    "wc_fold_channel_scale_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wc_unfold_channel_scale_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wc_stream_copy_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "wc_spectral_norm_workspace_bytes": (c_size_t, [c_int, c_int]),
     "wc_spectral_norm_batched_f32": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p]),

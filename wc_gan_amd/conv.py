@@ -325,6 +325,80 @@ class _FastConv(torch.autograd.Function):
         return dx, dw, db, None, None, None, None
 
 
+_ones = {}
+
+
+def _one(device):
+    """the device scalar 1.0: the `x scale` of planes that carry their scales per channel (folded into the weight instead)"""
+    t = _ones.get(device)
+    if t is None:
+        t = torch.ones(1, dtype=torch.float32, device=device)
+        if not torch.cuda.is_current_stream_capturing():
+            _ones[device] = t
+    return t
+
+
+class _SplitConv(torch.autograd.Function):
+    """A 1x1 convolution (the block's shortcut, generator.py:142-146) whose input arrives as the pre-split planes of the residual add
+    in front (ops.SplitTensor: x[c] = center[c] + (hi + lo)[c] / scale[c]): the kernel runs on the planes themselves with
+    wf[o][c] = w[o][c] / scale[c] and bf = bias + <center, w[o]> (wc_fold_channel_scale_f32), so x is neither converted back to fp32
+    nor split again (rounds 1-3: one pass for max |x| and one to split, per shortcut and step).  Backward: the data gradient with the
+    weight itself; the weight gradient of wf on the same planes, unfolded (wc_unfold_channel_scale_f32)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, plan, st):
+        from . import ops
+        gf, kf, nf = plan.fwd
+        wf, bf = ops.fold_channel_scale(w, bias, st.scale, st.center)
+        img = weight_image(wf, gf, kf, nf)
+        ctx.bwd_image = None
+        if ctx.needs_input_grad[0]:
+            gb, kb, nb = plan.bwd
+            ctx.bwd_image = weight_image(w, gb, kb, nb)
+        hi, lo = st.planes[0].view(st.shape), st.planes[1].view(st.shape)
+        one = _one(hi.device)
+        y = run((hi, lo, one), img, gf, bf, nbytes=plan.fwd_ws)
+        ctx.save_for_backward(w, hi, lo, one, st.scale, st.center)
+        ctx.plan, ctx.has_bias = plan, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import ops
+        w, xh, xl, one, scale, center = ctx.saved_tensors
+        plan = ctx.plan
+        gy = gy.contiguous()
+        need_w = ctx.needs_input_grad[1]
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        fused_db = need_w and _colsum_ok(gy.shape[-1])       # db rides on the split + the dW reduction (the unfolding needs it anyway)
+        g_planes = split_planes(gy, colsum=fused_db)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            gb, kb, nb = plan.bwd
+            image = ctx.bwd_image if ctx.bwd_image is not None else weight_image(w, gb, kb, nb)
+            dx = run(g_planes[:3], image, gb, nbytes=plan.bwd_ws)
+        if need_w:
+            gf, kf, nf = plan.fwd
+            if fused_db:
+                D, db = weight_gradient((xh, xl, one), g_planes, gf, w, kf, nf, nbytes=plan.wrw_ws, colsum=g_planes[3])
+            else:
+                D = weight_gradient((xh, xl, one), g_planes, gf, w, kf, nf, nbytes=plan.wrw_ws)
+                db = gy.sum((0, 1, 2))
+            dw = ops.unfold_channel_scale(D, db, scale, center)
+        elif need_b:
+            db = gy.sum((0, 1, 2))
+        return dx, dw, (db if need_b else None), None, None
+
+
+def split_conv(x, st, w, bias=None):
+    """conv1x1(x) for a handle x whose data is the ops.SplitTensor st (see _SplitConv).  Raises when the kernel does not take the
+    shape -- the producer asks takes_planes() before it writes planes."""
+    p = _plan('same', x, w)
+    if not (p and p.ok and tuple(w.shape[2:]) == (1, 1) and w.dtype == torch.float32):
+        raise _lib.WcHipError(f"split_conv: a pre-split handle reached a convolution without a planes path {tuple(x.shape)} x {tuple(w.shape)}")
+    return _SplitConv.apply(x, w, bias, p, st)
+
+
 def fast_conv_or_none(x, w, bias=None, kind='same', relu_input=False):
     """fast_conv when the kernel takes the call, else None (the caller's other path).  relu_input: conv(relu(x))."""
     handed = getattr(x, '_wc_planes', None)

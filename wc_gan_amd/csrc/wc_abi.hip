@@ -449,6 +449,60 @@ int wc_stats_split_f16x2(const void* xs, const float* xs_center, const float* xs
     return WC_OK;
 }
 
+// K1 + K2 on a pre-split input in one call (ABI 5): wc_stats_split_f16x2 followed by wc_factor_f64(training = 1), the K1 tail and
+// the K2 head as ONE launch (wc_whiten_f32's merge); the moments never leave the workspace
+size_t wc_whiten_split_workspace_bytes(int64_t M, int C, int groups)
+{
+    const size_t a = wc_stats_split_workspace_bytes(M, C, groups);
+    if (a == 0) return 0;
+    return a + slot_bytes((size_t)groups * C, 8) + slot_bytes((size_t)groups * C * C, 8);
+}
+
+size_t wc_whiten_split_error_offset(int64_t M, int C, int groups)
+{
+    const size_t in_tmp = wc_factor_error_offset(C, groups);
+    const size_t a = wc_stats_split_workspace_bytes(M, C, groups);
+    if (in_tmp == 0 || a == 0) return 0;
+    return a + slot_bytes((size_t)groups * C, 8) + in_tmp;
+}
+
+int wc_whiten_split_f16x2(const void* xs, const float* xs_center, const float* xs_scale, int64_t M, int C, int groups,
+                          double eps, double momentum, int ddof, float* moving_mean, float* moving_cov,
+                          float* mu, double* L, double* W, void* ws, size_t ws_bytes, wc_stream_t stream)
+{
+    if (!xs || !xs_center || !xs_scale || !mu || !L || !W || !ws) return WC_ERR_NULL;
+    if ((moving_mean == nullptr) != (moving_cov == nullptr)) return WC_ERR_NULL;
+    if (M <= 0 || groups <= 0 || (M % groups) != 0 || M / groups <= ddof) return WC_ERR_SHAPE;
+    if (bad_channels(C)) return WC_ERR_CHANNELS;
+    if (!(eps > 0.0) || eps >= 1.0 || momentum < 0.0 || momentum > 1.0 || ddof < 0 || ddof > 1) return WC_ERR_ARG;
+    if (!wc_stats_split_supported(M, C, groups)) return WC_ERR_SHAPE;
+    if (ws_bytes < wc_whiten_split_workspace_bytes(M, C, groups)) return WC_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int per_seg = groups > 1;
+    const int64_t Ns = groups, HWs = M / groups;
+    int nsplit, ntypes; int64_t rps;
+    const int nslab = wc_split_xtx_plan(Ns, HWs, C, per_seg, &nsplit, &rps, &ntypes);
+    Carver cv(ws, ws_bytes);
+    (void)cv.take<int>(64);
+    double* Sp = cv.take<double>((size_t)2 * groups * C);
+    float* colsum = cv.take<float>((size_t)nslab * C);
+    double* dfix = cv.take<double>((size_t)nslab * C);
+    double* P = cv.take<double>((size_t)nslab * C * C);
+    double* sum_scratch = cv.take<double>((size_t)groups * C);
+    double* tmp = cv.take<double>((size_t)groups * C * C);
+    WC_TRY(wc_launch_split_xtx(xs, xs_scale, Ns, HWs, C, per_seg, nsplit, rps, nslab, ntypes, P, colsum, dfix, st));
+    // (chan_scale = NULL: the apply's input scales are the planes' own, xs_scale -- the caller gives them to wc_color_f32)
+    WC_TRY(wc_launch_stats_prepare(P, colsum, xs_center, nslab / groups, HWs, C, groups, Sp, sum_scratch, dfix, nullptr, eps, momentum,
+                                   ddof, moving_mean, moving_cov, mu, nullptr, L, st, tmp, wc_fast_xty_offdiag_bias()));
+    if (wc_factor_is_fused(C)) {
+        WC_TRY(wc_launch_factor_fused(L, W, tmp, C, groups, st));
+        return WC_OK;
+    }
+    WC_TRY(wc_launch_cholesky(L, C, groups, st));
+    WC_TRY(wc_launch_tri_inverse(L, W, tmp, C, groups, st));
+    return WC_OK;
+}
+
 size_t wc_apply_split_workspace_bytes(int C, int Kc)
 {
     if (Kc <= 0 || bad_channels(C)) return 0;
@@ -474,11 +528,27 @@ int wc_apply_split_f16x2(const void* xs, const float* xs_center, const float* xs
                          const float* bias, const int32_t* slot, int64_t N, int64_t HW, int C, int Kc, int relu,
                          float* y, const void* plan, void* ws, size_t ws_bytes, wc_stream_t stream)
 {
-    if (!xs || !xs_scale || !A || !y || !ws) return WC_ERR_NULL;
+    if (!y) return WC_ERR_NULL;
+    return wc_apply_split_ex_f16x2(xs, xs_center, xs_scale, mu, A, bias, slot, N, HW, C, Kc, relu, y, nullptr, nullptr, nullptr,
+                                   plan, ws, ws_bytes, stream);
+}
+
+// K3 on a pre-split input with the epilogues of wc_apply_mask_f32 / wc_apply_planes_f32 (ABI 5)
+int wc_apply_split_ex_f16x2(const void* xs, const float* xs_center, const float* xs_scale, const float* mu, const float* A,
+                            const float* bias, const int32_t* slot, int64_t N, int64_t HW, int C, int Kc, int relu,
+                            float* y, void* relu_mask, void* planes, float* oscale,
+                            const void* plan, void* ws, size_t ws_bytes, wc_stream_t stream)
+{
+    if (!xs || !xs_scale || !A || !ws) return WC_ERR_NULL;
+    if ((y == nullptr) == (planes == nullptr)) return WC_ERR_NULL;            // exactly one destination
+    if (planes && !oscale) return WC_ERR_NULL;
     if (relu != 0 && relu != 1) return WC_ERR_ARG;
+    if (relu_mask && !relu) return WC_ERR_ARG;
     if (N <= 0 || HW <= 0 || Kc <= 0) return WC_ERR_SHAPE;
     if (bad_channels(C)) return WC_ERR_CHANNELS;
     if (!wc_split_apply_supported(N, HW, C)) return WC_ERR_SHAPE;
+    if (relu_mask && ((N * HW) % 32) != 0) return WC_ERR_SHAPE;
+    if (planes && (N * HW) / (8192 / C) > 1024 * 1024) return WC_ERR_SHAPE;
     const size_t need = slot_bytes((size_t)Kc * C, 4) + (plan ? 0 : wc_fast_affine_workspace(C, Kc));
     if (ws_bytes < need) return WC_ERR_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -498,7 +568,72 @@ int wc_apply_split_f16x2(const void* xs, const float* xs_center, const float* xs
         WC_TRY(wc_launch_split_bias(A, bias, xs_center, mu, Kc, C, bias2, st));
         eff = bias2;
     }
-    WC_TRY(wc_launch_apply_split(xs, xs_scale, A, Kc, eff, slot, N, HW, C, relu, y, phi, plo, pcol, nullptr, st));
+    WC_TRY(wc_launch_apply_split(xs, xs_scale, A, Kc, eff, slot, N, HW, C, relu, y, phi, plo, pcol, nullptr, st,
+                                 static_cast<unsigned*>(relu_mask), planes, oscale));
+    return WC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the residual add as the producer of the next site's input (ABI 5; wc_resadd.hip)
+int wc_resadd_split_supported(int64_t N, int64_t H, int64_t W, int C)
+{
+    return (N > 0 && H > 0 && W > 0 && (C == 128 || C == 256) && N * H * W < ((int64_t)1 << 31)) ? 1 : 0;
+}
+
+static int resadd_check(const float* h, int64_t N, int64_t H, int64_t W, int C, int up)
+{
+    if (!h) return WC_ERR_NULL;
+    if (up != 0 && up != 1) return WC_ERR_ARG;
+    if (N <= 0 || H <= 0 || W <= 0 || N * H * W >= ((int64_t)1 << 31)) return WC_ERR_SHAPE;
+    if (up && ((H % 2) != 0 || (W % 2) != 0)) return WC_ERR_SHAPE;
+    if (bad_channels(C)) return WC_ERR_CHANNELS;
+    return WC_OK;
+}
+
+int wc_resadd_f32(const float* h, const float* s, int64_t N, int64_t H, int64_t W, int C, int up, float* out, wc_stream_t stream)
+{
+    const int rc = resadd_check(h, N, H, W, C, up);
+    if (rc != WC_OK) return rc;
+    if (!out) return WC_ERR_NULL;
+    WC_TRY(wc_launch_resadd(h, s, N, H, W, C, up, nullptr, nullptr, nullptr, nullptr, out, static_cast<hipStream_t>(stream)));
+    return WC_OK;
+}
+
+int wc_resadd_split_f32(const float* h, const float* s, int64_t N, int64_t H, int64_t W, int C, int up,
+                        void* xs, float* center, float* scale, int* flag, float* x32, wc_stream_t stream)
+{
+    const int rc = resadd_check(h, N, H, W, C, up);
+    if (rc != WC_OK) return rc;
+    if (!xs || !center || !scale || !flag) return WC_ERR_NULL;
+    if (!wc_resadd_split_supported(N, H, W, C)) return WC_ERR_SHAPE;
+    WC_TRY(wc_launch_resadd(h, s, N, H, W, C, up, xs, center, scale, flag, x32, static_cast<hipStream_t>(stream)));
+    return WC_OK;
+}
+
+int wc_patch_sum_f32(const float* g, int64_t N, int64_t Hs, int64_t Ws, int C, float* out, wc_stream_t stream)
+{
+    if (!g || !out) return WC_ERR_NULL;
+    if (N <= 0 || Hs <= 0 || Ws <= 0) return WC_ERR_SHAPE;
+    if (bad_channels(C)) return WC_ERR_CHANNELS;
+    WC_TRY(wc_launch_patch_sum(g, N, Hs, Ws, C, out, static_cast<hipStream_t>(stream)));
+    return WC_OK;
+}
+
+int wc_fold_channel_scale_f32(const float* w, int64_t stride_o, int64_t stride_c, int Cout, int Cin, const float* bias,
+                              const float* scale, const float* center, float* wf, float* bf, wc_stream_t stream)
+{
+    if (!w || !scale || !center || !wf || !bf) return WC_ERR_NULL;
+    if (Cout <= 0 || Cin <= 0) return WC_ERR_SHAPE;
+    WC_TRY(wc_launch_fold_channel_scale(w, stride_o, stride_c, Cout, Cin, bias, scale, center, wf, bf, static_cast<hipStream_t>(stream)));
+    return WC_OK;
+}
+
+int wc_unfold_channel_scale_f32(const float* D, const float* db, int64_t stride_o, int64_t stride_c, int Cout, int Cin,
+                                const float* scale, const float* center, float* dW, wc_stream_t stream)
+{
+    if (!D || !db || !scale || !center || !dW) return WC_ERR_NULL;
+    if (Cout <= 0 || Cin <= 0) return WC_ERR_SHAPE;
+    WC_TRY(wc_launch_unfold_channel_scale(D, db, stride_o, stride_c, Cout, Cin, scale, center, dW, static_cast<hipStream_t>(stream)));
     return WC_OK;
 }
 

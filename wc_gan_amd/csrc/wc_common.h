@@ -164,7 +164,19 @@ hipError_t wc_launch_split_bias(const float* A, const float* bias, const float* 
                                 float* out, hipStream_t st);
 hipError_t wc_launch_apply_split(const void* xs, const float* xs_scale, const float* A, int Kc, const float* bias2,
                                  const int32_t* slot, int64_t N, int64_t HW, int C, int relu, float* y,
-                                 const void* plan_hi, const void* plan_lo, const float* plan_colscale, void* dbg, hipStream_t st);
+                                 const void* plan_hi, const void* plan_lo, const float* plan_colscale, void* dbg, hipStream_t st,
+                                 unsigned* relu_mask = nullptr /*the ReLU's bit mask (relu != 0)*/,
+                                 void* planes = nullptr, float* oscale = nullptr /*the output as the next convolution's planes*/);
+
+// ----- the residual add as the producer of pre-split activations (wc_resadd.hip) --------------
+hipError_t wc_launch_resadd(const float* h, const float* s, int64_t N, int64_t H, int64_t W, int C, int up,
+                            void* xs /*nullable: planes out*/, float* center, float* scale, int* flag, float* x32 /*nullable: fp32 out*/,
+                            hipStream_t st);
+hipError_t wc_launch_patch_sum(const float* g, int64_t N, int64_t Hs, int64_t Ws, int C, float* out, hipStream_t st);
+hipError_t wc_launch_fold_channel_scale(const float* w, int64_t so, int64_t sc, int Cout, int Cin, const float* bias,
+                                        const float* scale, const float* center, float* wf, float* bf, hipStream_t st);
+hipError_t wc_launch_unfold_channel_scale(const float* D, const float* db, int64_t so, int64_t sc, int Cout, int Cin,
+                                          const float* scale, const float* center, float* dW, hipStream_t st);
 
 int wc_split_xtx_plan(int64_t N, int64_t HW, int C, int per_sample, int* nsplit, int64_t* rows_per_slab, int* ntypes);      // wc_split_xty.hip
 hipError_t wc_launch_split_xtx(const void* xs, const float* scale, int64_t N, int64_t HW, int C, int per_sample, int nsplit,

@@ -169,9 +169,16 @@ struct SplitApplyArgs {
     float* out;
     int ntiles, tiles_per_wg;
     unsigned long long* dbg;
+    unsigned* maskout;                                                // MASK: the ReLU's one-bit gradient mask, [M/32][C] words (wc_apply_mask_f32's layout)
+    _Float16* phi; _Float16* plo;                                     // PL: the output as the next convolution's planes (hi | lo of os * y)
+    float* oscale; float* oamax; const float* gate; int ngate;        // PL: the scale record of wc_launch_out_scale (affine_ring_kernel's protocol)
 };
 
-template <int C, bool HAS_SLOT>
+constexpr int kSplitPlaneBounds = 1024;        // = kPlaneBounds of wc_fast.hip: per-table bounds / per-workgroup maxima in the scale record
+
+// MASK / PL: the two epilogues of affine_ring_kernel (wc_fast.hip) on this kernel -- round 4: the sites fed by the residual add
+// (wc_resadd.hip) read planes AND leave the ReLU's bit mask (all of them) or the next convolution's planes (bn1 of a block).
+template <int C, bool HAS_SLOT, bool MASK = false, bool PL = false>
 __global__ __launch_bounds__(512, 1) void apply_split_kernel(SplitApplyArgs a)
 {
     constexpr int TR = 8192 / C;                      // rows per tile: 32 KiB of hi | lo
@@ -199,10 +206,32 @@ __global__ __launch_bounds__(512, 1) void apply_split_kernel(SplitApplyArgs a)
         t_first = blockIdx.x; t_stride = gridDim.x;
         n = (a.ntiles - t_first + t_stride - 1) / t_stride;
     }
-    if (n <= 0) return;
+    float os = 1.f, omax = 0.f;      // PL: output scale; running max |scaled output|
+    if (PL) {
+        {       // the predicted scale: fold the per-table bounds of wc_launch_out_scale
+            const int nb = __builtin_bit_cast(int, a.oscale[1]);
+            float bnd = 0.f;
+            for (int i = lane; i < nb; i += 64) bnd = __builtin_fmaxf(bnd, a.oscale[2 + i]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) bnd = __builtin_fmaxf(bnd, __shfl_xor(bnd, o));
+            int e = 0;
+            if (bnd > 0.f && bnd < 3.0e38f) { (void)frexpf(bnd, &e); os = ldexpf(1.f, 14 - e); }
+        }
+        if (a.gate) {       // second launch: nothing to do unless the first one's planes overflowed
+            float am = 0.f;
+            for (int i = lane; i < a.ngate; i += 64) am = __builtin_fmaxf(am, a.gate[i]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) am = __builtin_fmaxf(am, __shfl_xor(am, o));
+            if (!(am > kSplitGuard)) return;
+            int e = 0;
+            if (am < 3.0e38f) { (void)frexpf(am, &e); os = ldexpf(os, 14 - e); } else os = 1.f;
+        }
+        if (blockIdx.x == 0 && tid == 0) a.oscale[0] = os;
+    }
+    if (n <= 0) { if (PL && a.oamax && tid == 0) a.oamax[blockIdx.x] = 0.f; return; }
     auto tile_of = [&](int i) { return t_first + i * t_stride; };
 
-    if (tid < 8) cnt[tid] = 0;
+    if (tid < 16) cnt[tid] = 0;
     __syncthreads();
 
     // ---- DMA: this wave's pieces q = 4 wave + i of a tile; lane j lands at plane offset o = (q % 16) KiB + 16 j, i.e. row
@@ -302,6 +331,11 @@ __global__ __launch_bounds__(512, 1) void apply_split_kernel(SplitApplyArgs a)
 #pragma unroll
     for (int j = 0; j < 4; ++j) rd_base[j] = (rbase + l15) * ROWB + ((64 * j) ^ ((lq ^ l15) << 4));
     unsigned ol_b = (unsigned)((rbase + 8 * lh) * C + cg * 32 + l31) * 4u;      // byte offset of this lane's outputs inside a row pair
+    // planes form (affine_ring_kernel's): a lane pair exchanges its packed halves (DPP quad_perm [1,0,3,2]) so that the EVEN lane holds
+    // row +0's columns (l31, l31 + 1) and the ODD lane row +4's columns (l31 - 1, l31): one dword per lane and plane
+    const unsigned pl_b = (unsigned)((rbase + 8 * lh + 4 * (l31 & 1)) * C + cg * 32 + (l31 & ~1)) * 2u;
+    const unsigned pl_sel = (l31 & 1) ? 0x03020706u : 0x05040100u;       // v_perm_b32(neighbour, own, sel)
+    const unsigned mk_b = (unsigned)(cg * 32 + l31) * 4u;                // mask word of column l31 (lanes 0-31 store)
     if (WC_SPLIT_STAGGER && wave >= 4 && n >= 4) __builtin_amdgcn_s_sleep(24);      // ~a quarter of a tile behind waves 0-3
 
     unsigned long long t_wait = 0, t_loop = 0, t_store = 0;
@@ -324,6 +358,9 @@ __global__ __launch_bounds__(512, 1) void apply_split_kernel(SplitApplyArgs a)
 #else
         asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" :: "v"(olb), "v"(v), "s"(p) : "memory");
 #endif
+    };
+    auto store_u32 = [&](const void* base, unsigned off, unsigned v) __attribute__((always_inline)) {      // plain store (planes, mask): the L2 pairs the 64-byte halves of a line
+        asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" :: "v"(off), "v"(v), "s"(base) : "memory");
     };
     // PUB_: the hand-counted vmcnt in front of the publication of tile t+1 (-1: no next tile); DMA_: tile t+3 exists;
     // FIRST_: tile 0 in DEF mode (table k-step by k-step); PEND_: the previous tile's stores ride in this loop; DEFER_: this
@@ -401,28 +438,67 @@ __global__ __launch_bounds__(512, 1) void apply_split_kernel(SplitApplyArgs a)
         asm volatile("" : "+s"(tq));      // opaque: no store bases of the peeled first tile precomputed (and spilled) ahead of the loop
         const float* const po = a.out + (int64_t)tile_of(tq) * (TR * C);      // wave-uniform
         float res[16];
+        unsigned bits = 0;
+        const float cs0 = PL ? cscale[0] * os : cscale[0], cs1 = PL ? cscale[1] * os : cscale[1];      // (PL: the planes hold os * y; folded per tile, the constants
+        const float ad0 = PL ? addv[0] * os : addv[0], ad1 = PL ? addv[1] * os : addv[1];              //  arrive by asm loads that are only known to have landed here)
         auto leave = [&](auto RL_) __attribute__((always_inline)) {
             constexpr bool RL = decltype(RL_)::value;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int rh = i >> 2, r = i & 3;
-                float v0 = acc[rh][0][r] * cscale[0] + addv[0], v1 = acc[rh][1][r] * cscale[1] + addv[1];
+                float v0 = acc[rh][0][r] * cs0 + ad0, v1 = acc[rh][1][r] * cs1 + ad1;
                 if (RL) {
                     v0 = !(v0 <= 0.f) ? v0 : 0.f;
                     v1 = !(v1 <= 0.f) ? v1 : 0.f;
                 }
                 asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(v0), "+v"(v1));
-                res[2 * i] = v0; res[2 * i + 1] = v1;      // rows r (lanes 0-31) and 8 + r | rows 4 + r and 12 + r: columns l31
+                if (MASK) {      // after the ReLU a value is +0 or passes: v0 is row 16 rh + r (+ 8 in lanes 32-63), v1 four rows below; column l31
+                    const unsigned b0 = __builtin_bit_cast(unsigned, v0), b1 = __builtin_bit_cast(unsigned, v1);
+                    bits |= (b0 < 1u ? b0 : 1u) << (16 * rh + r);
+                    bits |= (b1 < 1u ? b1 : 1u) << (16 * rh + r + 4);
+                }
+                if constexpr (PL) {
+                    omax = __builtin_fmaxf(omax, __builtin_fmaxf(fabsf(v0), fabsf(v1)));
+                    const unsigned H = pk_rne2(v0, v1);
+                    float r0, r1;
+                    asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(H), "v"(v0));
+                    asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(H), "v"(v1));
+                    const unsigned L = pk_rne2(r0, r1);
+                    const unsigned Hn = (unsigned)__builtin_amdgcn_update_dpp(0, (int)H, 0xB1, 0xF, 0xF, false);
+                    const unsigned Ln = (unsigned)__builtin_amdgcn_update_dpp(0, (int)L, 0xB1, 0xF, 0xF, false);
+                    res[2 * i] = __builtin_bit_cast(float, __builtin_amdgcn_perm(Hn, H, pl_sel));
+                    res[2 * i + 1] = __builtin_bit_cast(float, __builtin_amdgcn_perm(Ln, L, pl_sel));
+                } else {
+                    res[2 * i] = v0; res[2 * i + 1] = v1;      // rows r (lanes 0-31) and 8 + r | rows 4 + r and 12 + r: columns l31
+                }
             }
         };
-        if (a.relu) leave(std::true_type{}); else leave(std::false_type{});
-        if (DEFER_) {
+        if (MASK || a.relu) leave(std::true_type{}); else leave(std::false_type{});
+        if (PL) {        // 16 dword stores as the fp32 form, in 64-byte pieces: value i = (hi, lo) word of rows 16 rh + r (+ 4 in odd lanes)
+            const char* const bh = reinterpret_cast<const char*>(a.phi + (int64_t)tile_of(tq) * (TR * C));
+            const char* const bl = reinterpret_cast<const char*>(a.plo + (int64_t)tile_of(tq) * (TR * C));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int rh = i >> 2, r = i & 3;
+                store_u32(bh + (16 * rh + r) * (C * 2), pl_b, __builtin_bit_cast(unsigned, res[2 * i]));
+                store_u32(bl + (16 * rh + r) * (C * 2), pl_b, __builtin_bit_cast(unsigned, res[2 * i + 1]));
+            }
+        } else if (DEFER_) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) pend[i] = res[i];
             pend_po = po;
         } else {
 #pragma unroll
             for (int i = 0; i < 16; ++i) store_pair(po, i, res[i]);
+        }
+        if (MASK) {
+            // lanes l and l + 32 hold the two halves of column l31's 32 row bits (rows +0..7, +16..23 | +8..15, +24..31); one more
+            // store per tile than the schedule's count of 16: a hand-counted wait only gets more conservative by it
+            unsigned own = bits, other = bits;
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(own), "+v"(other));
+            const unsigned* pm = a.maskout + ((int64_t)tile_of(tq) * (TR / 32) + rg) * C;      // wave-uniform
+            const unsigned word = own | (other << 8);
+            if (lh == 0) store_u32(pm, mk_b, word);
         }
         if (WC_SPLIT_STAMPS) t_store += __builtin_amdgcn_s_memtime() - c2_;
     };
@@ -495,8 +571,33 @@ __global__ __launch_bounds__(512, 1) void apply_split_kernel(SplitApplyArgs a)
                 float accf = 0.f;
                 for (int k = 0; k < C; ++k) accf = fmaf(((float)xh[k] + (float)xl[k]) / a.xscale[k], Bf[(int64_t)k * C], accf);
                 const float v = accf + a.bias[(int64_t)slot * C + ecol];
-                a.out[(r0 + row) * C + ecol] = a.relu ? (!(v <= 0.f) ? v : 0.f) : v;
+                const float o = (MASK || a.relu) ? (!(v <= 0.f) ? v : 0.f) : v;
+                if (PL) {
+                    const float so = o * os;
+                    const _Float16 h = (_Float16)so;
+                    a.phi[(r0 + row) * C + ecol] = h;
+                    a.plo[(r0 + row) * C + ecol] = (_Float16)(so - (float)h);
+                    omax = __builtin_fmaxf(omax, fabsf(so));
+                } else a.out[(r0 + row) * C + ecol] = o;
+                if (MASK) {       // the redone element's mask bit (rare path: atomics on the word it shares with 31 rows)
+                    unsigned* pm = a.maskout + ((r0 + row) >> 5) * C + ecol;
+                    const unsigned bit = 1u << ((r0 + row) & 31);
+                    if (__builtin_bit_cast(unsigned, o) != 0u) atomicOr(pm, bit); else atomicAnd(pm, ~bit);
+                }
             }
+        }
+    }
+    if (PL && a.oamax) {        // this workgroup's max |scaled output| (one partial per workgroup: deterministic, nothing to clear)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) omax = __builtin_fmaxf(omax, __shfl_xor(omax, o));
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (lane == 0) cnt[8 + wave] = __builtin_bit_cast(int, omax);
+        __syncthreads();
+        if (tid == 0) {
+            float m = 0.f;
+            for (int w = 0; w < 8; ++w) m = __builtin_fmaxf(m, __builtin_bit_cast(float, (int)cnt[8 + w]));
+            a.oamax[blockIdx.x] = m;
         }
     }
 }
@@ -511,18 +612,33 @@ hipError_t launch_apply_split(const SplitApplyArgs& a0, hipStream_t st)
     int nwg = a.ntiles < 256 ? a.ntiles : 256;
     a.tiles_per_wg = (a.ntiles + nwg - 1) / nwg;
     nwg = (a.ntiles + a.tiles_per_wg - 1) / a.tiles_per_wg;
-#define WC_LAUNCH_SPLIT(SLOT_)                                                                                          \
+#define WC_LAUNCH_SPLIT(SLOT_, MASK_, PL_)                                                                              \
     do {                                                                                                                \
         static bool attr_set = false;                                                                                   \
         if (!attr_set) {                                                                                                \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(apply_split_kernel<C, SLOT_>),             \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(apply_split_kernel<C, SLOT_, MASK_, PL_>), \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
             if (e != hipSuccess) return e;                                                                              \
             attr_set = true;                                                                                            \
         }                                                                                                               \
-        hipLaunchKernelGGL((apply_split_kernel<C, SLOT_>), dim3(nwg), dim3(512), lds, st, a);                           \
+        hipLaunchKernelGGL((apply_split_kernel<C, SLOT_, MASK_, PL_>), dim3(nwg), dim3(512), lds, st, a);               \
     } while (0)
-    if (a.slot != nullptr) WC_LAUNCH_SPLIT(true); else WC_LAUNCH_SPLIT(false);
+    const bool mask = a.maskout != nullptr;
+    const bool has_slot = a.slot != nullptr;
+    if (a.phi != nullptr) {
+        // planes form: the pass itself, then the same kernel behind the gate (leaves at once unless the predicted scale overflowed);
+        // oscale: the record of wc_launch_out_scale, exactly as affine_ring_kernel<.., PL> uses it (wc_fast.hip)
+        if (nwg > kSplitPlaneBounds || a.oscale == nullptr) return hipErrorInvalidValue;
+        a.oamax = a.oscale + 2 + kSplitPlaneBounds; a.gate = nullptr; a.ngate = nwg;
+        for (int pass = 0; pass < 2; ++pass) {
+            if (has_slot) { if (mask) WC_LAUNCH_SPLIT(true, true, true); else WC_LAUNCH_SPLIT(true, false, true); }
+            else { if (mask) WC_LAUNCH_SPLIT(false, true, true); else WC_LAUNCH_SPLIT(false, false, true); }
+            a.gate = a.oscale + 2 + kSplitPlaneBounds; a.oamax = nullptr;
+        }
+        return hipGetLastError();
+    }
+    if (has_slot) { if (mask) WC_LAUNCH_SPLIT(true, true, false); else WC_LAUNCH_SPLIT(true, false, false); }
+    else { if (mask) WC_LAUNCH_SPLIT(false, true, false); else WC_LAUNCH_SPLIT(false, false, false); }
 #undef WC_LAUNCH_SPLIT
     return hipGetLastError();
 }
@@ -571,7 +687,8 @@ hipError_t wc_launch_split_bias(const float* A, const float* bias, const float* 
 // wc_launch_fast_plan_tables); bias2 from wc_launch_split_bias
 hipError_t wc_launch_apply_split(const void* xs, const float* xs_scale, const float* A, int Kc, const float* bias2,
                                  const int32_t* slot, int64_t N, int64_t HW, int C, int relu, float* y,
-                                 const void* plan_hi, const void* plan_lo, const float* plan_colscale, void* dbg, hipStream_t st)
+                                 const void* plan_hi, const void* plan_lo, const float* plan_colscale, void* dbg, hipStream_t st,
+                                 unsigned* relu_mask, void* planes, float* oscale)
 {
     SplitApplyArgs a = {};
     a.xs = static_cast<const _Float16*>(xs); a.plane = N * HW * C;
@@ -580,6 +697,12 @@ hipError_t wc_launch_apply_split(const void* xs, const float* xs_scale, const fl
     a.bias = bias2; a.slot = slot; a.M = N * HW; a.HW = HW; a.relu = relu;
     a.mixed = (slot != nullptr && (HW % (8192 / C)) != 0) ? 1 : 0;
     a.Bf = A; a.bf_stride = (int64_t)C * C; a.xscale = xs_scale; a.out = y;
+    a.maskout = relu_mask;
+    if (relu_mask && (!relu || ((N * HW) % 32) != 0)) return hipErrorInvalidValue;
+    if (planes) {       // the output as the next convolution's fp16 planes (hi | lo, N*HW*C halves each)
+        if (!oscale) return hipErrorInvalidValue;
+        a.phi = static_cast<_Float16*>(planes); a.plo = a.phi + N * HW * C; a.oscale = oscale;
+    }
     a.dbg = static_cast<unsigned long long*>(dbg ? dbg : (WC_SPLIT_STAMPS ? g_split_dbg : nullptr));
     (void)Kc;
     switch (C) {

@@ -37,16 +37,31 @@ def _allreduce_(tensors, group):
 class WhitenColorFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, slot, moving_mean, moving_cov, training, eps, momentum, ddof, process_group, relu=False,
-                planes_box=None):
+                planes_box=None, st=None):
         # x: (N, ..., C) float32 contiguous (NHWC); gamma (Kc,C,C)|None; beta (Kc,C)|None; slot int32 (N,)|None
         # planes_box: a list -> the output leaves as the next convolution's fp16 planes (conv_handoff below); the box receives them
+        # st: x is a HANDLE whose data is this ops.SplitTensor (the residual add wrote the pre-split planes, split_handle below):
+        #     K1 and K3 run on the planes (wc_whiten_split_f16x2, wc_apply_split_ex_f16x2), no conversion, no fp32 read
         C = x.shape[-1]
         M_local = x.numel() // C
-        x = x.contiguous()
         dev = x.device
         M = M_local
         mm = moving_mean.view(-1) if moving_mean is not None else None
-        if training and process_group is None and USE_WHITEN:
+        if st is None:
+            x = x.contiguous()
+        if st is not None:
+            if training and process_group is None:
+                mu, L, W = ops.whiten_split(st, eps, momentum, ddof, mm, moving_cov)
+            else:
+                if training:       # sync-WC: the additive moments of all replicas, one collective on K1's own buffer
+                    s, xtx, buf = ops.stats_split(st, flat=True)
+                    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=process_group)
+                    M = M_local * dist.get_world_size(process_group)
+                else:
+                    s = xtx = None
+                mu, L, W = ops.factor(s, xtx, M, C, eps, momentum, ddof, training, mm, moving_cov, dev)
+            chan_scale = st.scale          # the planes' own scales are the apply's input scales
+        elif training and process_group is None and USE_WHITEN:
             # per-replica statistics (the reference's behaviour): K1 and K2 as one call -- the moments never leave the workspace
             # and the K1 tail / K2 head run as one launch (wc_whiten_f32; identical results to the two calls below)
             mu, L, W, chan_scale = ops.whiten(x.view(M_local, C), eps, momentum, ddof, mm, moving_cov)
@@ -70,7 +85,23 @@ class WhitenColorFunction(torch.autograd.Function):
         # relu: folded into K3's epilogue (row N2).  Its gradient mask is kept as ONE BIT per element (K3 writes it): the
         # backward neither re-reads y (K4: 134 MB at the headline site) nor keeps y alive for it
         bits = bool(relu) and M_local % 32 == 0
-        if planes_box is not None:
+        if st is not None:
+            be = ops.split_bias(A, b, st, mu)          # beta + (center - mu) A: the planes' additive term, K3 is ONE launch
+            if planes_box is not None:
+                rec = ops.out_scale(g, b, C, dev)
+                out = ops.apply_split(st, None, A, be, slot, plan=plan, relu=relu, folded=True, want_mask=bits, oscale=rec)
+                planes_box.append((out[0], out[1], out[2] if bits else None))
+                y, mask = _nan_handle(x.shape, dev), planes_box[0][2]
+            elif bits:
+                y, mask = ops.apply_split(st, None, A, be, slot, plan=plan, relu=True, folded=True, want_mask=True)
+            else:
+                y, mask = ops.apply_split(st, None, A, be, slot, plan=plan, relu=relu, folded=True), None
+            # the backward's K4 / K6 read fp32 (round 4: the producer writes it beside the planes when a gradient is wanted)
+            if any(ctx.needs_input_grad[:3]):
+                x = st.x32 if st.x32 is not None else ops.unsplit(st)
+            else:
+                x = torch.empty(0, device=dev)
+        elif planes_box is not None:
             y = _apply_planes(x, mu, A, b, slot, plan, g, relu, bits, planes_box)
             mask = planes_box[0][2]
         elif bits:
@@ -143,7 +174,7 @@ class WhitenColorFunction(torch.autograd.Function):
                                                     want_dgamma=False, want_dbeta=False)
         if need_x:
             dx = ops.bwd_apply(gy, x, mu, At, S, gmean, slot, scales=scales, relu_mask=k6_mask)
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None
 
 
 # ---------------------------------------------------------------------------------------------
@@ -184,6 +215,51 @@ def attach_planes(handle, box):
     return handle
 
 
+def split_of(x):
+    """The ops.SplitTensor a handle carries (the residual add of the block in front wrote the tensor as pre-split planes), or None."""
+    return getattr(x, '_wc_split', None)
+
+
+def split_handle(st, shape, dev):
+    """A tensor that stands for a pre-split activation wherever a tensor object is needed (shape, device, autograd edge): the NaN
+    handle of the K3 -> convolution hand-off, with the data attached as `_wc_split`."""
+    h = _nan_handle(shape, dev)
+    h._wc_split = st
+    return h
+
+
+class ResidualAddFunction(torch.autograd.Function):
+    """out = h + upsample2x(s) (up) or h + s: the Add that ends a `resblock` (generator.py:142-146), csrc/wc_resadd.hip.
+    box is None: the fp32 sum.  box a list: the sum leaves in the pre-split format for the next WC site (and the next shortcut
+    convolution) -- the result is a handle and the SplitTensor lands in the box (with .x32 when a backward will read fp32)."""
+
+    @staticmethod
+    def forward(ctx, h, s, up, box):
+        h = h.contiguous(); s = s.contiguous()
+        ctx.up = bool(up)
+        if box is None:
+            return ops.resadd(h, s, up)
+        st = ops.resadd_split(h, s, up, want_x32=any(ctx.needs_input_grad[:2]))
+        box.append(st)
+        return _nan_handle(h.shape, h.device)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        return g, (ops.patch_sum(g) if ctx.up else g), None, None
+
+
+def residual_add(h, s, up, planes=False):
+    """h + (upsample2x of) s.  planes=True (the readers of the sum all have a planes path: layers.WhiteningColoring.takes_split,
+    generator.Conv2D.takes_split): a handle carrying the sum as pre-split planes (`split_of(handle)`)."""
+    if planes and ops.resadd_split_supported(h.shape):
+        box = []
+        out = ResidualAddFunction.apply(h, s, bool(up), box)
+        out._wc_split = box[0]
+        return out
+    return ResidualAddFunction.apply(h, s, bool(up), None)
+
+
 _SLOT_BASE = {}
 
 
@@ -212,12 +288,16 @@ def whiten_color_grouped(x, groups, gamma=None, beta=None, slot=None, moving_mea
     N, C = x.shape[0], x.shape[-1]
     if N % groups != 0:
         raise ValueError("N must be a multiple of groups")
-    x = x.detach().contiguous()
+    st = split_of(x)                    # the residual add in front wrote pre-split planes: K1 / K3 read those
+    x = x.detach() if st is not None else x.detach().contiguous()
     M = x.numel() // C
     Mg = M // groups
     dev = x.device
     mm = moving_mean.view(-1) if moving_mean is not None else None
-    if USE_WHITEN:
+    if st is not None:
+        mu, L, W = ops.whiten_split(st, eps, momentum, ddof, mm, moving_cov, groups)      # K1 + K2 (wc_whiten_split_f16x2)
+        cs = st.scale
+    elif USE_WHITEN:
         mu, L, W, cs = ops.whiten(x.view(M, C), eps, momentum, ddof, mm, moving_cov, groups)      # K1 + K2 (wc_whiten_f32)
     else:
         s, xtx = ops.stats(x.view(M, C), groups)
@@ -227,7 +307,15 @@ def whiten_color_grouped(x, groups, gamma=None, beta=None, slot=None, moving_mea
     b = beta.detach().contiguous() if beta is not None else None
     def finish(center, A, bias, slots, plan):
         # (the predicted scale follows from the coloring tables as given: every group's whitened batch has unit covariance)
-        if planes and conv_handoff_supported(x.shape, relu, 1 if g is None else g.shape[0]):
+        handoff = planes and conv_handoff_supported(x.shape, relu, 1 if g is None else g.shape[0])
+        if st is not None:
+            be = ops.split_bias(A, bias, st, center)
+            if handoff:
+                rec = ops.out_scale(g, b, C, dev)
+                both, rec = ops.apply_split(st, None, A, be, slots, plan=plan, relu=relu, folded=True, oscale=rec)
+                return attach_planes(_nan_handle(x.shape, dev), [(both, rec, None)])
+            return ops.apply_split(st, None, A, be, slots, plan=plan, relu=relu, folded=True)
+        if handoff:
             box = []
             return attach_planes(_apply_planes(x, center, A, bias, slots, plan, g, relu, False, box, beta=b), box)
         return ops.apply(x, center, A, bias, slots, plan=plan, relu=relu)
@@ -288,10 +376,20 @@ def whiten_color_eval_cached(x, cache, gamma=None, beta=None, slot=None, moving_
     C = x.shape[-1]
     mu, A, At, plan = cache.get(C, gamma, moving_mean, moving_cov, eps, x.device, gamma_key)
     b = beta.detach().contiguous() if beta is not None else None
+    st = split_of(x)
+    handoff = planes and conv_handoff_supported(x.shape, relu, A.shape[0])
+    g = gamma.detach().contiguous() if (gamma is not None and handoff) else None
+    if st is not None:
+        # on planes: the cached A, with the tables for THIS tensor's scales and the additive term beta + (center - mu) A built
+        # inside the call (three launches; the planes' scales come from a sample of the data, not from the cached statistics)
+        if handoff:
+            rec = ops.out_scale(g, b, C, x.device)
+            both, rec = ops.apply_split(st, mu, A, b, slot, relu=relu, oscale=rec)
+            return attach_planes(_nan_handle(x.shape, x.device), [(both, rec, None)])
+        return ops.apply_split(st, mu, A, b, slot, relu=relu)
     x = x.detach().contiguous()
-    if planes and conv_handoff_supported(x.shape, relu, A.shape[0]):
+    if handoff:
         box = []
-        g = gamma.detach().contiguous() if gamma is not None else None
         return attach_planes(_apply_planes(x, mu, A, b, slot, plan, g, relu, False, box), box)
     return ops.apply(x, mu, A, b, slot, plan=plan, relu=relu)
 
@@ -303,13 +401,26 @@ def whiten_color(x, gamma=None, beta=None, slot=None, moving_mean=None, moving_c
     result is a HANDLE -- a NaN tensor of y's shape without memory that carries the autograd edge -- with the output itself
     attached as the convolution's fp16 planes (handle._wc_planes); else the plain tensor."""
     Kt = 1 if gamma is None else gamma.shape[0]
+    st = split_of(x)
     if planes and conv_handoff_supported(x.shape, relu, Kt):
         box = []
         h = WhitenColorFunction.apply(x, gamma, beta, slot, moving_mean, moving_cov, bool(training),
-                                      float(eps), float(momentum), int(ddof), process_group, True, box)
+                                      float(eps), float(momentum), int(ddof), process_group, True, box, st)
         return attach_planes(h, box)
     return WhitenColorFunction.apply(x, gamma, beta, slot, moving_mean, moving_cov, bool(training),
-                                     float(eps), float(momentum), int(ddof), process_group, bool(relu))
+                                     float(eps), float(momentum), int(ddof), process_group, bool(relu), None, st)
+
+
+def split_route_supported(shape, training, groups=1):
+    """Can a WC site of this NHWC input shape read its input as pre-split planes (K1: wc_whiten_split_f16x2 in training mode, K3:
+    wc_apply_split_ex_f16x2)?  Shapes only."""
+    N, C = shape[0], shape[-1]
+    M = 1
+    for d in shape[:-1]:
+        M *= d
+    if not ops.apply_split_supported(tuple(shape)):
+        return False
+    return (not training) or ops.stats_split_supported(M, C, groups)
 
 
 # ---------------------------------------------------------------------------------------------

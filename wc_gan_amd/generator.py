@@ -25,6 +25,7 @@ import torch.nn.functional as F
 import os
 
 from . import conv as fast_conv_mod
+from .functional import residual_add, split_of
 from .layers import (CenterScale, ConditionalCenterScale, ConditionalConv11, Conv11, DecorelationNormalization,
                      FactorizedConv11, WhiteningColoring)
 
@@ -33,6 +34,9 @@ FAST_CONV = os.environ.get('WC_FAST_CONV', '1') != '0'
 # a WC site whose only reader is such a convolution writes that convolution's fp16 operand planes from its apply kernel
 # (WC_HANDOFF=0: fp32 out of the site, absmax + split in front of the convolution)
 HANDOFF = os.environ.get('WC_HANDOFF', '1') != '0'
+# the residual add of a block writes the next site's input as pre-split fp16 planes where every reader has a planes path
+# (SURVEY.md section 8f row N2 "residual Add feeding K1"; WC_SPLIT_PRODUCER=0: the fp32 sum, from the same HIP kernel)
+SPLIT_PRODUCER = os.environ.get('WC_SPLIT_PRODUCER', '1') != '0'
 
 NORMS = ['n', 'b', 'd', 'dr']
 AFTER_NORMS = ['ucs', 'ccs', 'uccs', 'uconv', 'fconv', 'ufconv', 'cconv', 'ucconv', 'ccsuconv', 'n']
@@ -114,6 +118,14 @@ class Conv2D(nn.Module):
             return False
         return c.weight.dtype == torch.float32 and fast_conv_mod.takes_planes(shape, c.weight.shape, kind)
 
+    def takes_split(self, shape):
+        """Will forward() read an input of this NHWC shape as the pre-split planes the residual add wrote (functional.residual_add)?
+        The 1x1 shortcut of a block: 1 / scale and centre fold into its weight and bias (conv.split_conv)."""
+        c = self.conv
+        if not (FAST_CONV and SPLIT_PRODUCER) or tuple(c.kernel_size) != (1, 1) or c.weight.dtype != torch.float32:
+            return False
+        return fast_conv_mod.takes_planes(shape, c.weight.shape, 'same')
+
     def forward_relu(self, x):
         """conv(relu(x)): on the fast path the ReLU happens while the activation is split (one kernel and one pass less)"""
         w = self._weight()
@@ -125,6 +137,9 @@ class Conv2D(nn.Module):
 
     def forward(self, x, _w=None):
         c = self.conv
+        st = split_of(x)
+        if st is not None:      # the block input as pre-split planes: the convolution reads those (weight and bias folded)
+            return fast_conv_mod.split_conv(x, st, self._weight() if _w is None else _w, c.bias)
         if (c.out_channels <= 4 and tuple(c.kernel_size) == (3, 3) and not hasattr(c, 'normalized_weight')
                 and x.is_cuda and x.is_contiguous()):
             return _NarrowConv3x3.apply(x, c.weight, c.bias)
@@ -302,7 +317,9 @@ class ResBlockUp(nn.Module):
         self.conv2 = conv_layer(nfilters, nfilters, (3, 3), name=name + '.conv2')
         self.shortcut = conv_layer(in_ch, nfilters, (1, 1), name=name + '.shortcut')
 
-    def forward(self, x, cls):
+    def forward(self, x, cls, readers=()):
+        """readers: the modules that read this block's output (the next block's bn1 and shortcut, or the generator's last norm) --
+        when each of them has a planes path for the output's shape, the residual add writes pre-split planes instead of fp32."""
         up = self.resample == 'UP' and x.shape[1] * x.shape[2] >= 64
         h = _norm_relu(self.bn1, x, cls, self.conv1 if (up or self.resample != 'UP') else None, 'up3' if up else 'same')
         # the 1x1 shortcut commutes with nearest-neighbour upsampling (every output pixel is the same per-pixel affine
@@ -330,8 +347,12 @@ class ResBlockUp(nn.Module):
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
             s.record_stream(torch.cuda.current_stream())
+        # the Add that ends the block (generator.py:142-146).  UP: h + upsample2x(s) without the upsampled tensor -- every 2x2
+        # output patch adds its one source pixel (csrc/wc_resadd.hip; rounds 1-3: a torch broadcast add)
+        if h.is_cuda and h.dtype == torch.float32 and h.shape[-1] % 32 == 0:
+            planes = (SPLIT_PRODUCER and len(readers) > 0 and all(r.takes_split(h.shape) for r in readers))
+            return residual_add(h, s, self.resample == 'UP', planes=planes)
         if self.resample == 'UP':
-            # h + upsample2x(s) without the upsampled tensor: every 2x2 output patch adds its one source pixel
             N, H, W, C = s.shape
             return (h.view(N, H, 2, W, 2, C) + s.view(N, H, 1, W, 1, C)).view(N, 2 * H, 2 * W, C)
         return h + s
@@ -389,8 +410,15 @@ class Generator(nn.Module):
         if self.emb is not None:
             y = torch.cat([self.emb(cls.reshape(-1).long()), z], dim=-1)
         y = self.dense(y).view(-1, *self.first_block_shape)
-        for blk in self.blocks:
-            y = blk(y, cls)
+        nb = len(self.blocks)
+        for i, blk in enumerate(self.blocks):
+            if isinstance(blk, ResBlockUp):
+                nxt = self.blocks[i + 1] if i + 1 < nb else None
+                readers = (self.final_norm,) if nxt is None else ((nxt.bn1, nxt.shortcut) if isinstance(nxt, ResBlockUp) else ())
+                readers = tuple(r for r in readers if hasattr(r, 'takes_split'))
+                y = blk(y, cls, readers if len(readers) == (1 if nxt is None else 2) else ())
+            else:
+                y = blk(y, cls)
         y = _norm_relu(self.final_norm, y, cls)
         return torch.tanh(self.final_conv(y))
 

@@ -157,6 +157,9 @@ class DecorelationNormalization(_Lazy):
         self._ensure(x)
         C = self.channels
         groups = _stat_groups() if self.training else 1
+        if WF.split_of(x) is not None and not self.takes_split(x.shape):
+            # (the producer asks takes_split() before it writes planes: this is a wiring error, not a data-dependent case)
+            raise RuntimeError(f"{self.layer_name}: a pre-split handle reached a route without a planes path")
         if groups > 1 and (C % 32 != 0 or self.decomposition != 'cholesky' or self.renorm):
             raise RuntimeError(f"{self.layer_name}: statistic_groups({groups}) has no grouped form for this layer "
                                "(zca / renorm / a width that is not a multiple of 32): run separate passes")
@@ -196,6 +199,21 @@ class DecorelationNormalization(_Lazy):
                                                self.epsilon, self.momentum, 1, relu)
         return WF.whiten_color(x, gamma, beta, slot, self.moving_mean, self.moving_cov, self.training,
                                self.epsilon, self.momentum, 1, self.process_group, relu=relu, planes=planes)
+
+    def takes_split(self, shape):
+        """Can this layer, in its present mode, read an input of this NHWC shape as pre-split planes (the residual add in front then
+        writes those instead of fp32: functional.residual_add)?  The fused Cholesky route only, C in {128, 256}, the shapes of
+        functional.split_route_supported."""
+        if self.channels is None or self.channels != shape[-1] or self.decomposition != 'cholesky' or USE_TORCH_OPS:
+            return False
+        if self.renorm and self.training:
+            return False
+        groups = _stat_groups() if self.training else 1
+        if groups > 1 and self.process_group is not None:
+            return False
+        if shape[0] % groups != 0:
+            return False
+        return WF.split_route_supported(tuple(shape), self.training, groups)
 
     def _renorm_gamma(self, x, gamma):
         # W_eff = L_mov^-1 . stop_grad(L_batch) . L_batch^-1 (row a4): the batch factor carries the gradient,
@@ -400,6 +418,10 @@ class WhiteningColoring(nn.Module):
         if gamma is not None and beta is not None and beta.shape[0] != gamma.shape[0]:
             beta = beta.expand(gamma.shape[0], -1)
         return gamma, beta, slot, per_sample
+
+    def takes_split(self, shape):
+        """See DecorelationNormalization.takes_split (every coloring variant reduces to one table: no further condition)."""
+        return self.npart.takes_split(shape)
 
     def forward(self, x, cls=None, relu=False, planes=False):
         if isinstance(x, (list, tuple)):

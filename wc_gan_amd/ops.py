@@ -247,10 +247,11 @@ class SplitTensor:
     x ~= center + (hi + lo) / scale.  `shape` is the NHWC shape of the tensor it stands for; `flag` (64,) int32: [0] != 0
     after a split that had to clamp (scales off by more than three decades)."""
 
-    __slots__ = ("planes", "center", "scale", "flag", "shape")
+    __slots__ = ("planes", "center", "scale", "flag", "shape", "x32")
 
-    def __init__(self, planes, center, scale, flag, shape):
+    def __init__(self, planes, center, scale, flag, shape, x32=None):
         self.planes, self.center, self.scale, self.flag, self.shape = planes, center, scale, flag, tuple(shape)
+        self.x32 = x32          # the same tensor in fp32, where the producer also wrote it (a reader without a planes path)
 
     @property
     def C(self):
@@ -345,26 +346,147 @@ def apply_split_workspace(C, Kc, device):
     return _workspace(_lib.load().wc_apply_split_workspace_bytes(C, Kc), device)
 
 
-def apply_split(xs, mu, A, bias, slot, plan=None, relu=False, out=None, folded=False, ws=None):
+def apply_split(xs, mu, A, bias, slot, plan=None, relu=False, out=None, folded=False, ws=None, want_mask=False, oscale=None):
     """K3 on a pre-split input: y[n] = (x[n] - mu) A[slot[n]] + bias[slot[n]].  `plan` must come from color(W, gamma,
     chan_scale=xs.scale) (None: the tables are built inside the call).  folded=True: `bias` is split_bias(...)'s result
-    (mu is ignored) and the call is a single launch."""
+    (mu is ignored) and the call is a single launch.
+    want_mask (relu, rows % 32 == 0): also the ReLU's one-bit gradient mask -> (y, mask).
+    oscale (the record out_scale() made): the output leaves as the next convolution's fp16 planes instead of y (wc_apply_split_ex_f16x2;
+    the protocol of apply_planes) -> (planes (2, *shape) float16, oscale[, mask])."""
     lib = _lib.load()
     N, C = xs.shape[0], xs.shape[-1]
     HW = xs.M // N
     Kc = A.shape[0]
+    dev = xs.planes.device
     if bias is not None:
         _need(bias, torch.float32, "bias", 2)
     if slot is not None:
         _need(slot, torch.int32, "slot", 1)
-    y = torch.empty(xs.shape, dtype=torch.float32, device=xs.planes.device) if out is None else out
     if ws is None:
-        ws = _workspace(lib.wc_apply_split_workspace_bytes(C, Kc), y.device)
-    _lib.check(lib.wc_apply_split_f16x2(_ptr(xs.planes), None if folded else _ptr(xs.center), _ptr(xs.scale), None if folded else _ptr(mu),
-                                        _ptr(A), _ptr(bias), _ptr(slot),
-                                        N, HW, C, Kc, 1 if relu else 0, _ptr(y), _ptr(plan), _ptr(ws), ws.numel(), _stream()),
-               "wc_apply_split_f16x2")
-    return y
+        ws = _workspace(lib.wc_apply_split_workspace_bytes(C, Kc), dev)
+    mask = None
+    if want_mask:
+        if not relu or xs.M % 32 != 0:
+            raise ValueError("want_mask needs relu=True and a row count that is a multiple of 32")
+        mask = torch.empty(xs.M // 32, C, dtype=torch.int32, device=dev)
+    planes = y = None
+    if oscale is not None:
+        planes = torch.empty((2,) + tuple(xs.shape), dtype=torch.float16, device=dev)
+    else:
+        y = torch.empty(xs.shape, dtype=torch.float32, device=dev) if out is None else out
+    _lib.check(lib.wc_apply_split_ex_f16x2(_ptr(xs.planes), None if folded else _ptr(xs.center), _ptr(xs.scale), None if folded else _ptr(mu),
+                                           _ptr(A), _ptr(bias), _ptr(slot), N, HW, C, Kc, 1 if relu else 0, _ptr(y), _ptr(mask),
+                                           _ptr(planes), _ptr(oscale), _ptr(plan), _ptr(ws), ws.numel(), _stream()),
+               "wc_apply_split_ex_f16x2")
+    if planes is not None:
+        return (planes, oscale, mask) if want_mask else (planes, oscale)
+    return (y, mask) if want_mask else y
+
+
+def whiten_split(xs, eps, momentum, ddof, moving_mean, moving_cov, groups=1):
+    """K1 + K2 on a SplitTensor as one call (wc_whiten_split_f16x2; training mode, per-replica statistics): -> (mu, L, W) as
+    factor(*stats_split(xs, groups), ...) returns them.  The apply's input scales are xs.scale (give them to color())."""
+    lib = _lib.load()
+    M, C = xs.M, xs.C
+    dev = xs.planes.device
+    lead = (groups,) if groups > 1 else ()
+    mu = torch.empty(*lead, C, dtype=torch.float32, device=dev)
+    L = torch.empty(*lead, C, C, dtype=torch.float64, device=dev)
+    W = torch.empty(*lead, C, C, dtype=torch.float64, device=dev)
+    if moving_mean is not None:
+        _need(moving_mean, torch.float32, "moving_mean")
+        _need(moving_cov, torch.float32, "moving_cov", 2)
+    nb = lib.wc_whiten_split_workspace_bytes(M, C, groups)
+    if nb == 0:
+        _lib.check(-2, "wc_whiten_split_f16x2")
+    ws = _workspace(nb, dev)
+    _lib.check(lib.wc_whiten_split_f16x2(_ptr(xs.planes), _ptr(xs.center), _ptr(xs.scale), M, C, groups, float(eps), float(momentum),
+                                         int(ddof), _ptr(moving_mean), _ptr(moving_cov), _ptr(mu), _ptr(L), _ptr(W), _ptr(ws), ws.numel(),
+                                         _stream()), "wc_whiten_split_f16x2")
+    if CHECK_K2:
+        _check_k2(ws, lib.wc_whiten_split_error_offset(M, C, groups), groups, "wc_whiten_split_f16x2")
+    return mu, L, W
+
+
+# ---------------------------------------------------------------------------------------------
+# the residual add of a generator block (generator.py:142-146) as the producer of the next site's input (csrc/wc_resadd.hip)
+# ---------------------------------------------------------------------------------------------
+def resadd_split_supported(shape):
+    N, H, W, C = shape
+    return bool(_lib.load().wc_resadd_split_supported(N, H, W, C))
+
+
+def _resadd_args(h, s, up):
+    _need(h, torch.float32, "h", 4)
+    N, H, W, C = h.shape
+    if s is not None:
+        _need(s, torch.float32, "s", 4)
+        want = (N, H // 2, W // 2, C) if up else (N, H, W, C)
+        if tuple(s.shape) != want:
+            raise ValueError(f"shortcut shape {tuple(s.shape)} does not fit the sum {tuple(h.shape)} (up={bool(up)})")
+    return N, H, W, C
+
+
+def resadd(h, s, up=False):
+    """h + (upsample2x of) s as an fp32 tensor: h (N, H, W, C), s (N, H >> up, W >> up, C) or None."""
+    lib = _lib.load()
+    N, H, W, C = _resadd_args(h, s, up)
+    out = torch.empty_like(h)
+    _lib.check(lib.wc_resadd_f32(_ptr(h), _ptr(s), N, H, W, C, 1 if up else 0, _ptr(out), _stream()), "wc_resadd_f32")
+    return out
+
+
+def resadd_split(h, s, up=False, want_x32=False):
+    """The same sum written in the pre-split format (one sampling launch + one pass over h and s): -> SplitTensor, with .x32 = the fp32
+    sum as well when want_x32 (a reader without a planes path)."""
+    lib = _lib.load()
+    N, H, W, C = _resadd_args(h, s, up)
+    dev = h.device
+    planes = torch.empty(2, N * H * W, C, dtype=torch.float16, device=dev)
+    center = torch.empty(C, dtype=torch.float32, device=dev)
+    scale = torch.empty(C, dtype=torch.float32, device=dev)
+    flag = torch.empty(64, dtype=torch.int32, device=dev)
+    x32 = torch.empty_like(h) if want_x32 else None
+    _lib.check(lib.wc_resadd_split_f32(_ptr(h), _ptr(s), N, H, W, C, 1 if up else 0, _ptr(planes), _ptr(center), _ptr(scale), _ptr(flag),
+                                       _ptr(x32), _stream()), "wc_resadd_split_f32")
+    return SplitTensor(planes, center, scale, flag, h.shape, x32)
+
+
+def patch_sum(g):
+    """(N, 2 Hs, 2 Ws, C) -> (N, Hs, Ws, C): every source pixel collects its 2x2 patch (the gradient of resadd(up=True) w.r.t. s)."""
+    lib = _lib.load()
+    _need(g, torch.float32, "g", 4)
+    N, H, W, C = g.shape
+    out = torch.empty(N, H // 2, W // 2, C, dtype=torch.float32, device=g.device)
+    _lib.check(lib.wc_patch_sum_f32(_ptr(g), N, H // 2, W // 2, C, _ptr(out), _stream()), "wc_patch_sum_f32")
+    return out
+
+
+def _oc_strides(w):
+    # a 1x1 kernel (Cout, Cin, 1, 1) in any dense layout: element (o, c) at o * so + c * sc
+    return w.stride(0), w.stride(1)
+
+
+def fold_channel_scale(w, bias, scale, center):
+    """(wf, bf): the 1x1 convolution weight / bias that act on a SplitTensor's planes as (w, bias) act on the tensor itself
+    (wc_fold_channel_scale_f32): wf[o, c] = w[o, c] / scale[c], bf[o] = bias[o] + <center, w[o]>."""
+    lib = _lib.load()
+    so, sc = _oc_strides(w)
+    wf = torch.empty_like(w)
+    bf = torch.empty(w.shape[0], dtype=torch.float32, device=w.device)
+    _lib.check(lib.wc_fold_channel_scale_f32(_ptr(w), so, sc, w.shape[0], w.shape[1], _ptr(bias), _ptr(scale), _ptr(center), _ptr(wf),
+                                             _ptr(bf), _stream()), "wc_fold_channel_scale_f32")
+    return wf, bf
+
+
+def unfold_channel_scale(D, db, scale, center):
+    """dW[o, c] = D[o, c] / scale[c] + center[c] db[o]: the weight gradient of the convolution on the tensor from the one on its planes."""
+    lib = _lib.load()
+    so, sc = _oc_strides(D)
+    dW = torch.empty_like(D)
+    _lib.check(lib.wc_unfold_channel_scale_f32(_ptr(D), _ptr(db), so, sc, D.shape[0], D.shape[1], _ptr(scale), _ptr(center), _ptr(dW),
+                                               _stream()), "wc_unfold_channel_scale_f32")
+    return dW
 
 
 def bwd_bits_supported(shape, has_slot):
