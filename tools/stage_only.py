@@ -1,7 +1,8 @@
 """Runs ONE stage of the WC path n times at the headline site 128x32x32x256 on the SURVEY section 8d kernel-bench input: the target
 of the round-3 rocprofv3 --kernel-trace / --pmc passes (tools/gpu_job_pmc_mode.sh <mode> <tag>; one kernel per run, so that what
 the previous launch left in the 256-MiB memory-side cache is the same tensor every time, as in bench.py's timing loops).
-usage: stage_only.py <n> <mode>;  mode = k3 | k3split | k3planes | k3mask | k1 | k1split | k4 | k4mask | k4bits | k6 | k6bits"""
+usage: stage_only.py <n> <mode>;  mode = k3 | k3split | k3planes | k3mask | k1 | k1split | k4 | k4mask | k4bits | k6 | k6bits |
+        k3splitmask | k3splitplanes | k1wsplit | resadd | resaddsplit | resaddtorch   (round 4: the producer and the planes route's epilogues)"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from wc_gan_amd import ops
@@ -19,18 +20,26 @@ y = torch.empty_like(x)
 s, xtx = ops.stats(x.view(M, C))
 mu, L, W, cs = ops.factor(s, xtx, M, C, 1e-3, 0.99, 1, True, None, None, x.device, want_scale=True)
 A, At, plan = ops.color(W, gamma, cs)
-if mode in ("k3split", "k1split"):
+if mode in ("k3split", "k1split", "k3splitmask", "k3splitplanes", "k1wsplit"):
     xs = ops.split(x)
     A2, At2, plan2 = ops.color(W, gamma, xs.scale)
     be = ops.split_bias(A2, b, xs, mu)
 if mode in ("k4mask", "k3mask", "k4bits", "k6bits"):
     _, mask = ops.apply(x, mu, A, b, None, plan=plan, relu=True, want_mask=True, out=y)
-if mode == "k3planes":
+if mode in ("k3planes", "k3splitplanes"):
     rec = ops.out_scale(gamma, b, C, x.device)
 if mode in ("k6", "k6bits"):
     R, gsum, scales = ops.bwd_reduce(x, mu, gy, None, 1, want_scales=True)
     _, _, S, gm = ops.bwd_factor(R, gsum, W, L, gamma, A, M, 1e-3, 1, True)
+if mode.startswith("resadd"):
+    hh = torch.randn(N, H, H, C, generator=g).cuda(); ss = torch.randn(N, H // 2, H // 2, C, generator=g).cuda()
 run = {
+    "k3splitmask": lambda: ops.apply_split(xs, None, A2, be, None, plan=plan2, out=y, relu=True, folded=True, want_mask=True),
+    "k3splitplanes": lambda: ops.apply_split(xs, None, A2, be, None, plan=plan2, relu=True, folded=True, want_mask=True, oscale=rec),
+    "k1wsplit": lambda: ops.whiten_split(xs, 1e-3, 0.99, 1, None, None),
+    "resadd": lambda: ops.resadd(hh, ss, True),
+    "resaddsplit": lambda: ops.resadd_split(hh, ss, True),
+    "resaddtorch": lambda: (hh.view(N, H // 2, 2, H // 2, 2, C) + ss.view(N, H // 2, 1, H // 2, 1, C)),
     "k3": lambda: ops.apply(x, mu, A, b, None, out=y, plan=plan),
     "k3mask": lambda: ops.apply(x, mu, A, b, None, out=y, plan=plan, relu=True, want_mask=True),
     "k3split": lambda: ops.apply_split(xs, None, A2, be, None, plan=plan2, out=y, folded=True),
