@@ -114,8 +114,8 @@ def time_kernel(fn, iters=20, warm=3, graph=False):
                 fn()
         g.replay()                        # once untimed: the first replay uploads the graph
         torch.cuda.synchronize()
-    best = None
-    for _ in range(2 if g is not None else 1):      # (a graph replay is timed twice and the faster kept: one replay in some dozen
+    ts = []
+    for _ in range(3 if g is not None else 1):      # (a graph replay is timed three times and the MEDIAN kept: one replay in some dozen
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)     # reads milliseconds -- a stall of the box, not of the kernels)
         e0.record()                       # torch's current stream == the stream the C ABI launches on
         if g is not None:
@@ -125,14 +125,19 @@ def time_kernel(fn, iters=20, warm=3, graph=False):
                 fn()
         e1.record()
         torch.cuda.synchronize()
-        t = e0.elapsed_time(e1) / iters * 1e-3
-        best = t if best is None else min(best, t)
-    return best
+        ts.append(e0.elapsed_time(e1) / iters * 1e-3)
+    return sorted(ts)[len(ts) // 2]
 
 
 def roofline_apply(dev):
+    """roofline.kernel = the K3 kernel THE LAYERS launch at the headline site: the site is built as the generator
+    builds Generator.BN.Final (create_norm('d', 'uconv'), generator.py:154), fed as the generator feeds it -- by the residual add of
+    the last block (functional.residual_add: pre-split planes since round 4) -- run once with ops.TRACE on, and the K3 entry point
+    that call made is the one timed.  Every other K3 variant is listed under k3_kernels with the same timing rule; none is picked."""
     import torch
     from wc_gan_amd import ops
+    from wc_gan_amd import functional as WF
+    from wc_gan_amd.generator import create_norm
     N, H, C = 128, 32, 256
     M = N * H * H
     g = torch.Generator(device="cpu"); g.manual_seed(1234)
@@ -142,142 +147,167 @@ def roofline_apply(dev):
     x = (z @ mix + 0.2).view(N, H, H, C).to(dev)
     gamma = (torch.randn(1, C, C, generator=g) / C ** 0.5).to(dev)
     b = (0.1 * torch.randn(1, C, generator=g)).to(dev)
-    # the apply exactly as the layer runs it: statistics -> factor -> color (which prepares the plan) -> K3
+    xb = M * C * 4
+    alg_bytes = 2 * xb + (C * C + C) * 4
+
+    # ---- the site as the generator runs it: the last block's residual add (h + upsampled shortcut = x), then the norm stack + ReLU
+    s_half = (0.05 * torch.randn(N, H // 2, H // 2, C, generator=g)).to(dev)
+    hh = (x.view(N, H // 2, 2, H // 2, 2, C) - s_half.view(N, H // 2, 1, H // 2, 1, C)).reshape(N, H, H, C).contiguous()
+    site = create_norm('d', 'uconv')(axis=-1, name='Generator.BN.Final', channels=C).to(dev)
+    with torch.no_grad():
+        site.branches[0].kernel.copy_(gamma.view(1, 1, C, C)); site.branches[0].bias.copy_(b.view(C))
+        xin = WF.residual_add(hh, s_half, True, planes=site.takes_split(x.shape))
+        on_planes = WF.split_of(xin) is not None
+        ops.TRACE = []
+        try:
+            site(xin, None, relu=True)
+            traced = list(ops.TRACE)
+        finally:
+            ops.TRACE = None
+    if len(traced) != 1:
+        raise RuntimeError(f"expected one K3 launch from the site, traced {[t[:2] for t in traced]}")
+    entry, kernel, k3_layers = traced[0]
+    masked = ", true, " in kernel.split("<")[1] if "apply_split" in kernel or "affine_ring" in kernel else False
+    alg_layers = alg_bytes + (xb // 32 if masked else 0)          # + the one-bit ReLU mask the epilogue writes
+
+    # ---- the other K3 variants on the same input (listed, never picked)
     s, xtx = ops.stats(x.view(M, C))
     mu, L, W, cs = ops.factor(s, xtx, M, C, 1e-3, 0.99, 1, True, None, None, dev, want_scale=True)
     A, At, plan = ops.color(W, gamma, cs)
     y = torch.empty_like(x)
-    t_f32 = time_kernel(lambda: ops.apply(x, mu, A, b, None, out=y, plan=plan))
-    # Round 3: the same K3 on the PRE-SPLIT input (include/wc_hip.h ABI 4, wc_apply_split_f16x2): the producer hands x over as
-    # fp16 hi/lo planes -- the bytes of the fp32 tensor -- and the kernel's staging is pure LDS-DMA.  The split itself
-    # (ops.split: the stand-in for a producer epilogue) and the table / bias folding are outside the timed launch, as the
-    # statistics and the plan are for the fp32-input kernel above.
     xs = ops.split(x)
     A2, At2, plan2 = ops.color(W, gamma, xs.scale)
     be = ops.split_bias(A2, b, xs, mu)
-    ws_split = ops.apply_split_workspace(C, 1, dev)        # (allocated once: with a torch.empty per call the Python loop, not the kernel, set the pace -- 54 us against 47.0 in the kernel trace)
-    k3_split = lambda: ops.apply_split(xs, None, A2, be, None, plan=plan2, out=y, folded=True, ws=ws_split)
-    k3_f32 = lambda: ops.apply(x, mu, A, b, None, out=y, plan=plan)
-    t = time_kernel(k3_split)
-    t_b2b = {"split": time_kernel(k3_split, graph=True), "f32": time_kernel(k3_f32, graph=True)}
-    # ... and each kernel IN THE LAYER'S FLOW ("isolated AND in the layer's flow"): the site's own K1 -> K2 -> color
-    # in front of every launch, HIP events around that one launch (the events' own ~1-2 us included), 20 times
-    def in_flow(front, k3_launch):
-        ev = []
-        for _ in range(23):
-            front()
-            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-            e0.record(); k3_launch(); e1.record()
-            ev.append((e0, e1))
-        torch.cuda.synchronize()
-        ts = [a.elapsed_time(b) for a, b in ev[3:]]
-        return sum(ts) / len(ts) * 1e-3
-    def front_f32():
-        s_, xtx_ = ops.stats(x.view(M, C))
-        mu_, _, W_, cs_ = ops.factor(s_, xtx_, M, C, 1e-3, 0.99, 1, True, None, None, dev, want_scale=True)
-        ops.color(W_, gamma, cs_)
-    def front_split():
-        s_, xtx_ = ops.stats_split(xs)
-        mu_, _, W_ = ops.factor(s_, xtx_, M, C, 1e-3, 0.99, 1, True, None, None, dev)
-        A_, _, _ = ops.color(W_, gamma, xs.scale)
-        ops.split_bias(A_, b, xs, mu_)
-    t_flow = {"split": in_flow(front_split, k3_split), "f32": in_flow(front_f32, k3_f32)}
-    y_f32 = ops.apply(x, mu, A, b, None, plan=plan)
-    split_vs_f32 = float((y - y_f32).abs().max() / y_f32.abs().max())
-    alg_bytes = 2 * M * C * 4 + (C * C + C) * 4
+    ws_split = ops.apply_split_workspace(C, 1, dev)
+    mask_buf = torch.empty(M // 32, C, dtype=torch.int32, device=dev)
+    planes_buf = torch.empty(2, N, H, H, C, dtype=torch.float16, device=dev)
+    orec = ops.out_scale(gamma, b, C, dev)
+    variants = {
+        "affine_ring_kernel<256, false, false, false> (wc_apply_f32: fp32 in, fp32 out)":
+            (lambda: ops.apply(x, mu, A, b, None, out=y, plan=plan), alg_bytes),
+        "affine_ring_kernel<256, false, true, false> (wc_apply_mask_f32: fp32 in, ReLU + bit mask)":
+            (lambda: ops.apply(x, mu, A, b, None, out=y, plan=plan, relu=True, want_mask=True, _mask_out=mask_buf), alg_bytes + xb // 32),
+        "affine_ring_kernel<256, false, true, true> (wc_apply_planes_f32: fp32 in, ReLU + bit mask + the next convolution's planes; two launches)":
+            (lambda: ops.apply_planes(x, mu, A, b, None, plan, orec, relu=True, want_mask=True, _mask_out=mask_buf, _planes_out=planes_buf), alg_bytes + xb // 32),
+        "apply_split_kernel<256, false, false, false> (wc_apply_split_f16x2: planes in, fp32 out)":
+            (lambda: ops.apply_split(xs, None, A2, be, None, plan=plan2, out=y, folded=True, ws=ws_split), alg_bytes),
+        "apply_split_kernel<256, false, true, false> (wc_apply_split_ex_f16x2: planes in, ReLU + bit mask)":
+            (lambda: ops.apply_split(xs, None, A2, be, None, plan=plan2, out=y, relu=True, folded=True, ws=ws_split, want_mask=True, _mask_out=mask_buf), alg_bytes + xb // 32),
+        "apply_split_kernel<256, false, true, true> (wc_apply_split_ex_f16x2: planes in, ReLU + bit mask + the next convolution's planes; two launches)":
+            (lambda: ops.apply_split(xs, None, A2, be, None, plan=plan2, relu=True, folded=True, ws=ws_split, want_mask=True, oscale=orec,
+                                     _mask_out=mask_buf, _planes_out=planes_buf), alg_bytes + xb // 32),
+    }
     y2 = torch.empty_like(x)
     t_copy = time_kernel(lambda: ops.stream_copy(x, y2))
-    achieved = alg_bytes / t / 1e9
-    # HBM bytes per launch: NOT measured in this run -- read from the committed PMC passes of the same command
+    copy_gbs = 2 * xb / t_copy / 1e9
+    k3 = {}
+    for name, (fn, nbytes) in variants.items():
+        t = time_kernel(fn)
+        k3[name] = {"launch_us": round(t * 1e6, 2), "algorithmic_bytes": nbytes, "frac": round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4),
+                    "frac_of_stream_copy": round(nbytes / t / 1e9 / copy_gbs, 4), "run_by_the_layers_at_this_site": kernel in name}
+
+    # ---- the layers' kernel: isolated, back to back in a graph, and in the site's own flow
+    t_layers = time_kernel(k3_layers)
+    t_b2b = time_kernel(k3_layers, graph=True)
+    def front():      # what stands in front of K3 at the site: K1 + K2 + color (+ the planes' bias fold), the layer's own calls
+        if on_planes:
+            st = WF.split_of(xin)
+            mu_, _, W_ = ops.whiten_split(st, 1e-3, 0.99, 1, None, None)
+            A_, _, _ = ops.color(W_, gamma, st.scale)
+            ops.split_bias(A_, b, st, mu_)
+        else:
+            mu_, _, W_, cs_ = ops.whiten(x.view(M, C), 1e-3, 0.99, 1, None, None)
+            ops.color(W_, gamma, cs_)
+    ev = []
+    for _ in range(23):
+        front()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(); k3_layers(); e1.record()
+        ev.append((e0, e1))
+    torch.cuda.synchronize()
+    ts = [a.elapsed_time(bb) for a, bb in ev[3:]]
+    t_flow = sum(ts) / len(ts) * 1e-3
+    achieved = alg_layers / t_layers / 1e9
+
+    # HBM bytes per launch: NOT measured in this run -- read from the committed PMC passes of the same kernel
     # (FETCH_SIZE x2 + WRITE_SIZE, collected as MI355X_MICROARCH.md's HBM section prescribes; see the file)
     traffic = src = None
-    for name in ("r3_apply_k3_pmc.json", "r2_apply_k3_pmc.json", "r1_apply_k3_pmc.json"):      # (both kernels: 1.008 x the algorithmic bytes)
+    cands = (("r4_apply_k3splitmask_pmc.json", "r3_apply_k3split_pmc.json") if "apply_split" in kernel else
+             ("r4_apply_k3mask_pmc.json", "r3_apply_k3_pmc.json", "r2_apply_k3_pmc.json"))
+    for name in cands:
         pmc = os.path.join(ROOT, "profiles", name)
         if os.path.exists(pmc):
             traffic, src = json.load(open(pmc)).get("traffic_bytes_per_launch"), "profiles/" + name
             break
-    # the whole forward site as the layer runs it (K1 -> K2 -> color -> K3), for the record: 3*M*C*4 algorithmic bytes
-    def site():
-        s_, xtx_ = ops.stats(x.view(M, C))
-        mu_, _, W_, cs_ = ops.factor(s_, xtx_, M, C, 1e-3, 0.99, 1, True, None, None, dev, want_scale=True)
-        A_, _, plan_ = ops.color(W_, gamma, cs_)
-        ops.apply(x, mu_, A_, b, None, out=y, plan=plan_)
-    t_site = time_kernel(site, iters=10)
-    def site_split():       # the same site on the planes (the producer's split not included: it replaces the producer's fp32 store)
-        s_, xtx_ = ops.stats_split(xs)
-        mu_, _, W_ = ops.factor(s_, xtx_, M, C, 1e-3, 0.99, 1, True, None, None, dev)
-        A_, _, plan_ = ops.color(W_, gamma, xs.scale)
-        be_ = ops.split_bias(A_, b, xs, mu_)
-        ops.apply_split(xs, None, A_, be_, None, plan=plan_, out=y, folded=True)
-    t_site_split = time_kernel(site_split, iters=10)
+
+    # ---- the whole forward site through the layer object (K1 -> K2 -> color -> K3, the layers' own route), and the producer
+    with torch.no_grad():
+        t_site = time_kernel(lambda: site(xin, None, relu=True), iters=10)
+        t_prod = time_kernel(lambda: WF.residual_add(hh, s_half, True, planes=on_planes), iters=10)
+        t_prod32 = time_kernel(lambda: ops.resadd(hh, s_half, True), iters=10)
+        t_torch_add = time_kernel(lambda: hh.view(N, H // 2, 2, H // 2, 2, C) + s_half.view(N, H // 2, 1, H // 2, 1, C), iters=10)
+        x32 = ops.resadd(hh, s_half, True)
+        t_site32 = time_kernel(lambda: site(x32, None, relu=True), iters=10)
     # every stage of the site on its own (HIP events, same inputs): the algorithmic bytes of SURVEY section 8d per stage
     gy = torch.randn(N, H, H, C, generator=g).to(dev)
     y_relu, relu_bits = ops.apply(x, mu, A, b, None, plan=plan, relu=True, want_mask=True)
     from wc_gan_amd import conv as fconv
-    orec = ops.out_scale(gamma, b, C, dev)
-    t_k3_mask = time_kernel(lambda: ops.apply(x, mu, A, b, None, out=y, plan=plan, relu=True, want_mask=True), iters=10)
     R, gsum, scales = ops.bwd_reduce(x, mu, gy, None, 1, want_scales=True)
     dg, db, S, gm = ops.bwd_factor(R, gsum, W, L, gamma, A, M, 1e-3, 1, True)
-    xb = M * C * 4
     stage = lambda fn, nbytes: (lambda tt: {"us": round(tt * 1e6, 1), "frac_of_peak": round(nbytes / tt / 1e9 / HBM_PEAK_GBS, 3)})(time_kernel(fn, iters=10))
+    only_us = lambda fn: {"us": round(time_kernel(fn, iters=10) * 1e6, 1)}
     stages = {
+        "producer: residual add -> pre-split planes (wc_resadd_split_f32: sample + one pass; what the generator runs in front of this site)": stage(lambda: ops.resadd_split(hh, s_half, True), int(2.25 * xb)),
+        "producer: residual add -> fp32 (wc_resadd_f32)": stage(lambda: ops.resadd(hh, s_half, True), int(2.25 * xb)),
+        "K1+K2 wc_whiten_split_f16x2 (planes: what the layers run at this site)": only_us(lambda: ops.whiten_split(xs, 1e-3, 0.99, 1, None, None)),
+        "K1+K2 wc_whiten_f32 (fp32 input)": only_us(lambda: ops.whiten(x.view(M, C), 1e-3, 0.99, 1, None, None)),
         "K1 wc_stats_f32": stage(lambda: ops.stats(x.view(M, C)), xb),
         "K1 wc_stats_split_f16x2 (planes)": stage(lambda: ops.stats_split(xs), xb),
-        "K2 wc_factor_f64": {"us": round(time_kernel(lambda: ops.factor(s, xtx, M, C, 1e-3, 0.99, 1, True, None, None, dev), iters=10) * 1e6, 1)},
-        "color wc_color_f32": {"us": round(time_kernel(lambda: ops.color(W, gamma, cs), iters=10) * 1e6, 1)},
-        "K3 wc_apply_f32": {"us": round(t_f32 * 1e6, 1), "frac_of_peak": round(alg_bytes / t_f32 / 1e9 / HBM_PEAK_GBS, 3)},
-        "K3 wc_apply_split_f16x2 (planes)": {"us": round(t * 1e6, 1), "frac_of_peak": round(achieved / HBM_PEAK_GBS, 3)},
-        "producer stand-in wc_split_f32": stage(lambda: ops.split(x, xs.center, xs.scale, xs.flag), 2 * xb),
+        "K2 wc_factor_f64": only_us(lambda: ops.factor(s, xtx, M, C, 1e-3, 0.99, 1, True, None, None, dev)),
+        "color wc_color_f32": only_us(lambda: ops.color(W, gamma, cs)),
+        "split_bias wc_split_bias_f32 (planes route only)": only_us(lambda: ops.split_bias(A2, b, xs, mu)),
+        "  replaces: wc_conv_split_f32 of y (absmax + split, two launches) where K3 writes the next convolution's planes": only_us(lambda: fconv.split_planes(y_relu)),
         "K4 wc_bwd_reduce_f32": stage(lambda: ops.bwd_reduce(x, mu, gy, None, 1), 2 * xb),
-        # what the generator runs: every WC site is followed by a ReLU (generator.py:144-151,154), so K4 also reads y and
-        # writes the masked gradient (the un-masked variant under-reported the backward site)
-        # round 3: the mask travels as ONE BIT per element, written by K3's epilogue (wc_apply_mask_f32) and read by K4
-        # (wc_bwd_reduce_mask_f32): x, gy in, masked gy out + 1/32 of a tensor -- this is what the layer runs now; the fp32-y
-        # form of round 2 beside it
-        "K3 wc_apply_mask_f32 (ReLU + bit mask: sites whose reader is not a block convolution)": {"us": round(t_k3_mask * 1e6, 1)},
-        # ... and where the site's only reader is a block convolution (5 of the 7 generator sites), K3 writes that convolution's
-        # fp16 operand planes itself (wc_apply_planes_f32: the pass + the gated launch), which is what the convolution's own
-        # absmax + split passes over an fp32 y would have produced
-        "K3 wc_apply_planes_f32 (ReLU + bit mask + the next convolution's planes, two launches: as the generator runs it)":
-            {"us": round(time_kernel(lambda: ops.apply_planes(x, mu, A, b, None, plan, orec, relu=True, want_mask=True), iters=10) * 1e6, 1)},
-        "  replaces: wc_conv_split_f32 of y (absmax + split, two launches)": {"us": round(time_kernel(lambda: fconv.split_planes(y_relu), iters=10) * 1e6, 1)},
         "K4 wc_bwd_reduce_bits_f32 (bit mask in, no masked copy out: as the generator runs it)":
             stage(lambda: ops.bwd_reduce(x, mu, gy, None, 1, want_scales=True, relu_mask=relu_bits, write_masked=False), 2 * xb + xb // 32),
         "K6 wc_bwd_apply_bits_f32 (applies the same bits to gy: as the generator runs it)":
             stage(lambda: ops.bwd_apply(gy, x, mu, At, S, gm, None, scales=scales, relu_mask=relu_bits), 3 * xb + xb // 32),
         "K4 wc_bwd_reduce_mask_f32 (writes the masked copy: shapes without the bits route)": stage(lambda: ops.bwd_reduce(x, mu, gy, None, 1, want_scales=True, relu_mask=relu_bits), 3 * xb),
-        "K4 wc_bwd_reduce_relu_f32 (round 2: mask from y in fp32)": stage(lambda: ops.bwd_reduce(x, mu, gy, None, 1, want_scales=True, relu_y=y_relu), 4 * xb),
-        "K5 wc_bwd_factor_f64": {"us": round(time_kernel(lambda: ops.bwd_factor(R, gsum, W, L, gamma, A, M, 1e-3, 1, True), iters=10) * 1e6, 1)},
+        "K5 wc_bwd_factor_f64": only_us(lambda: ops.bwd_factor(R, gsum, W, L, gamma, A, M, 1e-3, 1, True)),
         "K6 wc_bwd_apply_f32": stage(lambda: ops.bwd_apply(gy, x, mu, At, S, gm, None, scales=scales), 3 * xb),
     }
-    copy_gbs = 2 * M * C * 4 / t_copy / 1e9
-    # Two K3 kernels exist for this launch: the fp32-input ring kernel the layers run (wc_apply_f32) and the ABI-4 kernel on
-    # pre-split planes.  On real data both sit at the same power-limited ~50 us (the planes' kernel on ALL-ZERO planes takes
-    # 44-45 us: DESIGN.md section 4.9), box to box one or the other is ahead by 1-3 us: the line reports the faster of the
-    # two as measured in THIS run and names it; both are listed under k3_kernels.
-    k3 = {"apply_split_kernel<256,false> (wc_apply_split_f16x2: K3 on the pre-split planes, output fp32)": t,
-          "affine_ring_kernel<256,false> (wc_apply_f32 with plan, fp32 input)": t_f32}
-    best = min(k3, key=k3.get)
-    tb = k3[best]
-    achieved = alg_bytes / tb / 1e9
-    return {"bound": "hbm", "site_stages": stages, "kernel": best + ", 128x32x32x256",
+    return {"bound": "hbm", "kernel": kernel + ", 128x32x32x256", "kernel_match": kernel, "entry_point": entry,
+            "kernel_choice": "the K3 launch traced (ops.TRACE) from the layer call WhiteningColoring('Generator.BN.Final')(x, relu=True), x handed over by "
+                             "functional.residual_add as the generator hands it over; k3_kernels lists every variant, none is picked",
+            "site_input": "pre-split planes (wc_resadd_split_f32)" if on_planes else "fp32",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_from_committed_profile": src,
-            "launch_us": round(tb * 1e6, 2), "algorithmic_bytes": alg_bytes,
-            "timing": "launch_us: HIP events around 20 launches issued from Python on the launching stream; k3_kernels.*.back_to_back_us: the same 20 launches replayed as one hipGraph; in_flow_us: events around single launches behind the site's own K1 -> K2 -> color",
+            "launch_us": round(t_layers * 1e6, 2), "algorithmic_bytes": alg_layers,
+            "timing": "launch_us: HIP events around 20 launches issued from Python on the launching stream (mean; the same rule for every entry of k3_kernels); "
+                      "back_to_back_us: the same 20 launches replayed as one hipGraph (median of 3 replays); in_flow_us: events around single launches behind the site's own K1 -> K2 -> color",
             "stream_copy_GBs": round(copy_gbs, 1),
             "frac_of_stream_copy": round(achieved / copy_gbs, 4),
-            "k3_kernels": {k: {"launch_us": round(v * 1e6, 2), "frac": round(alg_bytes / v / 1e9 / HBM_PEAK_GBS, 4),
-                               "frac_of_stream_copy": round(alg_bytes / v / 1e9 / copy_gbs, 4),
-                               "back_to_back_us": round(t_b2b["split" if k.startswith("apply_split") else "f32"] * 1e6, 2),
-                               "in_flow_us": round(t_flow["split" if k.startswith("apply_split") else "f32"] * 1e6, 2),
-                               "in_flow_frac_of_stream_copy": round(alg_bytes / t_flow["split" if k.startswith("apply_split") else "f32"] / 1e9 / copy_gbs, 4)}
-                           for k, v in k3.items()},
-            "split_vs_fp32_input_rel_diff": split_vs_f32,
+            "back_to_back_us": round(t_b2b * 1e6, 2), "in_flow_us": round(t_flow * 1e6, 2),
+            "in_flow_frac_of_stream_copy": round(alg_layers / t_flow / 1e9 / copy_gbs, 4),
+            "k3_kernels": k3, "site_stages": stages,
             "forward_site_us": round(t_site * 1e6, 1),
-            "forward_site_frac_of_peak": round(3 * M * C * 4 / t_site / 1e9 / HBM_PEAK_GBS, 4),
-            "forward_site_on_planes_us": round(t_site_split * 1e6, 1),
-            "forward_site_on_planes_frac_of_peak": round(3 * M * C * 4 / t_site_split / 1e9 / HBM_PEAK_GBS, 4)}
+            "forward_site_route": "layer object, training mode, input " + ("on planes" if on_planes else "fp32") + " (producer not included: it replaces the block's residual add, timed below)",
+            "forward_site_frac_of_peak": round(3 * xb / t_site / 1e9 / HBM_PEAK_GBS, 4),
+            "forward_site_fp32_input_us": round(t_site32 * 1e6, 1),
+            "producer_us": {"residual add as the layers run it": round(t_prod * 1e6, 1), "residual add -> fp32 (HIP)": round(t_prod32 * 1e6, 1),
+                            "torch broadcast add (rounds 1-3)": round(t_torch_add * 1e6, 1)},
+            "forward_site_plus_producer_us": {"planes": round((t_site + t_prod) * 1e6, 1), "fp32 (HIP add)": round((t_site32 + t_prod32) * 1e6, 1),
+                                              "fp32 (torch add, rounds 1-3)": round((t_site32 + t_torch_add) * 1e6, 1)}}
+
+
+def safe(fn, what):
+    """A secondary measurement must not cost the run its result line (the first 8-GPU run cannot come back empty
+    because rank 0's roofline threw): -> fn()'s result, or {"error": ...} in its place."""
+    try:
+        return fn()
+    except Exception as exc:       # noqa: BLE001 -- anything: the line is printed regardless
+        print(f"[bench] {what} failed ({type(exc).__name__}: {str(exc)[:300]}); the line is printed without it", file=sys.stderr, flush=True)
+        return {"error": f"{type(exc).__name__}: {str(exc)[:300]}"}
 
 
 def conv_roofline(dev):
@@ -540,7 +570,9 @@ def dry_run(args, world, rank):
                           "value": round(4.0 * world * args.steps / dt, 2), "unit": "images/sec", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                           "replicas_identical": bool(same), "allreduce_order": orders, "finite": bool(torch.isfinite(w).all()),
-                          "config": {"launch": "eager", "launch_fallback": None}, "multi_gpu": diag}),
+                          "config": {"launch": "eager", "launch_fallback": None}, "multi_gpu": diag,
+                          # the GPU-only legs go through safe() here too: on the CPU they throw, and the line is printed all the same
+                          "roofline": safe(lambda: roofline_apply(torch.device("cpu")), "roofline_apply (dry run: expected to fail without a GPU)")}),
               flush=True)
     if world > 1:
         dist.barrier()
@@ -718,16 +750,17 @@ def main(argv=None):
         if dt1 is not None:
             extra["training_ratio_1"] = {"value": round(64.0 * world / dt1, 2), "unit": "images/sec", "ms_per_step": round(dt1 * 1e3, 3),
                                          "launch": launch1}
-        roof = roofline_apply(dev)
+        roof = safe(lambda: roofline_apply(dev), "roofline_apply")
         cpu = None
         if world == 1:
             sites = site_list(args.config)
-            extra["roofline_conv"] = conv_roofline(dev)
-            wc_gpu = wc_sites_gpu(dev, args.training_ratio, sites)
-            extra["wc_sites_gpu"] = {"value": round(64.0 / wc_gpu, 1), "unit": "images/sec (WC sites of one G+D step only)",
-                                     "ms": round(wc_gpu * 1e3, 3)}
+            extra["roofline_conv"] = safe(lambda: conv_roofline(dev), "conv_roofline")
+            def _wc_gpu():
+                wc_gpu = wc_sites_gpu(dev, args.training_ratio, sites)
+                return {"value": round(64.0 / wc_gpu, 1), "unit": "images/sec (WC sites of one G+D step only)", "ms": round(wc_gpu * 1e3, 3)}
+            extra["wc_sites_gpu"] = safe(_wc_gpu, "wc_sites_gpu")
             if not args.no_cpu_baseline:
-                cpu = cpu_baseline(args.training_ratio, sites, args.config)
+                cpu = safe(lambda: cpu_baseline(args.training_ratio, sites, args.config), "cpu_baseline")
                 if args.cpu_port:         # the C-ABI CPU restatement, 4.5 x slower than the torch-CPU leg and ~45 s of wall time: on request
                     try:
                         extra["cpu_port"] = cpu_port_baseline(args.training_ratio, sites, args.config)

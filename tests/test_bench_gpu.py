@@ -35,3 +35,30 @@ def test_bench_line_contract():
     assert abs(r_["frac"] - r_["achieved"] / r_["peak"]) < 1e-3
     assert 0.3 < r_["frac_of_stream_copy"] < 1.0
     assert r_["traffic"] is None or 0.9 < r_["traffic"] / r_["algorithmic_bytes"] < 1.5
+
+
+def test_roofline_names_a_kernel_that_the_generator_step_launches():
+    """`roofline.kernel` is the K3 kernel the LAYERS run at the headline site -- the same kernel name must show up
+    in a profiled generator update pass at batch 128 (CIFAR-10 uncond: Generator.BN.Final at 128 x 32 x 32 x 256), and it must be
+    the entry of k3_kernels marked as run by the layers; no best-of picking."""
+    import torch
+    from torch.profiler import ProfilerActivity, profile
+    sys.path.insert(0, ROOT)
+    import bench
+    from wc_gan_amd.train import CONFIGS
+    from wc_gan_amd.generator import make_generator
+    roof = bench.roofline_apply(torch.device("cuda", 0))
+    assert roof["kernel_match"] in roof["kernel"]
+    marked = [k for k, v in roof["k3_kernels"].items() if v["run_by_the_layers_at_this_site"]]
+    assert len(marked) == 1 and roof["kernel_match"] in marked[0]
+    assert abs(roof["k3_kernels"][marked[0]]["launch_us"] - roof["launch_us"]) < 0.15 * roof["launch_us"]       # the same kernel, timed twice
+    torch.manual_seed(0)
+    G = make_generator(**CONFIGS["cifar10_uncond"]["generator"]).cuda()
+    z = torch.randn(128, 128, device="cuda")
+    G(z).sum().backward()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        G(z).sum().backward()
+        torch.cuda.synchronize()
+    names = " | ".join(e.key for e in prof.key_averages())
+    assert roof["kernel_match"] in names, (roof["kernel_match"], names[:3000])

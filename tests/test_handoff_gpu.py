@@ -59,6 +59,24 @@ def test_planes_equal_the_fp32_output_and_its_mask(shape, Kc):
     assert err < 1e-4, err
 
 
+@pytest.mark.parametrize("shape,Kc", [((128, 32, 32, 256), 1), ((128, 16, 16, 256), 10)])
+def test_handoff_route_against_the_oracle_at_cond_1e6(shape, Kc):
+    """the route 5 of the 7 generator sites run (K3 writing the next convolution's planes) against the float64
+    oracle on ILL-conditioned input (cond(Sigma~) ~ 1e6), full size -- directly, not through `planes == fp32 K3`: 1e-4 relative."""
+    from wc_gan_amd import ops
+    x, G, B, slot = _site(shape, Kc, 13, cond="ill")
+    xd, Gd, Bd = dev(x), dev(G), dev(B)
+    sd = dev(slot, torch.int32) if slot is not None else None
+    mu, A, plan = _stages(xd, Gd, Bd, sd)
+    rec = ops.out_scale(Gd, Bd, shape[-1], xd.device)
+    planes, rec, pmask = ops.apply_planes(xd, mu, A, Bd, sd, plan, rec, relu=True, want_mask=True)
+    torch.cuda.synchronize()
+    back = (planes[0].double() + planes[1].double()) / float(rec[0])
+    ref = np.maximum(o.wc_forward(x.astype(np.float64), G.astype(np.float64), B.astype(np.float64), slot)[0], 0.0)
+    err = float(np.abs(back.cpu().numpy() - ref).max() / np.abs(ref).max())
+    assert err < 1e-4, err
+
+
 def test_the_gate_redoes_the_pass_when_the_predicted_scale_overflows():
     """A caller's bound that is far too small (scale far too large): s * y leaves fp16's range, the gated second launch sees it in the
     per-workgroup maxima and rewrites the planes with the scale the measured maximum asks for -- no host round trip."""

@@ -282,16 +282,34 @@ __global__ __launch_bounds__(512, 1) void apply_split_kernel(SplitApplyArgs a)
     int cur_slot = -1;
     const unsigned tb_lane = (unsigned)lane * 16u;
     const unsigned col_b = (unsigned)(cg * 32 + l15) * 4u;
+    // ASYNC_TABLE (one table for the whole launch): the table's loads are asm statements whose landing the hand-counted waits of the
+    // first tile cover, k-step by k-step.  With slots the table is re-loaded inside the tile loop, and the registers then meet at the
+    // loop header: hipcc may copy a table register between the asm load's ISSUE and its landing -- the data then lands in a register
+    // that has been handed to something else (round 4, C = 256 with the planes epilogue: whole workgroups scaled by garbage, racily;
+    // the lesson of DESIGN.md section 4.9b again).  So with slots the loads are plain loads hipcc tracks itself, drained at once.
+    constexpr bool ASYNC_TABLE = !HAS_SLOT;
     auto load_b = [&](int slot) {
         const char* ph = reinterpret_cast<const char*>(a.Bhi + (int64_t)slot * a.slot_stride + (int64_t)cg * KS * 512);
         const char* pl = reinterpret_cast<const char*>(a.Blo + (int64_t)slot * a.slot_stride + (int64_t)cg * KS * 512);
+        const char* pc = reinterpret_cast<const char*>(a.colscale + (a.slot_stride ? (int64_t)slot * C : 0));
+        const char* pb = reinterpret_cast<const char*>(a.bias + (int64_t)slot * C);
+        if (!ASYNC_TABLE) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                bhi[s] = *reinterpret_cast<const f16x8*>(ph + 1024 * s + tb_lane);
+                blo[s] = *reinterpret_cast<const f16x8*>(pl + 1024 * s + tb_lane);
+            }
+            cscale[0] = *reinterpret_cast<const float*>(pc + col_b); cscale[1] = *reinterpret_cast<const float*>(pc + col_b + 64);
+            addv[0] = *reinterpret_cast<const float*>(pb + col_b); addv[1] = *reinterpret_cast<const float*>(pb + col_b + 64);
+            __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), the BUILTIN: hipcc must see that the loads have completed here
+            cur_slot = slot;
+            return;
+        }
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(bhi[s]) : "v"(tb_lane), "s"(ph + 1024 * s) : "memory");
             asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(blo[s]) : "v"(tb_lane), "s"(pl + 1024 * s) : "memory");
         }
-        const char* pc = reinterpret_cast<const char*>(a.colscale + (a.slot_stride ? (int64_t)slot * C : 0));
-        const char* pb = reinterpret_cast<const char*>(a.bias + (int64_t)slot * C);
         asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(cscale[0]) : "v"(col_b), "s"(pc) : "memory");
         asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2 offset:64" : "=v"(cscale[1]) : "v"(col_b), "s"(pc) : "memory");
         asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(addv[0]) : "v"(col_b), "s"(pb) : "memory");
@@ -314,11 +332,12 @@ __global__ __launch_bounds__(512, 1) void apply_split_kernel(SplitApplyArgs a)
     // (every wave waits for the same "tile landed" event), so the matrix pipe idled through 1 500 of every 4 600 cycles
     // while both were storing.  Fewer tiles (the small sites): everything drains per tile, stores at the end of the tile.
     const bool def_mode = n >= 6;
+    if (!ASYNC_TABLE) load_b(a.slot[((int64_t)tile_of(0) * TR) / a.HW]);      // (drained: in front of the DMAs, whose counts start here)
     dma_tile(0);
-    load_b(HAS_SLOT ? a.slot[((int64_t)tile_of(0) * TR) / a.HW] : 0);
+    if (ASYNC_TABLE) load_b(0);
     if (n > 1) dma_tile(1);
     if (n > 2) dma_tile(2);
-    if (def_mode) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * KS + 4 + 8) : "memory");      // tile 0 only
+    if (def_mode && ASYNC_TABLE) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * KS + 4 + 8) : "memory");      // tile 0 only
     else if (n > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (n > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -439,8 +458,13 @@ __global__ __launch_bounds__(512, 1) void apply_split_kernel(SplitApplyArgs a)
         const float* const po = a.out + (int64_t)tile_of(tq) * (TR * C);      // wave-uniform
         float res[16];
         unsigned bits = 0;
-        const float cs0 = PL ? cscale[0] * os : cscale[0], cs1 = PL ? cscale[1] * os : cscale[1];      // (PL: the planes hold os * y; folded per tile, the constants
-        const float ad0 = PL ? addv[0] * os : addv[0], ad1 = PL ? addv[1] * os : addv[1];              //  arrive by asm loads that are only known to have landed here)
+        // PL: the planes hold os * y, folded into the two per-column constants HERE, per tile: the constants arrive by asm loads whose
+        // landing only the k-loop's counted waits guarantee, and a product that depends on nothing in the loop is hoisted above them
+        // by hipcc (first version: tile 0 of a workgroup scaled by whatever the registers held -- 0.06 % of the outputs wrong, racily).
+        // The empty asm ties the constants to this point of the program.
+        if (PL) asm volatile("" : "+v"(cscale[0]), "+v"(cscale[1]), "+v"(addv[0]), "+v"(addv[1]) :: "memory");
+        const float cs0 = PL ? cscale[0] * os : cscale[0], cs1 = PL ? cscale[1] * os : cscale[1];
+        const float ad0 = PL ? addv[0] * os : addv[0], ad1 = PL ? addv[1] * os : addv[1];
         auto leave = [&](auto RL_) __attribute__((always_inline)) {
             constexpr bool RL = decltype(RL_)::value;
 #pragma unroll
@@ -509,7 +533,7 @@ __global__ __launch_bounds__(512, 1) void apply_split_kernel(SplitApplyArgs a)
     auto pick_table = [&](int t) {       // conditional tables: a new slot's B' fragments (a full drain: every later count stays conservative)
         if (HAS_SLOT) {
             const int slot = a.slot[((int64_t)tile_of(t) * TR) / a.HW];
-            if (slot != cur_slot) { load_b(slot); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); touch_b(); }
+            if (slot != cur_slot) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); load_b(slot); touch_b(); }      // (load_b drains: plain loads with slots)
         }
     };
     unsigned long long k0_ = 0, rt_loop = 0;
@@ -528,7 +552,8 @@ __global__ __launch_bounds__(512, 1) void apply_split_kernel(SplitApplyArgs a)
         }
 #if !WC_SPLIT_DEFER
         // D0, table, D1, D2 | tile 0: D3, S0 | tile 1: D4, S1 | ... : 8, 20, 36 ... 36, 32
-        else if (t == 0) tile_body(t, P8{}, T_{}, T_{}, F_{}, F_{});
+        // (with slots the table is complete before tile 0 and tile 1 is published EARLY in tile 0's loop, ahead of D3: younger than D1 is D2 only)
+        else if (t == 0) { if (ASYNC_TABLE) tile_body(t, P8{}, T_{}, T_{}, F_{}, F_{}); else tile_body(t, P4{}, T_{}, F_{}, F_{}, F_{}); }
         else if (t == 1) tile_body(t, P20{}, T_{}, F_{}, F_{}, F_{});
         else if (dma) tile_body(t, P36{}, T_{}, F_{}, F_{}, F_{});
         else if (t + 2 < n) tile_body(t, P36{}, F_{}, F_{}, F_{}, F_{});

@@ -44,6 +44,20 @@ def _workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
+# Measurement hook (bench.py, tests): while TRACE is a list every K3 entry point appends (entry point, kernel it launches, a closure
+# that launches the same call again) -- so that a bench can time THE kernel a layer ran instead of one it picked itself.
+TRACE = None
+
+
+def _trace(entry, kernel, again):
+    if TRACE is not None:
+        TRACE.append((entry, kernel, again))
+
+
+def _tf(b):
+    return "true" if b else "false"
+
+
 def stats(x2d, groups=1, flat=False):
     """K1: x2d (M, C) float32 -> (sum (C,) f64, xtx (C, C) f64), the raw additive moments.
     groups > 1: M/groups consecutive rows per statistic group -> sum (G, C), xtx (G, C, C).
@@ -168,7 +182,7 @@ def group_bias(mu, A, beta, groups, Kc, per_group=False):
     return center, bias
 
 
-def apply(x, mu, A, bias, slot, out=None, fast=True, plan=None, relu=False, want_mask=False):
+def apply(x, mu, A, bias, slot, out=None, fast=True, plan=None, relu=False, want_mask=False, _mask_out=None):
     """K3: y[n] = (x[n] - mu) A[slot[n]] + bias[slot[n]];  x is (N, ..., C) with C contiguous.
     relu=True folds the ReLU that follows the site into the epilogue (wc_apply_act_f32).
     want_mask=True (with relu, N*HW % 32 == 0): -> (y, mask), mask the ReLU's one-bit gradient mask (int32 (M/32, C),
@@ -184,10 +198,16 @@ def apply(x, mu, A, bias, slot, out=None, fast=True, plan=None, relu=False, want
         _need(slot, torch.int32, "slot", 1)
     y = torch.empty_like(x) if out is None else out
     ws = _workspace(lib.wc_apply_workspace_bytes(N, HW, C, Kc), x.device) if (fast and plan is None) else None
+    _last_mask = [_mask_out]
+    if TRACE is not None and fast and plan is not None:
+        _trace("wc_apply_mask_f32" if want_mask else "wc_apply_act_f32",
+               f"affine_ring_kernel<{C}, {_tf(slot is not None)}, {_tf(want_mask)}, false>",
+               lambda: apply(x, mu, A, bias, slot, out=y, fast=fast, plan=plan, relu=relu, want_mask=want_mask, _mask_out=_last_mask[0]))
     if want_mask:
         if not relu or (N * HW) % 32 != 0:
             raise ValueError("want_mask needs relu=True and a row count that is a multiple of 32")
-        mask = torch.empty((N * HW) // 32, C, dtype=torch.int32, device=x.device)
+        mask = torch.empty((N * HW) // 32, C, dtype=torch.int32, device=x.device) if _mask_out is None else _mask_out
+        _last_mask[0] = mask
         _lib.check(lib.wc_apply_mask_f32(_ptr(x), _ptr(mu), _ptr(A), _ptr(bias), _ptr(slot), N, HW, C, Kc, _ptr(y), _ptr(mask),
                                          _ptr(plan) if fast else None, _ptr(ws), ws.numel() if ws is not None else 0, _stream()),
                    "wc_apply_mask_f32")
@@ -223,7 +243,7 @@ def out_scale(gamma, beta, C, device):
     return rec
 
 
-def apply_planes(x, mu, A, bias, slot, plan, oscale, relu=True, want_mask=False):
+def apply_planes(x, mu, A, bias, slot, plan, oscale, relu=True, want_mask=False, _mask_out=None, _planes_out=None):
     """K3 whose output leaves as the next convolution's operand (wc_apply_planes_f32): -> (planes (2, *x.shape) float16 = hi | lo,
     oscale) [, mask]; y ~= (hi + lo) / oscale[0].  oscale: the record out_scale() made."""
     lib = _lib.load()
@@ -235,8 +255,10 @@ def apply_planes(x, mu, A, bias, slot, plan, oscale, relu=True, want_mask=False)
         _need(bias, torch.float32, "bias", 2)
     if slot is not None:
         _need(slot, torch.int32, "slot", 1)
-    planes = torch.empty((2,) + tuple(x.shape), dtype=torch.float16, device=x.device)
-    mask = torch.empty((N * HW) // 32, C, dtype=torch.int32, device=x.device) if want_mask else None
+    planes = torch.empty((2,) + tuple(x.shape), dtype=torch.float16, device=x.device) if _planes_out is None else _planes_out
+    mask = (torch.empty((N * HW) // 32, C, dtype=torch.int32, device=x.device) if _mask_out is None else _mask_out) if want_mask else None
+    _trace("wc_apply_planes_f32", f"affine_ring_kernel<{C}, {_tf(slot is not None)}, {_tf(want_mask)}, true>",
+           lambda: apply_planes(x, mu, A, bias, slot, plan, oscale, relu=relu, want_mask=want_mask, _mask_out=mask, _planes_out=planes))
     _lib.check(lib.wc_apply_planes_f32(_ptr(x), _ptr(mu), _ptr(A), _ptr(bias), _ptr(slot), N, HW, C, Kc, 1 if relu else 0,
                                        _ptr(planes), _ptr(oscale), _ptr(mask), _ptr(plan), _stream()), "wc_apply_planes_f32")
     return (planes, oscale, mask) if want_mask else (planes, oscale)
@@ -346,7 +368,8 @@ def apply_split_workspace(C, Kc, device):
     return _workspace(_lib.load().wc_apply_split_workspace_bytes(C, Kc), device)
 
 
-def apply_split(xs, mu, A, bias, slot, plan=None, relu=False, out=None, folded=False, ws=None, want_mask=False, oscale=None):
+def apply_split(xs, mu, A, bias, slot, plan=None, relu=False, out=None, folded=False, ws=None, want_mask=False, oscale=None,
+                _mask_out=None, _planes_out=None):
     """K3 on a pre-split input: y[n] = (x[n] - mu) A[slot[n]] + bias[slot[n]].  `plan` must come from color(W, gamma,
     chan_scale=xs.scale) (None: the tables are built inside the call).  folded=True: `bias` is split_bias(...)'s result
     (mu is ignored) and the call is a single launch.
@@ -368,12 +391,15 @@ def apply_split(xs, mu, A, bias, slot, plan=None, relu=False, out=None, folded=F
     if want_mask:
         if not relu or xs.M % 32 != 0:
             raise ValueError("want_mask needs relu=True and a row count that is a multiple of 32")
-        mask = torch.empty(xs.M // 32, C, dtype=torch.int32, device=dev)
+        mask = torch.empty(xs.M // 32, C, dtype=torch.int32, device=dev) if _mask_out is None else _mask_out
     planes = y = None
     if oscale is not None:
-        planes = torch.empty((2,) + tuple(xs.shape), dtype=torch.float16, device=dev)
+        planes = torch.empty((2,) + tuple(xs.shape), dtype=torch.float16, device=dev) if _planes_out is None else _planes_out
     else:
         y = torch.empty(xs.shape, dtype=torch.float32, device=dev) if out is None else out
+    _trace("wc_apply_split_ex_f16x2", f"apply_split_kernel<{C}, {_tf(slot is not None)}, {_tf(want_mask)}, {_tf(oscale is not None)}>",
+           lambda: apply_split(xs, mu, A, bias, slot, plan=plan, relu=relu, out=y, folded=folded, ws=ws, want_mask=want_mask, oscale=oscale,
+                               _mask_out=mask, _planes_out=planes))      # (the re-run allocates nothing: the host must not set the pace)
     _lib.check(lib.wc_apply_split_ex_f16x2(_ptr(xs.planes), None if folded else _ptr(xs.center), _ptr(xs.scale), None if folded else _ptr(mu),
                                            _ptr(A), _ptr(bias), _ptr(slot), N, HW, C, Kc, 1 if relu else 0, _ptr(y), _ptr(mask),
                                            _ptr(planes), _ptr(oscale), _ptr(plan), _ptr(ws), ws.numel(), _stream()),
