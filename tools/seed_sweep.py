@@ -1,6 +1,12 @@
 """VERDICT r2 'parity depth' (ii): the cond-1e6 full-size sites over several seeds -- the 1e-4 contract was met with ONE seed per
 shape in tests/test_configs_gpu.py.  Prints every seed's relative errors (max-abs error / max-abs reference, float32 path vs the
-float64 oracle) and the worst per shape; exits non-zero if any exceeds 9e-5.   usage: python tools/seed_sweep.py [nseeds]"""
+float64 oracle) and the worst per shape; exits non-zero if any exceeds 9e-5.   usage: python tools/seed_sweep.py [nseeds]
+
+Round 4: --families runs the input FAMILIES on which the off-diagonal bias compensation of K1 (kXtyOffdiagBias,
+fitted on the gaussian-mix family) over- or under-corrects -- uniform, post-ReLU half-sparse and heavy-tailed elements, C = 128 and
+C = 64 sites -- each ill-conditioned by construction (per-channel scales over two decades + eight strong shared factors:
+cond((1-eps) Sigma + eps I) ~ 1e6) without a dense mix that would make every element gaussian again; --planes feeds the site through
+the residual add's pre-split planes (functional.residual_add).   usage: python tools/seed_sweep.py [nseeds] [--families] [--planes]"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,33 +15,73 @@ from wc_gan_amd import _lib
 if os.environ.get("WC_LIB"):          # development: another build of the library (tools/split_variants.py)
     _lib.LIB_PATH = os.environ["WC_LIB"]
 from wc_gan_amd.functional import whiten_color
-nseeds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-only = [tuple(int(v) for v in a.split("x")) for a in sys.argv[2:]]      # optional: shapes as 128x32x32x256
+FAMILIES = "--families" in sys.argv
+PLANES = "--planes" in sys.argv
+argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+nseeds = int(argv[0]) if argv else 5
+only = [tuple(int(v) for v in a.split("x")) for a in argv[1:]]      # optional: shapes as 128x32x32x256
+
+
+def family_input(rng, shape, family):
+    """x = z * s + (F V^T) a + 0.2: z (M, C) and F (M, 8) iid unit-variance draws of the family, s per-channel scales over two decades,
+    V (C, 8) gaussian, a = 2 (eight eigenvalues ~ 4 C, the smallest ~ 1e-4: cond of the shrunk covariance ~ 1e6 at C = 256)."""
+    C = shape[-1]
+    M = int(np.prod(shape[:-1]))
+    def draw(n):
+        if family == "uniform":
+            return rng.uniform(-np.sqrt(3.0), np.sqrt(3.0), (M, n))
+        if family == "relu":                    # post-ReLU, half of the elements exactly zero; unit variance
+            g = np.maximum(rng.standard_normal((M, n)), 0.0)
+            return g / np.sqrt(0.5 - 1.0 / (2 * np.pi))
+        if family == "heavy":                   # Student t, 3 degrees of freedom (variance 3)
+            return rng.standard_t(3.0, (M, n)) / np.sqrt(3.0)
+        return rng.standard_normal((M, n))
+    s = 10.0 ** rng.uniform(-2.0, 0.0, C)
+    V = rng.standard_normal((C, 8))
+    return (draw(C) * s + 2.0 * (draw(8) @ V.T) + 0.2).reshape(shape)
+
+
+def run_site(x, G, B, slot, gy):
+    xt = dev(x).requires_grad_(True); Gt = dev(G).requires_grad_(True); Bt = dev(B).requires_grad_(True)
+    xin = xt
+    if PLANES:
+        from wc_gan_amd.functional import residual_add
+        xin = residual_add(xt, torch.zeros_like(xt), False, planes=True)
+    y = whiten_color(xin, Gt, Bt, dev(slot, torch.int32) if slot is not None else None, None, None, True)
+    y.backward(dev(gy))
+    return y, xt, Gt, Bt
+
 rel = lambda a, b: float(np.abs(np.asarray(a, np.float64) - b).max() / max(np.abs(b).max(), 1e-30))
 dev = lambda a, t=torch.float32: torch.tensor(np.ascontiguousarray(a), dtype=t, device="cuda")
 worst_all = 0.0
-for shape, Kc in (((128, 32, 32, 256), 1), ((128, 12, 12, 256), 1), ((128, 16, 16, 256), 1), ((128, 32, 32, 128), 10)):
+SITES = (((128, 32, 32, 256), 1), ((128, 12, 12, 256), 1), ((128, 16, 16, 256), 1), ((128, 32, 32, 128), 10))
+FSITES = (((128, 32, 32, 256), 1), ((128, 16, 16, 256), 1), ((128, 32, 32, 128), 10), ((128, 32, 32, 64), 1))
+cases = [(sh, kc, "gauss-mix") for sh, kc in SITES if not (PLANES and sh[1] == 12)]
+if FAMILIES:
+    cases = [(sh, kc, fam) for fam in ("uniform", "relu", "heavy") for sh, kc in FSITES if not (PLANES and sh[-1] == 64)]
+for shape, Kc, fam in cases:
     if only and shape not in only:
         continue
     worst = {}
     for seed in range(100, 100 + nseeds):
         rng = np.random.default_rng(seed)
         N, C = shape[0], shape[-1]
-        x = o.synth_activation(rng, shape, "ill").astype(np.float32)
+        x = (o.synth_activation(rng, shape, "ill") if fam == "gauss-mix" else family_input(rng, shape, fam)).astype(np.float32)
         G, B = o.synth_coloring(rng, C, Kc)
         G = G.astype(np.float32); B = B.astype(np.float32)
         slot = rng.integers(0, Kc, N).astype(np.int32)
         gy = rng.standard_normal(shape).astype(np.float32)
         y_ref, cache = o.wc_forward(x, G, B, slot)
         dx_ref, dG_ref, dB_ref = o.wc_backward(gy, cache)
-        xt = dev(x).requires_grad_(True); Gt = dev(G).requires_grad_(True); Bt = dev(B).requires_grad_(True)
-        y = whiten_color(xt, Gt, Bt, dev(slot, torch.int32) if Kc > 1 else None, None, None, True)
-        y.backward(dev(gy))
+        y, xt, Gt, Bt = run_site(x, G, B, slot if Kc > 1 else None, gy)
         e = dict(y=rel(y.detach().cpu().numpy(), y_ref), dx=rel(xt.grad.cpu().numpy(), dx_ref), dG=rel(Gt.grad.cpu().numpy(), dG_ref),
                  dB=rel(Bt.grad.cpu().numpy(), dB_ref))
-        print(shape, Kc, "seed", seed, " ".join(f"{k} {v:.2e}" for k, v in e.items()), flush=True)
+        if seed == 100:
+            ev = np.linalg.eigvalsh((1 - 1e-3) * cache['sigma'] + 1e-3 * np.eye(C)) if 'sigma' in cache else None
+            if ev is not None: print(shape, fam, "cond of the shrunk covariance: %.2e" % (ev[-1] / ev[0]), flush=True)
+        print(shape, Kc, fam, "planes" if PLANES else "fp32", "seed", seed, " ".join(f"{k} {v:.2e}" for k, v in e.items()), flush=True)
         for k, v in e.items(): worst[k] = max(worst.get(k, 0.0), v)
-    print("WORST", shape, Kc, " ".join(f"{k} {v:.2e}" for k, v in worst.items()), flush=True)
+    print("WORST", shape, Kc, fam, "planes" if PLANES else "fp32", " ".join(f"{k} {v:.2e}" for k, v in worst.items()), flush=True)
     worst_all = max(worst_all, max(worst.values()))
 print("worst over everything: %.2e" % worst_all)
 sys.exit(1 if worst_all > 9e-5 else 0)

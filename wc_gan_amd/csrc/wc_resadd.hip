@@ -147,15 +147,9 @@ __global__ __launch_bounds__(256) void resadd_kernel(ResAddArgs a)
         c0 = *reinterpret_cast<const f32x4*>(a.center + c); c1 = *reinterpret_cast<const f32x4*>(a.center + c + 4);
     }
     bool over = false;
-    for (int64_t i = i0; i < n8; i += step, row += drow, cg += dcg) {
-        if (cg >= C8) { cg -= C8; ++row; }
-        const int64_t e = i * 8;
-        f32x4 v0 = *reinterpret_cast<const f32x4*>(a.h + e), v1 = *reinterpret_cast<const f32x4*>(a.h + e + 4);
-        if (a.s) {
-            const float* sp = a.s + src_row(a, (unsigned)row) * C + cg * 8;
-            v0 += *reinterpret_cast<const f32x4*>(sp);
-            v1 += *reinterpret_cast<const f32x4*>(sp + 4);
-        }
+    // two elements per trip: the loads of both (2 x 16 B of h, 2 x 16 B of s each) are in flight before the first is converted
+    auto advance = [&](int64_t& r, int& g) { r += drow; g += dcg; if (g >= C8) { g -= C8; ++r; } };
+    auto emit = [&](int64_t e, f32x4 v0, f32x4 v1) __attribute__((always_inline)) {
         if (F32) {
             *reinterpret_cast<f32x4*>(a.x32 + e) = v0;
             *reinterpret_cast<f32x4*>(a.x32 + e + 4) = v1;
@@ -179,6 +173,26 @@ __global__ __launch_bounds__(256) void resadd_kernel(ResAddArgs a)
             *reinterpret_cast<uint4*>(a.hi + e) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
             *reinterpret_cast<uint4*>(a.lo + e) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
         }
+    };
+    for (int64_t i = i0; i < n8; i += 2 * step) {
+        const int64_t ea = i * 8, eb = (i + step) * 8;
+        const bool two = i + step < n8;
+        int64_t rowb = row; int cgb = cg;
+        advance(rowb, cgb);
+        f32x4 a0 = *reinterpret_cast<const f32x4*>(a.h + ea), a1 = *reinterpret_cast<const f32x4*>(a.h + ea + 4);
+        f32x4 b0 = a0, b1 = a1;
+        if (two) { b0 = *reinterpret_cast<const f32x4*>(a.h + eb); b1 = *reinterpret_cast<const f32x4*>(a.h + eb + 4); }
+        if (a.s) {
+            const float* sa = a.s + src_row(a, (unsigned)row) * C + cg * 8;
+            const float* sb = a.s + src_row(a, (unsigned)(two ? rowb : row)) * C + (two ? cgb : cg) * 8;
+            const f32x4 p0 = *reinterpret_cast<const f32x4*>(sa), p1 = *reinterpret_cast<const f32x4*>(sa + 4);
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(sb), q1 = *reinterpret_cast<const f32x4*>(sb + 4);
+            a0 += p0; a1 += p1; b0 += q0; b1 += q1;
+        }
+        emit(ea, a0, a1);
+        if (two) emit(eb, b0, b1);
+        row = rowb; cg = cgb;
+        advance(row, cg);
     }
     if (SPLIT && a.flag && over) *a.flag = 1;
 }

@@ -411,16 +411,22 @@ def whiten_color(x, gamma=None, beta=None, slot=None, moving_mean=None, moving_c
                                      float(eps), float(momentum), int(ddof), process_group, bool(relu), None, st)
 
 
+_ROUTE = {}
+
+
 def split_route_supported(shape, training, groups=1):
     """Can a WC site of this NHWC input shape read its input as pre-split planes (K1: wc_whiten_split_f16x2 in training mode, K3:
-    wc_apply_split_ex_f16x2)?  Shapes only."""
-    N, C = shape[0], shape[-1]
-    M = 1
-    for d in shape[:-1]:
-        M *= d
-    if not ops.apply_split_supported(tuple(shape)):
-        return False
-    return (not training) or ops.stats_split_supported(M, C, groups)
+    wc_apply_split_ex_f16x2)?  Shapes only (cached: the producer asks on every pass)."""
+    key = (tuple(shape), bool(training), int(groups))
+    r = _ROUTE.get(key)
+    if r is None:
+        C = shape[-1]
+        M = 1
+        for d in shape[:-1]:
+            M *= d
+        r = ops.apply_split_supported(tuple(shape)) and ((not training) or ops.stats_split_supported(M, C, groups))
+        _ROUTE[key] = r
+    return r
 
 
 # ---------------------------------------------------------------------------------------------
