@@ -339,6 +339,26 @@ int wc_bwd_apply_scaled_f32(const float* gy, const float* x, const float* mu, co
                             int64_t N, int64_t HW, int C, int Kc, const float* scales /*[2C], nullable*/, float* dx,
                             void* ws, size_t ws_bytes, wc_stream_t stream);
 
+/* K4 / K6 of a site whose input exists as pre-split planes (ABI 5): the backward reads x from the planes the residual add wrote for the
+ * forward (wc_resadd_split_f32) -- no fp32 copy of x has to exist.  K4: the X threads take 8 bytes per plane and row and build the
+ * transposed fp16 image with one byte-permute per word (no centre / scale / split instructions); K6: a chunk of x is [hi row | lo row]
+ * and its conversion a copy.  (x - mu) = g / scale + (center - mu): K4 adds the rank-one term (center - mu) (sum gy)^T to R, K6 folds
+ * (center - mu) S into gmean.  relu_mask (nullable): the site's one-bit ReLU mask, applied by both as in wc_bwd_reduce_bits_f32 /
+ * wc_bwd_apply_bits_f32 (gy is then the gradient BEFORE the ReLU).  scales: float[2C]; K4 writes gy's scales to [C, 2C) and K6 reads
+ * them there ([0, C) is unused: x's scales are xs_scale).  wc_bwd_xsplit_supported: C = 256, the fast reduction and the one-pass K6,
+ * N*HW a multiple of 32; elsewhere WC_ERR_SHAPE (keep an fp32 x: wc_resadd_split_f32's x32).  Replace the same TF graph gradients as
+ * wc_bwd_reduce_f32 / wc_bwd_apply_f32 (run.py:93-94). */
+int    wc_bwd_xsplit_supported(int64_t N, int64_t HW, int C, int has_slot);
+int    wc_bwd_reduce_xsplit_f32(const void* xs, const float* xs_center, const float* xs_scale, const float* mu, const float* gy,
+                                const void* relu_mask /*nullable*/, const int32_t* slot, int64_t N, int64_t HW, int C, int Kc,
+                                double* R /*[Kc,C,C]*/, double* gsum /*[Kc,C]*/, float* scales_out /*[2C]*/,
+                                void* ws /*wc_bwd_reduce_workspace_bytes*/, size_t ws_bytes, wc_stream_t stream);
+size_t wc_bwd_apply_xsplit_workspace_bytes(int C, int Kc);
+int    wc_bwd_apply_xsplit_f32(const float* gy, const void* relu_mask /*nullable*/, const void* xs, const float* xs_center,
+                               const float* xs_scale, const float* mu, const float* At, const float* S, const float* gmean,
+                               const int32_t* slot, int64_t N, int64_t HW, int C, int Kc, const float* scales /*[2C] from the K4 above*/,
+                               float* dx, void* ws, size_t ws_bytes, wc_stream_t stream);
+
 /* K5: dgamma[k] = W R[k];  and, when training != 0, the statistics path
  *     Wbar = sum_k Gamma_k R_k^T;  Lbar = -tril(W^T Wbar W^T);  P = Phi(L^T Lbar);
  *     S = 2(1-eps)/(M-ddof) sym(W^T P W)  (float32, C x C);   gmean = (1/M) sum_k gsum_k A_k^T  (C).

@@ -224,6 +224,45 @@ def test_shortcut_convolution_on_the_planes(shape, Cout):
         assert _rel(a, r) < 1e-5, name
 
 
+@pytest.mark.parametrize("shape,Kc,masked", [((128, 32, 32, 256), 1, True), ((128, 32, 32, 256), 1, False), ((128, 16, 16, 256), 10, True),
+                                             ((64, 32, 32, 256), 1, True)])
+def test_backward_kernels_on_planes_match_the_fp32_kernels(shape, Kc, masked):
+    """K4 and K6 reading x from the producer's planes (wc_bwd_reduce_xsplit_f32 / wc_bwd_apply_xsplit_f32) against the same kernels on
+    the fp32 tensor (wc_bwd_reduce_bits_f32 / wc_bwd_apply_bits_f32): R, gsum and dx to 2e-6 of their maxima (both hold x to 22 bits;
+    kernel-level tolerance of tests/test_fast_gpu.py), with the one-bit ReLU mask, per-class tables, and a gradient element beyond
+    the fp16 range (the gated exact redo, which then also reads x from the planes)."""
+    from wc_gan_amd import ops
+    x, G, B, slot = _site(shape, Kc, 31, cond="ill")
+    C = shape[-1]
+    rng = np.random.default_rng(32)
+    gy = rng.standard_normal(shape).astype(np.float32)
+    xd, Gd, Bd, gyd = dev(x), dev(G), dev(B), dev(gy)
+    sd = dev(slot, torch.int32) if slot is not None else None
+    M = xd.numel() // C
+    assert ops.bwd_xsplit_supported(shape, slot is not None)
+    mu, L, W, cs = ops.whiten(xd.view(M, C), 1e-3, 0.99, 1, None, None)
+    A, At, plan = ops.color(W, Gd, cs)
+    mask = None
+    if masked:
+        _, mask = ops.apply(xd, mu, A, Bd, sd, plan=plan, relu=True, want_mask=True)
+    st = ops.split(xd)
+    for outlier in (False, True):
+        if outlier:
+            gyd = gyd.clone(); gyd[3, 5, 7, 11] = 4e6            # beyond 60000 after scaling: the gate raises, the exact kernel redoes K4
+        if masked:
+            R0, g0, sc0 = ops.bwd_reduce(xd, mu, gyd, sd, Kc, want_scales=True, relu_mask=mask, write_masked=False)
+        else:
+            R0, g0, sc0 = ops.bwd_reduce(xd, mu, gyd, sd, Kc, want_scales=True)
+        R1, g1, sc1 = ops.bwd_reduce_xsplit(st, mu, gyd, sd, Kc, relu_mask=mask)
+        assert _rel(R1, R0) < 2e-6 and _rel(g1, g0) < 1e-6
+        assert torch.equal(sc1[C:], sc0[C:])
+        _, _, S, gm = ops.bwd_factor(R0, g0, W, L, Gd, A, M, 1e-3, 1, True)
+        dx0 = ops.bwd_apply(gyd, xd, mu, At, S, gm, sd, scales=sc0, relu_mask=mask)
+        dx1 = ops.bwd_apply_xsplit(gyd, st, mu, At, S, gm, sd, sc1, relu_mask=mask)
+        torch.cuda.synchronize()
+        assert _rel(dx1, dx0) < 2e-6, outlier
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # the site on planes against the float64 oracle (forward + backward, cond 1e6, full size)
 # ---------------------------------------------------------------------------------------------------------------------

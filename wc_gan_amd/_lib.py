@@ -97,6 +97,12 @@ SIGNATURES = {
     "wc_patch_sum_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "wc_fold_channel_scale_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wc_unfold_channel_scale_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wc_bwd_xsplit_supported": (c_int, [c_int64, c_int64, c_int, c_int]),
+    "wc_bwd_reduce_xsplit_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wc_bwd_apply_xsplit_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "wc_bwd_apply_xsplit_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wc_stream_copy_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "wc_spectral_norm_workspace_bytes": (c_size_t, [c_int, c_int]),
     "wc_spectral_norm_batched_f32": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p]),

@@ -750,6 +750,79 @@ int wc_bwd_reduce_bits_f32(const float* x, const float* mu, const float* gy, con
                              scales_out, ws, ws_bytes, stream);
 }
 
+// ---- K4 / K6 on a pre-split x (ABI 5): the backward of a site whose input the residual add wrote as planes ---------------------
+int wc_bwd_xsplit_supported(int64_t N, int64_t HW, int C, int has_slot)
+{
+    if (N <= 0 || HW <= 0 || C != 256 || ((N * HW) % 32) != 0) return 0;
+    const int per_sample = has_slot != 0;
+    const XtyPlan p = plan_xty(per_sample ? N : 1, per_sample ? HW : N * HW, C, per_sample, 0);
+    return (p.fast && wc_fast_affine_supported(N, HW, C, has_slot != 0) && wc_bwd_apply_onepass_supported(N, HW, C)) ? 1 : 0;
+}
+
+int wc_bwd_reduce_xsplit_f32(const void* xs, const float* xs_center, const float* xs_scale, const float* mu, const float* gy,
+                             const void* relu_mask, const int32_t* slot, int64_t N, int64_t HW, int C, int Kc,
+                             double* R, double* gsum, float* scales_out, void* ws, size_t ws_bytes, wc_stream_t stream)
+{
+    if (!xs || !xs_center || !xs_scale || !mu || !gy || !R || !gsum || !scales_out || !ws) return WC_ERR_NULL;
+    if (N <= 0 || HW <= 0 || Kc <= 0 || (!slot && Kc != 1)) return WC_ERR_SHAPE;
+    if (bad_channels(C)) return WC_ERR_CHANNELS;
+    if (!wc_bwd_xsplit_supported(N, HW, C, slot != nullptr)) return WC_ERR_SHAPE;
+    if (ws_bytes < wc_bwd_reduce_workspace_bytes(N, HW, C, Kc, slot != nullptr)) return WC_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int per_sample = slot != nullptr;
+    const int64_t Ns = per_sample ? N : 1, HWs = per_sample ? HW : N * HW;
+    const XtyPlan p = plan_xty(Ns, HWs, C, per_sample, 0);
+    Carver cv(ws, ws_bytes);
+    int* gate = cv.take<int>(64);
+    (void)cv.take<float>(C); (void)cv.take<float>(C);
+    float* sy = scales_out + C;                              // the caller keeps it for wc_bwd_apply_xsplit_f32 ([0, C) is not used: x's scales are the planes')
+    float* colsum = cv.take<float>((size_t)p.nslab * C);
+    double* P = cv.take<double>((size_t)p.nslab * C * C);
+    const unsigned* mask = static_cast<const unsigned*>(relu_mask);
+    WC_TRY(wc_launch_channel_scale_gate(gy, nullptr, sy, N * HW, C, gate, st));       // gy's scales (sampled from the unmasked gradient), gate := 0
+    WC_TRY(wc_launch_fast_xty(nullptr, gy, nullptr, nullptr, xs_scale, sy, Ns, HWs, C, per_sample, p.nsplit, p.rps, p.nslab, p.ntypes,
+                              P, colsum, nullptr, gate, st, nullptr, nullptr, mask, xs));
+    WcXtyArgs a = {};       // the gated exact redo (gy beyond the fp16 range): the same reduction in fp32 / float64, x from the planes
+    a.X = nullptr; a.Y = gy; a.cx = nullptr; a.cy = nullptr; a.N = Ns; a.HW = HWs;
+    a.per_sample = per_sample; a.nsplit = p.nsplit; a.rows_per_slab = p.rps; a.C = C; a.sym = 0; a.P = P; a.colsum = colsum;
+    a.gate = gate; a.ymask = mask;
+    a.Xhi = static_cast<const _Float16*>(xs); a.Xlo = a.Xhi + N * HW * C; a.xscale = xs_scale;
+    WC_TRY(wc_launch_xty(a, p.nslab, st));
+    WC_TRY(wc_launch_bwd_combine(P, colsum, slot, N, p.nsplit, per_sample, C, Kc, R, gsum, st));
+    WC_TRY(wc_launch_rank1_add(R, gsum, xs_center, mu, C, Kc, st));      // (g / scale = x - center; f = x - mu)
+    return WC_OK;
+}
+
+size_t wc_bwd_apply_xsplit_workspace_bytes(int C, int Kc)
+{
+    if (Kc <= 0 || bad_channels(C)) return 0;
+    return wc_fast_affine_workspace(C, Kc) + wc_fast_affine_workspace(C, 1) + slot_bytes(C, 4);
+}
+
+int wc_bwd_apply_xsplit_f32(const float* gy, const void* relu_mask, const void* xs, const float* xs_center, const float* xs_scale,
+                            const float* mu, const float* At, const float* S, const float* gmean, const int32_t* slot,
+                            int64_t N, int64_t HW, int C, int Kc, const float* scales, float* dx,
+                            void* ws, size_t ws_bytes, wc_stream_t stream)
+{
+    if (!gy || !xs || !xs_center || !xs_scale || !mu || !At || !S || !gmean || !scales || !dx || !ws) return WC_ERR_NULL;
+    if (N <= 0 || HW <= 0 || Kc <= 0) return WC_ERR_SHAPE;
+    if (bad_channels(C)) return WC_ERR_CHANNELS;
+    if (!wc_bwd_xsplit_supported(N, HW, C, slot != nullptr)) return WC_ERR_SHAPE;
+    if (ws_bytes < wc_bwd_apply_xsplit_workspace_bytes(C, Kc)) return WC_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char* w = static_cast<char*>(ws);
+    void* plan0 = w;
+    void* plan1 = w + wc_fast_affine_workspace(C, Kc);
+    float* subf = reinterpret_cast<float*>(w + wc_fast_affine_workspace(C, Kc) + wc_fast_affine_workspace(C, 1));
+    // the tables of both halves in one launch: At for gy's scales, S for the planes' scales
+    WC_TRY(wc_launch_fast_plan_tables2(At, Kc, plan0, scales + C, S, 1, plan1, xs_scale, C, st));
+    // dx = gy At + (x - mu) S - gmean with x - mu = g / scale + (center - mu):  sub = gmean + (mu - center) S
+    WC_TRY(wc_launch_split_bias(S, gmean, mu, xs_center, 1, C, subf, st));
+    WC_TRY(wc_launch_bwd_apply_onepass(gy, nullptr, mu, At, Kc, S, subf, slot, N, HW, scales, dx, plan0, plan1, st,
+                                       static_cast<const unsigned*>(relu_mask), xs, xs_scale));
+    return WC_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Wbar = sum_k Gamma_k R_k^T is one workgroup grid walking all Kc terms; with many tables (per-sample tables: Kc = N) the sum
 // is cut into WC_WBAR_PARTS batches that run side by side and are added in a fixed order afterwards

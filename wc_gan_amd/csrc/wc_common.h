@@ -85,6 +85,7 @@ struct WcXtyArgs {
     float* colsum;                       // [nslab][C]
     const int* gate;                     // optional: run only when *gate != 0 (exact redo of a fast-path call)
     const unsigned* ymask;               // optional: Y is a gradient in front of a ReLU whose one-bit mask this is (wc_apply_mask_f32 layout): applied while Y is loaded
+    const _Float16* Xhi; const _Float16* Xlo; const float* xscale;      // optional: X as pre-split planes, X := (hi + lo) / xscale (cx ignored)
 };
 int  wc_xty_plan(int64_t N, int64_t HW, int C, int per_sample, int sym, int* nsplit, int64_t* rows_per_slab);  // returns nslab
 hipError_t wc_launch_xty(const WcXtyArgs& a, int nslab, hipStream_t st);
@@ -129,13 +130,16 @@ hipError_t wc_launch_fast_xty(const float* X, const float* Y, const float* cx, c
                               int per_sample, int nsplit, int64_t rows_per_slab, int nslab, int ntypes,
                               double* P, float* colsum, double* dfix /*[nslab][C], covariance only, nullable*/, int* gate, hipStream_t st,
                               const float* yrelu = nullptr, float* yout = nullptr,       // yrelu (C = 256, two operands): Y masked by yrelu > 0, written to yout
-                              const unsigned* ymask = nullptr);                          // ... or by K3's bit mask ([M/32][C] words)
+                              const unsigned* ymask = nullptr,                           // ... or by K3's bit mask ([M/32][C] words)
+                              const void* xs = nullptr);                                 // X as pre-split planes (C = 256, two operands; X may be NULL, sx = the planes' scales, cx NULL)
 hipError_t wc_launch_fast_plan_tables(const float* B, int Kc, int C, void* plan, hipStream_t st, const float* scale = nullptr);
 bool wc_bwd_apply_onepass_supported(int64_t N, int64_t HW, int C);
 hipError_t wc_launch_bwd_apply_onepass(const float* gy, const float* x, const float* mu, const float* At, int Kc, const float* S,
                                        const float* gmean, const int32_t* slot, int64_t N, int64_t HW, const float* scales /*[2C]: x | gy*/,
                                        float* dx, const void* plan0, const void* plan1, hipStream_t st,
-                                       const unsigned* relu_mask = nullptr /*gy is the gradient before the site's ReLU: masked while it is converted*/);
+                                       const unsigned* relu_mask = nullptr /*gy is the gradient before the site's ReLU: masked while it is converted*/,
+                                       const void* xs = nullptr, const float* xs_scale = nullptr /*x as pre-split planes (x may then be NULL); plan1 built
+                                                                                                   for xs_scale, gmean folded: gmean - (center - mu) S*/);
 hipError_t wc_launch_fast_plan_tables2(const float* B0, int Kc0, void* plan0, const float* scale0,
                                        const float* B1, int Kc1, void* plan1, const float* scale1, int C, hipStream_t st);
 float* wc_fast_plan_scale(void* plan);
@@ -152,6 +156,8 @@ hipError_t wc_launch_relu_mask_bits(const float* gy, const unsigned* mask, float
 hipError_t wc_launch_channel_scale(const float* in, const float* center, int64_t M, int C, float* scale, hipStream_t st);
 hipError_t wc_launch_channel_scale2(const float* in, const float* center, float* scale, const float* in2, const float* center2,
                                     float* scale2, int64_t M, int C, int* gate, hipStream_t st);
+hipError_t wc_launch_channel_scale_gate(const float* in, const float* center, float* scale, int64_t M, int C, int* gate, hipStream_t st);   // one operand + the gate's clearing
+hipError_t wc_launch_rank1_add(double* R, const double* gsum, const float* u, const float* v, int C, int Kc, hipStream_t st);   // R[k][i][j] += (u[i] - v[i]) gsum[k][j]  (wc_small.hip)
 
 void wc_fast_plan_parts(const void* plan, int C, int Kc, const float** scale, const float** colscale, const void** hi, const void** lo);
 

@@ -1153,6 +1153,7 @@ struct OnePassArgs {
     float* out;
     int ntiles, tiles_per_pair, mixed;
     const unsigned* gmask;        // MK kernels: the ReLU's one-bit mask of the site (wc_apply_mask_f32 layout); gy is masked while it is converted
+    const _Float16* xhi; const _Float16* xlo;      // XPL kernels: x as pre-split planes (wc_resadd.hip / wc_split.hip), sx = their scales, `sub` folded
 };
 
 // MK: gy is the gradient BEFORE the site's ReLU and a.gmask the activation's one-bit mask: the bits are applied while the gy chunks
@@ -1163,7 +1164,12 @@ struct OnePassArgs {
 // after every wave has passed the next tile's wait on that counter.  (A register-destination load was tried first: as inline asm
 // its results land asynchronously in registers hipcc may have moved meanwhile -- a memory fault at 128x32x32x256 and one wrong row
 // pair in 500 launches at 128x16x16x256; as a plain load hipcc waits for it with the DMAs' counter.)
-template <bool HAS_SLOT, bool MK = false>
+// XPL (round 4): x arrives as PRE-SPLIT planes (the residual add in front of the site wrote them: wc_resadd.hip), x ~= center + (hi + lo) / sx.
+// A chunk of x is then [hi row | lo row] of one row -- lanes 0-31 fetch 16 bytes of the hi plane, lanes 32-63 of the lo plane: the same
+// 1 KiB per row as the fp32 form -- and its "conversion" is a copy from the raw slot into the two images (one ds_read_b128, one
+// ds_write_b128: none of the scale / split instructions, half of this kernel's conversion work).  The term (center - mu) S is folded
+// into `sub` by the caller, the S table is built for the planes' scales; ring, counters and the hand-counted waits are unchanged.
+template <bool HAS_SLOT, bool MK = false, bool XPL = false>
 __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
 {
     constexpr int C = 256, TR = 16, K2 = 2 * C;
@@ -1200,7 +1206,10 @@ __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
     const unsigned ring_w = (unsigned)(size_t)((__attribute__((address_space(3))) char*)(ring + wave * RAWW));
     auto dma_chunk = [&](int tl, int p, int slot, int lane_) {
         const float* src = (p & 2) ? a.x : a.gy;
-        const char* g = reinterpret_cast<const char*>(src + ((int64_t)tile_of(tl) * TR + 2 * wave + (p & 1)) * C) + lane_ * 16;
+        const int64_t row_ = (int64_t)tile_of(tl) * TR + 2 * wave + (p & 1);
+        const char* g = reinterpret_cast<const char*>(src + row_ * C) + lane_ * 16;
+        if (XPL && (p & 2))      // [hi row | lo row]: 512 bytes of each plane
+            g = reinterpret_cast<const char*>(((lane_ >> 5) ? a.xlo : a.xhi) + row_ * C) + (lane_ & 31) * 16;
         const unsigned l = __builtin_amdgcn_readfirstlane(ring_w + slot * 1024);
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -1209,7 +1218,7 @@ __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
 
     // conversion of this wave's own chunks: lane = float4 of channels 4*lane.. of one row
     const f32x4 scl_g = ld4f(a.sg + 4 * lane), scl_x = ld4f(a.sx + 4 * lane);
-    const f32x4 ncs_x = -ld4f(a.mu + 4 * lane) * scl_x;
+    const f32x4 ncs_x = XPL ? scl_x : -ld4f(a.mu + 4 * lane) * scl_x;      // (XPL: unused)
     float gmax = 0.f;
     f32x4 craw, cg4;
     unsigned chw01 = 0, chw23 = 0, clw01 = 0, clw23 = 0;
@@ -1232,6 +1241,11 @@ __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
     u32x4_ mkw = {0u, 0u, 0u, 0u};          // MK: this lane's four channels' mask words of the tile being converted (read once per tile)
     auto mask_words = [&](int tl) { mkw = *reinterpret_cast<const u32x4_*>(mbuf + (tl % 3) * 1024 + lane * 16); };
     auto cv_scale = [&](int p, int tl) {
+        if (XPL && (p & 2)) {       // planes: the chunk IS the image's content; held until its write (craw is the next chunk's by then)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the read has RETURNED before the slot's refill may issue (no arithmetic here would make hipcc wait)
+            cg4 = craw;
+            return;
+        }
         if (p & 2) cg4 = craw * scl_x + ncs_x;
         else {
             cg4 = craw * scl_g;
@@ -1250,8 +1264,9 @@ __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
         gmax = __builtin_fmaxf(__builtin_fmaxf(gmax, fabsf(cg4[0])), fabsf(cg4[1]));
         gmax = __builtin_fmaxf(__builtin_fmaxf(gmax, fabsf(cg4[2])), fabsf(cg4[3]));
     };
-    auto cv_hi = [&]() { chw01 = pk_rne(cg4[0], cg4[1]); chw23 = pk_rne(cg4[2], cg4[3]); };
-    auto cv_lo = [&]() {
+    auto cv_hi = [&](int p) { if (XPL && (p & 2)) return; chw01 = pk_rne(cg4[0], cg4[1]); chw23 = pk_rne(cg4[2], cg4[3]); };
+    auto cv_lo = [&](int p) {
+        if (XPL && (p & 2)) return;
         float r0, r1, r2, r3;
         asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(chw01), "v"(cg4[0]));
         asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(chw01), "v"(cg4[1]));
@@ -1262,7 +1277,12 @@ __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
     };
     // image row 2w + (p & 1); gy in channels 0..255 of the row, x in 256..511
     const int woff0 = (2 * wave) * PITCH + lane * 8;
-    auto cv_write = [&](int fb, int p, int woff0_) {
+    const int xoff0 = (2 * wave) * PITCH + C * 2 + (lane & 31) * 16 + (lane >> 5) * IMG;      // XPL: this lane's 16 bytes of the x half (hi image | lo image)
+    auto cv_write = [&](int fb, int p, int woff0_, int xoff0_) {
+        if (XPL && (p & 2)) {
+            *reinterpret_cast<f32x4*>(fbuf + fb * FBUF + xoff0_ + (p & 1) * PITCH) = cg4;
+            return;
+        }
         char* dst = fbuf + fb * FBUF + woff0_ + (p & 1) * PITCH + (p >> 1) * (C * 2);
         *reinterpret_cast<uint2*>(dst) = make_uint2(chw01, chw23);
         *reinterpret_cast<uint2*>(dst + IMG) = make_uint2(clw01, clw23);
@@ -1331,7 +1351,7 @@ __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
         cv_scale(p, 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the slot has been read out
         if ((p + NSLOT) / 4 < n) dma_chunk((p + NSLOT) / 4, (p + NSLOT) % 4, p, lane);
-        cv_hi(); cv_lo(); cv_write(0, p, woff0);
+        cv_hi(p); cv_lo(p); cv_write(0, p, woff0, xoff0);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     arrive(0);
@@ -1350,8 +1370,8 @@ __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
         constexpr bool CONV_ = decltype(conv_tag)::value;
         constexpr int WM_ = decltype(wm_tag)::value;
         const int fnext = fcur == 2 ? 0 : fcur + 1;
-        int lane_t = lane, woff_t = woff0, rd_t = rd_off;
-        asm volatile("" : "+v"(lane_t), "+v"(woff_t), "+v"(rd_t));
+        int lane_t = lane, woff_t = woff0, rd_t = rd_off, xoff_t = xoff0;
+        asm volatile("" : "+v"(lane_t), "+v"(woff_t), "+v"(rd_t), "+v"(xoff_t));
         wait_for(0, 8 * (t + 1));          // (MK: also "tile t + 1's mask block is complete", and every wave is done with tile t's)
         if (CONV_) wait_for(1, 8 * (t - 1));
         // MK: this wave's piece of the block of tile t + 3 into the buffer tile t's block has just left (three buffers: the piece is
@@ -1390,9 +1410,9 @@ __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
                 if (tl < n) dma_chunk(tl, (p + NSLOT) % 4, rs[p], lane_t);
             } else if (st == 1) {
                 if (p + 1 < 4) { chunk_wait(p + 1); craw_read(rs[p + 1], lane_t); }
-            } else if (st == 2) cv_hi();
-            else if (st == 3) cv_lo();
-            else cv_write(fnext, p, woff_t);
+            } else if (st == 2) cv_hi(p);
+            else if (st == 3) cv_lo(p);
+            else cv_write(fnext, p, woff_t, xoff_t);
         };
         constexpr int G = 3 * KS;            // 48 MFMAs = issue gaps per tile
         constexpr int H = (G * 3) / 4;       // the next tile's conversion rides in the first three quarters
@@ -1484,7 +1504,7 @@ __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
                 const float* B0 = a.Bf0 + (int64_t)slot * a.bf0_stride + col;
                 const float* B1 = a.Bf1 + col;
                 const float* gr = a.gy + row * C;
-                const float* xr = a.x + row * C;
+                const float* xr = XPL ? a.gy : a.x + row * C;
                 float accf = 0.f;
                 if (MK) {
                     const unsigned* mr = a.gmask + (row >> 5) * C;
@@ -1492,6 +1512,11 @@ __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
                     for (int k = 0; k < C; ++k) accf = fmaf(((mr[k] >> bit) & 1u) ? gr[k] : 0.f, B0[(int64_t)k * C], accf);
                 } else
                 for (int k = 0; k < C; ++k) accf = fmaf(gr[k], B0[(int64_t)k * C], accf);
+                if (XPL) {          // (the planes' value / sx; centre and mu are in the folded `sub`)
+                    const _Float16* xh = a.xhi + row * C;
+                    const _Float16* xl = a.xlo + row * C;
+                    for (int k = 0; k < C; ++k) accf = fmaf(((float)xh[k] + (float)xl[k]) / a.sx[k], B1[(int64_t)k * C], accf);
+                } else
                 for (int k = 0; k < C; ++k) accf = fmaf(xr[k] - a.mu[k], B1[(int64_t)k * C], accf);
                 a.out[row * C + col] = accf - (a.sub_on ? a.sub[col] : 0.f);
             }
@@ -1691,6 +1716,13 @@ hipError_t wc_launch_channel_scale2(const float* in, const float* center, float*
     return hipGetLastError();
 }
 
+hipError_t wc_launch_channel_scale_gate(const float* in, const float* center, float* scale, int64_t M, int C, int* gate, hipStream_t st)
+{
+    hipLaunchKernelGGL(channel_scale_kernel, dim3((C + 63) / 64, 1), dim3(1024), 0, st, in, center, M, C, scale,
+                       (const float*)nullptr, (const float*)nullptr, (float*)nullptr, gate);
+    return hipGetLastError();
+}
+
 // Plan layout (also the layout of the per-call workspace): scale[C] | colscale[Kc*C] | hi[Kc*C*C] | lo[Kc*C*C] | stamps
 struct PlanView { float* scale; float* colscale; _Float16* hi; _Float16* lo; unsigned long long* dbg; };
 static PlanView plan_view(void* plan, int C, int Kc)
@@ -1783,12 +1815,16 @@ bool wc_bwd_apply_onepass_supported(int64_t N, int64_t HW, int C)
 
 hipError_t wc_launch_bwd_apply_onepass(const float* gy, const float* x, const float* mu, const float* At, int Kc, const float* S,
                                        const float* gmean, const int32_t* slot, int64_t N, int64_t HW, const float* scales,
-                                       float* dx, const void* plan0, const void* plan1, hipStream_t st, const unsigned* relu_mask)
+                                       float* dx, const void* plan0, const void* plan1, hipStream_t st, const unsigned* relu_mask,
+                                       const void* xs, const float* xs_scale)
 {
     constexpr int C = 256, TR = 16;
     const PlanView v0 = plan_view(const_cast<void*>(plan0), C, Kc), v1 = plan_view(const_cast<void*>(plan1), C, 1);
     OnePassArgs a = {};
     a.gy = gy; a.x = x; a.mu = mu; a.sg = scales + C; a.sx = scales;
+    if (xs) {       // x as pre-split planes: sx = the planes' scales, gmean = the caller's folded gmean - (center - mu) S
+        a.xhi = static_cast<const _Float16*>(xs); a.xlo = a.xhi + N * HW * C; a.sx = xs_scale;
+    }
     a.hi0 = v0.hi; a.lo0 = v0.lo; a.cs0 = v0.colscale; a.slot_stride0 = (int64_t)C * C;
     a.hi1 = v1.hi; a.lo1 = v1.lo; a.cs1 = v1.colscale;
     a.sub_on = gmean != nullptr; a.sub = gmean ? gmean : scales;
@@ -1802,19 +1838,22 @@ hipError_t wc_launch_bwd_apply_onepass(const float* gy, const float* x, const fl
     pairs = groups16 * 8;
     a.tiles_per_pair = (a.ntiles + pairs - 1) / pairs;
     const size_t lds = 3 * 2 * (size_t)(TR * (2 * C * 2 + 32)) + 8 * 7 * 1024 + 64 + (relu_mask ? 3072 : 0);      // + the three shared mask blocks
-#define WC_LAUNCH_ONEPASS(SLOT_, MK_)                                                                                  \
+#define WC_LAUNCH_ONEPASS(SLOT_, MK_, XPL_)                                                                            \
     do {                                                                                                                \
         static bool attr_set = false;                                                                                   \
         if (!attr_set) {                                                                                                \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(onepass_ring_kernel<SLOT_, MK_>),          \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(onepass_ring_kernel<SLOT_, MK_, XPL_>),    \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
             if (e != hipSuccess) return e;                                                                              \
             attr_set = true;                                                                                            \
         }                                                                                                               \
-        hipLaunchKernelGGL((onepass_ring_kernel<SLOT_, MK_>), dim3(groups16 * 16), dim3(512), lds, st, a);              \
+        hipLaunchKernelGGL((onepass_ring_kernel<SLOT_, MK_, XPL_>), dim3(groups16 * 16), dim3(512), lds, st, a);        \
     } while (0)
-    if (relu_mask) { if (slot) WC_LAUNCH_ONEPASS(true, true); else WC_LAUNCH_ONEPASS(false, true); }
-    else { if (slot) WC_LAUNCH_ONEPASS(true, false); else WC_LAUNCH_ONEPASS(false, false); }
+    if (xs) {
+        if (relu_mask) { if (slot) WC_LAUNCH_ONEPASS(true, true, true); else WC_LAUNCH_ONEPASS(false, true, true); }
+        else { if (slot) WC_LAUNCH_ONEPASS(true, false, true); else WC_LAUNCH_ONEPASS(false, false, true); }
+    } else if (relu_mask) { if (slot) WC_LAUNCH_ONEPASS(true, true, false); else WC_LAUNCH_ONEPASS(false, true, false); }
+    else { if (slot) WC_LAUNCH_ONEPASS(true, false, false); else WC_LAUNCH_ONEPASS(false, false, false); }
 #undef WC_LAUNCH_ONEPASS
     return hipGetLastError();
 }

@@ -80,6 +80,7 @@ struct FastXtyArgs {
     int* flag;
     const float* Yrelu; float* Yout;       // RELU form (two operands, quadrant scheme): Y := Y where Yrelu > 0 else 0, written to Yout
     const unsigned* Ymask;                 // RELU == 2: the same mask as ONE BIT per element, [M/32][C] words (wc_apply_mask_f32)
+    const _Float16* Xhi; const _Float16* Xlo;      // XPL: X as pre-split planes (wc_resadd.hip): sx = their scales, cx = NULL, X itself unused
 };
 
 // RELU (K4 behind a site whose ReLU rode in K3's epilogue): the gradient mask gy := gy where y > 0
@@ -89,10 +90,16 @@ struct FastXtyArgs {
 // RELU: 0 none; 1 the site's output y in fp32 (8 x 16 bytes per Y thread and stage); 2 the bit mask K3 left (ONE 16-byte load of
 // the thread's four columns' words per stage: the stage's 64 rows are two 32-row mask blocks, the thread's 8 rows one byte of a
 // word -- K4 then reads x, gy and 1/32 of a tensor instead of three tensors)
-template <int C, bool TWO, int RELU = 0>
+// XPL (round 4, quadrant form): the X operand (the site's input x) arrives as pre-split planes -- the X threads load 8 bytes of each
+// plane per row instead of 16 bytes of fp32, and their whole conversion (centre, scale, range guard, two packs and two mixed FMAs per
+// element pair) becomes ONE v_perm_b32 per image word: the 8 rows x 4 channels a thread holds are transposed into 4 channels x 8
+// rows by picking the matching half of two rows' words.  The planes hold g = (x - center) scale, the kernel reduces g / scale, and
+// the caller adds the rank-one term (center - mu) (sum gy)^T (wc_launch_rank1_add).
+template <int C, bool TWO, int RELU = 0, bool XPL = false>
 __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
 {
     static_assert(!RELU || xty_quad<C, TWO>(), "the masked form exists for the quadrant scheme only");
+    static_assert(!XPL || xty_quad<C, TWO>(), "X from planes: the quadrant scheme only");
     // QUAD (two operands at C = 256): the 8 x 8 blocks are cut into four 4 x 4 quadrants, one workgroup type each.  A
     // quadrant needs only 128 channels of X and 128 of Y, so a workgroup converts HALF of every row (the three types of
     // the plain scheme convert all of it three times), its images hold twice the rows (64 per stage: half the barriers)
@@ -214,8 +221,17 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
     f32x4 yr[RELU == 1 ? 8 : 1];
     uint4 ym = {0u, 0u, 0u, 0u};
     const bool y_wave = RELU && __builtin_amdgcn_readfirstlane(op) != 0;       // waves 4-7 stage Y (wave-uniform: a scalar branch)
+    const bool x_wave = XPL && __builtin_amdgcn_readfirstlane(op) == 0;        // waves 0-3 stage X (wave-uniform: a scalar branch)
     auto stage_load = [&](int st) {
         const int64_t off = (r0 + (int64_t)st * R + rgrp * 8) * C + cbase + 4 * c4;
+        if (XPL && x_wave) {        // 4 channels of 8 rows from each plane: xr[p] = (hi word 0, hi word 1, lo word 0, lo word 1) of row p
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const uint2 h = *reinterpret_cast<const uint2*>(a.Xhi + off + p * C), l = *reinterpret_cast<const uint2*>(a.Xlo + off + p * C);
+                xr[p] = __builtin_bit_cast(f32x4, make_uint4(h.x, h.y, l.x, l.y));
+            }
+            return;
+        }
         const float* base = src + off;
 #pragma unroll
         for (int p = 0; p < 8; ++p) xr[p] = ldg4(base + p * C);
@@ -253,6 +269,23 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
     double lsq[4] = {0.0, 0.0, 0.0, 0.0};      // per stage: a fresh 8-term fp32 chain, folded into float64
     auto stage_write = [&](int buf, int st_of_data) {
         char* img = smem + buf * (NOP * 2 * IMG);
+        if (XPL && x_wave) {        // transpose by byte permutes: channel j of rows (2 pp, 2 pp + 1) = half j & 1 of word j >> 1 of the two rows
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned sel = (j & 1) ? 0x07060302u : 0x05040100u;
+                unsigned hw[4], lw[4];
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) {
+                    const uint4 e = __builtin_bit_cast(uint4, xr[2 * pp]), o = __builtin_bit_cast(uint4, xr[2 * pp + 1]);
+                    const unsigned he = (j >> 1) ? e.y : e.x, ho = (j >> 1) ? o.y : o.x, le = (j >> 1) ? e.w : e.z, lo_ = (j >> 1) ? o.w : o.z;
+                    hw[pp] = __builtin_amdgcn_perm(ho, he, sel);
+                    lw[pp] = __builtin_amdgcn_perm(lo_, le, sel);
+                }
+                *reinterpret_cast<uint4*>(img + st_off[j]) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+                *reinterpret_cast<uint4*>(img + st_off[j] + IMG) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+            }
+            return;
+        }
         f32x4 g[8];
         if (RELU && y_wave) {
             if (RELU == 2) {
@@ -479,21 +512,21 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
 template <int C, bool TWO>
 constexpr int stage_rows() { return xty_quad<C, TWO>() ? 64 : (TWO ? (512 / (C / 4)) * 4 : (512 / (C / 4)) * 8); }
 
-template <int C, bool TWO, int RELU = 0>
+template <int C, bool TWO, int RELU = 0, bool XPL = false>
 hipError_t launch_xty_fast(const FastXtyArgs& a, hipStream_t st)
 {
     constexpr int R = stage_rows<C, TWO>();
     constexpr size_t lds = (size_t)2 * (TWO ? 2 : 1) * 2 * (xty_quad<C, TWO>() ? C / 2 : C) * R * 2;       // 128 KiB
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(xty_f16x3_kernel<C, TWO, RELU>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(xty_f16x3_kernel<C, TWO, RELU, XPL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const int slab_groups = (a.nslab + 7) / 8;
     const int grid = slab_groups * a.ntypes * 8;
-    hipLaunchKernelGGL((xty_f16x3_kernel<C, TWO, RELU>), dim3(grid), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((xty_f16x3_kernel<C, TWO, RELU, XPL>), dim3(grid), dim3(512), lds, st, a);
     return hipGetLastError();
 }
 
@@ -546,21 +579,27 @@ hipError_t wc_launch_fast_xty(const float* X, const float* Y, const float* cx, c
                               const float* sx, const float* sy, int64_t N, int64_t HW, int C,
                               int per_sample, int nsplit, int64_t rows_per_slab, int nslab, int ntypes,
                               double* P, float* colsum, double* dfix, int* gate, hipStream_t st,
-                              const float* yrelu, float* yout, const unsigned* ymask)
+                              const float* yrelu, float* yout, const unsigned* ymask, const void* xs)
 {
     FastXtyArgs a = {};
     a.Yrelu = yrelu; a.Yout = yout; a.Ymask = ymask;
+    if (xs) {       // X as pre-split planes: the quadrant form (two operands, C = 256) only; sx = the planes' scales, cx = NULL
+        if (C != 256 || yrelu || cx) return hipErrorInvalidValue;
+        a.Xhi = static_cast<const _Float16*>(xs); a.Xlo = a.Xhi + N * HW * C;      // (N * HW = all rows in either slab layout)
+    }
     a.dfix = (Y == X) ? dfix : nullptr;
     a.X = X; a.Y = Y; a.cx = cx; a.cy = cy; a.sx = sx; a.sy = sy; a.N = N; a.HW = HW;
     a.per_sample = per_sample; a.nsplit = nsplit; a.rows_per_slab = rows_per_slab; a.nslab = nslab; a.ntypes = ntypes;
     a.P = P; a.colsum = colsum; a.flag = gate;
-    const bool two = (Y != X);
+    const bool two = (Y != X) || xs != nullptr;
     switch (C) {
         case 32: return two ? launch_xty_fast<32, true>(a, st) : launch_xty_fast<32, false>(a, st);
         case 64: return two ? launch_xty_fast<64, true>(a, st) : launch_xty_fast<64, false>(a, st);
         case 128: return two ? launch_xty_fast<128, true>(a, st) : launch_xty_fast<128, false>(a, st);
-        case 256: return two ? (ymask ? launch_xty_fast<256, true, 2>(a, st) : yrelu ? launch_xty_fast<256, true, 1>(a, st) : launch_xty_fast<256, true>(a, st))
-                             : launch_xty_fast<256, false>(a, st);
+        case 256:
+            if (xs) return ymask ? launch_xty_fast<256, true, 2, true>(a, st) : launch_xty_fast<256, true, 0, true>(a, st);
+            return two ? (ymask ? launch_xty_fast<256, true, 2>(a, st) : yrelu ? launch_xty_fast<256, true, 1>(a, st) : launch_xty_fast<256, true>(a, st))
+                       : launch_xty_fast<256, false>(a, st);
     }
     return hipErrorInvalidValue;
 }

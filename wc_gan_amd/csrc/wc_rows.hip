@@ -224,6 +224,15 @@ __global__ __launch_bounds__(256) void xty_kernel(WcXtyArgs a, int ntiles, int n
         for (int p = 0; p < 4; ++p) {
             const int64_t m = m0 + rbase + 8 * p;
             const bool ok = m < r1;
+            if (a.Xhi) {        // X as pre-split planes (the exact redo of a K4 whose x exists as planes only): (hi + lo) / scale
+                xv[p] = zero4;
+                if (ok && vi) {
+                    const f16x4 h = *reinterpret_cast<const f16x4*>(a.Xhi + m * C + ci), l = *reinterpret_cast<const f16x4*>(a.Xlo + m * C + ci);
+                    const f32x4 sc = ld4(a.xscale + ci);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xv[p][e] = ((float)h[e] + (float)l[e]) / sc[e];
+                }
+            } else
             xv[p] = (ok && vi) ? ld4(a.X + m * C + ci) - cx : zero4;
             if (!diag) {
                 yv[p] = (ok && vj) ? ld4(a.Y + m * C + cj) : zero4;

@@ -1686,3 +1686,22 @@ hipError_t wc_launch_f64_to_f32(const double* src, float* dst, int64_t n, hipStr
     hipLaunchKernelGGL(f64_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n);
     return hipGetLastError();
 }
+
+
+// K4 on a pre-split x (wc_fast_xty.hip, XPL): the kernel reduced g / scale = x - center; R needs f = x - mu:
+//     R[k] += (center - mu) gsum[k]^T          (float64, one thread per element)
+__global__ __launch_bounds__(256) void rank1_add_kernel(double* __restrict__ R, const double* __restrict__ gsum,
+                                                        const float* __restrict__ u, const float* __restrict__ v, int C)
+{
+    const int k = blockIdx.y;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)C * C) return;
+    const int i = (int)(e / C), j = (int)(e % C);
+    R[(int64_t)k * C * C + e] += ((double)u[i] - (double)v[i]) * gsum[(int64_t)k * C + j];
+}
+
+hipError_t wc_launch_rank1_add(double* R, const double* gsum, const float* u, const float* v, int C, int Kc, hipStream_t st)
+{
+    hipLaunchKernelGGL(rank1_add_kernel, dim3((C * C + 255) / 256, Kc), dim3(256), 0, st, R, gsum, u, v, C);
+    return hipGetLastError();
+}

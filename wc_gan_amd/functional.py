@@ -20,6 +20,9 @@ from . import _state, ops
 USE_WHITEN = os.environ.get('WC_WHITEN', '1') != '0'
 # the ReLU'd backward without a masked copy of the gradient (K4 and K6 both apply the bit mask; WC_BWD_BITS=0: K4 writes the copy)
 USE_BWD_BITS = os.environ.get('WC_BWD_BITS', '1') != '0'
+# the backward of a site on pre-split planes reads x from the planes too (wc_bwd_reduce_xsplit_f32 / wc_bwd_apply_xsplit_f32); WC_BWD_XSPLIT=0:
+# from the fp32 sum the producer then writes beside the planes
+USE_BWD_XSPLIT = os.environ.get('WC_BWD_XSPLIT', '1') != '0'
 
 
 def _allreduce_(tensors, group):
@@ -96,9 +99,16 @@ class WhitenColorFunction(torch.autograd.Function):
                 y, mask = ops.apply_split(st, None, A, be, slot, plan=plan, relu=True, folded=True, want_mask=True)
             else:
                 y, mask = ops.apply_split(st, None, A, be, slot, plan=plan, relu=relu, folded=True), None
-            # the backward's K4 / K6 read fp32 (round 4: the producer writes it beside the planes when a gradient is wanted)
+            # the backward: K4 / K6 read x from the same planes where they can (wc_bwd_*_xsplit_f32: C = 256 fast paths); elsewhere
+            # from the fp32 sum the producer wrote beside the planes (st.x32), or -- no such copy -- from one made here
+            ctx.xsplit = None
             if any(ctx.needs_input_grad[:3]):
-                x = st.x32 if st.x32 is not None else ops.unsplit(st)
+                if USE_BWD_XSPLIT and ops.bwd_xsplit_supported(x.shape, slot is not None) and (not relu or bits):
+                    ctx.xsplit = (st.shape,)
+                    ctx.xs_tensors = (st.planes, st.center, st.scale)
+                    x = torch.empty(0, device=dev)
+                else:
+                    x = st.x32 if st.x32 is not None else ops.unsplit(st)
             else:
                 x = torch.empty(0, device=dev)
         elif planes_box is not None:
@@ -108,9 +118,13 @@ class WhitenColorFunction(torch.autograd.Function):
             y, mask = ops.apply(x, mu, A, b, slot, plan=plan, relu=True, want_mask=True)
         else:
             y, mask = ops.apply(x, mu, A, b, slot, plan=plan, relu=relu), None
+        xs_t = getattr(ctx, 'xs_tensors', None) or ()
+        ctx.xs_tensors = None
         ctx.save_for_backward(x, mu, L, W, A, At, g if g is not None else torch.empty(0, device=dev),
                               slot if slot is not None else torch.empty(0, dtype=torch.int32, device=dev),
-                              mask if bits else (y if relu else torch.empty(0, device=dev)))
+                              mask if bits else (y if relu else torch.empty(0, device=dev)), *xs_t)
+        if st is None:
+            ctx.xsplit = None
         ctx.relu = bool(relu)
         ctx.mask_bits = bits
         ctx.has_gamma = g is not None
@@ -122,7 +136,11 @@ class WhitenColorFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
-        x, mu, L, W, A, At, g, slot, y = ctx.saved_tensors
+        x, mu, L, W, A, At, g, slot, y = ctx.saved_tensors[:9]
+        xs = None
+        if ctx.xsplit is not None:          # x lives in the producer's planes: K4 / K6 read those
+            pl, cen, sc = ctx.saved_tensors[9:12]
+            xs = ops.SplitTensor(pl, cen, sc, None, ctx.xsplit[0])
         g = g if ctx.has_gamma else None
         slot = slot if ctx.has_slot else None
         gy = gy.contiguous()
@@ -147,18 +165,24 @@ class WhitenColorFunction(torch.autograd.Function):
             rm = y if (ctx.relu and ctx.mask_bits) else None          # (the saved tensor is the bit mask then)
             # with the bits and a K6 that masks for itself (C = 256 fast paths) K4 writes no masked copy of the gradient at all
             bits_only = rm is not None and share and need_x and USE_BWD_BITS and ops.bwd_bits_supported(x.shape, slot is not None)
-            if ctx.group is None:
-                out = ops.bwd_reduce(x, mu, gy, slot, Kc, want_scales=share, relu_y=ry, relu_mask=rm, write_masked=not bits_only)
+            if xs is not None:
+                out = ops.bwd_reduce_xsplit(xs, mu, gy, slot, Kc, relu_mask=rm, flat=ctx.group is not None)
                 R, gsum = out[0], out[1]
+                rbuf = out[2] if ctx.group is not None else None
+                scales, k6_mask = out[-1], rm
             else:
-                out = ops.bwd_reduce(x, mu, gy, slot, Kc, flat=True, want_scales=share, relu_y=ry, relu_mask=rm, write_masked=not bits_only)
-                R, gsum, rbuf = out[0], out[1], out[2]
-            if share:
-                scales = out[-1]
-            if bits_only:
-                k6_mask = rm
-            elif ry is not None or rm is not None:
-                gy = out[-2] if share else out[-1]
+                if ctx.group is None:
+                    out = ops.bwd_reduce(x, mu, gy, slot, Kc, want_scales=share, relu_y=ry, relu_mask=rm, write_masked=not bits_only)
+                    R, gsum = out[0], out[1]
+                else:
+                    out = ops.bwd_reduce(x, mu, gy, slot, Kc, flat=True, want_scales=share, relu_y=ry, relu_mask=rm, write_masked=not bits_only)
+                    R, gsum, rbuf = out[0], out[1], out[2]
+                if share:
+                    scales = out[-1]
+                if bits_only:
+                    k6_mask = rm
+                elif ry is not None or rm is not None:
+                    gy = out[-2] if share else out[-1]
             if ctx.group is None:
                 dgamma, dbeta, S, gmean = ops.bwd_factor(R, gsum, W, L, g, A, ctx.M, ctx.eps, ctx.ddof, stats_path,
                                                          want_dgamma=want_g, want_dbeta=want_b)
@@ -173,7 +197,13 @@ class WhitenColorFunction(torch.autograd.Function):
                     _, _, S, gmean = ops.bwd_factor(R, gsum, W, L, g, A, ctx.M, ctx.eps, ctx.ddof, True,
                                                     want_dgamma=False, want_dbeta=False)
         if need_x:
-            dx = ops.bwd_apply(gy, x, mu, At, S, gmean, slot, scales=scales, relu_mask=k6_mask)
+            if xs is not None and S is not None and scales is not None:
+                dx = ops.bwd_apply_xsplit(gy, xs, mu, At, S, gmean, slot, scales, relu_mask=k6_mask)
+            else:
+                if xs is not None and k6_mask is not None:          # (evaluation-mode site with a gradient: no statistics path, dx = masked gy At)
+                    gy, k6_mask = ops.relu_mask_bits(gy, k6_mask), None
+                dx = ops.bwd_apply(gy, x if xs is None else None, mu if xs is None else None, At, S if xs is None else None,
+                                   gmean if xs is None else None, slot, scales=scales if xs is None else None, relu_mask=k6_mask)
         return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None
 
 
@@ -234,30 +264,32 @@ class ResidualAddFunction(torch.autograd.Function):
     convolution) -- the result is a handle and the SplitTensor lands in the box (with .x32 when a backward will read fp32)."""
 
     @staticmethod
-    def forward(ctx, h, s, up, box):
+    def forward(ctx, h, s, up, box, x32):
         h = h.contiguous(); s = s.contiguous()
         ctx.up = bool(up)
         if box is None:
             return ops.resadd(h, s, up)
-        st = ops.resadd_split(h, s, up, want_x32=any(ctx.needs_input_grad[:2]))
+        st = ops.resadd_split(h, s, up, want_x32=bool(x32) and any(ctx.needs_input_grad[:2]))
         box.append(st)
         return _nan_handle(h.shape, h.device)
 
     @staticmethod
     def backward(ctx, g):
         g = g.contiguous()
-        return g, (ops.patch_sum(g) if ctx.up else g), None, None
+        return g, (ops.patch_sum(g) if ctx.up else g), None, None, None
 
 
-def residual_add(h, s, up, planes=False):
+def residual_add(h, s, up, planes=False, x32=True):
     """h + (upsample2x of) s.  planes=True (the readers of the sum all have a planes path: layers.WhiteningColoring.takes_split,
-    generator.Conv2D.takes_split): a handle carrying the sum as pre-split planes (`split_of(handle)`)."""
+    generator.Conv2D.takes_split): a handle carrying the sum as pre-split planes (`split_of(handle)`).  x32=False: no reader's backward
+    needs the fp32 sum either (layers.WhiteningColoring.backward_takes_split) -- else it is written beside the planes while a gradient
+    is wanted."""
     if planes and ops.resadd_split_supported(h.shape):
         box = []
-        out = ResidualAddFunction.apply(h, s, bool(up), box)
+        out = ResidualAddFunction.apply(h, s, bool(up), box, bool(x32))
         out._wc_split = box[0]
         return out
-    return ResidualAddFunction.apply(h, s, bool(up), None)
+    return ResidualAddFunction.apply(h, s, bool(up), None, False)
 
 
 _SLOT_BASE = {}

@@ -351,7 +351,10 @@ class ResBlockUp(nn.Module):
         # output patch adds its one source pixel (csrc/wc_resadd.hip; rounds 1-3: a torch broadcast add)
         if h.is_cuda and h.dtype == torch.float32 and h.shape[-1] % 32 == 0:
             planes = (SPLIT_PRODUCER and len(readers) > 0 and all(r.takes_split(h.shape) for r in readers))
-            return residual_add(h, s, self.resample == 'UP', planes=planes)
+            # the fp32 sum beside the planes: only while a backward will read it (a site whose K4 / K6 have no planes form)
+            x32 = planes and torch.is_grad_enabled() and not all(r.backward_takes_split(h.shape) for r in readers
+                                                                  if hasattr(r, 'backward_takes_split'))
+            return residual_add(h, s, self.resample == 'UP', planes=planes, x32=x32)
         if self.resample == 'UP':
             N, H, W, C = s.shape
             return (h.view(N, H, 2, W, 2, C) + s.view(N, H, 1, W, 1, C)).view(N, 2 * H, 2 * W, C)

@@ -423,6 +423,12 @@ class WhiteningColoring(nn.Module):
         """See DecorelationNormalization.takes_split (every coloring variant reduces to one table: no further condition)."""
         return self.npart.takes_split(shape)
 
+    def backward_takes_split(self, shape):
+        """Will the backward of this site read x from the planes as well (functional.USE_BWD_XSPLIT: K4 / K6 on planes)?  Then the
+        producer need not write an fp32 copy of the sum beside them."""
+        has_slot = any(br.conditional for br in self.branches)
+        return WF.USE_BWD_XSPLIT and self.npart.training and WF.ops.bwd_xsplit_supported(tuple(shape), has_slot)
+
     def forward(self, x, cls=None, relu=False, planes=False):
         if isinstance(x, (list, tuple)):
             x, cls = x

@@ -575,6 +575,57 @@ def bwd_reduce(x, mu, gy, slot, Kc, flat=False, want_scales=False, relu_y=None, 
     return out + (scales,) if want_scales else out
 
 
+def bwd_xsplit_supported(shape, has_slot):
+    """Can K4 and K6 of a site of this NHWC shape read x from pre-split planes (bwd_reduce_xsplit / bwd_apply_xsplit: C = 256, the fast
+    reduction and the one-pass K6)?  Then no fp32 copy of x has to exist for the backward."""
+    N, C = shape[0], shape[-1]
+    HW = 1
+    for d in shape[1:-1]:
+        HW *= d
+    return bool(_lib.load().wc_bwd_xsplit_supported(N, HW, C, int(bool(has_slot))))
+
+
+def bwd_reduce_xsplit(xs, mu, gy, slot, Kc, relu_mask=None, flat=False):
+    """K4 with x as a SplitTensor (wc_bwd_reduce_xsplit_f32): -> (R, gsum[, buf], scales); relu_mask: the site's one-bit ReLU mask, applied
+    while gy is staged (gy is then the gradient before the ReLU; bwd_apply_xsplit(relu_mask=) masks for itself)."""
+    lib = _lib.load()
+    _need(gy, torch.float32, "gy")
+    N, C = gy.shape[0], gy.shape[-1]
+    HW = gy.numel() // (N * C)
+    dev = gy.device
+    buf = None
+    if flat:
+        buf = torch.empty(Kc * (C * C + C), dtype=torch.float64, device=dev)
+        R, gsum = buf[:Kc * C * C].view(Kc, C, C), buf[Kc * C * C:].view(Kc, C)
+    else:
+        R = torch.empty(Kc, C, C, dtype=torch.float64, device=dev)
+        gsum = torch.empty(Kc, C, dtype=torch.float64, device=dev)
+    if relu_mask is not None:
+        _need(relu_mask, torch.int32, "relu_mask", 2)
+    ws = _workspace(lib.wc_bwd_reduce_workspace_bytes(N, HW, C, Kc, int(slot is not None)), dev)
+    scales = torch.empty(2 * C, dtype=torch.float32, device=dev)
+    _lib.check(lib.wc_bwd_reduce_xsplit_f32(_ptr(xs.planes), _ptr(xs.center), _ptr(xs.scale), _ptr(mu), _ptr(gy), _ptr(relu_mask), _ptr(slot),
+                                            N, HW, C, Kc, _ptr(R), _ptr(gsum), _ptr(scales), _ptr(ws), ws.numel(), _stream()),
+               "wc_bwd_reduce_xsplit_f32")
+    return (R, gsum, buf, scales) if buf is not None else (R, gsum, scales)
+
+
+def bwd_apply_xsplit(gy, xs, mu, At, S, gmean, slot, scales, relu_mask=None):
+    """K6 with x as a SplitTensor (wc_bwd_apply_xsplit_f32): dx[n] = gy[n] At[slot[n]] + (x[n] - mu) S - gmean; scales from
+    bwd_reduce_xsplit of the same site."""
+    lib = _lib.load()
+    _need(gy, torch.float32, "gy")
+    N, C = gy.shape[0], gy.shape[-1]
+    HW = gy.numel() // (N * C)
+    Kc = At.shape[0]
+    dx = torch.empty_like(gy)
+    ws = _workspace(lib.wc_bwd_apply_xsplit_workspace_bytes(C, Kc), gy.device)
+    _lib.check(lib.wc_bwd_apply_xsplit_f32(_ptr(gy), _ptr(relu_mask), _ptr(xs.planes), _ptr(xs.center), _ptr(xs.scale), _ptr(mu), _ptr(At),
+                                           _ptr(S), _ptr(gmean), _ptr(slot), N, HW, C, Kc, _ptr(scales), _ptr(dx), _ptr(ws), ws.numel(),
+                                           _stream()), "wc_bwd_apply_xsplit_f32")
+    return dx
+
+
 def relu_mask_bits(gy, mask):
     """gy where the one-bit mask says the activation passed, else 0 (the elementwise form; K4 does the same while it stages)."""
     lib = _lib.load()
