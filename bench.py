@@ -241,13 +241,14 @@ def roofline_apply(dev):
             break
 
     # ---- the whole forward site through the layer object (K1 -> K2 -> color -> K3, the layers' own route), and the producer
+    # (hipGraph replays: through the layer objects the Python loop, not the GPU, would set the pace -- ~300 us of host time per call)
     with torch.no_grad():
-        t_site = time_kernel(lambda: site(xin, None, relu=True), iters=10)
-        t_prod = time_kernel(lambda: WF.residual_add(hh, s_half, True, planes=on_planes), iters=10)
-        t_prod32 = time_kernel(lambda: ops.resadd(hh, s_half, True), iters=10)
-        t_torch_add = time_kernel(lambda: hh.view(N, H // 2, 2, H // 2, 2, C) + s_half.view(N, H // 2, 1, H // 2, 1, C), iters=10)
+        t_site = time_kernel(lambda: site(xin, None, relu=True), iters=10, graph=True)
+        t_prod = time_kernel(lambda: WF.residual_add(hh, s_half, True, planes=on_planes), iters=10, graph=True)
+        t_prod32 = time_kernel(lambda: ops.resadd(hh, s_half, True), iters=10, graph=True)
+        t_torch_add = time_kernel(lambda: hh.view(N, H // 2, 2, H // 2, 2, C) + s_half.view(N, H // 2, 1, H // 2, 1, C), iters=10, graph=True)
         x32 = ops.resadd(hh, s_half, True)
-        t_site32 = time_kernel(lambda: site(x32, None, relu=True), iters=10)
+        t_site32 = time_kernel(lambda: site(x32, None, relu=True), iters=10, graph=True)
     # every stage of the site on its own (HIP events, same inputs): the algorithmic bytes of SURVEY section 8d per stage
     gy = torch.randn(N, H, H, C, generator=g).to(dev)
     y_relu, relu_bits = ops.apply(x, mu, A, b, None, plan=plan, relu=True, want_mask=True)
@@ -273,6 +274,10 @@ def roofline_apply(dev):
         "K6 wc_bwd_apply_bits_f32 (applies the same bits to gy: as the generator runs it)":
             stage(lambda: ops.bwd_apply(gy, x, mu, At, S, gm, None, scales=scales, relu_mask=relu_bits), 3 * xb + xb // 32),
         "K4 wc_bwd_reduce_mask_f32 (writes the masked copy: shapes without the bits route)": stage(lambda: ops.bwd_reduce(x, mu, gy, None, 1, want_scales=True, relu_mask=relu_bits), 3 * xb),
+        "K4 wc_bwd_reduce_xsplit_f32 (x from the producer's planes, bit mask in: as the generator runs the sites fed by a residual add)":
+            stage(lambda: ops.bwd_reduce_xsplit(xs, mu, gy, None, 1, relu_mask=relu_bits), 2 * xb + xb // 32),
+        "K6 wc_bwd_apply_xsplit_f32 (x from the planes, the same bits applied to gy)":
+            stage(lambda: ops.bwd_apply_xsplit(gy, xs, mu, At, S, gm, None, scales, relu_mask=relu_bits), 3 * xb + xb // 32),
         "K5 wc_bwd_factor_f64": only_us(lambda: ops.bwd_factor(R, gsum, W, L, gamma, A, M, 1e-3, 1, True)),
         "K6 wc_bwd_apply_f32": stage(lambda: ops.bwd_apply(gy, x, mu, At, S, gm, None, scales=scales), 3 * xb),
     }
@@ -291,7 +296,7 @@ def roofline_apply(dev):
             "in_flow_frac_of_stream_copy": round(alg_layers / t_flow / 1e9 / copy_gbs, 4),
             "k3_kernels": k3, "site_stages": stages,
             "forward_site_us": round(t_site * 1e6, 1),
-            "forward_site_route": "layer object, training mode, input " + ("on planes" if on_planes else "fp32") + " (producer not included: it replaces the block's residual add, timed below)",
+            "forward_site_route": "layer object (hipGraph replay of 10 calls), training mode, input " + ("on planes" if on_planes else "fp32") + " (producer not included: it replaces the block's residual add, timed below)",
             "forward_site_frac_of_peak": round(3 * xb / t_site / 1e9 / HBM_PEAK_GBS, 4),
             "forward_site_fp32_input_us": round(t_site32 * 1e6, 1),
             "producer_us": {"residual add as the layers run it": round(t_prod * 1e6, 1), "residual add -> fp32 (HIP)": round(t_prod32 * 1e6, 1),

@@ -346,8 +346,8 @@ def _launched_split(G, z, cls, train=True):
     import wc_gan_amd.functional as WF
     seen = []
     orig = WF.residual_add
-    def spy(h, s, up, planes=False):
-        out = orig(h, s, up, planes)
+    def spy(h, s, up, planes=False, x32=True):
+        out = orig(h, s, up, planes, x32)
         seen.append(WF.split_of(out) is not None)
         return out
     import wc_gan_amd.generator as gen

@@ -20,15 +20,15 @@ y = torch.empty_like(x)
 s, xtx = ops.stats(x.view(M, C))
 mu, L, W, cs = ops.factor(s, xtx, M, C, 1e-3, 0.99, 1, True, None, None, x.device, want_scale=True)
 A, At, plan = ops.color(W, gamma, cs)
-if mode in ("k3split", "k1split", "k3splitmask", "k3splitplanes", "k1wsplit"):
+if mode in ("k3split", "k1split", "k3splitmask", "k3splitplanes", "k1wsplit", "k4xsplit", "k6xsplit"):
     xs = ops.split(x)
     A2, At2, plan2 = ops.color(W, gamma, xs.scale)
     be = ops.split_bias(A2, b, xs, mu)
-if mode in ("k4mask", "k3mask", "k4bits", "k6bits"):
+if mode in ("k4mask", "k3mask", "k4bits", "k6bits", "k4xsplit", "k6xsplit"):
     _, mask = ops.apply(x, mu, A, b, None, plan=plan, relu=True, want_mask=True, out=y)
 if mode in ("k3planes", "k3splitplanes"):
     rec = ops.out_scale(gamma, b, C, x.device)
-if mode in ("k6", "k6bits"):
+if mode in ("k6", "k6bits", "k6xsplit"):
     R, gsum, scales = ops.bwd_reduce(x, mu, gy, None, 1, want_scales=True)
     _, _, S, gm = ops.bwd_factor(R, gsum, W, L, gamma, A, M, 1e-3, 1, True)
 if mode.startswith("resadd"):
@@ -36,6 +36,8 @@ if mode.startswith("resadd"):
 run = {
     "k3splitmask": lambda: ops.apply_split(xs, None, A2, be, None, plan=plan2, out=y, relu=True, folded=True, want_mask=True),
     "k3splitplanes": lambda: ops.apply_split(xs, None, A2, be, None, plan=plan2, relu=True, folded=True, want_mask=True, oscale=rec),
+    "k4xsplit": lambda: ops.bwd_reduce_xsplit(xs, mu, gy, None, 1, relu_mask=mask),
+    "k6xsplit": lambda: ops.bwd_apply_xsplit(gy, xs, mu, At, S, gm, None, scales, relu_mask=mask),
     "k1wsplit": lambda: ops.whiten_split(xs, 1e-3, 0.99, 1, None, None),
     "resadd": lambda: ops.resadd(hh, ss, True),
     "resaddsplit": lambda: ops.resadd_split(hh, ss, True),
