@@ -49,13 +49,17 @@ def _workspace(nbytes, device):
 TRACE = None
 
 
-def _trace(entry, kernel, again):
-    if TRACE is not None:
-        TRACE.append((entry, kernel, again))
-
-
 def _tf(b):
     return "true" if b else "false"
+
+
+def _call(fn, args, what, entry=None, kernel=None, keep=()):
+    """fn(*args, stream) through the error check; under TRACE also records a closure that repeats exactly this launch -- the raw
+    foreign call on the then-current stream, nothing else: a timing loop over it is not paced by Python (the wrappers' checks and
+    allocations cost 30-60 us per call, more than a 50-us kernel)."""
+    if TRACE is not None and entry is not None:
+        TRACE.append((entry, kernel, lambda: fn(*args, _stream()), keep))     # keep: the tensors behind the raw pointers
+    _lib.check(fn(*args, _stream()), what)
 
 
 def stats(x2d, groups=1, flat=False):
@@ -198,23 +202,20 @@ def apply(x, mu, A, bias, slot, out=None, fast=True, plan=None, relu=False, want
         _need(slot, torch.int32, "slot", 1)
     y = torch.empty_like(x) if out is None else out
     ws = _workspace(lib.wc_apply_workspace_bytes(N, HW, C, Kc), x.device) if (fast and plan is None) else None
-    _last_mask = [_mask_out]
-    if TRACE is not None and fast and plan is not None:
-        _trace("wc_apply_mask_f32" if want_mask else "wc_apply_act_f32",
-               f"affine_ring_kernel<{C}, {_tf(slot is not None)}, {_tf(want_mask)}, false>",
-               lambda: apply(x, mu, A, bias, slot, out=y, fast=fast, plan=plan, relu=relu, want_mask=want_mask, _mask_out=_last_mask[0]))
+    traced = fast and plan is not None
+    kern = f"affine_ring_kernel<{C}, {_tf(slot is not None)}, {_tf(want_mask)}, false>" if (traced and TRACE is not None) else None
+    keep = (x, mu, A, bias, slot, y, plan, ws)
     if want_mask:
         if not relu or (N * HW) % 32 != 0:
             raise ValueError("want_mask needs relu=True and a row count that is a multiple of 32")
         mask = torch.empty((N * HW) // 32, C, dtype=torch.int32, device=x.device) if _mask_out is None else _mask_out
-        _last_mask[0] = mask
-        _lib.check(lib.wc_apply_mask_f32(_ptr(x), _ptr(mu), _ptr(A), _ptr(bias), _ptr(slot), N, HW, C, Kc, _ptr(y), _ptr(mask),
-                                         _ptr(plan) if fast else None, _ptr(ws), ws.numel() if ws is not None else 0, _stream()),
-                   "wc_apply_mask_f32")
+        _call(lib.wc_apply_mask_f32, (_ptr(x), _ptr(mu), _ptr(A), _ptr(bias), _ptr(slot), N, HW, C, Kc, _ptr(y), _ptr(mask),
+                                      _ptr(plan) if fast else None, _ptr(ws), ws.numel() if ws is not None else 0),
+              "wc_apply_mask_f32", "wc_apply_mask_f32" if traced else None, kern, keep + (mask,))
         return y, mask
-    _lib.check(lib.wc_apply_act_f32(_ptr(x), _ptr(mu), _ptr(A), _ptr(bias), _ptr(slot), N, HW, C, Kc, 1 if relu else 0,
-                                    _ptr(y), _ptr(plan) if fast else None, _ptr(ws), ws.numel() if ws is not None else 0,
-                                    _stream()), "wc_apply_act_f32")
+    _call(lib.wc_apply_act_f32, (_ptr(x), _ptr(mu), _ptr(A), _ptr(bias), _ptr(slot), N, HW, C, Kc, 1 if relu else 0,
+                                 _ptr(y), _ptr(plan) if fast else None, _ptr(ws), ws.numel() if ws is not None else 0),
+          "wc_apply_act_f32", "wc_apply_act_f32" if traced else None, kern, keep)
     return y
 
 
@@ -257,11 +258,10 @@ def apply_planes(x, mu, A, bias, slot, plan, oscale, relu=True, want_mask=False,
         _need(slot, torch.int32, "slot", 1)
     planes = torch.empty((2,) + tuple(x.shape), dtype=torch.float16, device=x.device) if _planes_out is None else _planes_out
     mask = (torch.empty((N * HW) // 32, C, dtype=torch.int32, device=x.device) if _mask_out is None else _mask_out) if want_mask else None
-    if TRACE is not None:
-        _trace("wc_apply_planes_f32", f"affine_ring_kernel<{C}, {_tf(slot is not None)}, {_tf(want_mask)}, true>",
-               lambda: apply_planes(x, mu, A, bias, slot, plan, oscale, relu=relu, want_mask=want_mask, _mask_out=mask, _planes_out=planes))
-    _lib.check(lib.wc_apply_planes_f32(_ptr(x), _ptr(mu), _ptr(A), _ptr(bias), _ptr(slot), N, HW, C, Kc, 1 if relu else 0,
-                                       _ptr(planes), _ptr(oscale), _ptr(mask), _ptr(plan), _stream()), "wc_apply_planes_f32")
+    _call(lib.wc_apply_planes_f32, (_ptr(x), _ptr(mu), _ptr(A), _ptr(bias), _ptr(slot), N, HW, C, Kc, 1 if relu else 0,
+                                    _ptr(planes), _ptr(oscale), _ptr(mask), _ptr(plan)), "wc_apply_planes_f32", "wc_apply_planes_f32",
+          None if TRACE is None else f"affine_ring_kernel<{C}, {_tf(slot is not None)}, {_tf(want_mask)}, true>",
+          (x, mu, A, bias, slot, planes, oscale, mask, plan))
     return (planes, oscale, mask) if want_mask else (planes, oscale)
 
 
@@ -398,14 +398,12 @@ def apply_split(xs, mu, A, bias, slot, plan=None, relu=False, out=None, folded=F
         planes = torch.empty((2,) + tuple(xs.shape), dtype=torch.float16, device=dev) if _planes_out is None else _planes_out
     else:
         y = torch.empty(xs.shape, dtype=torch.float32, device=dev) if out is None else out
-    if TRACE is not None:
-        _trace("wc_apply_split_ex_f16x2", f"apply_split_kernel<{C}, {_tf(slot is not None)}, {_tf(want_mask)}, {_tf(oscale is not None)}>",
-               lambda: apply_split(xs, mu, A, bias, slot, plan=plan, relu=relu, out=y, folded=folded, ws=ws, want_mask=want_mask, oscale=oscale,
-                                   _mask_out=mask, _planes_out=planes))      # (the re-run allocates nothing: the host must not set the pace)
-    _lib.check(lib.wc_apply_split_ex_f16x2(_ptr(xs.planes), None if folded else _ptr(xs.center), _ptr(xs.scale), None if folded else _ptr(mu),
-                                           _ptr(A), _ptr(bias), _ptr(slot), N, HW, C, Kc, 1 if relu else 0, _ptr(y), _ptr(mask),
-                                           _ptr(planes), _ptr(oscale), _ptr(plan), _ptr(ws), ws.numel(), _stream()),
-               "wc_apply_split_ex_f16x2")
+    _call(lib.wc_apply_split_ex_f16x2, (_ptr(xs.planes), None if folded else _ptr(xs.center), _ptr(xs.scale), None if folded else _ptr(mu),
+                                        _ptr(A), _ptr(bias), _ptr(slot), N, HW, C, Kc, 1 if relu else 0, _ptr(y), _ptr(mask),
+                                        _ptr(planes), _ptr(oscale), _ptr(plan), _ptr(ws), ws.numel()),
+          "wc_apply_split_ex_f16x2", "wc_apply_split_ex_f16x2",
+          None if TRACE is None else f"apply_split_kernel<{C}, {_tf(slot is not None)}, {_tf(want_mask)}, {_tf(oscale is not None)}>",
+          (xs.planes, xs.center, xs.scale, mu, A, bias, slot, y, mask, planes, oscale, plan, ws))
     if planes is not None:
         return (planes, oscale, mask) if want_mask else (planes, oscale)
     return (y, mask) if want_mask else y
