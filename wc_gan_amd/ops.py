@@ -138,6 +138,9 @@ def whiten(x2d, eps, momentum, ddof, moving_mean, moving_cov, groups=1):
 # WC_CHECK_K2=1: read K2's error words back after every call (a host synchronisation per site: for shared / time-sliced GPUs and for
 # debugging -- not under graph capture).  The one-launch K2 waits, with a bounded spin, for a workgroup of its own launch.
 CHECK_K2 = os.environ.get("WC_CHECK_K2", "0") == "1"
+# WC_CHECK_SPLIT=1: read the saturation flag of every resadd_split / split back (a host synchronisation per call: debugging, or data
+# whose outliers may exceed ~3700 x a channel's sampled maximum -- the planes route saturates there, the fp32 route has an exact redo)
+CHECK_SPLIT = os.environ.get("WC_CHECK_SPLIT", "0") == "1"
 
 
 def _check_k2(ws, offset, groups, what):
@@ -475,6 +478,9 @@ def resadd_split(h, s, up=False, want_x32=False):
     x32 = torch.empty_like(h) if want_x32 else None
     _lib.check(lib.wc_resadd_split_f32(_ptr(h), _ptr(s), N, H, W, C, 1 if up else 0, _ptr(planes), _ptr(center), _ptr(scale), _ptr(flag),
                                        _ptr(x32), _stream()), "wc_resadd_split_f32")
+    if CHECK_SPLIT and not torch.cuda.is_current_stream_capturing() and int(flag[0]) != 0:
+        raise _lib.WcHipError("wc_resadd_split_f32: an element beyond +-60000 after scaling saturated (flag[0] = 1); "
+                              "run with WC_SPLIT_PRODUCER=0 (the fp32 sum and the fp32 route's exact redo) for such data")
     return SplitTensor(planes, center, scale, flag, h.shape, x32)
 
 
