@@ -54,12 +54,16 @@ __device__ __forceinline__ int64_t src_row(const ResAddArgs& a, unsigned row)
 // centre / scale of the sum from <= 256 sampled rows: subsample_mean_scale_kernel (wc_rows.hip) on h + up(s).  Same sample
 // (rows r * (M / 256)), same statistics, same results as that kernel gives on the fp32 sum -- bit for bit: the sum of two floats is
 // the float the fp32 tensor would hold.
-__global__ __launch_bounds__(1024) void resadd_sample_kernel(ResAddArgs a)
+// (16 channels per 256-thread workgroup, C / 16 workgroups: the kernel is a chain of latencies -- 32 loads per thread, three meetings --
+// and 16 small workgroups on 16 CUs run it in 8-9 us where 4 workgroups of 1024 threads took 12.8)
+constexpr int kSampCh = 16;
+__global__ __launch_bounds__(256) void resadd_sample_kernel(ResAddArgs a)
 {
-    __shared__ float red[16][64];
+    __shared__ float red[16][kSampCh];
     const int C = a.C;
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int part = threadIdx.x >> 6;
+    const int cl = threadIdx.x & (kSampCh - 1);
+    const int c = blockIdx.x * kSampCh + cl;
+    const int part = threadIdx.x / kSampCh;
     const int64_t nsamp = a.M < 256 ? a.M : 256;
     const int64_t stride = a.M / nsamp;
     if (blockIdx.x == 0 && threadIdx.x < 64) a.flag[threadIdx.x] = 0;
@@ -76,16 +80,16 @@ __global__ __launch_bounds__(1024) void resadd_sample_kernel(ResAddArgs a)
         }
         sacc += v[i];
     }
-    red[part][threadIdx.x & 63] = sacc;
+    red[part][cl] = sacc;
     __syncthreads();
-    __shared__ float centre2[2][64];             // [0] mean, [1] median of the 16 group means (the outlier-proof centre)
-    if (threadIdx.x < 64) {
+    __shared__ float centre2[2][kSampCh];        // [0] mean, [1] median of the 16 group means (the outlier-proof centre)
+    if (threadIdx.x < kSampCh) {
         float t = 0.f, pm[16];
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
             const float ps = red[p][threadIdx.x];
             t += ps;
-            const int64_t cnt = (nsamp - p + 15) / 16;
+            const int cnt = (int)((nsamp - p + 15) / 16);
             pm[p] = cnt > 0 ? ps / (float)cnt : 0.f;
         }
         const float mean_ = t / (float)nsamp;
@@ -93,18 +97,19 @@ __global__ __launch_bounds__(1024) void resadd_sample_kernel(ResAddArgs a)
         centre2[1][threadIdx.x] = nsamp >= 16 ? wc_median16(pm) : mean_;
     }
     __syncthreads();
-    const float mean = centre2[0][threadIdx.x & 63], med = centre2[1][threadIdx.x & 63];
+    const float mean = centre2[0][cl], med = centre2[1][cl];
     float mx = 0.f, mx2 = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int64_t r = part + 16 * i;
         if (c < C && r < nsamp) { mx = fmaxf(mx, fabsf(v[i] - mean)); mx2 = fmaxf(mx2, fabsf(v[i] - med)); }
     }
-    __shared__ float red2[16][64];
-    red[part][threadIdx.x & 63] = mx;
-    red2[part][threadIdx.x & 63] = mx2;
+    __shared__ float red2[16][kSampCh];
     __syncthreads();
-    if (threadIdx.x < 64 && c < C) {
+    red[part][cl] = mx;
+    red2[part][cl] = mx2;
+    __syncthreads();
+    if (threadIdx.x < kSampCh && c < C) {
         float g1[16], g2[16];
 #pragma unroll
         for (int p = 0; p < 16; ++p) { g1[p] = red[p][threadIdx.x]; g2[p] = red2[p][threadIdx.x]; }
@@ -279,7 +284,7 @@ hipError_t wc_launch_resadd(const float* h, const float* s, int64_t N, int64_t H
     int64_t blocks = (n8 + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     if (xs) {
-        hipLaunchKernelGGL(resadd_sample_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, a);
+        hipLaunchKernelGGL(resadd_sample_kernel, dim3((C + kSampCh - 1) / kSampCh), dim3(256), 0, st, a);
         if (x32) hipLaunchKernelGGL((resadd_kernel<true, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((resadd_kernel<true, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
     } else {
