@@ -221,8 +221,7 @@ def roofline_apply(dev):
         if on_planes:
             st = WF.split_of(xin)
             mu_, _, W_ = ops.whiten_split(st, 1e-3, 0.99, 1, None, None)
-            A_, _, _ = ops.color(W_, gamma, st.scale)
-            ops.split_bias(A_, b, st, mu_)
+            ops.color_split(W_, gamma, st, mu_, b)
         else:
             mu_, _, W_, cs_ = ops.whiten(x.view(M, C), 1e-3, 0.99, 1, None, None)
             ops.color(W_, gamma, cs_)
@@ -274,7 +273,7 @@ def roofline_apply(dev):
         "K1 wc_stats_split_f16x2 (planes)": stage(lambda: ops.stats_split(xs), xb),
         "K2 wc_factor_f64": only_us(lambda: ops.factor(s, xtx, M, C, 1e-3, 0.99, 1, True, None, None, dev)),
         "color wc_color_f32": only_us(lambda: ops.color(W, gamma, cs)),
-        "split_bias wc_split_bias_f32 (planes route only)": only_us(lambda: ops.split_bias(A2, b, xs, mu)),
+        "color wc_color_split_f32 (planes route: tables for the planes' scales + the additive term, same launch count)": only_us(lambda: ops.color_split(W, gamma, xs, mu, b)),
         "  replaces: wc_conv_split_f32 of y (absmax + split, two launches) where K3 writes the next convolution's planes": only_us(lambda: fconv.split_planes(y_relu)),
         "K4 wc_bwd_reduce_f32": stage(lambda: ops.bwd_reduce(x, mu, gy, None, 1), 2 * xb),
         "K4 wc_bwd_reduce_bits_f32 (bit mask in, no masked copy out: as the generator runs it)":

@@ -235,6 +235,20 @@ int    wc_whiten_split_f16x2(const void* xs, const float* xs_center, const float
                              float* mu /*[groups,C]*/, double* L /*[groups,C,C]*/, double* W /*[groups,C,C]*/,
                              void* ws, size_t ws_bytes, wc_stream_t stream);
 
+/* The planes route's glue (ABI 5).  wc_color_split_f32: wc_color_f32 (one statistic group) for a site whose input is pre-split -- A, At,
+ * the apply's tables for the PLANES' scales, and in the same launch bias_eff[k] = beta[k] + (xs_center - mu) A[k], the additive term
+ * wc_apply_split_ex_f16x2 takes as `bias` with mu = xs_center = NULL (wc_split_bias_f32 as a launch of its own cost the forward site
+ * 5 us).  C in {32, 64, 128, 256}.  wc_group_bias_centered_f32: wc_group_bias_f32 with the common centre GIVEN (the planes' centre):
+ * bias[g*Kc+k] = beta[k] - (mu[g] - center) A[g*Kc+k] is then the grouped planes route's additive term directly.
+ * Replace the same reference call sites as wc_color_f32 / wc_group_bias_f32 (generator.py:28-80 coloring layers folded into W). */
+int wc_color_split_f32(const double* W /*[C,C]*/, const float* gamma /*[Kc,C,C] or NULL*/, int Kc, int C, float* A /*[Kc,C,C] out*/,
+                       float* At /*nullable*/, const float* xs_scale, const float* xs_center, const float* mu /*[C]*/,
+                       const float* beta /*[Kc,C], nullable*/, void* plan /*out: wc_apply_plan_bytes(C, Kc)*/, float* bias_eff /*[Kc,C] out*/,
+                       void* ws, size_t ws_bytes, wc_stream_t stream);
+int wc_group_bias_centered_f32(const float* mu /*[groups,C]*/, const float* A /*[groups*Kc,C,C]*/, const float* beta /*nullable*/,
+                               const float* center /*[C] in*/, int groups, int Kc, int C, int per_group, float* bias /*[groups*Kc,C] out*/,
+                               wc_stream_t stream);
+
 /* K3 on a pre-split input with the epilogues the generator's sites use (ABI 5): as wc_apply_split_f16x2, and
  *   relu_mask (nullable; relu = 1, N*HW a multiple of 32): the ReLU's one-bit gradient mask, as wc_apply_mask_f32 leaves it;
  *   planes + oscale instead of y (exactly one of y / planes is given): the output as the next convolution's fp16 planes,

@@ -97,6 +97,9 @@ SIGNATURES = {
     "wc_patch_sum_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "wc_fold_channel_scale_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wc_unfold_channel_scale_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wc_color_split_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wc_group_bias_centered_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "wc_bwd_xsplit_supported": (c_int, [c_int64, c_int64, c_int, c_int]),
     "wc_bwd_reduce_xsplit_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -262,6 +262,44 @@ int wc_group_bias_f32(const float* mu, const float* A, const float* beta, int gr
     return WC_OK;
 }
 
+// The planes route's glue (ABI 5): as wc_color_f32 / wc_group_bias_f32, with the additive term of an apply on a pre-split input
+// produced by the same launches (no wc_split_bias_f32 launch in front of K3).
+int wc_color_split_f32(const double* W, const float* gamma, int Kc, int C, float* A, float* At, const float* xs_scale, const float* xs_center,
+                       const float* mu, const float* beta, void* plan, float* bias_eff, void* ws, size_t ws_bytes, wc_stream_t stream)
+{
+    (void)ws; (void)ws_bytes;
+    if (!W || !A || !xs_scale || !plan || !bias_eff) return WC_ERR_NULL;
+    if (bad_channels(C)) return WC_ERR_CHANNELS;
+    if (!(C == 32 || C == 64 || C == 128 || C == 256)) return WC_ERR_CHANNELS;
+    if (Kc <= 0 || (!gamma && Kc != 1)) return WC_ERR_SHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!gamma) WC_TRY(wc_launch_transpose_to_f32(W, C, 1, A, At, st));
+    else {
+        const int64_t CC = (int64_t)C * C;
+        WcGemm g = {};
+        g.A = W; g.a_rs = 1; g.a_cs = C; g.a_bs = 0;                         // W^T
+        g.B = gamma; g.b_is_f32 = 1; g.b_rs = C; g.b_cs = 1; g.b_bs = CC;
+        g.Cm = A; g.c_is_f32 = 1; g.c_rs = C; g.c_cs = 1; g.c_bs = CC;
+        g.Cm2 = At; g.c2_rs = 1; g.c2_cs = C; g.c2_bs = CC;
+        g.m = C; g.n = C; g.k = C; g.batch = Kc; g.nred = 1; g.alpha = 1.0; g.epi = WC_EPI_NONE;
+        g.batch2 = 1; g.a_b2s = CC; g.b_b2s = 0; g.c_b2s = (int64_t)Kc * CC;
+        WC_TRY(wc_launch_gemm(g, st));
+    }
+    // the tables for the planes' scales AND bias_eff[k] = beta[k] + (center - mu) A[k] in ONE launch
+    WC_TRY(wc_launch_fast_plan_tables_bias(A, Kc, C, plan, st, xs_scale, beta, xs_center, mu, bias_eff));
+    return WC_OK;
+}
+
+int wc_group_bias_centered_f32(const float* mu, const float* A, const float* beta, const float* center, int groups, int Kc, int C,
+                               int per_group, float* bias, wc_stream_t stream)
+{
+    if (!mu || !A || !center || !bias) return WC_ERR_NULL;
+    if (groups <= 0 || Kc <= 0) return WC_ERR_SHAPE;
+    if (bad_channels(C)) return WC_ERR_CHANNELS;
+    WC_TRY(wc_launch_group_bias(mu, A, beta, groups, Kc, C, per_group, nullptr, bias, static_cast<hipStream_t>(stream), center));
+    return WC_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 size_t wc_apply_workspace_bytes(int64_t N, int64_t HW, int C, int Kc)
 {
@@ -815,9 +853,8 @@ int wc_bwd_apply_xsplit_f32(const float* gy, const void* relu_mask, const void* 
     void* plan1 = w + wc_fast_affine_workspace(C, Kc);
     float* subf = reinterpret_cast<float*>(w + wc_fast_affine_workspace(C, Kc) + wc_fast_affine_workspace(C, 1));
     // the tables of both halves in one launch: At for gy's scales, S for the planes' scales
-    WC_TRY(wc_launch_fast_plan_tables2(At, Kc, plan0, scales + C, S, 1, plan1, xs_scale, C, st));
-    // dx = gy At + (x - mu) S - gmean with x - mu = g / scale + (center - mu):  sub = gmean + (mu - center) S
-    WC_TRY(wc_launch_split_bias(S, gmean, mu, xs_center, 1, C, subf, st));
+    // ... and, in the same launch:  dx = gy At + (x - mu) S - gmean with x - mu = g / scale + (center - mu):  sub = gmean + (mu - center) S
+    WC_TRY(wc_launch_fast_plan_tables2_bias(At, Kc, plan0, scales + C, S, plan1, xs_scale, C, st, gmean, mu, xs_center, subf));
     WC_TRY(wc_launch_bwd_apply_onepass(gy, nullptr, mu, At, Kc, S, subf, slot, N, HW, scales, dx, plan0, plan1, st,
                                        static_cast<const unsigned*>(relu_mask), xs, xs_scale));
     return WC_OK;

@@ -142,6 +142,11 @@ hipError_t wc_launch_bwd_apply_onepass(const float* gy, const float* x, const fl
                                                                                                    for xs_scale, gmean folded: gmean - (center - mu) S*/);
 hipError_t wc_launch_fast_plan_tables2(const float* B0, int Kc0, void* plan0, const float* scale0,
                                        const float* B1, int Kc1, void* plan1, const float* scale1, int C, hipStream_t st);
+hipError_t wc_launch_fast_plan_tables_bias(const float* B, int Kc, int C, void* plan, hipStream_t st, const float* scale,
+                                           const float* bias, const float* center, const float* mu, float* bias_out);
+hipError_t wc_launch_fast_plan_tables2_bias(const float* B0, int Kc0, void* plan0, const float* scale0,
+                                            const float* B1, void* plan1, const float* scale1, int C, hipStream_t st,
+                                            const float* bias, const float* center, const float* mu, float* bias_out);
 float* wc_fast_plan_scale(void* plan);
 hipError_t wc_launch_fast_affine_planned(const float* in, const float* center, const float* B, int Kc, bool shared_table,
                                          const float* bias, const float* sub, const int32_t* slot,
@@ -235,7 +240,7 @@ hipError_t wc_launch_gemm_pair_dd_fd(const WcGemm& g0, const WcGemm& g1, hipStre
 
 hipError_t wc_launch_transpose_to_f32(const double* W, int C, int groups, float* A, float* At, hipStream_t st);  // A = W^T, At = W
 hipError_t wc_launch_group_bias(const float* mu, const float* A, const float* beta, int G, int Kc, int C, int per_group,
-                                float* center, float* bias, hipStream_t st);
+                                float* center, float* bias, hipStream_t st, const float* center_in = nullptr /*given: the common centre (center is not written)*/);
 hipError_t wc_launch_f64_to_f32(const double* src, float* dst, int64_t n, hipStream_t st);
 hipError_t wc_launch_bwd_tail(const double* Q, int C, double scale, float* S, const double* gsum, const float* A, int Kc,
                               int64_t M, float* gmean, float* dbeta, hipStream_t st);      // S = scale sym(Q), gmean, dbeta = float(gsum) in one launch

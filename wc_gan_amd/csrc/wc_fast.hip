@@ -117,8 +117,28 @@ __global__ __launch_bounds__(1024) void channel_scale_kernel(const float* __rest
 // --------------------------------------------------------------------------------------------
 // (two tables in one launch: K6 builds At's and S's together; a single table passes rows1 = 0)
 struct SplitJob { const float* B; const float* scale; _Float16* hi; _Float16* lo; float* colscale; float* scale_out; int rows; };
-__global__ __launch_bounds__(64) void split_table_kernel(SplitJob j0, SplitJob j1, int C)
+// (round 4) a third, independent job in the same launch: the additive term of an apply on pre-split planes,
+//     out[slot][n] = bias[slot][n] + sum_k (center[k] - mu[k]) A[slot][k][n]          (wc_split.hip's split_bias_kernel)
+// -- it needs A only, as the tables do, and as a launch of its own it cost the forward site 5 us between the tables and K3
+struct BiasJob { const float* A; const float* bias; const float* center; const float* mu; float* out; int slots; };
+__global__ __launch_bounds__(64) void split_table_kernel(SplitJob j0, SplitJob j1, int C, BiasJob bj)
 {
+    if ((int)blockIdx.x >= j0.rows + j1.rows) {      // bias job: one workgroup per (slot, 32 columns); thread (q, n) sums the rows k = q mod 2
+        __shared__ double red[64];
+        const int bb = (int)blockIdx.x - j0.rows - j1.rows, nch = C / 32;
+        const int slot = bb / nch, n = (bb % nch) * 32 + (threadIdx.x & 31), q = threadIdx.x >> 5;
+        const float* a = bj.A + (int64_t)slot * C * C + n;
+        double acc = 0.0;
+#pragma unroll 8
+        for (int k = q; k < C; k += 2) {
+            const double d = (double)(bj.center ? bj.center[k] : 0.f) - (double)(bj.mu ? bj.mu[k] : 0.f);
+            acc += d * (double)a[(int64_t)k * C];
+        }
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        if (q == 0) bj.out[(int64_t)slot * C + n] = (float)(red[threadIdx.x] + red[threadIdx.x + 32] + (bj.bias ? (double)bj.bias[(int64_t)slot * C + n] : 0.0));
+        return;
+    }
     const bool second = (int)blockIdx.x >= j0.rows;
     const float* __restrict__ B = second ? j1.B : j0.B;
     const float* __restrict__ scale = second ? j1.scale : j0.scale;
@@ -1748,15 +1768,36 @@ static SplitJob split_job(const float* B, int Kc, int C, void* plan, const float
 hipError_t wc_launch_fast_plan_tables(const float* B, int Kc, int C, void* plan, hipStream_t st, const float* scale)
 {
     SplitJob none = {};
-    hipLaunchKernelGGL(split_table_kernel, dim3((unsigned)(Kc * C)), dim3(64), 0, st, split_job(B, Kc, C, plan, scale), none, C);
+    BiasJob nob = {};
+    hipLaunchKernelGGL(split_table_kernel, dim3((unsigned)(Kc * C)), dim3(64), 0, st, split_job(B, Kc, C, plan, scale), none, C, nob);
+    return hipGetLastError();
+}
+// the tables of B and, in the same launch, bias_out[slot] = bias[slot] + (center - mu) B[slot]  (the planes route's additive term)
+hipError_t wc_launch_fast_plan_tables_bias(const float* B, int Kc, int C, void* plan, hipStream_t st, const float* scale,
+                                           const float* bias, const float* center, const float* mu, float* bias_out)
+{
+    SplitJob none = {};
+    BiasJob bj = {B, bias, center, mu, bias_out, Kc};
+    hipLaunchKernelGGL(split_table_kernel, dim3((unsigned)(Kc * C + Kc * (C / 32))), dim3(64), 0, st, split_job(B, Kc, C, plan, scale), none, C, bj);
     return hipGetLastError();
 }
 // two plans (with their input scales given) in one launch
 hipError_t wc_launch_fast_plan_tables2(const float* B0, int Kc0, void* plan0, const float* scale0,
                                        const float* B1, int Kc1, void* plan1, const float* scale1, int C, hipStream_t st)
 {
+    BiasJob nob = {};
     hipLaunchKernelGGL(split_table_kernel, dim3((unsigned)((Kc0 + Kc1) * C)), dim3(64), 0, st,
-                       split_job(B0, Kc0, C, plan0, scale0), split_job(B1, Kc1, C, plan1, scale1), C);
+                       split_job(B0, Kc0, C, plan0, scale0), split_job(B1, Kc1, C, plan1, scale1), C, nob);
+    return hipGetLastError();
+}
+// ... and K6 on a pre-split x: gmean folded with (mu - center) S in the same launch (bias job on the second table)
+hipError_t wc_launch_fast_plan_tables2_bias(const float* B0, int Kc0, void* plan0, const float* scale0,
+                                            const float* B1, void* plan1, const float* scale1, int C, hipStream_t st,
+                                            const float* bias, const float* center, const float* mu, float* bias_out)
+{
+    BiasJob bj = {B1, bias, center, mu, bias_out, 1};
+    hipLaunchKernelGGL(split_table_kernel, dim3((unsigned)((Kc0 + 1) * C + C / 32)), dim3(64), 0, st,
+                       split_job(B0, Kc0, C, plan0, scale0), split_job(B1, 1, C, plan1, scale1), C, bj);
     return hipGetLastError();
 }
 

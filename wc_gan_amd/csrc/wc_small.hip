@@ -1420,16 +1420,22 @@ __global__ __launch_bounds__(128) void bwd_tail_kernel(const double* __restrict_
 // s = g*Kc + k.  One block per slot s.
 __global__ __launch_bounds__(256) void group_bias_kernel(const float* __restrict__ mu, const float* __restrict__ A,
                                                          const float* __restrict__ beta, int G, int Kc, int C, int per_group,
-                                                         float* __restrict__ center, float* __restrict__ bias)
+                                                         float* __restrict__ center, float* __restrict__ bias,
+                                                         const float* __restrict__ center_in)
 {
     __shared__ double dm[1024];
     const int s_ = blockIdx.x, g = s_ / Kc, k = s_ % Kc;
     for (int c = threadIdx.x; c < C; c += 256) {
+        // center_in (round 4): the common centre is GIVEN -- the centre of a pre-split input's planes -- so that the biases are the
+        // planes route's additive terms beta - (mu_g - center) A directly (no wc_split_bias_f32 launch behind this one)
         double m = 0.0;
-        for (int gg = 0; gg < G; ++gg) m += (double)mu[(int64_t)gg * C + c];
-        m /= (double)G;
+        if (center_in) m = (double)center_in[c];
+        else {
+            for (int gg = 0; gg < G; ++gg) m += (double)mu[(int64_t)gg * C + c];
+            m /= (double)G;
+            if (s_ == 0) center[c] = (float)m;
+        }
         dm[c] = (double)mu[(int64_t)g * C + c] - m;
-        if (s_ == 0) center[c] = (float)m;
     }
     __syncthreads();
     const float* As = A + (int64_t)s_ * C * C;
@@ -1675,9 +1681,9 @@ hipError_t wc_launch_bwd_tail(const double* Q, int C, double scale, float* S, co
 }
 
 hipError_t wc_launch_group_bias(const float* mu, const float* A, const float* beta, int G, int Kc, int C, int per_group,
-                                float* center, float* bias, hipStream_t st)
+                                float* center, float* bias, hipStream_t st, const float* center_in)
 {
-    hipLaunchKernelGGL(group_bias_kernel, dim3(G * Kc), dim3(256), 0, st, mu, A, beta, G, Kc, C, per_group, center, bias);
+    hipLaunchKernelGGL(group_bias_kernel, dim3(G * Kc), dim3(256), 0, st, mu, A, beta, G, Kc, C, per_group, center, bias, center_in);
     return hipGetLastError();
 }
 

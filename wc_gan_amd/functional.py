@@ -84,12 +84,14 @@ class WhitenColorFunction(torch.autograd.Function):
             _touched(moving_mean, moving_cov)
         g = gamma.contiguous() if gamma is not None else None
         b = beta.contiguous() if beta is not None else None
-        A, At, plan = ops.color(W, g, chan_scale)      # plan: the apply's fp16 tables, so K3 is one launch
+        if st is not None:      # ... and, on planes, the additive term beta + (center - mu) A from the same launch as the tables
+            A, At, plan, be = ops.color_split(W, g, st, mu, b)
+        else:
+            A, At, plan = ops.color(W, g, chan_scale)      # plan: the apply's fp16 tables, so K3 is one launch
         # relu: folded into K3's epilogue (row N2).  Its gradient mask is kept as ONE BIT per element (K3 writes it): the
         # backward neither re-reads y (K4: 134 MB at the headline site) nor keeps y alive for it
         bits = bool(relu) and M_local % 32 == 0
         if st is not None:
-            be = ops.split_bias(A, b, st, mu)          # beta + (center - mu) A: the planes' additive term, K3 is ONE launch
             if planes_box is not None:
                 rec = ops.out_scale(g, b, C, dev)
                 out = ops.apply_split(st, None, A, be, slot, plan=plan, relu=relu, folded=True, want_mask=bits, oscale=rec)
@@ -341,7 +343,7 @@ def whiten_color_grouped(x, groups, gamma=None, beta=None, slot=None, moving_mea
         # (the predicted scale follows from the coloring tables as given: every group's whitened batch has unit covariance)
         handoff = planes and conv_handoff_supported(x.shape, relu, 1 if g is None else g.shape[0])
         if st is not None:
-            be = ops.split_bias(A, bias, st, center)
+            be = bias            # (already beta - (mu_g - st.center) A: group_bias_centered)
             if handoff:
                 rec = ops.out_scale(g, b, C, dev)
                 both, rec = ops.apply_split(st, None, A, be, slots, plan=plan, relu=relu, folded=True, oscale=rec)
@@ -352,16 +354,22 @@ def whiten_color_grouped(x, groups, gamma=None, beta=None, slot=None, moving_mea
             return attach_planes(_apply_planes(x, center, A, bias, slots, plan, g, relu, False, box, beta=b), box)
         return ops.apply(x, center, A, bias, slots, plan=plan, relu=relu)
 
+    def gbias(A, Kc, per_group):
+        # on planes the common centre is the planes' own: the biases are then the additive terms of the split apply directly
+        if st is not None:
+            return st.center, ops.group_bias_centered(mu.view(groups, C), A, b, st.center, groups, Kc, per_group=per_group)
+        return ops.group_bias(mu.view(groups, C), A, b, groups, Kc, per_group=per_group)
+
     if per_sample:
         if g is None or g.shape[0] != N:
             raise ValueError("per_sample needs one coloring table per sample")
         Kc = N // groups
         A, At, plan = ops.color(W, g, cs, groups, per_group=True)
-        center, bias = ops.group_bias(mu.view(groups, C), A, b, groups, Kc, per_group=True)
+        center, bias = gbias(A, Kc, True)
         return finish(center, A, bias, _group_slot_base(N, N, 1, dev), plan)
     Kc = 1 if g is None else g.shape[0]
     A, At, plan = ops.color(W, g, cs, groups)
-    center, bias = ops.group_bias(mu.view(groups, C), A, b, groups, Kc)
+    center, bias = gbias(A, Kc, False)
     full_slot = _group_slot_base(N, groups, Kc, dev)
     if slot is not None:
         full_slot = (full_slot + slot.view(-1)).to(torch.int32).contiguous()

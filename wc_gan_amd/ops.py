@@ -178,6 +178,38 @@ def color(W, gamma, chan_scale=None, groups=1, per_group=False):
     return A, At
 
 
+def color_split(W, gamma, xs, mu, beta):
+    """color() for a site whose input is the SplitTensor xs (one statistic group): -> (A, At, plan, bias_eff) with the tables built for
+    the planes' scales and bias_eff = beta + (xs.center - mu) A from the same launch (wc_color_split_f32): apply_split(xs, None, A,
+    bias_eff, ..., plan=plan, folded=True) is then K3's single launch."""
+    lib = _lib.load()
+    C = W.shape[-1]
+    Kc = 1 if gamma is None else gamma.shape[0]
+    if gamma is not None:
+        _need(gamma, torch.float32, "gamma", 3)
+    if beta is not None:
+        _need(beta, torch.float32, "beta", 2)
+    dev = W.device
+    A = torch.empty(Kc, C, C, dtype=torch.float32, device=dev)
+    At = torch.empty(Kc, C, C, dtype=torch.float32, device=dev)
+    plan = _workspace(lib.wc_apply_plan_bytes(C, Kc), dev)
+    be = torch.empty(Kc, C, dtype=torch.float32, device=dev)
+    _lib.check(lib.wc_color_split_f32(_ptr(W), _ptr(gamma), Kc, C, _ptr(A), _ptr(At), _ptr(xs.scale), _ptr(xs.center), _ptr(mu), _ptr(beta),
+                                      _ptr(plan), _ptr(be), None, 0, _stream()), "wc_color_split_f32")
+    return A, At, plan, be
+
+
+def group_bias_centered(mu, A, beta, center, groups, Kc, per_group=False):
+    """group_bias() with the common centre given (a SplitTensor's centre): -> bias (groups*Kc, C), the grouped planes route's additive
+    term beta - (mu_g - center) A directly."""
+    lib = _lib.load()
+    C = mu.shape[-1]
+    bias = torch.empty(groups * Kc, C, dtype=torch.float32, device=mu.device)
+    _lib.check(lib.wc_group_bias_centered_f32(_ptr(mu), _ptr(A), _ptr(beta), _ptr(center), groups, Kc, C, int(bool(per_group)), _ptr(bias),
+                                              _stream()), "wc_group_bias_centered_f32")
+    return bias
+
+
 def group_bias(mu, A, beta, groups, Kc, per_group=False):
     """Grouped forward glue -> (center (C,), bias (groups*Kc, C)); see wc_group_bias_f32."""
     lib = _lib.load()
