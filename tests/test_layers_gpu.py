@@ -610,6 +610,23 @@ def test_sync_wc_path_with_a_one_rank_rccl_group(tmp_path):
                 outs.append((y.detach(), xt.grad, Gt.grad, Bt.grad, mc))
             for a, b in zip(*outs):
                 assert torch.equal(a, b)
+        # round 4: the same with the site's input arriving as pre-split planes (K1 on planes -> one collective on its buffer -> K2;
+        # K4 on planes -> one collective on its buffer): per-replica == one-rank sync-WC, bit for bit
+        from wc_gan_amd.functional import residual_add
+        shape, C = (32, 32, 32, 256), 256
+        x = o.synth_activation(rng, shape, "ill").astype(np.float32)
+        G, B = o.synth_coloring(rng, C, 1)
+        gy = dev(rng.standard_normal(shape))
+        outs = []
+        for group in (None, dist.group.WORLD):
+            xt = dev(x).requires_grad_(True); Gt = dev(G).requires_grad_(True); Bt = dev(B).requires_grad_(True)
+            mm = torch.zeros(C, 1, device="cuda"); mc = torch.eye(C, device="cuda")
+            xin = residual_add(xt, torch.zeros_like(xt), False, planes=True, x32=False)
+            y = whiten_color(xin, Gt, Bt, None, mm, mc, True, process_group=group, relu=True)
+            y.backward(gy)
+            outs.append((y.detach(), xt.grad, Gt.grad, Bt.grad, mc))
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
     finally:
         dist.destroy_process_group()
 
