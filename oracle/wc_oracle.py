@@ -294,6 +294,29 @@ def synth_activation(rng, shape, conditioning='ill'):
     return (z @ mix + 0.2).reshape(shape)
 
 
+def synth_activation_family(rng, shape, family):
+    """Ill-conditioned inputs whose ELEMENTS are not gaussian (round 4, VERDICT r3 item 6: the families on which a constant fitted on
+    gaussian mixes could over- or under-correct):  x = z * s + 2 (F V^T) + 0.2  with z (M, C) and F (M, 8) iid unit-variance draws of
+    `family` ('uniform', 'relu' = post-ReLU half-sparse, 'heavy' = Laplace, anything else: gaussian), s per-channel scales over two
+    decades, V (C, 8) gaussian: eight eigenvalues ~ 4 C on top of idiosyncratic variances down to 1e-4 -- cond((1 - eps) Sigma + eps I)
+    ~ 1.2e6 at C = 256 without a dense mix (which would make every element gaussian again).  The whitening's cancellation ratio is
+    ~500 here (~30 for synth_activation's 'ill'): the reference's own op order in fp32 is 5e-3 .. 1e-2 from float64 on these."""
+    C = shape[-1]
+    M = int(np.prod(shape[:-1]))
+
+    def draw(n):
+        if family == "uniform":
+            return rng.uniform(-np.sqrt(3.0), np.sqrt(3.0), (M, n))
+        if family == "relu":                    # post-ReLU: half of the elements exactly zero; unit second moment about the mean
+            return np.maximum(rng.standard_normal((M, n)), 0.0) / np.sqrt(0.5 - 1.0 / (2 * np.pi))
+        if family == "heavy":                   # Laplace (kurtosis 6; the largest of 8e9 draws ~ 16 sigma)
+            return rng.laplace(0.0, 1.0 / np.sqrt(2.0), (M, n))
+        return rng.standard_normal((M, n))
+    s = 10.0 ** rng.uniform(-2.0, 0.0, C)
+    V = rng.standard_normal((C, 8))
+    return (draw(C) * s + 2.0 * (draw(8) @ V.T) + 0.2).reshape(shape)
+
+
 def synth_coloring(rng, C, Kc=1):
     gamma = rng.standard_normal((Kc, C, C)) / np.sqrt(C)
     beta = 0.1 * rng.standard_normal((Kc, C))

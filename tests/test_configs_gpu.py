@@ -89,6 +89,37 @@ def test_seed_sweep_cases_hold_the_contract_with_margin(shape, seed):
     assert all(v < 9e-5 for v in errs.values()), errs
 
 
+@pytest.mark.parametrize("family,shape", [("uniform", (128, 32, 32, 256)), ("relu", (128, 16, 16, 256)), ("heavy", (128, 32, 32, 256)),
+                                          ("uniform", (128, 32, 32, 128)), ("relu", (128, 32, 32, 64))])
+def test_non_gaussian_families_hold_their_documented_bounds(family, shape):
+    """the off-diagonal bias compensation of K1 (kXtyOffdiagBias) was fitted on gaussian mixes -- full-size,
+    cond(Sigma~) ~ 1e6 cases on the families where it could over-correct: uniform, post-ReLU half-sparse and heavy-tailed (Laplace)
+    elements, C = 256 / 128 / 64 (oracle.synth_activation_family).  These inputs are HARDER than the contract's kernel-bench input (the
+    whitening cancels terms of size ~500 into results of size 1, ~30 there), and the arithmetic the contract names -- the reference's op
+    order in fp32 -- is itself 5e-3 .. 1e-2 (y) and 1e-2 .. 3e-2 (dx) from float64 on them (tools/seed_sweep.py --families --ref32,
+    profiles/r4_seed_sweep.txt).  Documented bounds of this build over 3 seeds x 4 sites per family: y <= 1.2e-4, dx <= 3.6e-4, dGamma
+    <= 1.9e-4 with the compensation (dx <= 4.5e-4 without: it helps on every family, by 20-35 %).  Asserted here with a margin: y 2e-4,
+    dx 5e-4, dGamma 3e-4 -- 50 x closer to float64 than the fp32 reference order."""
+    from wc_gan_amd.functional import whiten_color
+    rng = np.random.default_rng(100)
+    C = shape[-1]
+    x = o.synth_activation_family(rng, shape, family).astype(np.float32)
+    G, B = o.synth_coloring(rng, C, 1)
+    G = G.astype(np.float32); B = B.astype(np.float32)
+    gy = rng.standard_normal(shape).astype(np.float32)
+    y_ref, cache = o.wc_forward(x, G, B, None)
+    ev = np.linalg.eigvalsh((1 - 1e-3) * cache['sigma'] + 1e-3 * np.eye(C))
+    assert ev[-1] / ev[0] > (1e6 if C == 256 else 3e5)
+    dx_ref, dG_ref, dB_ref = o.wc_backward(gy, cache)
+    xt = dev(x).requires_grad_(True); Gt = dev(G).requires_grad_(True); Bt = dev(B).requires_grad_(True)
+    y = whiten_color(xt, Gt, Bt, None, None, None, True)
+    y.backward(dev(gy))
+    errs = dict(y=rel(y.detach().cpu().numpy(), y_ref), dx=rel(xt.grad.cpu().numpy(), dx_ref), dG=rel(Gt.grad.cpu().numpy(), dG_ref),
+                dB=rel(Bt.grad.cpu().numpy(), dB_ref))
+    print(family, shape, errs)
+    assert errs['y'] < 2e-4 and errs['dx'] < 5e-4 and errs['dG'] < 3e-4 and errs['dB'] < 1e-5, errs
+
+
 def _remaining_sites():
     """Every (shape, Kc) of the four configurations' generator sites at the generator update's batch (N = 128), taken from
     train.wc_sites() so that the list cannot drift from the recipes, minus what FULL_SITES above already runs.  Kc: block

@@ -23,23 +23,7 @@ nseeds = int(argv[0]) if argv else 5
 only = [tuple(int(v) for v in a.split("x")) for a in argv[1:]]      # optional: shapes as 128x32x32x256
 
 
-def family_input(rng, shape, family):
-    """x = z * s + (F V^T) a + 0.2: z (M, C) and F (M, 8) iid unit-variance draws of the family, s per-channel scales over two decades,
-    V (C, 8) gaussian, a = 2 (eight eigenvalues ~ 4 C, the smallest ~ 1e-4: cond of the shrunk covariance ~ 1e6 at C = 256)."""
-    C = shape[-1]
-    M = int(np.prod(shape[:-1]))
-    def draw(n):
-        if family == "uniform":
-            return rng.uniform(-np.sqrt(3.0), np.sqrt(3.0), (M, n))
-        if family == "relu":                    # post-ReLU, half of the elements exactly zero; unit variance
-            g = np.maximum(rng.standard_normal((M, n)), 0.0)
-            return g / np.sqrt(0.5 - 1.0 / (2 * np.pi))
-        if family == "heavy":                   # Laplace (kurtosis 6; the largest of 8e9 draws ~ 16 sigma).  (Student t with 3 degrees of freedom was tried first:
-            return rng.laplace(0.0, 1.0 / np.sqrt(2.0), (M, n))      # single elements of ~2000 sigma then carry the whole variance of a channel -- not a batch statistic any more)
-        return rng.standard_normal((M, n))
-    s = 10.0 ** rng.uniform(-2.0, 0.0, C)
-    V = rng.standard_normal((C, 8))
-    return (draw(C) * s + 2.0 * (draw(8) @ V.T) + 0.2).reshape(shape)
+family_input = o.synth_activation_family        # (oracle/wc_oracle.py: x = z * s + 2 F V^T + 0.2, elements of the named family)
 
 
 def ref32_site(x, G, B, gy, eps=1e-3):
