@@ -438,7 +438,8 @@ def cpu_baseline(ratio, sites, config_name):
     t_med = timed(10)
     torch.set_num_threads(prev)
     return {"value": round(64.0 / t_med, 3), "unit": "images/sec (WC sites of one G+D step only)",
-            "cores": best, "host_cores": cores, "kind": "unfused-fp32",
+            "cores": best, "host_cores": cores, "kind": "port",
+            "port_of": "the reference's UNFUSED fp32 op order (SURVEY rows a2 + a6) as a torch-CPU sequence -- the reference itself (py2 / TF 1.5 / Keras 2.0.8, arithmetic in an empty submodule) cannot run here",
             "threads_sweep_s": {str(k): round(v, 3) for k, v in sweep.items()},
             "checked_vs_oracle_rel_err": err,
             "sample": f"torch-CPU fp32, the reference's unfused op order (transpose, mean, f f^T/(M-1), shrink, cholesky, "
