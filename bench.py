@@ -129,6 +129,25 @@ def time_kernel(fn, iters=20, warm=3, graph=False):
     return sorted(ts)[len(ts) // 2]
 
 
+def time_isolated(fn, iters=20, warm=3):
+    """Mean duration of ONE fn() between two HIP events on the launching stream, the GPU idle before every launch (a host
+    synchronisation in front of each): the kernel by itself, as rocprofv3's per-dispatch durations of a spaced loop give it, plus the
+    ~1-2 us between an event and the launch beside it.  A plain loop of raw C-ABI calls is NOT that: the host queues 20 launches within
+    a few hundred microseconds and every launch but the first runs beside its predecessor's write-back (round 4: the masked K3 variants
+    read 60-67 us that way against 49-53 in the kernel trace) -- that figure is reported separately as back_to_back_us."""
+    import torch
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(iters):
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return sum(ts) / len(ts) * 1e-3
+
+
 def roofline_apply(dev):
     """roofline.kernel = the K3 kernel THE LAYERS launch at the headline site: the site is built as the generator
     builds Generator.BN.Final (create_norm('d', 'uconv'), generator.py:154), fed as the generator feeds it -- by the residual add of
@@ -198,7 +217,7 @@ def roofline_apply(dev):
                                      _mask_out=mask_buf, _planes_out=planes_buf), alg_bytes + xb // 32),
     }
     y2 = torch.empty_like(x)
-    t_copy = time_kernel(lambda: ops.stream_copy(x, y2))
+    t_copy = time_isolated(lambda: ops.stream_copy(x, y2))           # the yardstick, timed by the same rule as the kernels it is compared with
     copy_gbs = 2 * xb / t_copy / 1e9
     k3 = {}
     keep_alive = []
@@ -210,12 +229,12 @@ def roofline_apply(dev):
             keep_alive.append(keep)
         finally:
             ops.TRACE = None
-        t = time_kernel(fn)
+        t = time_isolated(fn)
         k3[name] = {"launch_us": round(t * 1e6, 2), "algorithmic_bytes": nbytes, "frac": round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4),
                     "frac_of_stream_copy": round(nbytes / t / 1e9 / copy_gbs, 4), "run_by_the_layers_at_this_site": kernel in name}
 
     # ---- the layers' kernel: isolated, back to back in a graph, and in the site's own flow
-    t_layers = time_kernel(k3_layers)
+    t_layers = time_isolated(k3_layers)
     t_b2b = time_kernel(k3_layers, graph=True)
     def front():      # what stands in front of K3 at the site: K1 + K2 + color (+ the planes' bias fold), the layer's own calls
         if on_planes:
@@ -295,7 +314,7 @@ def roofline_apply(dev):
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_from_committed_profile": src,
             "launch_us": round(t_layers * 1e6, 2), "algorithmic_bytes": alg_layers,
-            "timing": "launch_us: HIP events around 20 launches of the raw C-ABI call issued from Python on the launching stream (mean; the same rule for every entry of k3_kernels; no wrapper code in the loop); "
+            "timing": "launch_us: mean over 20 single launches of the raw C-ABI call, each between two HIP events on the launching stream with the GPU idle before it (the same rule for every entry of k3_kernels and for the stream copy); "
                       "back_to_back_us: the same 20 launches replayed as one hipGraph (median of 3 replays); in_flow_us: events around single launches behind the site's own K1 -> K2 -> color",
             "stream_copy_GBs": round(copy_gbs, 1),
             "frac_of_stream_copy": round(achieved / copy_gbs, 4),
