@@ -129,22 +129,42 @@ def time_kernel(fn, iters=20, warm=3, graph=False):
     return sorted(ts)[len(ts) // 2]
 
 
+_SPIN = {}
+
+
+def _spin_cycles(us=200.0):
+    """torch.cuda._sleep cycles that keep the GPU busy (no memory traffic) for about `us` microseconds: calibrated once with events."""
+    import torch
+    if "per_us" not in _SPIN:
+        torch.cuda._sleep(1000); torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(); torch.cuda._sleep(2_000_000); e1.record(); torch.cuda.synchronize()
+        _SPIN["per_us"] = 2_000_000 / max(e0.elapsed_time(e1) * 1e3, 1.0)
+    return max(int(_SPIN["per_us"] * us), 1000)
+
+
 def time_isolated(fn, iters=20, warm=3):
-    """Mean duration of ONE fn() between two HIP events on the launching stream, the GPU idle before every launch (a host
-    synchronisation in front of each): the kernel by itself, as rocprofv3's per-dispatch durations of a spaced loop give it, plus the
-    ~1-2 us between an event and the launch beside it.  A plain loop of raw C-ABI calls is NOT that: the host queues 20 launches within
-    a few hundred microseconds and every launch but the first runs beside its predecessor's write-back (round 4: the masked K3 variants
-    read 60-67 us that way against 49-53 in the kernel trace) -- that figure is reported separately as back_to_back_us."""
+    """Mean duration of ONE fn() between two HIP events on the launching stream, with nothing else touching memory around it: each
+    launch is queued behind a ~200 us register-only spin (torch.cuda._sleep), so the host has finished enqueueing event, kernel and event
+    before the GPU reaches them (no host latency inside the bracket -- with an idle GPU in front the ctypes call itself, 5-10 us for a
+    20-argument entry, lands between the events) and the kernel runs beside no predecessor's write-back.  That is the kernel by itself,
+    what rocprofv3's per-dispatch durations of a spaced loop give.  A plain loop of raw C-ABI calls is NOT that: the host queues 20 launches
+    within a few hundred microseconds and every launch but the first runs beside its predecessor's write-back (round 4: the masked K3
+    variants read 60-67 us that way against 49-53 in the kernel trace) -- that figure is reported separately as back_to_back_us."""
     import torch
     for _ in range(warm):
         fn()
-    ts = []
+    spin = _spin_cycles()
+    evs = []
     for _ in range(iters):
-        torch.cuda.synchronize()
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(spin)
         e0.record(); fn(); e1.record()
-        torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1))
+        evs.append((e0, e1))
+        if len(evs) % 5 == 0:
+            torch.cuda.synchronize()                                  # bounded queue depth; the spin in front of the next launch restores the lead
+    torch.cuda.synchronize()
+    ts = [a_.elapsed_time(b_) for a_, b_ in evs]
     return sum(ts) / len(ts) * 1e-3
 
 
@@ -314,7 +334,7 @@ def roofline_apply(dev):
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_from_committed_profile": src,
             "launch_us": round(t_layers * 1e6, 2), "algorithmic_bytes": alg_layers,
-            "timing": "launch_us: mean over 20 single launches of the raw C-ABI call, each between two HIP events on the launching stream with the GPU idle before it (the same rule for every entry of k3_kernels and for the stream copy); "
+            "timing": "launch_us: mean over 20 single launches of the raw C-ABI call, each between two HIP events on the launching stream, queued behind a register-only spin so that no host latency and no predecessor's write-back falls inside the bracket (the same rule for every entry of k3_kernels and for the stream copy); "
                       "back_to_back_us: the same 20 launches replayed as one hipGraph (median of 3 replays); in_flow_us: events around single launches behind the site's own K1 -> K2 -> color",
             "stream_copy_GBs": round(copy_gbs, 1),
             "frac_of_stream_copy": round(achieved / copy_gbs, 4),

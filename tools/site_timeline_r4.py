@@ -14,6 +14,8 @@ for _ in range(6):
     x = F.residual_add(h, s, True, planes=True, x32=False)
     y = F.whiten_color(x, gamma, beta, None, mm, mc, True, relu=True)
     y.backward(gy)
+    for t in (gamma, beta, h, s):
+        t.grad = None                      # no accumulation adds in the trace: a site's gradients are written, not summed, in the generator's flow
 torch.cuda.synchronize()
 hg = torch.randn(320, 32, 32, C, device='cuda'); sg = torch.randn(320, 16, 16, C, device='cuda')
 with torch.no_grad():
@@ -26,4 +28,6 @@ for _ in range(6):
     hh = F.whiten_color(x, gamma, beta, None, mm, mc, True, relu=True, planes=True)
     assert getattr(hh, '_wc_planes', None) is not None
     hh.backward(gy)
+    for t in (gamma, beta, h, s):
+        t.grad = None
 torch.cuda.synchronize()
