@@ -144,7 +144,7 @@ def _spin_cycles(us=200.0):
 
 
 def time_isolated(fn, iters=20, warm=3):
-    """Mean duration of ONE fn() between two HIP events on the launching stream, with nothing else touching memory around it: each
+    """Median duration of ONE fn() between two HIP events on the launching stream, with nothing else touching memory around it: each
     launch is queued behind a ~200 us register-only spin (torch.cuda._sleep), so the host has finished enqueueing event, kernel and event
     before the GPU reaches them (no host latency inside the bracket -- with an idle GPU in front the ctypes call itself, 5-10 us for a
     20-argument entry, lands between the events) and the kernel runs beside no predecessor's write-back.  That is the kernel by itself,
@@ -164,8 +164,8 @@ def time_isolated(fn, iters=20, warm=3):
         if len(evs) % 5 == 0:
             torch.cuda.synchronize()                                  # bounded queue depth; the spin in front of the next launch restores the lead
     torch.cuda.synchronize()
-    ts = [a_.elapsed_time(b_) for a_, b_ in evs]
-    return sum(ts) / len(ts) * 1e-3
+    ts = sorted(a_.elapsed_time(b_) for a_, b_ in evs)
+    return ts[len(ts) // 2] * 1e-3                                   # the median: one launch in 20 met a multi-millisecond pause of the box in round 4
 
 
 def roofline_apply(dev):
@@ -239,6 +239,7 @@ def roofline_apply(dev):
     y2 = torch.empty_like(x)
     t_copy = time_isolated(lambda: ops.stream_copy(x, y2))           # the yardstick, timed by the same rule as the kernels it is compared with
     copy_gbs = 2 * xb / t_copy / 1e9
+    copy_loop_gbs = 2 * xb / time_kernel(lambda: ops.stream_copy(x, y2)) / 1e9      # rounds 1-3's yardstick: a plain loop, launches overlapping head to tail
     k3 = {}
     keep_alive = []
     for name, (fn, nbytes) in variants.items():
@@ -334,9 +335,11 @@ def roofline_apply(dev):
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_from_committed_profile": src,
             "launch_us": round(t_layers * 1e6, 2), "algorithmic_bytes": alg_layers,
-            "timing": "launch_us: mean over 20 single launches of the raw C-ABI call, each between two HIP events on the launching stream, queued behind a register-only spin so that no host latency and no predecessor's write-back falls inside the bracket (the same rule for every entry of k3_kernels and for the stream copy); "
+            "timing": "launch_us: median of 20 single launches of the raw C-ABI call, each between two HIP events on the launching stream, queued behind a register-only spin so that no host latency and no predecessor's write-back falls inside the bracket (the same rule for every entry of k3_kernels and for the stream copy); "
                       "back_to_back_us: the same 20 launches replayed as one hipGraph (median of 3 replays); in_flow_us: events around single launches behind the site's own K1 -> K2 -> color",
             "stream_copy_GBs": round(copy_gbs, 1),
+            "stream_copy_loop_GBs": round(copy_loop_gbs, 1),
+            "frac_of_stream_copy_loop": round(achieved / copy_loop_gbs, 4),
             "frac_of_stream_copy": round(achieved / copy_gbs, 4),
             "back_to_back_us": round(t_b2b * 1e6, 2), "in_flow_us": round(t_flow * 1e6, 2),
             "in_flow_frac_of_stream_copy": round(alg_layers / t_flow / 1e9 / copy_gbs, 4),

@@ -46,6 +46,9 @@
 #endif
 #define WC_NO_PIPE 0   // development: 1 leaves the ring kernel's k-loop to hipcc's own schedule
 #endif
+#ifndef WC_K6_ABL
+#define WC_K6_ABL 0   // development, one-pass K6 only (results wrong; tools/k6_variants.py): 1 no dx stores, 2 no MFMA, 4 no fragment reads (with 2), 8 no conversion arithmetic / image writes, 32 no waits for the DMAs, 64 no hand-off waits (counters)
+#endif
 #ifndef WC_ABL
 #define WC_ABL 0      // development ablation bits: 1 no stores, 2 no MFMA, 4 no staging writes, 8 no loads, 16 no counters, 32 MFMA operands from registers only
 #endif
@@ -1321,11 +1324,22 @@ __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
         }
     };
     auto wait_for = [&](int which, int target) {
+        if (WC_K6_ABL & 64) return;         // (development: no hand-off waits at all)
         const unsigned addr = cnt_lds + 4u * which;
         for (;;) {
             int v;
             asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
             if (__builtin_amdgcn_readfirstlane(v) >= target) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
+
+    auto wait_both = [&](int target0, int target1) {      // cnt[0] >= target0 and cnt[1] >= target1
+        if (WC_K6_ABL & 64) return;
+        for (;;) {
+            int2 v;
+            asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(cnt_lds) : "memory");
+            if (__builtin_amdgcn_readfirstlane(v.x) >= target0 && __builtin_amdgcn_readfirstlane(v.y) >= target1) break;
             __builtin_amdgcn_s_sleep(1);
         }
     };
@@ -1390,6 +1404,7 @@ __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
 
     int rslot = 4;
     int fcur = 0;
+    int2 pre = {0, 0};                  // counters 0 and 1 as read at the end of the previous tile's body
     using T_ = std::integral_constant<bool, true>;
     using F_ = std::integral_constant<bool, false>;
     auto tile_body = [&](int t, auto conv_tag, auto wm_tag) {
@@ -1398,8 +1413,12 @@ __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
         const int fnext = fcur == 2 ? 0 : fcur + 1;
         int lane_t = lane, woff_t = woff0, rd_t = rd_off, xoff_t = xoff0;
         asm volatile("" : "+v"(lane_t), "+v"(woff_t), "+v"(rd_t), "+v"(xoff_t));
-        wait_for(0, 8 * (t + 1));          // (MK: also "tile t + 1's mask block is complete", and every wave is done with tile t's)
-        if (CONV_) wait_for(1, 8 * (t - 1));
+        // counter 0: tile t converted by all (MK: also "tile t + 1's mask block is complete", and every wave is done with tile t's);
+        // counter 1 (CONV_): image t - 2 read by all.  ONE 8-byte read for both: a poll is an LDS round trip with nothing to hide it
+        // ... and that read is issued at the END of the previous tile's body, in front of its stores: the counters only grow, so a value
+        // that already satisfies both targets needs no poll at all (the common case: the arrivals are three quarters of a loop old)
+        if (!(__builtin_amdgcn_readfirstlane(pre.x) >= 8 * (t + 1) && __builtin_amdgcn_readfirstlane(pre.y) >= (CONV_ ? 8 * (t - 1) : 0)))
+            wait_both(8 * (t + 1), CONV_ ? 8 * (t - 1) : 0);
         // MK: this wave's piece of the block of tile t + 3 into the buffer tile t's block has just left (three buffers: the piece is
         // waited for at the NEXT tile's arrival, by when it is a tile and a half old).  One more DMA per tile than the waits below
         // count: they only get more conservative by it
@@ -1408,6 +1427,7 @@ __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
 #pragma unroll
         for (int p = 0; p < 4; ++p) { const int v = rslot + p; rs[p] = v >= NSLOT ? v - NSLOT : v; }
         auto chunk_wait = [&](int p) {      // younger vector-memory operations behind chunk p's DMA (header)
+            if (WC_K6_ABL & 32) return;     // (development: what the tile chain costs when no load is ever waited for)
             if (WM_ == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
             else if (WM_ == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else if (WM_ == 4 && p == 0) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
@@ -1436,6 +1456,7 @@ __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
                 if (tl < n) dma_chunk(tl, (p + NSLOT) % 4, rs[p], lane_t);
             } else if (st == 1) {
                 if (p + 1 < 4) { chunk_wait(p + 1); craw_read(rs[p + 1], lane_t); }
+            } else if (WC_K6_ABL & 8) {
             } else if (st == 2) cv_hi(p);
             else if (st == 3) cv_lo(p);
             else cv_write(fnext, p, woff_t, xoff_t);
@@ -1447,10 +1468,13 @@ __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
                 const int g = 3 * s + m, tb = s >> 3;
+                if (WC_K6_ABL & 2) { asm volatile("" :: "v"(al), "v"(ah), "v"(bhi[s]), "v"(blo[s])); }
+                else {
                 if (m == 0) acc[tb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bhi[s], acc[tb][0], 0, 0, 0);
                 if (m == 1) acc[tb][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, blo[s], acc[tb][1], 0, 0, 0);
                 if (m == 2) acc[tb][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bhi[s], acc[tb][2], 0, 0, 0);
-                if (s + 1 < KS) {
+                }
+                if (s + 1 < KS && !(WC_K6_ABL & 4)) {
                     if (m == 0) nh = frag(hrow, s + 1);
                     if (m == 1) nl = frag(lrow, s + 1);
                 }
@@ -1476,11 +1500,18 @@ __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my reads of image t are done
         arrive(1);
+        {       // (a plain 8-byte load: hipcc waits for it where the next tile's body reads it)
+            typedef int i32x2_ __attribute__((ext_vector_type(2)));
+            const i32x2_ pv = *reinterpret_cast<const volatile i32x2_*>(cnt);
+            pre.x = pv[0]; pre.y = pv[1];
+        }
         float* po = a.out + (int64_t)tile_of(t) * (TR * C) + out_lane;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float v0 = (acc[0][0][r] + acc[0][1][r]) + acc[0][2][r], v1 = (acc[1][0][r] + acc[1][1][r]) + acc[1][2][r];
-#if WC_NT_STORE_K6
+#if WC_K6_ABL & 1
+            asm volatile("" :: "v"(v0 * cs0v + (v1 * cs1v - subv)), "v"(po));
+#elif WC_NT_STORE_K6
             __builtin_nontemporal_store(v0 * cs0v + (v1 * cs1v - subv), &po[r * C]);
 #else
             po[r * C] = v0 * cs0v + (v1 * cs1v - subv);
