@@ -10,6 +10,9 @@ T=${1:-r4z}
 [ -f gpurun_out/${T}_summary.txt ] && cp gpurun_out/${T}_summary.txt profiles/r4_kernel_trace_stages_128x32x32x256.txt
 [ -f gpurun_out/${T}_k6_spread.txt ] && cp gpurun_out/${T}_k6_spread.txt profiles/r4_k6_spread.txt
 [ -f gpurun_out/${T}_k3_zero_planes.txt ] && cp gpurun_out/${T}_k3_zero_planes.txt profiles/r4_k3_zero_planes.txt
+[ -f gpurun_out/${T}_k2_stamps.txt ] && cp gpurun_out/${T}_k2_stamps.txt profiles/r4_k2_wave_timeline.txt
+[ -f gpurun_out/${T}_k2_pipe_check.txt ] && cp gpurun_out/${T}_k2_pipe_check.txt profiles/r4_k2_pipe_check.txt
+[ -f gpurun_out/${T}_k6_variants.txt ] && cp gpurun_out/${T}_k6_variants.txt profiles/r4_k6_ablations.txt
 [ -f gpurun_out/${T}_other_configs.txt ] && cp gpurun_out/${T}_other_configs.txt profiles/r4_other_configs.txt
 [ -f gpurun_out/${T}_tests.txt ] && tail -3 gpurun_out/${T}_tests.txt > profiles/r4_gpu_suite.txt
 if [ -f gpurun_out/r4_seed_sweep_base.txt ]; then

@@ -16,6 +16,10 @@ cd $R
 python tools/site_timeline_print.py gpurun_out/r4z_site_tl/s_kernel_trace.csv resadd_sample > gpurun_out/r4z_site_timeline.txt 2>&1
 python tools/k6_spread.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r4z_k6_spread.txt
 python tools/k3_zero_planes.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r4z_k3_zero_planes.txt
+# K2: every wave's barrier arrivals / departures (a -DCF_STAMPS=1 build of wc_small.hip made beforehand: tools/build_var.py wc_small st=-DCF_STAMPS=1) and the per-call times
+[ -f wc_gan_amd/csrc/build/var/lib_st.so ] && python tools/k2_stamps.py 256 wc_gan_amd/csrc/build/var/lib_st.so 2>&1 | grep -v amdgpu.ids > gpurun_out/r4z_k2_stamps.txt
+python tools/k2_pipe_check.py 10 2>&1 | grep -v amdgpu.ids > gpurun_out/r4z_k2_pipe_check.txt
+python tools/k6_variants.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r4z_k6_variants.txt
 for CFG in cifar10_cond stl10_uncond tinyimagenet_cond_sa; do
   timeout 600 python bench.py --config $CFG --steps 8 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
@@ -35,12 +39,12 @@ for mode in "k3splitmask k3mask k1wsplit k1 k4bits k4xsplit k6bits k6xsplit k3sp
         d = sorted(d)
         print(f"{mode:14s} {k:100s} n={len(d):3d} min {d[0]:7.1f} med {d[len(d)//2]:7.1f} avg {sum(d)/len(d):7.1f} max {d[-1]:7.1f}")
 PY
-tail -4 gpurun_out/r4z_tests.txt; cat gpurun_out/r4z_summary.txt gpurun_out/r4z_other_configs.txt gpurun_out/r4z_k6_spread.txt gpurun_out/r4z_k3_zero_planes.txt; tail -c 1500 gpurun_out/r4z_bench.err
+tail -4 gpurun_out/r4z_tests.txt; cat gpurun_out/r4z_summary.txt gpurun_out/r4z_other_configs.txt gpurun_out/r4z_k6_spread.txt gpurun_out/r4z_k3_zero_planes.txt gpurun_out/r4z_k2_pipe_check.txt; tail -c 1500 gpurun_out/r4z_bench.err
 python - <<'PY'
 import json
 d = json.loads(open('gpurun_out/r4z_bench.json').read().strip().splitlines()[-1]); r = d['roofline']
 print("value", d['value'], "ms", d['ms_per_step'], "eager", d.get('eager_launch'), "ratio1", d.get('training_ratio_1'))
-for k in ('kernel', 'launch_us', 'frac', 'frac_of_stream_copy', 'back_to_back_us', 'in_flow_us', 'forward_site_us', 'forward_site_fp32_input_us', 'producer_us', 'forward_site_plus_producer_us', 'stream_copy_GBs', 'error'):
+for k in ('kernel', 'launch_us', 'frac', 'frac_of_stream_copy', 'frac_of_stream_copy_loop', 'stream_copy_loop_GBs', 'back_to_back_us', 'in_flow_us', 'forward_site_us', 'forward_site_fp32_input_us', 'producer_us', 'forward_site_plus_producer_us', 'stream_copy_GBs', 'error'):
     print(k, r.get(k))
 for k, v in r.get('k3_kernels', {}).items(): print("  ", v['launch_us'], v['frac_of_stream_copy'], k[:80])
 print(d.get('cpu_baseline'))

@@ -3,6 +3,8 @@ widths / group counts, repeated (the hand-off is a race if it is wrong), and the
 default (one launch), WC_K2_SPLIT=1 (the four-waves-per-column inverse as its own launch), WC_K2_TWO_LAUNCH=1 (round-2a kernels)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from wc_gan_amd import _lib
+if len(sys.argv) > 2: _lib.LIB_PATH = sys.argv[2]      # a variant library (tools/build_var.py wc_small ...)
 from wc_gan_amd import ops
 def t(fn, it=30):
     for _ in range(5): fn()

@@ -3,6 +3,7 @@ usage (GPU box): WC_EXTRA_FLAGS=-DCF_STAMPS=1 python -m wc_gan_amd.build --force
 import os, sys, ctypes, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from wc_gan_amd import _lib, ops
+if len(sys.argv) > 2: _lib.LIB_PATH = sys.argv[2]      # a -DCF_STAMPS=1 library built with tools/build_var.py wc_small stamps=-DCF_STAMPS=1
 lib = _lib.load()
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 M = 16384
@@ -10,16 +11,14 @@ g = torch.Generator(device='cpu'); g.manual_seed(1)
 x = torch.randn(M, C, generator=g).cuda()
 s, xtx = ops.stats(x)
 mu = torch.empty(C, device='cuda'); L = torch.empty(C, C, dtype=torch.float64, device='cuda'); W = torch.empty_like(L)
-ws = torch.zeros(max(lib.wc_factor_workspace_bytes(C, 1), 8 * (8192 + 512)), dtype=torch.uint8, device='cuda')
+ws = torch.zeros(max(lib.wc_factor_workspace_bytes(C, 1), 8 * (8192 + 16 * 128)), dtype=torch.uint8, device='cuda')
 for _ in range(3):
     _lib.check(lib.wc_factor_f64(s.data_ptr(), xtx.data_ptr(), M, C, 1, 1e-3, 0.99, 1, 1, None, None, mu.data_ptr(), None,
                                  L.data_ptr(), W.data_ptr(), ws.data_ptr(), ws.numel(), None), "factor")
 torch.cuda.synchronize()
-st = ws.view(torch.int64)[8192:8192 + 384].cpu().numpy().reshape(3, 128)
-for name, row in zip(("wave 0 (factor)", "wave 1 (solver)", "wave 5 (owner)"), st):
-    n = int(row[127]); t = row[:n].astype(np.int64)
-    d = np.diff(t)
-    print(name, "stamps", n, "total cycles", int(t[-1] - t[0]))
-    # stamps alternate: before barrier, after barrier; so d[0::2] = wait inside a barrier, d[1::2] = work between barriers
-    print("  barrier waits:", d[0::2][:60].tolist())
-    print("  work segments:", d[1::2][:60].tolist())
+st = ws.view(torch.int64)[8192:8192 + 16 * 128].cpu().numpy().reshape(16, 128)
+t0 = min(int(r[0]) for r in st if int(r[127]) > 0)
+# every wave stamps before and after each of its barriers / counter waits: per wave the list (arrive, leave) relative to the first stamp
+for w, row in enumerate(st):
+    n = int(row[127]); t = (row[:n].astype(np.int64) - t0)
+    print("wave %2d (SIMD %d): " % (w, w & 3) + " ".join("%d>%d" % (t[k], t[k + 1]) for k in range(0, min(n - 1, 24), 2)))

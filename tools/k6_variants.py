@@ -1,5 +1,5 @@
 """Development: the one-pass K6 (bits mode: fp32 x, ReLU bit mask) timed with every library under csrc/build/var/ (tools/build_var.py wc_fast
-tag=-DWC_K6_ABL=<bits> ...): one launch at a time behind a register-only spin.  Ablated builds compute wrong
+k6base= k6abl<bits>=-DWC_K6_ABL=<bits> ...): one launch at a time behind a register-only spin.  Ablated builds compute wrong
 results: only their times mean anything."""
 import glob, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -31,7 +31,7 @@ for rep in range(15):
 ts.sort()
 print("min %%.1f median %%.1f" %% (ts[0], ts[len(ts) // 2]), flush=True)
 ''' % ROOT
-for lib in sorted(glob.glob(os.path.join(ROOT, "wc_gan_amd", "csrc", "build", "var", "lib_*.so"))):
+for lib in sorted(glob.glob(os.path.join(ROOT, "wc_gan_amd", "csrc", "build", "var", "lib_k6*.so"))):
     line = os.path.basename(lib).ljust(16)
     r = subprocess.run([sys.executable, "-c", child, lib], capture_output=True, text=True, timeout=300)
     line += " | call (tables + kernel) us: %s" % (r.stdout.strip() or ("FAILED " + r.stderr.strip()[-200:]))

@@ -832,10 +832,17 @@ __global__ __launch_bounds__(1024) void tri_inverse_split_kernel(const double* _
 #ifndef CF_OWN
 #define CF_OWN 15                   // waves that own trailing blocks and solve the panel.  (12 = all but 4, 8, 12, which share wave 0's
 #endif                              // SIMD: measured 74 against 69 us -- the early steps are bound by the CU's f64-MFMA rate and lose a quarter of it)
-constexpr int CF_SLOTS = (120 + CF_OWN - 1) / CF_OWN;      // 120 blocks at C = 256 (16 waves x 128 VGPRs: 10 blocks = 80 of them)
+constexpr int CF_SLOTS = (120 + CF_OWN - 1) / CF_OWN;
+// (CF_SPLIT_B counts one s_barrier per step for every wave: the idle-wave form of CF_OWN = 12 keeps two)
+#if CF_OWN != 15 && !defined(CF_SPLIT_B)
+#define CF_SPLIT_B 0
+#endif      // 120 blocks at C = 256 (16 waves x 128 VGPRs: 10 blocks = 80 of them)
 
 #ifndef CF_NEWTON
 #define CF_NEWTON 1        // Newton steps on v_rsq_f64 per pivot (measured: L to 1e-13 with one, 1e-7 with none)
+#endif
+#ifndef CF_SPLIT_B
+#define CF_SPLIT_B 1     // round 4: barrier (B) is a counter among the owner waves only; wave 0 solves the next diagonal block's rows itself and never waits for the panel
 #endif
 #ifndef CF_STAMPS
 #define CF_STAMPS 0      // development: s_memtime stamps around every barrier of waves 0, 1 and 5 into the workspace behind Linv
@@ -862,6 +869,8 @@ __global__ __launch_bounds__(1024) void cholesky_fused_kernel(double* __restrict
     double* Pn = Praw + 2 * C * 17;             // [16][ldp]   solved panel, column-major: the update's MFMA operands
     double* Dinv = Pn + 16 * ldp;               // [2][16][17] INVERSE of the factored diagonal block (even / odd steps)
     double* Dpre = Dinv + 2 * 16 * 17;          // [2][16][17] diagonal block (b, b) with every update but the last one, b even / odd
+    volatile int* const cntB = reinterpret_cast<volatile int*>(Dpre + 2 * 16 * 17);      // CF_SPLIT_B: owner waves through the panel solve (running count)
+    const unsigned cntB_lds = (unsigned)(size_t)((__attribute__((address_space(3))) char*)(Dpre + 2 * 16 * 17));
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lq = lane >> 4;
@@ -870,12 +879,13 @@ __global__ __launch_bounds__(1024) void cholesky_fused_kernel(double* __restrict
     const int nb = C >> 4;
     const int nblk = (nb - 1) * nb / 2;         // blocks (bi >= bj >= 1); block column 0 goes straight to LDS
 
+    if (tid == 0) cntB[0] = 0;
     for (int e = tid; e < C * 16; e += 1024) Praw[(e >> 4) * 17 + (e & 15)] = T[(int64_t)(e >> 4) * C + (e & 15)];
     if (nb > 1)
         for (int e = tid; e < 256; e += 1024) Dpre[16 * 17 + (e >> 4) * 17 + (e & 15)] = T[(int64_t)(16 + (e >> 4)) * C + 16 + (e & 15)];    // block (1,1) as it stands
     __syncthreads();
-    const bool stamp_ok = CF_STAMPS && lane == 0 && (wave == 0 || wave == 1 || wave == 5) && blockIdx.x == 0;
-    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(Linv + 8192) + (wave == 0 ? 0 : wave == 1 ? 128 : 256);
+    const bool stamp_ok = CF_STAMPS && lane == 0 && blockIdx.x == 0;
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(Linv + 8192) + wave * 128;
     int nstamp = 0;
     (void)stamps; (void)nstamp; (void)stamp_ok;
 
@@ -940,18 +950,42 @@ __global__ __launch_bounds__(1024) void cholesky_fused_kernel(double* __restrict
                 }
                 break;
             }
-            CF_BARRIER();                                          // (B) the others have solved panel j
             // the last update of block (j+1, j+1): D -= X X^T with X = rows 16(j+1).. of the solved panel; through LDS into
             // the lane = row layout of the factorisation
             double* dp = Dpre + ((j + 1) & 1) * (16 * 17);
-            const double* px = Pn + lq * ldp + 16 * (j + 1) + li;
             f64x4 d4, d5 = {0.0, 0.0, 0.0, 0.0};
+#if CF_SPLIT_B
+            // Those 16 rows of X are solved HERE as well (the owner of row block 0 publishes them for everybody else): X^T = Linv P^T with
+            // the operand roles of the owners' product swapped, same pairs of k-groups in the same order, so register kk of the result is
+            // X[li][lq + 4 kk] -- exactly the A (and B) operand of the update below.  Wave 0 then needs nothing the other waves produce
+            // between (A) and the next (A): it does not take part in (B), which is a counter among the owners.  (Steps 5-15 are bound by
+            // this wave's chain, stamps of round 4: 1 300 - 2 000 cycles of waiting for the slowest solver per step, 10 % of the kernel.)
+            {
+                const double* pr = Praw + (j & 1) * (C * 17) + (16 * (j + 1) + li) * 17 + lq;
+                const double* dv0 = Dinv + (j & 1) * (16 * 17) + li * 17 + lq;
+                f64x4 xa = {0.0, 0.0, 0.0, 0.0}, xb = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d4[r] = dp[(lq + 4 * r) * 17 + li];
+                xa = __builtin_amdgcn_mfma_f64_16x16x4f64(dv0[0], pr[0], xa, 0, 0, 0);
+                xb = __builtin_amdgcn_mfma_f64_16x16x4f64(dv0[4], pr[4], xb, 0, 0, 0);
+                xa = __builtin_amdgcn_mfma_f64_16x16x4f64(dv0[8], pr[8], xa, 0, 0, 0);
+                xb = __builtin_amdgcn_mfma_f64_16x16x4f64(dv0[12], pr[12], xb, 0, 0, 0);
+                xa += xb;
+                d4 = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[0], xa[0], d4, 0, 0, 0);
+                d5 = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[1], xa[1], d5, 0, 0, 0);
+                d4 = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[2], xa[2], d4, 0, 0, 0);
+                d5 = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[3], xa[3], d5, 0, 0, 0);
+            }
+#else
+            CF_BARRIER();                                          // (B) the others have solved panel j
+            const double* px = Pn + lq * ldp + 16 * (j + 1) + li;
 #pragma unroll
             for (int r = 0; r < 4; ++r) d4[r] = dp[(lq + 4 * r) * 17 + li];
             d4 = __builtin_amdgcn_mfma_f64_16x16x4f64(-px[0], px[0], d4, 0, 0, 0);
             d5 = __builtin_amdgcn_mfma_f64_16x16x4f64(-px[4 * ldp], px[4 * ldp], d5, 0, 0, 0);
             d4 = __builtin_amdgcn_mfma_f64_16x16x4f64(-px[8 * ldp], px[8 * ldp], d4, 0, 0, 0);
             d5 = __builtin_amdgcn_mfma_f64_16x16x4f64(-px[12 * ldp], px[12 * ldp], d5, 0, 0, 0);
+#endif
             d4 += d5;
 #pragma unroll
             for (int r = 0; r < 4; ++r) dp[(lq + 4 * r) * 17 + li] = d4[r];
@@ -1027,7 +1061,22 @@ __global__ __launch_bounds__(1024) void cholesky_fused_kernel(double* __restrict
                     }
                 }
             }
+#if CF_SPLIT_B
+            {   // (B) among the owners: every owner's rows of the solved panel are in LDS
+                if (CF_STAMPS && stamp_ok) stamps[nstamp++] = __builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) { const unsigned one = 1u; asm volatile("ds_add_u32 %0, %1" :: "v"(cntB_lds), "v"(one) : "memory"); }
+                const int target = CF_OWN * (j + 1);
+                for (;;) {
+                    int v;
+                    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(cntB_lds) : "memory");
+                    if (__builtin_amdgcn_readfirstlane(v) >= target) break;
+                }
+                if (CF_STAMPS && stamp_ok) stamps[nstamp++] = __builtin_amdgcn_s_memtime();
+            }
+#else
             CF_BARRIER();                                          // (B) panel j is solved
+#endif
             // (S4) this wave's active slots are [0, n34): ranks below R4 lie right of the next panel, the next nb-j-1 ranks ARE
             // the next panel (column j+1; rank = owner index + CF_OWN * slot).  The next panel's blocks go first and leave for the other
             // panel buffer -- except the diagonal one, which wave 0 updates and factors itself.  The diagonal block after
@@ -1529,7 +1578,7 @@ hipError_t wc_launch_stats_prepare(const double* P, const float* colsum, const f
 hipError_t wc_launch_factor_fused(double* T, double* W, double* tmp, int C, int groups, hipStream_t st)
 {
     const int nb = C >> 4, ldp = C + 2;
-    size_t lds = (size_t)(2 * C * 17 + 16 * ldp + 4 * 16 * 17) * sizeof(double);
+    size_t lds = (size_t)(2 * C * 17 + 16 * ldp + 4 * 16 * 17 + 2) * sizeof(double);      // (+ the owners' panel counter)
     const bool one = factor_one_launch(C, groups);
     static const bool split = getenv("WC_K2_SPLIT") != nullptr;         // development: the four-waves-per-column inverse as a launch of its own
     const size_t lds_role = ti_role_lds_doubles(C) * sizeof(double);
