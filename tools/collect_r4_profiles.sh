@@ -14,7 +14,7 @@ T=${1:-r4z}
 [ -f gpurun_out/${T}_k2_pipe_check.txt ] && cp gpurun_out/${T}_k2_pipe_check.txt profiles/r4_k2_pipe_check.txt
 [ -f gpurun_out/${T}_k6_variants.txt ] && cp gpurun_out/${T}_k6_variants.txt profiles/r4_k6_ablations.txt
 [ -f gpurun_out/${T}_other_configs.txt ] && cp gpurun_out/${T}_other_configs.txt profiles/r4_other_configs.txt
-[ -f gpurun_out/${T}_tests.txt ] && tail -3 gpurun_out/${T}_tests.txt > profiles/r4_gpu_suite.txt
+[ -f gpurun_out/${T}_tests.txt ] && grep -E "passed|failed|error" gpurun_out/${T}_tests.txt | tail -3 > profiles/r4_gpu_suite.txt
 if [ -f gpurun_out/r4_seed_sweep_base.txt ]; then
   { echo "# tools/seed_sweep.py (tools/gpu_job_r4_sweep.sh): relative errors (max-abs / max-abs reference) against the float64 oracle, full-size sites";
     for f in base base_planes families families_planes families_nocomp; do echo; echo "## $f"; grep -v "^$" gpurun_out/r4_seed_sweep_$f.txt; done; } > profiles/r4_seed_sweep.txt

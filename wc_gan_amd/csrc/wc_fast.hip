@@ -126,15 +126,17 @@ struct SplitJob { const float* B; const float* scale; _Float16* hi; _Float16* lo
 struct BiasJob { const float* A; const float* bias; const float* center; const float* mu; float* out; int slots; };
 __global__ __launch_bounds__(64) void split_table_kernel(SplitJob j0, SplitJob j1, int C, BiasJob bj)
 {
-    if ((int)blockIdx.x >= j0.rows + j1.rows) {      // bias job: one workgroup per (slot, 8 columns); thread (q, n) sums the rows k = q mod 8
-        // (32 terms per thread with all of them in flight: as 2 x 128-term chains per column this job took 28 us and the tables' launch with it)
+    if ((int)blockIdx.x >= j0.rows + j1.rows) {      // bias job: one workgroup per (slot, 2 columns); thread (q, n) sums the rows k = q mod 32
+        // (8 terms per thread, every load of the thread in flight at once: A was written by the launch in front on other XCDs, so a
+        // dependent batch of loads costs a memory round trip -- 2 x 128-term chains per column took 28 us, 32 terms per thread 11.6 us
+        // and the tables' launch with them; the tables alone take 5.2)
         __shared__ double red[64];
-        const int bb = (int)blockIdx.x - j0.rows - j1.rows, nch = C / 8;
-        const int slot = bb / nch, n = (bb % nch) * 8 + (threadIdx.x & 7), q = threadIdx.x >> 3;
+        const int bb = (int)blockIdx.x - j0.rows - j1.rows, nch = C / 2;
+        const int slot = bb / nch, n = (bb % nch) * 2 + (threadIdx.x & 1), q = threadIdx.x >> 1;
         const float* a = bj.A + (int64_t)slot * C * C + n;
         double acc = 0.0;
 #pragma unroll 8
-        for (int k = q; k < C; k += 8) {
+        for (int k = q; k < C; k += 32) {
             const double d = (double)(bj.center ? bj.center[k] : 0.f) - (double)(bj.mu ? bj.mu[k] : 0.f);
             acc += d * (double)a[(int64_t)k * C];
         }
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(64) void split_table_kernel(SplitJob j0, SplitJob j
         if (q == 0) {
             double t = 0.0;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) t += red[threadIdx.x + 8 * i];
+            for (int i = 0; i < 32; ++i) t += red[threadIdx.x + 2 * i];
             bj.out[(int64_t)slot * C + n] = (float)(t + (bj.bias ? (double)bj.bias[(int64_t)slot * C + n] : 0.0));
         }
         return;
@@ -1815,7 +1817,7 @@ hipError_t wc_launch_fast_plan_tables_bias(const float* B, int Kc, int C, void* 
 {
     SplitJob none = {};
     BiasJob bj = {B, bias, center, mu, bias_out, Kc};
-    hipLaunchKernelGGL(split_table_kernel, dim3((unsigned)(Kc * C + Kc * (C / 8))), dim3(64), 0, st, split_job(B, Kc, C, plan, scale), none, C, bj);
+    hipLaunchKernelGGL(split_table_kernel, dim3((unsigned)(Kc * C + Kc * (C / 2))), dim3(64), 0, st, split_job(B, Kc, C, plan, scale), none, C, bj);
     return hipGetLastError();
 }
 // two plans (with their input scales given) in one launch
@@ -1833,7 +1835,7 @@ hipError_t wc_launch_fast_plan_tables2_bias(const float* B0, int Kc0, void* plan
                                             const float* bias, const float* center, const float* mu, float* bias_out)
 {
     BiasJob bj = {B1, bias, center, mu, bias_out, 1};
-    hipLaunchKernelGGL(split_table_kernel, dim3((unsigned)((Kc0 + 1) * C + C / 8)), dim3(64), 0, st,
+    hipLaunchKernelGGL(split_table_kernel, dim3((unsigned)((Kc0 + 1) * C + C / 2)), dim3(64), 0, st,
                        split_job(B0, Kc0, C, plan0, scale0), split_job(B1, 1, C, plan1, scale1), C, bj);
     return hipGetLastError();
 }
