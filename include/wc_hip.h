@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define WC_ABI_VERSION 5
+#define WC_ABI_VERSION 6
 
 #define WC_OK                 0
 #define WC_ERR_NULL          -1   /* a required pointer is NULL                     */
@@ -248,6 +248,23 @@ int wc_color_split_f32(const double* W /*[C,C]*/, const float* gamma /*[Kc,C,C] 
 int wc_group_bias_centered_f32(const float* mu /*[groups,C]*/, const float* A /*[groups*Kc,C,C]*/, const float* beta /*nullable*/,
                                const float* center /*[C] in*/, int groups, int Kc, int C, int per_group, float* bias /*[groups*Kc,C] out*/,
                                wc_stream_t stream);
+
+/* The dictionary mix of the soft-assignment coloring "cWC_sa" (ABI 6):
+ *     out[t] = base + sum_{e < E} alpha[idx[t], e] * dict[e],   t = 0 .. Kc-1   (C x C each)
+ * dict (E, C, C): the filter dictionary, alpha (K, E): the per-class coefficients, idx (Kc) int32: the class of table t (NULL: t itself,
+ * then Kc must equal K), base (C, C): the unconditional 1x1 kernel the reference adds (NULL: none).  Only the Kc tables the batch uses
+ * are formed (K = 200 / 1000 classes at batch 64: run.py:172-173).  E <= 32, C a multiple of 4 (wc_factor_mix_supported).
+ * wc_factor_mix_bwd_f32: from dout (Kc, C, C) -> ddict (E, C, C), dalpha (K, E; written whole, zero for absent classes), dbase (C, C); each
+ * nullable; dalpha needs wc_factor_mix_bwd_workspace_bytes(E, Kc) of workspace.  Deterministic (fixed summation order).
+ * Replace: generator.py:69-78 -- FactorizedConv11(number_of_classes, filters, filters_emb, use_bias=False)([x, cls]) + Conv2D 1x1 -> Add,
+ * i.e. the (N, E) x (E, C^2) mix + gather of the (missing) gan.conditional_layers.FactorizedConv11 and TF's gradients of it. */
+int    wc_factor_mix_supported(int E, int C);
+int    wc_factor_mix_f32(const float* dict, const float* alpha, const int32_t* idx /*nullable*/, const float* base /*nullable*/,
+                         int E, int C, int K, int Kc, float* out /*[Kc,C,C]*/, wc_stream_t stream);
+size_t wc_factor_mix_bwd_workspace_bytes(int E, int Kc);
+int    wc_factor_mix_bwd_f32(const float* dict, const float* alpha, const int32_t* idx /*nullable*/, const float* dout /*[Kc,C,C]*/,
+                             int E, int C, int K, int Kc, float* ddict /*nullable*/, float* dalpha /*nullable*/, float* dbase /*nullable*/,
+                             void* ws, size_t ws_bytes, wc_stream_t stream);
 
 /* K3 on a pre-split input with the epilogues the generator's sites use (ABI 5): as wc_apply_split_f16x2, and
  *   relu_mask (nullable; relu = 1, N*HW a multiple of 32): the ReLU's one-bit gradient mask, as wc_apply_mask_f32 leaves it;

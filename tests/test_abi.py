@@ -36,7 +36,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_abi_version_and_error_strings(lib):
     from wc_gan_amd import _lib
-    assert lib.wc_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.wc_abi_version() == _lib.ABI_VERSION == 6
     assert b"multiple of 32" in lib.wc_error_string(-3)
     assert lib.wc_error_string(0) == b"ok"
 
@@ -63,6 +63,19 @@ def test_argument_checks_return_codes_without_touching_the_gpu(lib):
     assert lib.wc_color_f32(one, None, 2, 64, 1, 0, one, None, None, None, None, 0, None) == -2
     assert lib.wc_bwd_reduce_f32(one, None, one, None, 4, 16, 64, 3, one, one, one, 1 << 30, None) == -2
     assert lib.wc_stream_copy_f32(one, one, 6, None) == -2
+
+
+def test_factor_mix_entry_points_check_their_arguments(lib):
+    """ABI 6 (the soft-assignment coloring's dictionary mix): support predicate, sizes and rejections, no kernel launched."""
+    one = ctypes.c_void_p(16)
+    assert lib.wc_factor_mix_supported(15, 128) == 1 and lib.wc_factor_mix_supported(32, 256) == 1
+    assert lib.wc_factor_mix_supported(33, 128) == 0 and lib.wc_factor_mix_supported(0, 128) == 0 and lib.wc_factor_mix_supported(4, 30) == 0
+    assert lib.wc_factor_mix_bwd_workspace_bytes(15, 128) >= 15 * 128 * 8 and lib.wc_factor_mix_bwd_workspace_bytes(0, 128) == 0
+    assert lib.wc_factor_mix_f32(None, one, None, None, 4, 32, 10, 10, one, None) == -1
+    assert lib.wc_factor_mix_f32(one, one, None, None, 4, 32, 10, 7, one, None) == -2          # no idx: one table per class
+    assert lib.wc_factor_mix_f32(one, one, one, None, 40, 32, 10, 7, one, None) == -2          # E beyond 32
+    assert lib.wc_factor_mix_bwd_f32(one, one, one, None, 4, 32, 10, 7, one, one, None, None, 0, None) == -1
+    assert lib.wc_factor_mix_bwd_f32(one, one, one, one, 4, 32, 10, 7, one, one, None, one, 8, None) == -4
 
 
 def test_split_entry_points_check_their_arguments(lib):

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwc_hip.so")
 
 WC_OK = 0
-ABI_VERSION = 5          # WC_ABI_VERSION of include/wc_hip.h
+ABI_VERSION = 6          # WC_ABI_VERSION of include/wc_hip.h
 ERRORS = {-1: "WC_ERR_NULL", -2: "WC_ERR_SHAPE", -3: "WC_ERR_CHANNELS", -4: "WC_ERR_WORKSPACE", -5: "WC_ERR_ARG"}
 
 # name -> (restype, argtypes); mirrors include/wc_hip.h one to one
@@ -99,6 +99,11 @@ SIGNATURES = {
     "wc_unfold_channel_scale_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wc_color_split_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wc_factor_mix_supported": (c_int, [c_int, c_int]),
+    "wc_factor_mix_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "wc_factor_mix_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "wc_factor_mix_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_size_t, c_void_p]),
     "wc_group_bias_centered_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "wc_bwd_xsplit_supported": (c_int, [c_int64, c_int64, c_int, c_int]),
     "wc_bwd_reduce_xsplit_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,

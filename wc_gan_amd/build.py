@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwc_hip.so")
-SOURCES = ["wc_rows.hip", "wc_fast.hip", "wc_split.hip", "wc_split_xty.hip", "wc_resadd.hip", "wc_fast_xty.hip", "wc_small.hip", "wc_sn.hip", "wc_conv.hip", "wc_abi.hip"]
+SOURCES = ["wc_rows.hip", "wc_fast.hip", "wc_split.hip", "wc_split_xty.hip", "wc_resadd.hip", "wc_fast_xty.hip", "wc_small.hip", "wc_mix.hip", "wc_sn.hip", "wc_conv.hip", "wc_abi.hip"]
 HEADERS = ["wc_common.h", os.path.join("..", "..", "include", "wc_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-function"] + \
     os.environ.get("WC_EXTRA_FLAGS", "").split()

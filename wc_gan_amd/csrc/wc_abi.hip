@@ -301,6 +301,33 @@ int wc_group_bias_centered_f32(const float* mu, const float* A, const float* bet
 }
 
 // ---------------------------------------------------------------------------------------------
+// the dictionary mix of the soft-assignment coloring (wc_mix.hip)
+int wc_factor_mix_supported(int E, int C) { return wc_mix_supported(E, C) ? 1 : 0; }
+
+int wc_factor_mix_f32(const float* dict, const float* alpha, const int32_t* idx, const float* base, int E, int C, int K, int Kc,
+                      float* out, wc_stream_t stream)
+{
+    if (!dict || !alpha || !out) return WC_ERR_NULL;
+    if (K <= 0 || Kc <= 0 || (!idx && Kc != K)) return WC_ERR_SHAPE;
+    if (!wc_mix_supported(E, C)) return WC_ERR_SHAPE;
+    WC_TRY(wc_launch_mix_fwd(dict, alpha, idx, base, E, C, Kc, out, static_cast<hipStream_t>(stream)));
+    return WC_OK;
+}
+
+size_t wc_factor_mix_bwd_workspace_bytes(int E, int Kc) { return (E <= 0 || Kc <= 0) ? 0 : wc_mix_bwd_workspace(E, Kc); }
+
+int wc_factor_mix_bwd_f32(const float* dict, const float* alpha, const int32_t* idx, const float* dout, int E, int C, int K, int Kc,
+                          float* ddict, float* dalpha, float* dbase, void* ws, size_t ws_bytes, wc_stream_t stream)
+{
+    if (!dict || !alpha || !dout) return WC_ERR_NULL;
+    if (K <= 0 || Kc <= 0 || (!idx && Kc != K)) return WC_ERR_SHAPE;
+    if (!wc_mix_supported(E, C)) return WC_ERR_SHAPE;
+    if (dalpha && (!ws || ws_bytes < wc_mix_bwd_workspace(E, Kc))) return WC_ERR_WORKSPACE;
+    WC_TRY(wc_launch_mix_bwd(dict, alpha, idx, dout, E, C, K, Kc, ddict, dalpha, dbase, ws, static_cast<hipStream_t>(stream)));
+    return WC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 size_t wc_apply_workspace_bytes(int64_t N, int64_t HW, int C, int Kc)
 {
     if (N <= 0 || HW <= 0 || Kc <= 0 || bad_channels(C)) return 0;

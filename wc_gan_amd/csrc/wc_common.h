@@ -162,6 +162,13 @@ hipError_t wc_launch_channel_scale(const float* in, const float* center, int64_t
 hipError_t wc_launch_channel_scale2(const float* in, const float* center, float* scale, const float* in2, const float* center2,
                                     float* scale2, int64_t M, int C, int* gate, hipStream_t st);
 hipError_t wc_launch_channel_scale_gate(const float* in, const float* center, float* scale, int64_t M, int C, int* gate, hipStream_t st);   // one operand + the gate's clearing
+// wc_mix.hip: the soft-assignment coloring's dictionary mix and its gradients
+bool wc_mix_supported(int E, int C);
+hipError_t wc_launch_mix_fwd(const float* dict, const float* alpha, const int32_t* idx, const float* base, int E, int C, int Kc, float* out,
+                             hipStream_t st);
+size_t wc_mix_bwd_workspace(int E, int Kc);
+hipError_t wc_launch_mix_bwd(const float* dict, const float* alpha, const int32_t* idx, const float* dout, int E, int C, int K, int Kc,
+                             float* ddict, float* dalpha, float* dbase, void* ws, hipStream_t st);
 hipError_t wc_launch_rank1_add(double* R, const double* gsum, const float* u, const float* v, int C, int Kc, hipStream_t st);   // R[k][i][j] += (u[i] - v[i]) gsum[k][j]  (wc_small.hip)
 
 void wc_fast_plan_parts(const void* plan, int C, int Kc, const float** scale, const float** colscale, const void** hi, const void** lo);

@@ -473,6 +473,30 @@ def split_route_supported(shape, training, groups=1):
 # Modular pieces: the same HIP kernels exposed as two differentiable ops, so that a C x C stage
 # written in torch (ZCA's eigendecomposition, renorm's constant factor) can sit between them.
 # ---------------------------------------------------------------------------------------------
+class FactorMixFunction(torch.autograd.Function):
+    """Tables of the soft-assignment coloring (generator.py:69-78): out[t] = base + sum_e alpha[idx[t], e] dictionary[e] through
+    wc_factor_mix_f32 / wc_factor_mix_bwd_f32 -- only the tables the batch uses, one launch forward, two to three backward."""
+
+    @staticmethod
+    def forward(ctx, dictionary, alpha, idx, base):
+        dictionary, alpha = dictionary.contiguous(), alpha.contiguous()
+        base = None if base is None else base.contiguous()
+        ctx.save_for_backward(dictionary, alpha, idx)
+        ctx.has_base = base is not None
+        return ops.factor_mix(dictionary, alpha, idx, base)
+
+    @staticmethod
+    def backward(ctx, dout):
+        dictionary, alpha, idx = ctx.saved_tensors
+        dd, da, db = ops.factor_mix_bwd(dictionary, alpha, idx, dout.contiguous(), ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                        ctx.has_base and ctx.needs_input_grad[3])
+        return dd, da, None, db
+
+
+def factor_mix(dictionary, alpha, idx=None, base=None):
+    return FactorMixFunction.apply(dictionary, alpha, idx, base)
+
+
 class MomentsFunction(torch.autograd.Function):
     """(sum, xtx) = K1(x).  backward: dx[m] = gsum + x[m] (gxtx + gxtx^T)  -- one K3 launch."""
 

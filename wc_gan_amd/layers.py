@@ -37,6 +37,9 @@ from . import functional as WF
 _TLS = threading.local()          # per host thread: two trainers on two threads do not see each other's setting
 
 
+USE_FACTOR_MIX = os.environ.get("WC_FACTOR_MIX", "1") != "0"      # 0: the soft-assignment tables as torch matmul + add + gather (rounds 1-3)
+
+
 def _stat_groups():
     return getattr(_TLS, 'groups', 1)
 
@@ -392,7 +395,38 @@ class WhiteningColoring(nn.Module):
         self.npart = npart
         self.branches = nn.ModuleList(branches)
 
+    def _mixed_table(self, x, cls):
+        """cWC_sa (after_norm ufconv / fconv: one FactorizedConv11 beside at most unconditional 1x1 branches) on a HIP tensor: the tables
+        the batch uses straight from the dictionary (wc_factor_mix_f32) -- no (K, C, C) table of all classes, no broadcast add, no gather."""
+        fact = [br for br in self.branches if isinstance(br, FactorizedConv11)]
+        rest = [br for br in self.branches if not isinstance(br, FactorizedConv11)]
+        if not USE_FACTOR_MIX or len(fact) != 1 or fact[0].use_bias or not all(type(br) is Conv11 for br in rest) or not x.is_cuda or cls is None:
+            return None
+        for br in self.branches:
+            br._ensure(x)
+        f = fact[0]
+        C, K, N = f.channels, f.number_of_classes, x.shape[0]
+        if not WF.ops.factor_mix_supported(f.filters_emb, C):
+            return None
+        base = beta = None
+        for br in rest:
+            base = br.kernel.view(C, C) if base is None else base + br.kernel.view(C, C)
+            if br.bias is not None:
+                beta = br.bias.view(1, C) if beta is None else beta + br.bias.view(1, C)
+        slot = _cls_index(cls)
+        groups = _stat_groups() if self.npart.training else 1
+        per_sample = K > N // max(groups, 1)
+        gamma = WF.factor_mix(f.kernel, f.class_matrix, slot if per_sample else None, base)
+        if per_sample:
+            slot = torch.arange(N, dtype=torch.int32, device=x.device)
+        if beta is not None:
+            beta = beta.expand(gamma.shape[0], -1)
+        return gamma, beta, slot, per_sample
+
     def coloring_table(self, x, cls):
+        mixed = self._mixed_table(x, cls)
+        if mixed is not None:
+            return mixed
         gamma = beta = slot = None
         for br in self.branches:
             br._ensure(x)

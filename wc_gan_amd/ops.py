@@ -199,6 +199,44 @@ def color_split(W, gamma, xs, mu, beta):
     return A, At, plan, be
 
 
+def factor_mix_supported(E, C):
+    return bool(_lib.load().wc_factor_mix_supported(int(E), int(C)))
+
+
+def factor_mix(dictionary, alpha, idx=None, base=None):
+    """Soft-assignment coloring tables (wc_factor_mix_f32): out[t] = base + sum_e alpha[idx[t], e] dictionary[e].
+    dictionary (E, C, C), alpha (K, E), idx (Kc,) int32 or None (one table per class), base (C, C) or None -> (Kc, C, C)."""
+    lib = _lib.load()
+    _need(dictionary, torch.float32, "dictionary", 3); _need(alpha, torch.float32, "alpha", 2)
+    E, C = dictionary.shape[0], dictionary.shape[-1]
+    K = alpha.shape[0]
+    if idx is not None:
+        _need(idx, torch.int32, "idx", 1)
+    if base is not None:
+        _need(base, torch.float32, "base", 2)
+    Kc = K if idx is None else idx.numel()
+    out = torch.empty(Kc, C, C, dtype=torch.float32, device=dictionary.device)
+    _lib.check(lib.wc_factor_mix_f32(_ptr(dictionary), _ptr(alpha), _ptr(idx), _ptr(base), E, C, K, Kc, _ptr(out), _stream()), "wc_factor_mix_f32")
+    return out
+
+
+def factor_mix_bwd(dictionary, alpha, idx, dout, want_dict=True, want_alpha=True, want_base=False):
+    """Gradients of factor_mix from dout (Kc, C, C) -> (ddictionary, dalpha, dbase), None where not wanted."""
+    lib = _lib.load()
+    _need(dout, torch.float32, "dout", 3)
+    E, C = dictionary.shape[0], dictionary.shape[-1]
+    K = alpha.shape[0]
+    Kc = dout.shape[0]
+    dev = dout.device
+    dd = torch.empty_like(dictionary) if want_dict else None
+    da = torch.empty_like(alpha) if want_alpha else None
+    db = torch.empty(C, C, dtype=torch.float32, device=dev) if want_base else None
+    ws = _workspace(lib.wc_factor_mix_bwd_workspace_bytes(E, Kc), dev) if want_alpha else None
+    _lib.check(lib.wc_factor_mix_bwd_f32(_ptr(dictionary), _ptr(alpha), _ptr(idx), _ptr(dout), E, C, K, Kc, _ptr(dd), _ptr(da), _ptr(db),
+                                         _ptr(ws), 0 if ws is None else ws.numel(), _stream()), "wc_factor_mix_bwd_f32")
+    return dd, da, db
+
+
 def group_bias_centered(mu, A, beta, center, groups, Kc, per_group=False):
     """group_bias() with the common centre given (a SplitTensor's centre): -> bias (groups*Kc, C), the grouped planes route's additive
     term beta - (mu_g - center) A directly."""
