@@ -5,6 +5,9 @@ usage: stage_only.py <n> <mode>;  mode = k3 | k3split | k3planes | k3mask | k1 |
         k3splitmask | k3splitplanes | k1wsplit | resadd | resaddsplit | resaddtorch   (round 4: the producer and the planes route's epilogues)"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from wc_gan_amd import _lib
+if os.environ.get("WC_LIB"):          # development: another build of the library (tools/build_var.py)
+    _lib.LIB_PATH = os.environ["WC_LIB"]
 from wc_gan_amd import ops
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 mode = sys.argv[2] if len(sys.argv) > 2 else "k3"

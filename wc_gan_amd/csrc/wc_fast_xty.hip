@@ -42,6 +42,9 @@ constexpr int BW_PLAIN = 3;                // 32x32 blocks per wave
 #ifndef XTY_ALLLIVE
 #define XTY_ALLLIVE 1
 #endif
+#ifndef XTY_ALT
+#define XTY_ALT 0       // 1: covariance (K1): every other MFMA chain runs on the NEGATED A fragments and is subtracted at the float64 flush (see the stage loop)
+#endif
 #ifndef XTY_FLUSH_STAGES
 #define XTY_FLUSH_STAGES 1     // covariance (K1): stages per fp32 MFMA chain before the float64 flush.  Development knob, measured in round 3
                                // (tools/seed_sweep.py, worst dx over three seeds at 128x32x32x256, cond 1e6): 1 stage = 12 MFMA accumulations
@@ -404,6 +407,12 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
         // ALL: every block of this wave is live (a scalar, per wave) -- the loop is then ONE basic block; with a `live` test per
         // block and k-step (a per-lane value as far as hipcc can tell: exec-mask branches) every three MFMAs sat in a block of
         // their own (K1 kernel 60 -> 56 us)
+        // XTY_ALT (round 4): v_mfma_f32_32x32x16_f16's accumulation is biased -- every chain comes out low by ~1e-9 of sqrt(S_ii S_jj)
+        // whatever the sign of its sum (rounds 3-4 added a fitted constant back) -- so every ODD stage runs on the
+        // negated A fragments and its chain is SUBTRACTED at the flush: the sums add up as before, the biases of consecutive chains
+        // cancel (measured: mean off-diagonal error -9.7e-10 -> +5e-12 of sqrt(S_ii S_jj), the same on uniform / post-ReLU / Laplace
+        // inputs).  The f16 MFMAs have no neg modifier: one v_xor per fragment register with a wave-uniform mask (0 in even stages).
+        const unsigned sgn = (XTY_ALT && !TWO && FS == 1 && (st & 1)) ? 0x80008000u : 0u;
         auto products = [&](auto ALL_, auto NL_) __attribute__((always_inline)) {
             constexpr bool ALL = decltype(ALL_)::value;
             constexpr int NL = decltype(NL_)::value;          // blocks 0 .. NL-1 (all live when ALL)
@@ -412,7 +421,12 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
 #pragma unroll
                 for (int b = 0; b < NL; ++b) {
                     if (!ALL && !live[b]) continue;
-                    const f16x8 ah = frag(a_base[b], ks, 0), al = frag(a_base[b], ks, 1);
+                    f16x8 ah = frag(a_base[b], ks, 0), al = frag(a_base[b], ks, 1);
+                    if (XTY_ALT && !TWO && FS == 1 && sgn) {       // (a scalar branch: even stages skip the eight v_xor)
+                        typedef unsigned u32x4v_ __attribute__((ext_vector_type(4)));
+                        ah = __builtin_bit_cast(f16x8, __builtin_bit_cast(u32x4v_, ah) ^ sgn);
+                        al = __builtin_bit_cast(f16x8, __builtin_bit_cast(u32x4v_, al) ^ sgn);
+                    }
                     const f16x8 bh = frag(b_base[b], ks, 0), bl = frag(b_base[b], ks, 1);
                     acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[b], 0, 0, 0);
                     acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[b], 0, 0, 0);
@@ -443,17 +457,18 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
         else if (any_live) products(std::false_type{}, std::integral_constant<int, BW>{});
         XS();
         // float64 flush: the fp32 rounding chain never exceeds one stage (3*KS MFMA accumulations)
+        const double fsg = sgn ? -1.0 : 1.0;             // (wave-uniform: the chain's sign)
         if (FS > 1 && st % FS != FS - 1 && st + 1 < nst) {}
         else if (two_live) {
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc64[b][r] += (double)acc[b][r];
+                for (int r = 0; r < 16; ++r) acc64[b][r] = __builtin_fma((double)acc[b][r], fsg, acc64[b][r]);
         } else if (any_live) {
 #pragma unroll
             for (int b = 0; b < BW; ++b)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc64[b][r] += (double)acc[b][r];
+                for (int r = 0; r < 16; ++r) acc64[b][r] = __builtin_fma((double)acc[b][r], fsg, acc64[b][r]);
         }
         XS();
         // LDS hand-off only (__syncthreads() would also drain vmcnt, i.e. wait for the loads of stage st+2 issued a moment ago)

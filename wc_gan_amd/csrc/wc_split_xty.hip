@@ -35,6 +35,9 @@
 #ifndef SXT_DMA_FRONT
 #define SXT_DMA_FRONT 0     // 1: a stage's DMA pieces leave right behind its barrier (0: behind the block-steps' MFMAs)
 #endif
+#ifndef SXT_ALT
+#define SXT_ALT 0      // 1: every other MFMA chain runs on the negated A fragments and is subtracted at the flush -- the matrix pipe's accumulation bias cancels (wc_fast_xty.hip, XTY_ALT; measured and left off: DESIGN.md section 2)
+#endif
 #ifndef SXT_ABL
 #define SXT_ABL 0      // development ablation bits: 1 no VALU statistics, 2 no fragment reads / MFMAs, 4 no DMAs after the prologue
 #endif
@@ -223,9 +226,10 @@ __global__ __launch_bounds__(512, 1) void xtx_split_kernel(SplitXtxArgs a)
     // own one block where waves 0-3 own two: a stage is one barrier interval for all eight waves, and with every wave in the
     // same phase the vector ALU (two float64 instructions per accumulator element and flush) and the matrix pipe took
     // turns -- the first version ran 12 vector instructions per MFMA, as many as the converting kernel, at 59 us.
-    auto stage = [&](int s, auto NL_, auto ZERO_, auto FL_, auto MODE_) __attribute__((always_inline)) {
+    auto stage = [&](int s, auto NL_, auto ZERO_, auto FL_, auto MODE_, bool neg) __attribute__((always_inline)) {
         constexpr int NL = decltype(NL_)::value;
         constexpr bool ZERO = decltype(ZERO_)::value, FL = decltype(FL_)::value;
+        const unsigned sgn = (SXT_ALT && neg) ? 0x80008000u : 0u;       // (wave-uniform: the sign of this stage's chain)
         unsigned long long c0_ = 0;
         if (SXT_STAMPS) c0_ = __builtin_amdgcn_s_memtime();
         // my pieces of stage s have landed (younger: my pieces of stages s+1 and s+2, where those exist)
@@ -245,6 +249,11 @@ __global__ __launch_bounds__(512, 1) void xtx_split_kernel(SplitXtxArgs a)
         auto read_a = [&](int set, int ks, int b) __attribute__((always_inline)) {
             const char* pa = sb + ks * (NB * 1024) + fa_off[b];
             F[set][0] = tr_read8(pa); F[set][1] = tr_read8(pa + 2 * NB * 1024);
+            if (SXT_ALT && sgn) {       // (a scalar branch: positive chains skip the eight v_xor)
+                typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+                F[set][0] = __builtin_bit_cast(f16x8, __builtin_bit_cast(u32x4v, F[set][0]) ^ sgn);
+                F[set][1] = __builtin_bit_cast(f16x8, __builtin_bit_cast(u32x4v, F[set][1]) ^ sgn);
+            }
         };
         auto read_b = [&](int set, int ks, int b) __attribute__((always_inline)) {
             const char* pb = sb + ks * (NB * 1024) + fb_off[b];
@@ -280,10 +289,11 @@ __global__ __launch_bounds__(512, 1) void xtx_split_kernel(SplitXtxArgs a)
             }
         }
         if (FL) {
+            const double fsg = sgn ? -1.0 : 1.0;
 #pragma unroll
             for (int b = 0; b < NL; ++b)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc64[b][r] += (double)acc[b][r];
+                for (int r = 0; r < 16; ++r) { if (SXT_ALT) acc64[b][r] = __builtin_fma((double)acc[b][r], fsg, acc64[b][r]); else acc64[b][r] += (double)acc[b][r]; }
         }
         if (SXT_STAMPS) t_mfma += __builtin_amdgcn_s_memtime() - c2_;
     };
@@ -292,9 +302,9 @@ __global__ __launch_bounds__(512, 1) void xtx_split_kernel(SplitXtxArgs a)
     using M0 = std::integral_constant<int, 0>;
     if (wave >= 4) {        // one block; chains [odd stage, even stage]; stage 0 continues the zero-initialised accumulator
         auto loop_b = [&](auto MODE_) __attribute__((always_inline)) {
-            for (int s = 0; s < nst; s += 2) {
-                stage(s, N1{}, F_{}, T_{}, MODE_);
-                stage(s + 1, N1{}, T_{}, F_{}, MODE_);
+            for (int s = 0; s < nst; s += 2) {      // chain k = stages 2k - 1 (zero start) and 2k (flush): stage s ends chain s / 2
+                stage(s, N1{}, F_{}, T_{}, MODE_, ((s >> 1) & 1) != 0);
+                stage(s + 1, N1{}, T_{}, F_{}, MODE_, (((s >> 1) + 1) & 1) != 0);
             }
         };
         const int mode = (want_csum ? 1 : 0) | (want_dfix ? 2 : 0);
@@ -302,19 +312,23 @@ __global__ __launch_bounds__(512, 1) void xtx_split_kernel(SplitXtxArgs a)
         else if (mode == 2) loop_b(std::integral_constant<int, 2>{});
         else if (mode == 1) loop_b(std::integral_constant<int, 1>{});
         else loop_b(M0{});
+        if (SXT_ALT && (nst & 2)) {                                         // the last (odd) stage's half chain: negated when nst = 2 (mod 4)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc64[0][r] -= (double)acc[0][r];
+        } else
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc64[0][r] += (double)acc[0][r];      // the last (odd) stage's half chain
 #pragma unroll
         for (int e = 0; e < 8; ++e) lsq[e] += (double)sq[e];                // ... and its squares
     } else if (nlive == 2) {
-        for (int s = 0; s < nst; s += 2) {
-            stage(s, N2{}, T_{}, F_{}, M0{});
-            stage(s + 1, N2{}, F_{}, T_{}, M0{});
+        for (int s = 0; s < nst; s += 2) {          // chain k = stages 2k, 2k + 1
+            stage(s, N2{}, T_{}, F_{}, M0{}, ((s >> 1) & 1) != 0);
+            stage(s + 1, N2{}, F_{}, T_{}, M0{}, ((s >> 1) & 1) != 0);
         }
     } else {
         for (int s = 0; s < nst; s += 2) {
-            stage(s, N1{}, T_{}, F_{}, M0{});
-            stage(s + 1, N1{}, F_{}, T_{}, M0{});
+            stage(s, N1{}, T_{}, F_{}, M0{}, ((s >> 1) & 1) != 0);
+            stage(s + 1, N1{}, F_{}, T_{}, M0{}, ((s >> 1) & 1) != 0);
         }
     }
     if (SXT_STAMPS && a.dbg && lane == 0) {
