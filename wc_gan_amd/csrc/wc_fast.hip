@@ -47,7 +47,7 @@
 #define WC_NO_PIPE 0   // development: 1 leaves the ring kernel's k-loop to hipcc's own schedule
 #endif
 #ifndef WC_K6_ABL
-#define WC_K6_ABL 0   // development, one-pass K6 only (results wrong; tools/k6_variants.py): 1 no dx stores, 2 no MFMA, 4 no fragment reads (with 2), 8 no conversion arithmetic / image writes, 32 no waits for the DMAs, 64 no hand-off waits (counters)
+#define WC_K6_ABL 0   // development, one-pass K6 only (results wrong; tools/k6_variants.py): 1 no dx stores, 2 no MFMA, 4 no fragment reads (with 2), 8 no conversion arithmetic / image writes, 32 no waits for the DMAs, 64 no hand-off waits (counters), 256 no DMAs of x (half of the kernel's LDS-DMA instructions)
 #endif
 #ifndef WC_ABL
 #define WC_ABL 0      // development ablation bits: 1 no stores, 2 no MFMA, 4 no staging writes, 8 no loads, 16 no counters, 32 MFMA operands from registers only
@@ -1243,6 +1243,7 @@ __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
             g = reinterpret_cast<const char*>(((lane_ >> 5) ? a.xlo : a.xhi) + row_ * C) + (lane_ & 31) * 16;
         const unsigned l = __builtin_amdgcn_readfirstlane(ring_w + slot * 1024);
         unsigned keep;
+        if ((WC_K6_ABL & 256) && (p & 2)) return;   // (development, timing only: no x chunks at all)
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(g), "s"(l) : "memory");
     };
