@@ -836,6 +836,14 @@ def main(argv=None):
             "roofline": roof, "cpu_baseline": cpu,
         }
         out.update(extra)
+        # whatever the C side has buffered for stdout (RCCL's version banner when a communicator exists) goes out FIRST: the result is
+        # then the last line a reader of this process's stdout sees, not followed by C-stdio text flushed at exit
+        try:
+            import ctypes
+            sys.stdout.flush()
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
     if in_group:
         dist.barrier()
