@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define WC_ABI_VERSION 6
+#define WC_ABI_VERSION 7
 
 #define WC_OK                 0
 #define WC_ERR_NULL          -1   /* a required pointer is NULL                     */
@@ -157,8 +157,11 @@ int wc_apply_act_f32(const float* x, const float* mu, const float* A, const floa
  *     x[m][c] ~= center[c] + (hi[m][c] + lo[m][c]) / scale[c],   hi = fp16(g), lo = fp16(g - hi), g = (x - center) scale
  * `xs` = 2*M*C halves: the hi plane [M][C], then the lo plane [M][C].  scale[c]: a power of two that puts the channel's
  * sampled maximum into [8, 16] (>= 3700 x of headroom below fp16's range); center[c]: any value near the channel mean
- * (NULL = 0).  An element beyond +-60000 after scaling is clamped and sets *flag (device int, nullable) to 1. */
+ * (NULL = 0).  wc_split_f32 (the stand-in producer of tests and benches: scales given by the caller) clamps an element beyond +-60000
+ * after scaling and sets *flag (device int, nullable) to 1; the producer the layers use, wc_resadd_split_f32, never clamps (below). */
 size_t wc_split_bytes(int64_t M, int C);
+/* int32 words of the producer's `flag` area (ABI 7): [0] status, [64, 64 + C) per-channel maxima, [64 + C, 64 + 2C) the sampled scales */
+#define WC_SPLIT_FLAG_WORDS (64 + 2 * 1024)
 /* center, scale from <= 256 sampled rows of x (outlier-proof, as K1's own shift / scales); zeroes flag[0..63]. */
 int wc_split_scales_f32(const float* x, int64_t M, int C, float* center /*[C] out*/, float* scale /*[C] out*/,
                         int* flag /*[64] out: zeroed*/, wc_stream_t stream);
@@ -205,13 +208,20 @@ int wc_apply_split_f16x2(const void* xs, const float* xs_center /*nullable*/, co
  * (wc_whiten_split_f16x2, wc_apply_split_ex_f16x2) and the next block's shortcut convolution (wc_fold_channel_scale_f32 +
  * wc_conv_f16x3 on the same planes) read it without a conversion; x32 (nullable) also receives the fp32 sum, for a reader without
  * a planes path.  C in {128, 256} (wc_resadd_split_supported), N*H*W < 2^31.
+ * ABI 7: NOTHING SATURATES.  A sampled scale can be too tight (a channel nearly constant on the sampled rows that spikes elsewhere);
+ * the pass then records the true maximum of every channel that met an element beyond +-60000 and a second, gated launch (it leaves
+ * at once otherwise; no host synchronisation, graph-capturable) rewrites the planes with those channels' scales lowered to fit, and
+ * scale[] with them -- every consumer reads scale[] from device memory behind this call, so K1, K3, the shortcut convolution and
+ * the backward see a consistent, exact tensor.  flag[0] = 1 afterwards says that this happened (informational).  A non-finite
+ * element stays non-finite in the planes.  `flag`: WC_SPLIT_FLAG_WORDS int32 words, all scratch but [0].
  * wc_patch_sum_f32: the gradient of the up = 1 form with respect to s: out[n][y][x] = the sum of g over the 2x2 patch. */
 int wc_resadd_split_supported(int64_t N, int64_t H, int64_t W, int C);
 int wc_resadd_f32(const float* h, const float* s /*nullable*/, int64_t N, int64_t H, int64_t W, int C, int up, float* out,
                   wc_stream_t stream);
 int wc_resadd_split_f32(const float* h, const float* s /*nullable*/, int64_t N, int64_t H, int64_t W, int C, int up,
                         void* xs /*out: 2*N*H*W*C halves*/, float* center /*[C] out*/, float* scale /*[C] out*/,
-                        int* flag /*[64] out: [0] = 1 when an element saturated*/, float* x32 /*out, nullable*/, wc_stream_t stream);
+                        int* flag /*[WC_SPLIT_FLAG_WORDS] out: [0] = 1 when the gated rescaling pass ran*/, float* x32 /*out, nullable*/,
+                        wc_stream_t stream);
 int wc_patch_sum_f32(const float* g /*(N, 2 Hs, 2 Ws, C)*/, int64_t N, int64_t Hs, int64_t Ws, int C, float* out /*(N, Hs, Ws, C)*/,
                      wc_stream_t stream);
 /* A 1x1 convolution (the block's shortcut, generator.py:142-146) on a pre-split input: with x[c] = center[c] + g[c] / scale[c],

@@ -69,16 +69,137 @@ def test_resadd_split_writes_what_split_makes_of_the_fp32_sum(shape, up):
     assert ops.resadd_split(h, s, up).x32 is None
 
 
-def test_resadd_split_saturates_and_flags_an_element_beyond_the_range():
+def _off_sample_rows(M, count, rng):
+    """`count` distinct rows that the <= 256-row subsample does NOT visit (ops.sample_rows mirrors wc_sample_row of csrc/wc_common.h)."""
+    from wc_gan_amd import ops
+    taken = set(ops.sample_rows(M))
+    rows = [r for r in rng.permutation(M)[:count + 600].tolist() if r not in taken][:count]
+    assert len(rows) == count
+    return np.asarray(rows)
+
+
+def test_samples_cover_the_image_interior():
+    """rows r * (M / 256) of a 128 x 32 x 32 (128 x 16 x 16) tensor all sit in the x = 0 border column; wc_sample_row spreads them."""
+    from wc_gan_amd import ops
+    for (N, H, W) in ((128, 32, 32), (128, 16, 16), (320, 32, 32), (64, 48, 48)):
+        rows = np.asarray(ops.sample_rows(N * H * W))
+        assert len(set(rows.tolist())) == 256 and rows.max() < N * H * W
+        xs, ys = rows % W, (rows // W) % H
+        assert len(set(xs.tolist())) >= W // 2 and len(set(ys.tolist())) >= H // 2
+        assert len(set((rows // (H * W)).tolist())) >= min(N, 256) // 2          # ... and over the samples of the batch
+
+
+@pytest.mark.parametrize("spike", [3e7, 4e4])
+def test_resadd_split_rescales_instead_of_saturating(spike):
+    """VERDICT r4 item 1 / ADVICE r4: an element beyond +-60000 after scaling (a spike on a row the sample did not visit) used to be CLAMPED,
+    with a flag nothing read.  Now the gated second pass redoes the planes with that channel's true maximum: flag[0] says so, scale[c] is
+    lowered by a power of two, every element of the channel -- the spike included -- is represented to 2^-20 of the channel's maximum, and
+    every other channel is bit for bit what it was without the spike."""
     from wc_gan_amd import ops
     torch.manual_seed(2)
     h = torch.randn(64, 16, 16, 256, device="cuda")
     s = torch.randn(64, 8, 8, 256, device="cuda")
-    h[5, 3, 3, 17] = 3e7            # (not on a sampled row: rows r * (M / 256))
+    clean = ops.resadd_split(h, s, True)
+    M = 64 * 16 * 16
+    row = int(_off_sample_rows(M, 1, np.random.default_rng(0))[0])
+    n, y, x = row // 256, (row // 16) % 16, row % 16
+    h[n, y, x, 17] = spike
+    ref = h + _up(s)
     st = ops.resadd_split(h, s, True)
     torch.cuda.synchronize()
+    assert int(clean.flag[0]) == 0 and int(st.flag[0]) == 1
+    assert bool(torch.isfinite(st.planes.float()).all()) and float(st.planes.float().abs().max()) < 2.0 ** 15
+    ratio = float(clean.scale[17] / st.scale[17])
+    assert ratio > 1 and np.log2(ratio) == int(np.log2(ratio))
+    others = [c for c in range(256) if c != 17]
+    assert torch.equal(st.scale[others], clean.scale[others]) and torch.equal(st.center, clean.center)
+    assert torch.equal(st.planes.view(2, M, 256)[:, :, others], clean.planes.view(2, M, 256)[:, :, others])
+    back = ops.unsplit(st)
+    err = (back.double() - ref.double()).abs().view(M, 256).amax(0)
+    span = (ref.double() - st.center.double()).abs().view(M, 256).amax(0)
+    assert bool((err <= span * 2.0 ** -20).all())
+    assert abs(float(back[n, y, x, 17]) / float(ref[n, y, x, 17]) - 1) < 2.0 ** -20          # the spike itself: not clamped
+    # a second call on ordinary data through the same path clears the status word again
+    assert int(ops.resadd_split(torch.randn_like(h), s, True).flag[0]) == 0
+
+
+def _spiky_sum(shape, rng, c0=5, ratio=2.0e4, frac=0.004):
+    """h, s whose sum is an ordinary well-conditioned activation except channel c0: nearly constant (1e-3 sigma) everywhere the subsample looks,
+    with spikes `ratio` times that on a fraction of the other rows -- a sparse feature map, the case the sampled scale misjudges by > 3700 x."""
+    N, H, W, C = shape
+    M = N * H * W
+    x = o.synth_activation(rng, shape, "well").astype(np.float32).reshape(M, C)
+    x[:, c0] = 0.3 + 1e-3 * rng.standard_normal(M)
+    rows = _off_sample_rows(M, int(frac * M), rng)
+    x[rows, c0] += (1e-3 * ratio) * rng.standard_normal(len(rows))
+    x = x.reshape(shape)
+    s = (0.5 * rng.standard_normal((N, H // 2, W // 2, C))).astype(np.float32)
+    up = np.repeat(np.repeat(s, 2, axis=1), 2, axis=2)
+    h = (x - up).astype(np.float32)
+    return h, s, h.astype(np.float64) + up.astype(np.float64)
+
+
+@pytest.mark.parametrize("shape,relu", [((128, 16, 16, 256), True), ((64, 32, 32, 256), False), ((64, 32, 32, 128), True)])
+def test_spiky_channel_through_the_planes_route_meets_the_contract(shape, relu):
+    """The same case through the layers' route, default environment: residual_add(planes=True) -> whiten_color (K1 + K2, K3, K4, K5, K6
+    all on the rescaled planes), forward + backward against the float64 oracle on the exact sum: 1e-4 (north_star's contract) on y, dh, ds
+    and the coloring gradients.  With round 4's clamp the spikes of channel c0 were cut to 3700 x the sampled maximum: y off by 0.3."""
+    from wc_gan_amd.functional import residual_add, split_of, whiten_color
+    rng = np.random.default_rng(41)
+    N, H, W, C = shape
+    h, s, xsum = _spiky_sum(shape, rng)
+    G, B = o.synth_coloring(rng, C, 1)
+    gy = rng.standard_normal(shape).astype(np.float32)
+    ht, st_ = dev(h).requires_grad_(True), dev(s).requires_grad_(True)
+    Gt, Bt = dev(G).requires_grad_(True), dev(B).requires_grad_(True)
+    mm, mc = torch.zeros(C, 1, device="cuda"), torch.eye(C, device="cuda")
+    xh = residual_add(ht, st_, True, planes=True, x32=(C != 256))
+    st = split_of(xh)
+    assert st is not None
+    y = whiten_color(xh, Gt, Bt, None, mm, mc, True, relu=relu)
+    y.backward(dev(gy))
+    torch.cuda.synchronize()
+    assert int(st.flag[0]) == 1, "the case is not the one this test is about: no sampled scale was too tight"
+    y_ref, cache = o.wc_forward(xsum, G, B, None, moving_mean=np.zeros(C), moving_cov=np.eye(C))
+    yn = y.detach().cpu().numpy()
+    gm = gy.astype(np.float64) * (yn > 0) if relu else gy
+    dx_ref, dG_ref, dB_ref = o.wc_backward(gm, cache)
+    dx_ref = dx_ref.reshape(shape)
+    ds_ref = dx_ref.reshape(N, H // 2, 2, W // 2, 2, C).sum((2, 4))
+    errs = dict(y=_rel(yn, np.maximum(y_ref, 0).reshape(shape) if relu else y_ref.reshape(shape)), dh=_rel(ht.grad, dx_ref), ds=_rel(st_.grad, ds_ref),
+                dG=_rel(Gt.grad, dG_ref), dB=_rel(Bt.grad, dB_ref), mc=_rel(mc, cache['moving_cov']))
+    print(shape, relu, errs)
+    assert all(v < 1e-4 for v in errs.values()), errs
+
+
+def test_spiky_channel_through_the_shortcut_convolution():
+    """... and through the next block's 1x1 shortcut on the same planes (conv.split_conv: 1 / scale folded into the weight): output and all
+    four gradients to 1e-5 of their maxima, the convolution kernels' own tolerance."""
+    from wc_gan_amd import conv as fc
+    from wc_gan_amd.functional import residual_add, split_of
+    rng = np.random.default_rng(43)
+    shape, Cout = (64, 16, 16, 256), 256
+    N, H, W, C = shape
+    h, s, xsum = _spiky_sum(shape, rng)
+    ht, st_ = dev(h).requires_grad_(True), dev(s).requires_grad_(True)
+    torch.manual_seed(7)
+    w = (torch.randn(Cout, C, 1, 1, device="cuda") / C ** 0.5).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    b = torch.randn(Cout, device="cuda").requires_grad_(True)
+    gy = torch.randn(N, H, W, Cout, device="cuda")
+    x = residual_add(ht, st_, True, planes=True)
+    st = split_of(x)
+    y = fc.split_conv(x, st, w, b)
+    y.backward(gy)
+    torch.cuda.synchronize()
     assert int(st.flag[0]) == 1
-    assert bool(torch.isfinite(st.planes.float()).all())
+    got = (y.detach(), ht.grad.clone(), st_.grad.clone(), w.grad.clone(), b.grad.clone())
+    xr = torch.tensor(xsum, device="cuda").requires_grad_(True)
+    wd, bd = w.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xr.permute(0, 3, 1, 2), wd, bd).permute(0, 2, 3, 1)
+    yr.backward(gy.double())
+    dsr = xr.grad.view(N, H // 2, 2, W // 2, 2, C).sum((2, 4))
+    for name, a, r in zip(("y", "dh", "ds", "dw", "db"), got, (yr.detach(), xr.grad, dsr, wd.grad, bd.grad)):
+        assert _rel(a, r) < 1e-5, name
 
 
 def test_fold_and_unfold_channel_scale():
@@ -371,7 +492,9 @@ def test_generator_update_pass_with_and_without_the_producer(conditional):
         G(z, cls)
     snap = _snapshot(G)
     gimg = torch.randn(128, 32, 32, 3, device="cuda")
+    import wc_gan_amd.functional as WF
     res = {}
+    masks = []
     for on in (True, False):
         _restore(G, snap)
         gen.SPLIT_PRODUCER = on
@@ -382,25 +505,37 @@ def test_generator_update_pass_with_and_without_the_producer(conditional):
                 flags = _launched_split(G, z, cls)
                 assert flags[-1] and flags[1], flags            # block 2 -> Final (32x32) and block 1 -> block 2 (16x16) at least
                 _restore(G, snap)
+            WF.MASK_TAP = {'record': masks} if on else {'replay': list(masks)}
             img = G(z, cls)
+            assert on or not WF.MASK_TAP['replay'], "the two routes did not run the same ReLU'd sites"
+            WF.MASK_TAP = None
             img.backward(gimg)
             res[on] = (img.detach().clone(), [p.grad.clone() for p in G.parameters()], [b.detach().clone() for b in G.buffers()])
         finally:
             gen.SPLIT_PRODUCER = True
+            WF.MASK_TAP = None
+    assert len(masks) == 7, len(masks)          # every WC site of the generator is ReLU'd and keeps a one-bit mask
     assert _rel(res[True][0], res[False][0]) < 2e-5
     for a, b in zip(res[True][2], res[False][2]):
         assert _rel(a, b) < 2e-5
-    # The gradients: the two routes' K3 outputs differ in the last bits (two roundings of the same 22-bit operands), so a few dozen of
-    # the 33 million pre-activations per site that lie within 1e-6 of zero take the other side of the ReLU -- k flipped terms of a sum
-    # of N change it by ~sqrt(k / N) ~ 1e-3 of its size.  (Each route by itself is pinned to the float64 oracle at 1e-4 for the mask it
-    # produced: test_relud_site_on_planes_meets_the_contract_at_cond_1e6; with the hand-off, where the masks are equal bit for bit, the
-    # same comparison holds to 2e-5: tests/test_handoff_gpu.py.)  Here: 1e-2 of each gradient's norm.
+    # The gradients.  The two routes' K3 outputs differ in the last bits (two roundings of the same 22-bit operands), so
+    # a few dozen of the 33 million pre-activations per site that lie within 1e-6 of zero would take the other side of the ReLU and move a
+    # gradient by ~1e-3 of its size -- round 4 compared at 1e-2 for that reason, which would not catch a 0.5 % bug in the planes backward.
+    # Here the masks are identical BY CONSTRUCTION: the fp32 route's sites save the masks the planes route produced
+    # (functional.MASK_TAP), so every parameter gradient is pinned through the whole generator at 2e-5 of its maximum.
     # (gradients that are zero in exact arithmetic -- the bias of a convolution in front of a WC site: the site removes the mean -- are
-    # rounding noise on either route, 1e-3 beside gradients of size 600: those are bounded by 1e-5 of the largest gradient's norm)
+    # rounding noise on either route, 1e-3 beside gradients of size 600: those are bounded by 2e-6 of the largest gradient's maximum)
     names = [n for n, _ in G.named_parameters()]
-    top = max(float(b.double().norm()) for b in res[False][1])
+    top = max(float(b.abs().max()) for b in res[False][1])
+    worst, bad = 0.0, {}
     for n, a, b in zip(names, res[True][1], res[False][1]):
-        assert float((a.double() - b.double()).norm()) <= max(1e-2 * float(b.double().norm()), 1e-5 * top), n
+        d = float((a.double() - b.double()).abs().max())
+        rel_own, rel_top = d / max(float(b.abs().max()), 1e-30), d / top
+        if rel_own > 2e-5 and rel_top > 2e-6:
+            bad[n] = (rel_own, rel_top)
+        worst = max(worst, min(rel_own, rel_top * 10))
+    print("worst gradient difference, planes route vs fp32 route on the same masks:", worst)
+    assert not bad, bad
 
 
 @pytest.mark.parametrize("conditional", [False, True])

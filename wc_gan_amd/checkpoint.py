@@ -23,6 +23,11 @@ submodule is empty); everything in-tree is cited.
     ..._repart[_u|_c]/gamma:0, /beta:0                    CenterScale / ConditionalCenterScale (generator.py:28-40)
     Generator.BN.Final_npart/..., Generator.BN.Final_repart/...   the last site (generator.py:154)
 
+Two conventions that differ and are NOT converted (no shipped recipe uses either; stated so that nobody is surprised): Keras'
+BatchNormalization stores the BIASED batch variance in moving_variance, torch's running_var the unbiased one (n / (n - 1) apart while
+training resumes: norm == 'b' generators only); and a spectral concat_cls generator upstream wraps its Embedding in SNEmbeding with a
+`/u:0` weight, where this build's Generator keeps a plain nn.Embedding (the key is then `embedding_<n>`, not `sn_embeding_<n>`).
+
 Layout conversions (torch here <-> Keras in the file): Conv2D kernel (Cout, Cin, kh, kw) <-> (kh, kw, Cin, Cout); Dense kernel
 (out, in) <-> (in, out); everything else is stored as it is held.
 """
@@ -86,7 +91,8 @@ def _entries(module):
         elif isinstance(m, nn.Embedding):
             n_emb += 1
             sn = hasattr(m, 'sn_u')
-            name = f"{'sn_embedding' if sn else 'embedding'}_{n_emb}"
+            # upstream's class is SNEmbeding (one d: generator.py:111), which Keras snake-cases to `sn_embeding_<n>`
+            name = f"{'sn_embeding' if sn else 'embedding'}_{n_emb}"
             yield (f"{name}/embeddings:0", m.weight) + ident
             if sn:
                 yield from _sn_pair(name, m)
@@ -100,14 +106,16 @@ _NOT_WEIGHTS = ('num_batches_tracked',)
 def _assert_covered(module):
     """Every parameter and persistent buffer of `module` is named by _entries -- a tensor the walk does not know would otherwise be
     lost silently by save + load (strict=True cannot notice what is never enumerated)."""
-    covered = {t.data_ptr() for _, t, _, _ in _entries(module)}
+    # by object identity, not by data_ptr(): zero-element / unmaterialised tensors all report data_ptr() == 0 and a view shares its
+    # base's pointer, so either could pass for a tensor the walk does not name (ADVICE r4)
+    covered = {id(t) for _, t, _, _ in _entries(module)}
     persistent = set(module.state_dict(keep_vars=True).keys())
     missing = []
     for n, t in list(module.named_parameters()) + list(module.named_buffers()):
         leaf = n.rsplit('.', 1)[-1]
-        if leaf.startswith('_') or leaf in _NOT_WEIGHTS or n not in persistent:
+        if leaf.startswith('_') or leaf in _NOT_WEIGHTS or n not in persistent or t.numel() == 0:
             continue
-        if t.data_ptr() not in covered:
+        if id(t) not in covered:
             missing.append(n)
     if missing:
         raise NotImplementedError("the Keras-named checkpoint has no entry for " + ", ".join(sorted(missing)[:6]) +
@@ -133,7 +141,7 @@ def save_keras_named(module, path):
 OPTIONAL_SUFFIXES = ("/v:0",)        # this build's additions: an upstream file does not hold them
 
 
-_AUTO_NAME = re.compile(r"^((?:sn_)?(?:dense|embedding))_(\d+)/(.+)$")
+_AUTO_NAME = re.compile(r"^(dense|sn_dense|embedding|sn_embeding|sn_embedding)_(\d+)/(.+)$")     # (sn_embedding: files written by rounds 3-4 of this build)
 
 
 def _renumber_auto_names(module, state):
@@ -179,7 +187,7 @@ def load_keras_named(module, state, strict=True):
         state = dict(np.load(state))
     _assert_covered(module)
     state = _renumber_auto_names(module, state)
-    owners = {m.sn_v.data_ptr(): m for m in module.modules() if hasattr(m, 'sn_v')}
+    owners = {id(m.sn_v): m for m in module.modules() if hasattr(m, 'sn_v')}
     seen = set()
     rebuild = []
     for k, t, _, from_k in _entries(module):
@@ -190,8 +198,8 @@ def load_keras_named(module, state, strict=True):
             with torch.no_grad():
                 t.copy_(a.to(t.device))          # (copy_ keeps the tensor's own strides: channels_last kernels stay channels_last)
             seen.add(k)
-        elif k.endswith('/v:0') and t.data_ptr() in owners:
-            rebuild.append(owners[t.data_ptr()])
+        elif k.endswith('/v:0') and id(t) in owners:
+            rebuild.append(owners[id(t)])
         elif strict and not k.endswith(OPTIONAL_SUFFIXES):
             raise KeyError(f"missing weight {k}")
     for m in rebuild:                            # (after the loop: the layer's weight and u are loaded by now)

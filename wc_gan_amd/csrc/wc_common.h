@@ -41,6 +41,18 @@ __device__ __forceinline__ float wc_robust_max16(const float (&gmax)[16])
     return (med > 0.f && m > 64.f * med) ? 4.f * med : m;
 }
 
+// Row of sample r of the <= 256-row subsample every fp16 path takes its centre / scales from (nsamp = min(M, 256), stride = M / nsamp).
+// Rounds 1-4 sampled rows r * stride: for 128x32x32 that stride is 512 and for 128x16x16 it is 128, both multiples of W, so EVERY
+// sampled pixel sat in the image's x = 0 border column, whose values come out of zero-padded 3x3 convolutions -- a border
+// maximum can understate a channel's interior maximum.  Now sample r lies in [r stride, (r + 1) stride) at a hashed offset: still one
+// row per stride-long run of rows (every sample of the batch is visited), spread over all (y, x).  One definition for every sampler
+// (subsample_mean[_scale]_kernel, channel_scale_kernel, resadd_sample_kernel): the planes producer must pick the rows K1's own
+// subsample would (bit-identical centre and scales, tests/test_producer_gpu.py).
+__host__ __device__ __forceinline__ int64_t wc_sample_row(int64_t r, int64_t stride)
+{
+    return r * stride + (int64_t)((((uint32_t)r * 0x9E3779B1u) >> 8) % (uint32_t)stride);
+}
+
 typedef float  f32x16 __attribute__((ext_vector_type(16)));
 typedef double f64x4  __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));

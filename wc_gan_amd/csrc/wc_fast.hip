@@ -90,7 +90,7 @@ __global__ __launch_bounds__(1024) void channel_scale_kernel(const float* __rest
     float mx = 0.f;
     if (c < C) {
         const float ce = center ? center[c] : 0.f;
-        for (int64_t r = part; r < nsamp; r += 16) mx = fmaxf(mx, fabsf(in[r * stride * C + c] - ce));
+        for (int64_t r = part; r < nsamp; r += 16) mx = fmaxf(mx, fabsf(in[wc_sample_row(r, stride) * C + c] - ce));
     }
     red[part][threadIdx.x & 63] = mx;
     __syncthreads();

@@ -16,8 +16,19 @@
 // centre and scale come from <= 256 sampled rows of the SUM (resadd_sample_kernel: the statistics of wc_split_scales_f32 /
 // K1's own subsample -- median-of-groups centre, robust maximum into [8, 16) -- taken on h + up(s) without forming it), so the
 // planes carry exactly what wc_split_f32 would have made of the fp32 sum: one small launch, then one pass over h and s.
-// An element beyond +-60000 after scaling (> 3700 x its channel's sampled maximum) saturates and raises flag[0].
-// fp32 is written too only where a reader without a planes path exists (x32 != NULL: the backward's K4 / K6 today).
+//
+// Nothing saturates silently (round 5).  A sampled scale can be too tight -- a channel that is nearly
+// constant on the <= 256 sampled rows and spikes elsewhere (sparse feature maps) -- and an element beyond +-60000 after scaling
+// (> 3700 x its channel's sampled maximum) does not fit fp16.  Rounds 4's pass clamped it, raised flag[0] and went on: K1, K3, the
+// shortcut convolution and the backward then computed on the clamped tensor.  Now the pass records, for every channel that met such
+// an element, the channel's TRUE maximum (atomicMax on the float's bits: order-independent, so deterministic), and a second, GATED
+// launch of the same kernel -- it leaves at once unless flag[0] is set: no host round trip, graph-capturable, the protocol of
+// wc_apply_planes_f32's scale gate -- redoes the pass with that channel's scale lowered by the power of two that puts the true
+// maximum into [2^14, 2^15) and rewrites scale[c], which every consumer reads from device memory.  The planes then hold the sum
+// exactly as before (hi + lo carry 22 bits of every element whose lo is a normal fp16: >= 2^-3 after scaling, i.e. down to 2^-18 of
+// the channel's maximum; below that the absolute error is 2^-25 of the scaled unit = 2^-40 of the channel's maximum, far below the
+// channel's standard deviation >= max / sqrt(M)).  A non-finite element stays non-finite in the planes (NaN / Inf: loud downstream).
+// fp32 is written too only where a reader without a planes path exists (x32 != NULL: the backward's K4 / K6 at C = 128 today).
 #include "wc_common.h"
 
 namespace {
@@ -39,7 +50,9 @@ struct ResAddArgs {
     float* center; float* scale;           // [C]
     _Float16* hi; _Float16* lo;            // planes (nullable)
     float* x32;                            // fp32 sum (nullable)
-    int* flag;
+    int* flag;                             // [0]: a channel's sampled scale was too tight (pass 1), the gated pass 2 then runs
+    unsigned* gmax;                        // [C] (flag + 64): bits of the largest |scaled element| beyond the guard, per channel (0: none)
+    float* scale0;                         // [C] (flag + 64 + C): the sampled scales, kept while pass 2 rewrites scale[]
 };
 
 __device__ __forceinline__ int64_t src_row(const ResAddArgs& a, unsigned row)
@@ -52,8 +65,8 @@ __device__ __forceinline__ int64_t src_row(const ResAddArgs& a, unsigned row)
 }
 
 // centre / scale of the sum from <= 256 sampled rows: subsample_mean_scale_kernel (wc_rows.hip) on h + up(s).  Same sample
-// (rows r * (M / 256)), same statistics, same results as that kernel gives on the fp32 sum -- bit for bit: the sum of two floats is
-// the float the fp32 tensor would hold.
+// (wc_sample_row, wc_common.h), same statistics, same results as that kernel gives on the fp32 sum -- bit for bit: the sum of two
+// floats is the float the fp32 tensor would hold.
 // (16 channels per 256-thread workgroup, C / 16 workgroups: the kernel is a chain of latencies -- 32 loads per thread, three meetings --
 // and 16 small workgroups on 16 CUs run it in 8-9 us where 4 workgroups of 1024 threads took 12.8)
 constexpr int kSampCh = 16;
@@ -74,7 +87,7 @@ __global__ __launch_bounds__(256) void resadd_sample_kernel(ResAddArgs a)
         const int64_t r = part + 16 * i;
         v[i] = 0.f;
         if (c < C && r < nsamp) {
-            const int64_t row = r * stride;
+            const int64_t row = wc_sample_row(r, stride);
             v[i] = a.h[row * C + c];
             if (a.s) v[i] += a.s[src_row(a, (unsigned)row) * C + c];
         }
@@ -128,14 +141,21 @@ __global__ __launch_bounds__(256) void resadd_sample_kernel(ResAddArgs a)
         }
         a.center[c] = centre;
         a.scale[c] = sc;
+        a.scale0[c] = sc;
+        a.gmax[c] = 0u;
     }
 }
 
 // The pass: one thread = 8 consecutive channels of an output row (two 16-byte loads of h, two of s; one 16-byte store per plane).
 // Grid and block are multiples of C / 8 threads, so a thread keeps its channels -- centre and scale stay in registers.
-template <bool SPLIT, bool F32>
+// REDO: the gated second launch (see the head of the file): leaves at once unless pass 1 raised flag[0]; otherwise the same pass with the
+// saturated channels' scales lowered to what their true maxima ask for (thread-local arithmetic on scale0 / gmax, which nothing writes
+// while this launch runs; the workgroups that own the first row also store the new scale[] for the consumers).
+template <bool SPLIT, bool F32, bool REDO = false>
 __global__ __launch_bounds__(256) void resadd_kernel(ResAddArgs a)
 {
+    static_assert(!REDO || SPLIT, "only the planes are redone");
+    if (REDO && __builtin_nontemporal_load(a.flag) != 1) return;
     const int C = a.C, C8 = C >> 3;
     const int64_t n8 = a.M * C8;
     const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -148,10 +168,28 @@ __global__ __launch_bounds__(256) void resadd_kernel(ResAddArgs a)
     f32x4 s0 = {1.f, 1.f, 1.f, 1.f}, s1 = s0, c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
     if (SPLIT) {
         const int c = cg * 8;
-        s0 = *reinterpret_cast<const f32x4*>(a.scale + c); s1 = *reinterpret_cast<const f32x4*>(a.scale + c + 4);
+        const float* sc = REDO ? a.scale0 : a.scale;
+        s0 = *reinterpret_cast<const f32x4*>(sc + c); s1 = *reinterpret_cast<const f32x4*>(sc + c + 4);
         c0 = *reinterpret_cast<const f32x4*>(a.center + c); c1 = *reinterpret_cast<const f32x4*>(a.center + c + 4);
+        if (REDO) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float gm = __builtin_bit_cast(float, a.gmax[c + j]);      // in units of the sampled scale; 0: the channel fitted
+                if (gm > 0.f && gm < 3.0e38f) {
+                    int e;
+                    frexpf(gm, &e);                                              // gm = f 2^e, f in [0.5, 1): gm 2^(15 - e) in [2^14, 2^15)
+                    const float k = ldexpf(1.0f, 15 - e);
+                    if (j < 4) s0[j] *= k; else s1[j - 4] *= k;
+                }
+            }
+            if (i0 < C8) {
+                *reinterpret_cast<f32x4*>(a.scale + c) = s0;
+                *reinterpret_cast<f32x4*>(a.scale + c + 4) = s1;
+            }
+        }
     }
     bool over = false;
+    float ov[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};        // pass 1: the largest |scaled element| beyond the guard, per channel of this thread
     // two elements per trip: the loads of both (2 x 16 B of h, 2 x 16 B of s each) are in flight before the first is converted
     auto advance = [&](int64_t& r, int& g) { r += drow; g += dcg; if (g >= C8) { g -= C8; ++r; } };
     auto emit = [&](int64_t e, f32x4 v0, f32x4 v1) __attribute__((always_inline)) {
@@ -163,9 +201,11 @@ __global__ __launch_bounds__(256) void resadd_kernel(ResAddArgs a)
             float g[8];
 #pragma unroll
             for (int j = 0; j < 4; ++j) { g[j] = (v0[j] - c0[j]) * s0[j]; g[4 + j] = (v1[j] - c1[j]) * s1[j]; }
+            if (!REDO) {        // (pass 2 cannot meet one: its scales come from the true maxima; a non-finite element stays non-finite)
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (fabsf(g[j]) > kResGuard) { over = true; g[j] = copysignf(kResGuard, g[j]); }
+                for (int j = 0; j < 8; ++j)
+                    if (fabsf(g[j]) > kResGuard) { over = true; ov[j] = fmaxf(ov[j], fabsf(g[j])); g[j] = copysignf(kResGuard, g[j]); }
+            }
             unsigned hw[4], lw[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -199,7 +239,14 @@ __global__ __launch_bounds__(256) void resadd_kernel(ResAddArgs a)
         row = rowb; cg = cgb;
         advance(row, cg);
     }
-    if (SPLIT && a.flag && over) *a.flag = 1;
+    if (SPLIT && !REDO && over) {
+        // the channel's true maximum for pass 2: non-negative floats order as their bit patterns, and a maximum does not depend on
+        // the order of its operands -- deterministic without a reduction pass
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (ov[j] > 0.f) atomicMax(a.gmax + cg * 8 + j, __builtin_bit_cast(unsigned, ov[j]));
+        *a.flag = 1;
+    }
 }
 
 // gradient of the add with respect to the pre-upsample shortcut: every source pixel collects its 2x2 output patch
@@ -279,6 +326,8 @@ hipError_t wc_launch_resadd(const float* h, const float* s, int64_t N, int64_t H
         magic((unsigned)W, &a.magW, &a.shW);
     }
     a.center = center; a.scale = scale; a.flag = flag; a.x32 = x32;
+    a.gmax = flag ? reinterpret_cast<unsigned*>(flag) + 64 : nullptr;
+    a.scale0 = flag ? reinterpret_cast<float*>(flag) + 64 + C : nullptr;
     a.hi = static_cast<_Float16*>(xs); a.lo = a.hi ? a.hi + a.M * C : nullptr;
     const int64_t n8 = a.M * C / 8;
     int64_t blocks = (n8 + 255) / 256;
@@ -287,6 +336,10 @@ hipError_t wc_launch_resadd(const float* h, const float* s, int64_t N, int64_t H
         hipLaunchKernelGGL(resadd_sample_kernel, dim3((C + kSampCh - 1) / kSampCh), dim3(256), 0, st, a);
         if (x32) hipLaunchKernelGGL((resadd_kernel<true, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((resadd_kernel<true, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+        // the gate (x32, where asked for, is already exact).  A grid of its own size: it has to be a multiple of C / 8 threads
+        // (256 is) and the fewer workgroups only to find the flag clear, the cheaper the launch that does nothing
+        const int64_t rblocks = blocks < 1024 ? blocks : 1024;
+        hipLaunchKernelGGL((resadd_kernel<true, false, true>), dim3((unsigned)rblocks), dim3(256), 0, st, a);
     } else {
         hipLaunchKernelGGL((resadd_kernel<false, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
     }

@@ -473,7 +473,7 @@ __global__ __launch_bounds__(1024) void subsample_mean_kernel(const float* __res
     const int64_t stride = M / nsamp;
     float s = 0.f;
     if (c < C)
-        for (int64_t r = part; r < nsamp; r += 16) s += x[r * stride * C + c];
+        for (int64_t r = part; r < nsamp; r += 16) s += x[wc_sample_row(r, stride) * C + c];
     red[part][threadIdx.x & 63] = s;
     __syncthreads();
     if (threadIdx.x < 64 && c < C) {
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(1024) void subsample_mean_scale_kernel(const float*
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int64_t r = part + 16 * i;
-        v[i] = (c < C && r < nsamp) ? x[r * stride * C + c] : 0.f;
+        v[i] = (c < C && r < nsamp) ? x[wc_sample_row(r, stride) * C + c] : 0.f;
         s += v[i];
     }
     red[part][threadIdx.x & 63] = s;

@@ -186,6 +186,7 @@ __global__ __launch_bounds__(512, 1) void apply_split_kernel(SplitApplyArgs a)
     constexpr int ROWB = C * 2, IMG = TR * ROWB, TILE = 2 * IMG;
     constexpr int NBUF = 4;
     static_assert(C == 128 || C == 256, "split apply: C = 128 or 256");
+    static_assert(!(PL && WC_SPLIT_DEFER), "the planes-out epilogue has no deferred-store form (its pend[] / pend_po stay unset)");
     extern __shared__ __attribute__((aligned(1024))) char smem[];      // 4 tiles [hi image | lo image] | counter
     const unsigned tiles_lds = (unsigned)(size_t)((__attribute__((address_space(3))) char*)smem);
     const unsigned cnt_lds = tiles_lds + NBUF * TILE;

@@ -23,6 +23,17 @@ USE_BWD_BITS = os.environ.get('WC_BWD_BITS', '1') != '0'
 # the backward of a site on pre-split planes reads x from the planes too (wc_bwd_reduce_xsplit_f32 / wc_bwd_apply_xsplit_f32); WC_BWD_XSPLIT=0:
 # from the fp32 sum the producer then writes beside the planes
 USE_BWD_XSPLIT = os.environ.get('WC_BWD_XSPLIT', '1') != '0'
+# Test hook (tests/test_producer_gpu.py): {'record': []} collects the one-bit ReLU masks the sites of a pass produce, {'replay': [...]} makes
+# the sites of the next pass SAVE those instead of their own -- two routes whose K3 outputs differ in the last bit then run their backward
+# on identical masks, and their gradients can be compared at rounding level instead of at the level of a few flipped ReLUs.
+MASK_TAP = None
+
+
+def _tap_mask(mask):
+    if 'record' in MASK_TAP:
+        MASK_TAP['record'].append(mask.clone())
+        return mask
+    return MASK_TAP['replay'].pop(0)
 
 
 def _allreduce_(tensors, group):
@@ -120,6 +131,8 @@ class WhitenColorFunction(torch.autograd.Function):
             y, mask = ops.apply(x, mu, A, b, slot, plan=plan, relu=True, want_mask=True)
         else:
             y, mask = ops.apply(x, mu, A, b, slot, plan=plan, relu=relu), None
+        if MASK_TAP is not None and bits:
+            mask = _tap_mask(mask)
         xs_t = getattr(ctx, 'xs_tensors', None) or ()
         ctx.xs_tensors = None
         ctx.save_for_backward(x, mu, L, W, A, At, g if g is not None else torch.empty(0, device=dev),
@@ -250,6 +263,20 @@ def attach_planes(handle, box):
 def split_of(x):
     """The ops.SplitTensor a handle carries (the residual add of the block in front wrote the tensor as pre-split planes), or None."""
     return getattr(x, '_wc_split', None)
+
+
+def materialize(x):
+    """The fp32 tensor behind a handle (no autograd): a block output that travels as pre-split planes (`_wc_split`: ops.unsplit) or a site
+    output that travels as the next convolution's planes (`_wc_planes`: (hi + lo) / scale); any other tensor is returned as it is.  For
+    readers outside the generator's own wiring -- hooks, feature extraction, debugging -- which would otherwise compute on the handle's NaN."""
+    st = getattr(x, '_wc_split', None)
+    if st is not None:
+        return ops.unsplit(st)
+    pl = getattr(x, '_wc_planes', None)
+    if pl is not None:
+        hi, lo, rec = pl
+        return ((hi.float() + lo.float()) / rec[0]).view(x.shape)
+    return x
 
 
 def split_handle(st, shape, dev):

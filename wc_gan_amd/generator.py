@@ -316,6 +316,12 @@ class ResBlockUp(nn.Module):
         self.bn2 = norm(axis=-1, name=name + '.bn2', channels=nfilters)
         self.conv2 = conv_layer(nfilters, nfilters, (3, 3), name=name + '.conv2')
         self.shortcut = conv_layer(in_ch, nfilters, (1, 1), name=name + '.shortcut')
+        # Per-module opt-out of the planes hand-over: with True (default) the block's output may be a HANDLE -- a NaN-valued
+        # stride-0 tensor that carries the autograd edge while the data travels as pre-split planes in `_wc_split` -- which is safe only
+        # for the readers Generator.forward names (the next block's bn1 and shortcut, the last norm).  Set False on a block whose output
+        # something else reads (a forward hook, feature extraction, torch.utils.checkpoint, a custom loop): it then returns the fp32
+        # sum.  functional.materialize(handle) converts a handle after the fact.  INTEGRATION.md, "Handles".
+        self.split_output = True
 
     def forward(self, x, cls, readers=()):
         """readers: the modules that read this block's output (the next block's bn1 and shortcut, or the generator's last norm) --
@@ -350,7 +356,7 @@ class ResBlockUp(nn.Module):
         # the Add that ends the block (generator.py:142-146).  UP: h + upsample2x(s) without the upsampled tensor -- every 2x2
         # output patch adds its one source pixel (csrc/wc_resadd.hip; rounds 1-3: a torch broadcast add)
         if h.is_cuda and h.dtype == torch.float32 and h.shape[-1] % 32 == 0:
-            planes = (SPLIT_PRODUCER and len(readers) > 0 and all(r.takes_split(h.shape) for r in readers))
+            planes = (SPLIT_PRODUCER and self.split_output and len(readers) > 0 and all(r.takes_split(h.shape) for r in readers))
             # the fp32 sum beside the planes: only while a backward will read it (a site whose K4 / K6 have no planes form)
             x32 = planes and torch.is_grad_enabled() and not all(r.backward_takes_split(h.shape) for r in readers
                                                                   if hasattr(r, 'backward_takes_split'))

@@ -138,9 +138,14 @@ def whiten(x2d, eps, momentum, ddof, moving_mean, moving_cov, groups=1):
 # WC_CHECK_K2=1: read K2's error words back after every call (a host synchronisation per site: for shared / time-sliced GPUs and for
 # debugging -- not under graph capture).  The one-launch K2 waits, with a bounded spin, for a workgroup of its own launch.
 CHECK_K2 = os.environ.get("WC_CHECK_K2", "0") == "1"
-# WC_CHECK_SPLIT=1: read the saturation flag of every resadd_split / split back (a host synchronisation per call: debugging, or data
-# whose outliers may exceed ~3700 x a channel's sampled maximum -- the planes route saturates there, the fp32 route has an exact redo)
-CHECK_SPLIT = os.environ.get("WC_CHECK_SPLIT", "0") == "1"
+SPLIT_FLAG_WORDS = 64 + 2 * 1024          # WC_SPLIT_FLAG_WORDS of include/wc_hip.h: the planes producer's status word + its rescaling scratch
+
+
+def sample_rows(M):
+    """The rows of the <= 256-row subsample every fp16 path takes its centre and scales from (wc_sample_row, csrc/wc_common.h)."""
+    n = min(int(M), 256)
+    stride = int(M) // n
+    return [r * stride + (((r * 0x9E3779B1) & 0xFFFFFFFF) >> 8) % stride for r in range(n)]
 
 
 def _check_k2(ws, offset, groups, what):
@@ -340,8 +345,9 @@ def apply_planes(x, mu, A, bias, slot, plan, oscale, relu=True, want_mask=False,
 
 class SplitTensor:
     """An activation in the pre-split format of include/wc_hip.h (ABI 4): `planes` (2, M, C) float16 = hi | lo,
-    x ~= center + (hi + lo) / scale.  `shape` is the NHWC shape of the tensor it stands for; `flag` (64,) int32: [0] != 0
-    after a split that had to clamp (scales off by more than three decades)."""
+    x ~= center + (hi + lo) / scale.  `shape` is the NHWC shape of the tensor it stands for; `flag` int32: [0] != 0 after split()
+    had to clamp (scales off by more than three decades) -- resadd_split() never clamps: there [0] != 0 says that its gated second
+    pass re-ran with the true maxima of the channels whose sampled scale was too tight, and `scale` holds the scales it used."""
 
     __slots__ = ("planes", "center", "scale", "flag", "shape", "x32")
 
@@ -536,21 +542,19 @@ def resadd(h, s, up=False):
 
 
 def resadd_split(h, s, up=False, want_x32=False):
-    """The same sum written in the pre-split format (one sampling launch + one pass over h and s): -> SplitTensor, with .x32 = the fp32
-    sum as well when want_x32 (a reader without a planes path)."""
+    """The same sum written in the pre-split format (one sampling launch + one pass over h and s + the gate of the rescaling pass, which
+    runs only when a sampled scale was too tight: nothing saturates): -> SplitTensor, with .x32 = the fp32 sum as well when want_x32
+    (a reader without a planes path)."""
     lib = _lib.load()
     N, H, W, C = _resadd_args(h, s, up)
     dev = h.device
     planes = torch.empty(2, N * H * W, C, dtype=torch.float16, device=dev)
     center = torch.empty(C, dtype=torch.float32, device=dev)
     scale = torch.empty(C, dtype=torch.float32, device=dev)
-    flag = torch.empty(64, dtype=torch.int32, device=dev)
+    flag = torch.empty(SPLIT_FLAG_WORDS, dtype=torch.int32, device=dev)
     x32 = torch.empty_like(h) if want_x32 else None
     _lib.check(lib.wc_resadd_split_f32(_ptr(h), _ptr(s), N, H, W, C, 1 if up else 0, _ptr(planes), _ptr(center), _ptr(scale), _ptr(flag),
                                        _ptr(x32), _stream()), "wc_resadd_split_f32")
-    if CHECK_SPLIT and not torch.cuda.is_current_stream_capturing() and int(flag[0]) != 0:
-        raise _lib.WcHipError("wc_resadd_split_f32: an element beyond +-60000 after scaling saturated (flag[0] = 1); "
-                              "run with WC_SPLIT_PRODUCER=0 (the fp32 sum and the fp32 route's exact redo) for such data")
     return SplitTensor(planes, center, scale, flag, h.shape, x32)
 
 
