@@ -224,6 +224,30 @@ int wc_resadd_split_f32(const float* h, const float* s /*nullable*/, int64_t N, 
                         wc_stream_t stream);
 int wc_patch_sum_f32(const float* g /*(N, 2 Hs, 2 Ws, C)*/, int64_t N, int64_t Hs, int64_t Ws, int C, float* out /*(N, Hs, Ws, C)*/,
                      wc_stream_t stream);
+/* The producer FEEDING K1 (ABI 7): wc_resadd_split_f32 whose pass also accumulates the next site's covariance
+ * moments -- the rows are summed, centred, scaled and split once, the words go to the planes AND, transposed, through the LDS into the
+ * block triangle of X^T X on the matrix pipe (the covariance kernel of wc_stats_f32's fast path with the add in front and the planes'
+ * stores behind its conversion), so the next site's K1 pass over the tensor (wc_stats_split_f16x2's kernel: 134 MB re-read at
+ * 128x32x32x256) does not exist.  xs / center / scale / flag / x32: exactly wc_resadd_split_f32's outputs (bit for bit, gated rescaling
+ * pass included -- it then redoes the partials as well).  `groups`: the statistic groups of the CONSUMING site (runs of N/groups
+ * samples; slabs never cross them).  ws (wc_resadd_stats_workspace_bytes) receives the per-slab partials; it is what
+ * wc_whiten_presummed_f16x2 (K1 tail + K2: = wc_whiten_split_f16x2 without its pass) or wc_stats_presummed_f16x2 (the raw moments, for
+ * sync-WC's all-reduce: = wc_stats_split_f16x2 without its pass) take -- same M, C, groups, the same buffer.
+ * wc_resadd_stats_supported: C in {128, 256}, up = 1 (every block of the shipped generators), W % 8 == 0, N*H*W/groups >= 20480 rows
+ * in whole stages (64 rows at C = 256, 128 at C = 128); elsewhere WC_ERR_SHAPE: wc_resadd_split_f32 + wc_whiten_split_f16x2.
+ * Replaces: the Add that ends `resblock` (generator.py:142-146) + the moments part of DecorelationNormalization.call (generator.py:24). */
+int    wc_resadd_stats_supported(int64_t N, int64_t H, int64_t W, int C, int up, int groups);
+size_t wc_resadd_stats_workspace_bytes(int64_t N, int64_t H, int64_t W, int C, int groups);
+int    wc_resadd_stats_split_f32(const float* h, const float* s /*required*/, int64_t N, int64_t H, int64_t W, int C, int up, int groups,
+                                 void* xs /*out*/, float* center /*[C] out*/, float* scale /*[C] out*/, int* flag /*[WC_SPLIT_FLAG_WORDS]*/,
+                                 float* x32 /*out, nullable*/, void* ws /*out: the partials*/, size_t ws_bytes, wc_stream_t stream);
+size_t wc_whiten_presummed_error_offset(int64_t M, int C, int groups);
+int    wc_whiten_presummed_f16x2(const float* xs_center, int64_t M, int C, int groups, double eps, double momentum, int ddof,
+                                 float* moving_mean /*nullable*/, float* moving_cov /*nullable*/, float* mu /*[groups,C]*/,
+                                 double* L /*[groups,C,C]*/, double* W /*[groups,C,C]*/, void* ws /*from wc_resadd_stats_split_f32*/,
+                                 size_t ws_bytes, wc_stream_t stream);
+int    wc_stats_presummed_f16x2(const float* xs_center, int64_t M, int C, int groups, double* sum /*[groups,C]*/,
+                                double* xtx /*[groups,C,C]*/, void* ws /*from wc_resadd_stats_split_f32*/, size_t ws_bytes, wc_stream_t stream);
 /* A 1x1 convolution (the block's shortcut, generator.py:142-146) on a pre-split input: with x[c] = center[c] + g[c] / scale[c],
  *     sum_c x[c] w[o][c] + b[o] = sum_c g[c] wf[o][c] + bf[o],   wf[o][c] = w[o][c] / scale[c],  bf[o] = b[o] + <center, w[o]>
  * so wc_conv_f16x3 runs on the planes themselves (x scale 1) with the folded weight and bias; its weight gradient D (of wf, from

@@ -27,13 +27,13 @@ def test_bench_line_contract():
     assert "workload" in d["config"] and d["config"]["launch"] in ("hipgraph", "eager", "segments")
     assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] / 1e3 - 64.0) < 0.5          # images/sec x s/step = the batch of 64
     r_ = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "launch_us", "algorithmic_bytes", "stream_copy_GBs", "frac_of_stream_copy",
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "launch_us", "algorithmic_bytes", "isolated_copy_GBs", "loop_copy_GBs", "frac_of_isolated_copy", "frac_of_loop_copy",
               "k3_kernels", "site_stages", "forward_site_us"):
         assert k in r_, k
     assert r_["bound"] == "hbm" and r_["unit"] == "GB/s" and r_["peak"] == 8000.0
     assert abs(r_["achieved"] - r_["algorithmic_bytes"] / r_["launch_us"] / 1e3) < 0.02 * r_["achieved"]
     assert abs(r_["frac"] - r_["achieved"] / r_["peak"]) < 1e-3
-    assert 0.3 < r_["frac_of_stream_copy"] < 1.0 and "error" not in r_
+    assert 0.3 < r_["frac_of_loop_copy"] <= r_["frac_of_isolated_copy"] * 1.05 < 1.05 and "error" not in r_
     assert r_["traffic"] is None or 0.9 < r_["traffic"] / r_["algorithmic_bytes"] < 1.5
 
 

@@ -2,7 +2,8 @@
 of the round-3 rocprofv3 --kernel-trace / --pmc passes (tools/gpu_job_pmc_mode.sh <mode> <tag>; one kernel per run, so that what
 the previous launch left in the 256-MiB memory-side cache is the same tensor every time, as in bench.py's timing loops).
 usage: stage_only.py <n> <mode>;  mode = k3 | k3split | k3planes | k3mask | k1 | k1split | k4 | k4mask | k4bits | k6 | k6bits |
-        k3splitmask | k3splitplanes | k1wsplit | resadd | resaddsplit | resaddtorch   (round 4: the producer and the planes route's epilogues)"""
+        k3splitmask | k3splitplanes | k1wsplit | resadd | resaddsplit | resaddtorch   (round 4: the producer and the planes route's epilogues)
+        | resaddstats | resaddstatsk2 | resaddsplitk1k2   (round 5: the producer with K1's partials accumulated in its own pass)"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from wc_gan_amd import _lib
@@ -44,6 +45,9 @@ run = {
     "k1wsplit": lambda: ops.whiten_split(xs, 1e-3, 0.99, 1, None, None),
     "resadd": lambda: ops.resadd(hh, ss, True),
     "resaddsplit": lambda: ops.resadd_split(hh, ss, True),
+    "resaddstats": lambda: ops.resadd_stats_split(hh, ss, True, 1),                                 # round 5: the add's pass + K1's partials
+    "resaddstatsk2": lambda: ops.whiten_presummed(ops.resadd_stats_split(hh, ss, True, 1), 1e-3, 0.99, 1, None, None),      # ... + K1 tail + K2
+    "resaddsplitk1k2": lambda: ops.whiten_split(ops.resadd_split(hh, ss, True), 1e-3, 0.99, 1, None, None),                # round 4's chain
     "resaddtorch": lambda: (hh.view(N, H // 2, 2, H // 2, 2, C) + ss.view(N, H // 2, 1, H // 2, 1, C)),
     "k3": lambda: ops.apply(x, mu, A, b, None, out=y, plan=plan),
     "k3mask": lambda: ops.apply(x, mu, A, b, None, out=y, plan=plan, relu=True, want_mask=True),

@@ -92,6 +92,14 @@ SIGNATURES = {
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wc_resadd_split_supported": (c_int, [c_int64, c_int64, c_int64, c_int]),
     "wc_resadd_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "wc_resadd_stats_supported": (c_int, [c_int64, c_int64, c_int64, c_int, c_int, c_int]),
+    "wc_resadd_stats_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int, c_int]),
+    "wc_resadd_stats_split_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wc_whiten_presummed_error_offset": (c_size_t, [c_int64, c_int, c_int]),
+    "wc_whiten_presummed_f16x2": (c_int, [c_void_p, c_int64, c_int, c_int, c_double, c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wc_stats_presummed_f16x2": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wc_resadd_split_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p]),
     "wc_patch_sum_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p]),

@@ -675,6 +675,115 @@ int wc_resadd_split_f32(const float* h, const float* s, int64_t N, int64_t H, in
     return WC_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// the producer feeding K1 (ABI 7; resadd_xtx_kernel of wc_resadd.hip): sample + pass with the covariance partials + gate, then the
+// tails of wc_whiten_split_f16x2 / wc_stats_split_f16x2 on those partials
+namespace {
+struct PresumLayout { int nslab, nsplit, ntypes; int64_t rps; double *Sp, *dfix, *P, *sum_scratch, *tmp; float* colsum; };
+// one carve for the producer and both tails (the layout of wc_whiten_split_f16x2's workspace with the fp32-input kernel's slab plan)
+bool presum_layout(int64_t M, int C, int groups, void* ws, size_t ws_bytes, PresumLayout* o)
+{
+    o->nslab = wc_fast_xty_plan(groups, M / groups, C, groups > 1, 0, &o->nsplit, &o->rps, &o->ntypes);
+    if (o->nslab <= 0) return false;
+    Carver cv(ws, ws_bytes);
+    (void)cv.take<int>(64);
+    o->Sp = cv.take<double>((size_t)2 * groups * C);
+    o->colsum = cv.take<float>((size_t)o->nslab * C);
+    o->dfix = cv.take<double>((size_t)o->nslab * C);
+    o->P = cv.take<double>((size_t)o->nslab * C * C);
+    o->sum_scratch = cv.take<double>((size_t)groups * C);
+    o->tmp = cv.take<double>((size_t)groups * C * C);
+    return true;
+}
+size_t presum_bytes(int64_t M, int C, int groups)
+{
+    if (M <= 0 || groups <= 0 || (M % groups) != 0 || bad_channels(C)) return 0;
+    int nsplit, ntypes; int64_t rps;
+    const int nslab = wc_fast_xty_plan(groups, M / groups, C, groups > 1, 0, &nsplit, &rps, &ntypes);
+    if (nslab <= 0) return 0;
+    return 256 + slot_bytes((size_t)2 * groups * C, 8) + slot_bytes((size_t)nslab * C, 4) + slot_bytes((size_t)nslab * C, 8) +
+           slot_bytes((size_t)nslab * C * C, 8) + slot_bytes((size_t)groups * C, 8) + slot_bytes((size_t)groups * C * C, 8);
+}
+}  // namespace
+
+int wc_resadd_stats_supported(int64_t N, int64_t H, int64_t W, int C, int up, int groups)
+{
+    if (!wc_resadd_split_supported(N, H, W, C) || groups <= 0) return 0;
+    return wc_resadd_xtx_supported(N, H, W, C, up, groups) ? 1 : 0;
+}
+
+size_t wc_resadd_stats_workspace_bytes(int64_t N, int64_t H, int64_t W, int C, int groups)
+{
+    if (N <= 0 || H <= 0 || W <= 0) return 0;
+    return presum_bytes(N * H * W, C, groups);
+}
+
+int wc_resadd_stats_split_f32(const float* h, const float* s, int64_t N, int64_t H, int64_t W, int C, int up, int groups,
+                              void* xs, float* center, float* scale, int* flag, float* x32, void* ws, size_t ws_bytes, wc_stream_t stream)
+{
+    const int rc = resadd_check(h, N, H, W, C, up);
+    if (rc != WC_OK) return rc;
+    if (!s || !xs || !center || !scale || !flag || !ws) return WC_ERR_NULL;
+    if (!wc_resadd_stats_supported(N, H, W, C, up, groups)) return WC_ERR_SHAPE;
+    if (ws_bytes < wc_resadd_stats_workspace_bytes(N, H, W, C, groups)) return WC_ERR_WORKSPACE;
+    PresumLayout l;
+    if (!presum_layout(N * H * W, C, groups, ws, ws_bytes, &l)) return WC_ERR_SHAPE;
+    WC_TRY(wc_launch_resadd_xtx(h, s, N, H, W, C, up, groups, xs, center, scale, flag, x32, l.nsplit, l.rps, l.nslab, l.ntypes,
+                                l.P, l.colsum, l.dfix, static_cast<hipStream_t>(stream)));
+    return WC_OK;
+}
+
+size_t wc_whiten_presummed_error_offset(int64_t M, int C, int groups)
+{
+    const size_t in_tmp = wc_factor_error_offset(C, groups);
+    const size_t all = presum_bytes(M, C, groups);
+    if (in_tmp == 0 || all == 0) return 0;
+    return all - slot_bytes((size_t)groups * C * C, 8) + in_tmp;          // tmp is the last block of the workspace
+}
+
+int wc_whiten_presummed_f16x2(const float* xs_center, int64_t M, int C, int groups, double eps, double momentum, int ddof,
+                              float* moving_mean, float* moving_cov, float* mu, double* L, double* W, void* ws, size_t ws_bytes,
+                              wc_stream_t stream)
+{
+    if (!xs_center || !mu || !L || !W || !ws) return WC_ERR_NULL;
+    if ((moving_mean == nullptr) != (moving_cov == nullptr)) return WC_ERR_NULL;
+    if (M <= 0 || groups <= 0 || (M % groups) != 0 || M / groups <= ddof) return WC_ERR_SHAPE;
+    if (bad_channels(C)) return WC_ERR_CHANNELS;
+    if (!(eps > 0.0) || eps >= 1.0 || momentum < 0.0 || momentum > 1.0 || ddof < 0 || ddof > 1) return WC_ERR_ARG;
+    const size_t need = presum_bytes(M, C, groups);
+    if (need == 0) return WC_ERR_SHAPE;
+    if (ws_bytes < need) return WC_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    PresumLayout l;
+    if (!presum_layout(M, C, groups, ws, ws_bytes, &l)) return WC_ERR_SHAPE;
+    // (the partials are those of xty_f16x3_kernel's accumulation scheme: its off-diagonal compensation applies)
+    WC_TRY(wc_launch_stats_prepare(l.P, l.colsum, xs_center, l.nslab / groups, M / groups, C, groups, l.Sp, l.sum_scratch, l.dfix, nullptr, eps,
+                                   momentum, ddof, moving_mean, moving_cov, mu, nullptr, L, st, l.tmp, wc_fast_xty_offdiag_bias()));
+    if (wc_factor_is_fused(C)) {
+        WC_TRY(wc_launch_factor_fused(L, W, l.tmp, C, groups, st));
+        return WC_OK;
+    }
+    WC_TRY(wc_launch_cholesky(L, C, groups, st));
+    WC_TRY(wc_launch_tri_inverse(L, W, l.tmp, C, groups, st));
+    return WC_OK;
+}
+
+int wc_stats_presummed_f16x2(const float* xs_center, int64_t M, int C, int groups, double* sum, double* xtx, void* ws, size_t ws_bytes,
+                             wc_stream_t stream)
+{
+    if (!xs_center || !sum || !xtx || !ws) return WC_ERR_NULL;
+    if (M <= 0 || groups <= 0 || (M % groups) != 0) return WC_ERR_SHAPE;
+    if (bad_channels(C)) return WC_ERR_CHANNELS;
+    const size_t need = presum_bytes(M, C, groups);
+    if (need == 0) return WC_ERR_SHAPE;
+    if (ws_bytes < need) return WC_ERR_WORKSPACE;
+    PresumLayout l;
+    if (!presum_layout(M, C, groups, ws, ws_bytes, &l)) return WC_ERR_SHAPE;
+    WC_TRY(wc_launch_stats_finalize(l.P, l.colsum, xs_center, l.nslab / groups, M / groups, C, groups, l.Sp, sum, xtx, l.dfix, nullptr,
+                                    static_cast<hipStream_t>(stream), wc_fast_xty_offdiag_bias()));
+    return WC_OK;
+}
+
 int wc_patch_sum_f32(const float* g, int64_t N, int64_t Hs, int64_t Ws, int C, float* out, wc_stream_t stream)
 {
     if (!g || !out) return WC_ERR_NULL;

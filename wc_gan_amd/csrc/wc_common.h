@@ -202,6 +202,11 @@ hipError_t wc_launch_apply_split(const void* xs, const float* xs_scale, const fl
 hipError_t wc_launch_resadd(const float* h, const float* s, int64_t N, int64_t H, int64_t W, int C, int up,
                             void* xs /*nullable: planes out*/, float* center, float* scale, int* flag, float* x32 /*nullable: fp32 out*/,
                             hipStream_t st);
+// the same pass with the next site's covariance partials accumulated in it (resadd_xtx_kernel; slab plan: wc_fast_xty_plan, two = 0)
+bool wc_resadd_xtx_supported(int64_t N, int64_t H, int64_t W, int C, int up, int groups);
+hipError_t wc_launch_resadd_xtx(const float* h, const float* s, int64_t N, int64_t H, int64_t W, int C, int up, int groups,
+                                void* xs, float* center, float* scale, int* flag, float* x32,
+                                int nsplit, int64_t rows_per_slab, int nslab, int ntypes, double* P, float* colsum, double* dfix, hipStream_t st);
 hipError_t wc_launch_patch_sum(const float* g, int64_t N, int64_t Hs, int64_t Ws, int C, float* out, hipStream_t st);
 hipError_t wc_launch_fold_channel_scale(const float* w, int64_t so, int64_t sc, int Cout, int Cin, const float* bias,
                                         const float* scale, const float* center, float* wf, float* bf, hipStream_t st);

@@ -30,6 +30,7 @@
 // channel's standard deviation >= max / sqrt(M)).  A non-finite element stays non-finite in the planes (NaN / Inf: loud downstream).
 // fp32 is written too only where a reader without a planes path exists (x32 != NULL: the backward's K4 / K6 at C = 128 today).
 #include "wc_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -249,6 +250,344 @@ __global__ __launch_bounds__(256) void resadd_kernel(ResAddArgs a)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The producer that FEEDS K1 LITERALLY (round 5): the residual add's pass and the next site's covariance reduction
+// as ONE kernel.  Round 4 wrote the planes (resadd_kernel: a pure stream with the matrix pipe idle) and xtx_split_kernel then read all
+// of them back (134 MB at 128x32x32x256, 1.18 x over-fetched) to form the moments.  Here the rows are summed, centred, scaled and split
+// ONCE, the hi | lo words leave for the planes in global memory and, byte-permuted into the transposed [channel][row] fragment image,
+// for the LDS -- and the block triangle of X^T X runs on them in the same stage: the structure of xty_f16x3_kernel's covariance form
+// (wc_fast_xty.hip: 64-row stages at C = 256, two stage buffers, fp32 chains of one stage flushed into float64 registers, the 36 blocks
+// as 18 + 18 on two workgroups of a slab that stream the same rows -- the second reads h and s from L2 --, the diagonal on the VALU, the
+// column sums) with the add in front of its conversion and the planes' stores behind it (each workgroup type stores one plane).
+// The partials P / colsum / dfix go where wc_whiten_split_f16x2's tail expects them (wc_whiten_presummed_f16x2 runs that tail), so the
+// site's K1 launch does not exist.  Saturation: as resadd_kernel -- the channel's true maximum is recorded, the gated second launch
+// redoes planes AND partials with the lowered scales.
+#ifndef WC_RX_ABL
+#define WC_RX_ABL 0      // development ablation bits (wrong results, times only): 1 no plane stores, 2 no shortcut rows, 4 no MFMAs, 8 no float64 flush, 16 the planes as 16-byte stores (misplaced)
+#endif
+
+struct ResXtxArgs {
+    ResAddArgs r;                          // h, s, geometry, centre / scale / flag area, planes, x32
+    int64_t N, HW;                         // segments (statistic groups) x rows per segment; N * HW = r.M
+    int per_sample, nsplit;
+    int64_t rows_per_slab;
+    int nslab, ntypes;
+    double* P; float* colsum; double* dfix;
+};
+
+template <int C, bool F32, bool REDO>
+__global__ __launch_bounds__(512, 1) void resadd_xtx_kernel(ResXtxArgs a)
+{
+    static_assert(C == 128 || C == 256, "fused producer: C = 128 or 256");
+    if (REDO && __builtin_nontemporal_load(a.r.flag) != 1) return;
+    constexpr bool BAL = C == 256;                    // 36 blocks as 18 + 18 on the two workgroup types of a slab (wc_fast_xty.hip)
+    constexpr int BW = 3;
+    constexpr int C4 = C / 4;
+    constexpr int RGRP = 512 / C4;
+    constexpr int R = RGRP * 8;                       // rows per stage: 64 (C = 256) / 128 (C = 128)
+    constexpr int CPR = R / 8;
+    constexpr int KS = R / 16;
+    constexpr int IMG = C * R * 2;
+    constexpr int NB = C / 32;
+    constexpr int NBLK = NB * (NB + 1) / 2;
+    static_assert(2 * IMG == 65536, "the stage buffers are 64 KiB apart");
+    // LDS: [2 stage buffers][hi | lo] (128 KiB) | per-thread accumulators that would not fit the registers beside the float64 blocks, the
+    // prefetched stage and the shortcut's rows (column sums 16 B, the diagonal's float64 sums 32 B per thread: 24 KiB) | scale[C] | -centre scale[C]
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const aux = smem + 4 * IMG;
+    f32x4* const cs_acc = reinterpret_cast<f32x4*>(aux);                         // [512]
+    double* const sq_acc = reinterpret_cast<double*>(aux + 512 * 16);             // [512][4]
+    float* const sc_sh = reinterpret_cast<float*>(aux + 512 * 48);                // [C]
+    float* const nc_sh = sc_sh + C;                                               // [C]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int type = q % a.ntypes;
+    const int64_t z = (int64_t)(q / a.ntypes) * 8 + xcd;
+    if (z >= a.nslab) return;
+
+    int64_t r0, r1;
+    if (a.per_sample) {
+        const int64_t n = z / a.nsplit, qq = z % a.nsplit;
+        r0 = n * a.HW + qq * a.rows_per_slab;
+        r1 = r0 + a.rows_per_slab;
+        const int64_t end = (n + 1) * a.HW;
+        if (r1 > end) r1 = end;
+    } else {
+        const int64_t M = a.N * a.HW;
+        r0 = z * a.rows_per_slab;
+        r1 = r0 + a.rows_per_slab;
+        if (r1 > M) r1 = M;
+    }
+    const int nst = (int)((r1 - r0) / R);
+
+    int ib[BW], jb[BW]; bool live[BW];
+#pragma unroll
+    for (int b = 0; b < BW; ++b) {
+        int L = (type * 8 + wave) * BW + b;
+        live[b] = L < NBLK;
+        if (BAL) {
+            L = type * (NBLK / 2) + (wave < 2 ? wave * 3 : 6 + (wave - 2) * 2) + b;
+            live[b] = b < (wave < 2 ? 3 : 2);
+        }
+        if (!live[b]) L = 0;
+        int i = 0; while (L >= NB - i) { L -= NB - i; ++i; }
+        ib[b] = i; jb[b] = i + L;
+    }
+    bool all_ = true, any_ = false;
+#pragma unroll
+    for (int b = 0; b < BW; ++b) { all_ = all_ && live[b]; any_ = any_ || live[b]; }
+    const bool all_live = __builtin_amdgcn_readfirstlane(all_ ? 1 : 0) != 0;
+    const bool two_live = __builtin_amdgcn_readfirstlane((live[0] && live[1] && !live[BW - 1]) ? 1 : 0) != 0;
+    const bool any_live = __builtin_amdgcn_readfirstlane(any_ ? 1 : 0) != 0;
+
+    const int c4 = tid % C4, rgrp = tid / C4;
+    {
+        f32x4 scl = *reinterpret_cast<const f32x4*>((REDO ? a.r.scale0 : a.r.scale) + 4 * c4);
+        if (REDO) {         // the scales the true maxima ask for (resadd_kernel's rule); the first slab's type-0 workgroup stores them
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float gm = __builtin_bit_cast(float, a.r.gmax[4 * c4 + j]);
+                if (gm > 0.f && gm < 3.0e38f) {
+                    int e;
+                    frexpf(gm, &e);
+                    scl[j] *= ldexpf(1.0f, 15 - e);
+                }
+            }
+            if (z == 0 && type == 0 && rgrp == 0) *reinterpret_cast<f32x4*>(a.r.scale + 4 * c4) = scl;
+        }
+        if (rgrp == 0) {
+            *reinterpret_cast<f32x4*>(sc_sh + 4 * c4) = scl;
+            *reinterpret_cast<f32x4*>(nc_sh + 4 * c4) = -(*reinterpret_cast<const f32x4*>(a.r.center + 4 * c4)) * scl;
+        }
+        cs_acc[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sq_acc[tid * 4 + j] = 0.0;
+    }
+    __syncthreads();
+
+    auto swz = [](int c) -> int {        // xty_f16x3_kernel's conflict-free chunk swizzles (write groups AND read groups)
+        if (CPR == 8) return (((c >> 1) ^ (c >> 2)) & 1) | (((c >> 3) & 1) << 1) | (((c >> 4) & 1) << 2);
+        return ((c ^ (c >> 2)) & 1) | (((c >> 3) & 1) << 1) | (((c >> 4) & 1) << 2) | (((c >> 1) & 1) << 3);
+    };
+    int st_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = 4 * c4 + j;
+        st_off[j] = c * (R * 2) + ((rgrp ^ swz(c)) * 16);
+    }
+
+    // rows of a stage: this thread takes 8 consecutive rows (row0 a multiple of 8: one image row, W % 8 == 0) of its 4 channels; with
+    // up = 1 they add 4 consecutive source pixels of s, each twice
+    f32x4 xr[8], sr[4];
+    constexpr bool has_s = true;                         // (the launcher refuses a call without a shortcut: every block of the generators has one)
+    auto stage_load = [&](int st) {
+        const int64_t row0 = r0 + (int64_t)st * R + rgrp * 8;
+        const float* base = a.r.h + row0 * C + 4 * c4;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) xr[p] = *reinterpret_cast<const f32x4*>(base + p * C);
+        if (has_s && !(WC_RX_ABL & 2)) {
+            const float* sb = a.r.s + src_row(a.r, (unsigned)row0) * C + 4 * c4;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) sr[p] = *reinterpret_cast<const f32x4*>(sb + p * C);
+        }
+    };
+    const bool want_csum = a.colsum != nullptr && type == 0;
+    const bool want_dfix = a.dfix != nullptr && type == a.ntypes - 1;
+    // which plane this workgroup stores: with two types of a slab each takes one (both hold every word); one type stores both
+    const bool st_hi = a.ntypes == 1 || type == 0, st_lo = a.ntypes == 1 || type == 1;
+    auto stage_write = [&](int buf, int st_of_data) {
+        char* img = smem + buf * (2 * IMG);
+        const int64_t row0 = r0 + (int64_t)st_of_data * R + rgrp * 8;
+        const f32x4 scl = *reinterpret_cast<const f32x4*>(sc_sh + 4 * c4), ncs = *reinterpret_cast<const f32x4*>(nc_sh + 4 * c4);
+        f32x4 g[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            f32x4 v = xr[p];
+            if (has_s && !(WC_RX_ABL & 2)) v += sr[p >> 1];
+            if (F32 && st_hi) *reinterpret_cast<f32x4*>(a.r.x32 + (row0 + p) * C + 4 * c4) = v;
+            g[p] = v * scl + ncs;
+        }
+        if (!REDO) {        // the saturation test: the stage's maximum against the guard; the per-channel maxima only behind it (rare)
+            float m = 0.f;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                m = __builtin_fmaxf(__builtin_fmaxf(m, fabsf(g[p][0])), fabsf(g[p][1]));
+                m = __builtin_fmaxf(__builtin_fmaxf(m, fabsf(g[p][2])), fabsf(g[p][3]));
+            }
+            if (!(m <= kResGuard)) {        // (a NaN raises the gate too; pass 2 then leaves the NaN in the planes: loud)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float mj = 0.f;
+#pragma unroll
+                    for (int p = 0; p < 8; ++p) mj = __builtin_fmaxf(mj, fabsf(g[p][j]));
+                    if (mj > kResGuard) atomicMax(a.r.gmax + 4 * c4 + j, __builtin_bit_cast(unsigned, mj));
+                }
+                *a.r.flag = 1;
+            }
+        }
+        if (want_csum) {
+            f32x4 cs = cs_acc[tid];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) cs += g[p];
+            cs_acc[tid] = cs;
+        }
+        if (want_dfix) {
+            f32x4 sq = g[0] * g[0];
+#pragma unroll
+            for (int p = 1; p < 8; ++p) sq += g[p] * g[p];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sq_acc[tid * 4 + j] += (double)sq[j];
+        }
+        // row-major words (what the planes hold: H[p][w] = channels (2w, 2w + 1) of row p, the remainders likewise) leave for global
+        // memory, then go transposed into the fragment image -- channel j of rows (2 pp, 2 pp + 1) = half j & 1 of word j >> 1 of the two
+        // rows: one v_perm_b32 per image word, one ds_write_b128 per channel and plane (8-byte halves met two-way in the banks: 24 % of
+        // the LDS cycles, first version)
+        unsigned H[8][2], Lw[8][2];
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                const float v0 = g[p][2 * w], v1 = g[p][2 * w + 1];
+                H[p][w] = pk_rne2r(v0, v1);
+                float q0, q1;
+                asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(q0) : "v"(H[p][w]), "v"(v0));
+                asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(q1) : "v"(H[p][w]), "v"(v1));
+                Lw[p][w] = pk_rne2r(q0, q1);
+            }
+        if (WC_RX_ABL & 16) {        // timing only: the same bytes as four 16-byte stores per plane (rows p, p + 1 are 1 KiB contiguous; data misplaced)
+            if (st_hi) {
+#pragma unroll
+                for (int p = 0; p < 8; p += 2) *reinterpret_cast<uint4*>(a.r.hi + (row0 + p) * C + 8 * c4) = make_uint4(H[p][0], H[p][1], H[p + 1][0], H[p + 1][1]);
+            }
+            if (st_lo) {
+#pragma unroll
+                for (int p = 0; p < 8; p += 2) *reinterpret_cast<uint4*>(a.r.lo + (row0 + p) * C + 8 * c4) = make_uint4(Lw[p][0], Lw[p][1], Lw[p + 1][0], Lw[p + 1][1]);
+            }
+        } else if (!(WC_RX_ABL & 1)) {
+            if (st_hi) {
+#pragma unroll
+                for (int p = 0; p < 8; ++p) *reinterpret_cast<uint2*>(a.r.hi + (row0 + p) * C + 4 * c4) = make_uint2(H[p][0], H[p][1]);
+            }
+            if (st_lo) {
+#pragma unroll
+                for (int p = 0; p < 8; ++p) *reinterpret_cast<uint2*>(a.r.lo + (row0 + p) * C + 4 * c4) = make_uint2(Lw[p][0], Lw[p][1]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned sel = (j & 1) ? 0x07060302u : 0x05040100u;
+            unsigned hw[4], lw[4];
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+                hw[pp] = __builtin_amdgcn_perm(H[2 * pp + 1][j >> 1], H[2 * pp][j >> 1], sel);
+                lw[pp] = __builtin_amdgcn_perm(Lw[2 * pp + 1][j >> 1], Lw[2 * pp][j >> 1], sel);
+            }
+            *reinterpret_cast<uint4*>(img + st_off[j]) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+            *reinterpret_cast<uint4*>(img + st_off[j] + IMG) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+        }
+    };
+
+    double acc64[BW][16];
+#pragma unroll
+    for (int b = 0; b < BW; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc64[b][r] = 0.0;
+    int a_base[BW], b_base[BW];
+#pragma unroll
+    for (int b = 0; b < BW; ++b) {
+        const int ca = ib[b] * 32 + l31, cb = jb[b] * 32 + l31;
+        a_base[b] = ca * (R * 2) + ((lh ^ swz(ca)) << 4);
+        b_base[b] = cb * (R * 2) + ((lh ^ swz(cb)) << 4);
+    }
+
+    if (nst > 0) {
+        stage_load(0);
+        stage_write(0, 0);
+        if (nst > 1) stage_load(1);
+    }
+    __syncthreads();
+    f32x16 acc[BW];
+    for (int st = 0; st < nst; ++st) {
+        const int cur = st & 1;
+        if (st + 1 < nst) stage_write(cur ^ 1, st + 1);
+        if (st + 2 < nst) stage_load(st + 2);
+#pragma unroll
+        for (int b = 0; b < BW; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+        const int kbuf = cur << 16;
+        auto frag = [&](int base, int ks, int lo) __attribute__((always_inline)) {
+            return *reinterpret_cast<const f16x8*>(smem + (base ^ ((ks << 5) | kbuf)) + lo * IMG);
+        };
+        auto products = [&](auto ALL_, auto NL_) __attribute__((always_inline)) {
+            constexpr bool ALL = decltype(ALL_)::value;
+            constexpr int NL = decltype(NL_)::value;
+#pragma unroll 4
+            for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                for (int b = 0; b < NL; ++b) {
+                    if (!ALL && !live[b]) continue;
+                    const f16x8 ah = frag(a_base[b], ks, 0), al = frag(a_base[b], ks, 1);
+                    const f16x8 bh = frag(b_base[b], ks, 0), bl = frag(b_base[b], ks, 1);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[b], 0, 0, 0);
+                }
+            }
+        };
+        if (WC_RX_ABL & 4) {}
+        else if (all_live) products(std::true_type{}, std::integral_constant<int, BW>{});
+        else if (two_live) products(std::true_type{}, std::integral_constant<int, 2>{});
+        else if (any_live) products(std::false_type{}, std::integral_constant<int, BW>{});
+        if (WC_RX_ABL & 8) {}
+        else if (two_live) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc64[b][r] += (double)acc[b][r];
+        } else if (any_live) {
+#pragma unroll
+            for (int b = 0; b < BW; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc64[b][r] += (double)acc[b][r];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+
+    double* P = a.P + z * (int64_t)C * C;
+#pragma unroll
+    for (int b = 0; b < BW; ++b) {
+        if (!live[b]) continue;
+        const int j = jb[b] * 32 + l31;
+        const double isj = 1.0 / (double)sc_sh[j];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = ib[b] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            P[(int64_t)i * C + j] = acc64[b][r] * isj / (double)sc_sh[i];
+        }
+    }
+    // column sums / the diagonal: the row groups' per-thread sums are already in LDS, thread (rgrp, c4) at slot tid = rgrp * C4 + c4
+    __syncthreads();
+    if (want_csum) {
+        const float* red = reinterpret_cast<const float*>(cs_acc);
+        for (int c = tid; c < C; c += 512) {
+            float t = 0.f;
+            for (int g = 0; g < RGRP; ++g) t += red[(g * C4 + (c >> 2)) * 4 + (c & 3)];
+            a.colsum[z * C + c] = t / sc_sh[c];
+        }
+    }
+    if (want_dfix) {
+        for (int c = tid; c < C; c += 512) {
+            double t = 0.0;
+            for (int g = 0; g < RGRP; ++g) t += sq_acc[(g * C4 + (c >> 2)) * 4 + (c & 3)];
+            a.dfix[z * C + c] = t / ((double)sc_sh[c] * (double)sc_sh[c]);
+        }
+    }
+}
+
 // gradient of the add with respect to the pre-upsample shortcut: every source pixel collects its 2x2 output patch
 __global__ __launch_bounds__(256) void patch_sum_kernel(const float* __restrict__ g, int64_t n4, int Hs, int Ws, int C4, float* __restrict__ out)
 {
@@ -343,6 +682,59 @@ hipError_t wc_launch_resadd(const float* h, const float* s, int64_t N, int64_t H
     } else {
         hipLaunchKernelGGL((resadd_kernel<false, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
     }
+    return hipGetLastError();
+}
+
+
+// The fused producer (resadd_xtx_kernel): sample, the pass with the covariance's partials, its gate.  The slab plan is the fp32-input
+// covariance kernel's (wc_fast_xty_plan with two = 0), the partials' layout what stats_colsum / stats_xtx_prepare read.
+bool wc_resadd_xtx_supported(int64_t N, int64_t H, int64_t W, int C, int up, int groups)
+{
+    if (!(C == 128 || C == 256) || !up || groups <= 0 || (N % groups) != 0 || (W % 8) != 0 || (H % 2) != 0) return false;
+    int nsplit, ntypes; int64_t rps;
+    return wc_fast_xty_plan(groups, (N / groups) * H * W, C, groups > 1, 0, &nsplit, &rps, &ntypes) > 0;
+}
+
+hipError_t wc_launch_resadd_xtx(const float* h, const float* s, int64_t N, int64_t H, int64_t W, int C, int up, int groups,
+                                void* xs, float* center, float* scale, int* flag, float* x32,
+                                int nsplit, int64_t rows_per_slab, int nslab, int ntypes, double* P, float* colsum, double* dfix, hipStream_t st)
+{
+    if (!s || !up) return hipErrorInvalidValue;
+    ResXtxArgs a = {};
+    ResAddArgs& r = a.r;
+    r.h = h; r.s = s; r.M = N * H * W; r.H = (int)H; r.W = (int)W; r.C = C; r.up = up;
+    if (up) {
+        magic((unsigned)(H * W), &r.magHW, &r.shHW);
+        magic((unsigned)W, &r.magW, &r.shW);
+    }
+    r.center = center; r.scale = scale; r.flag = flag; r.x32 = x32;
+    r.gmax = reinterpret_cast<unsigned*>(flag) + 64;
+    r.scale0 = reinterpret_cast<float*>(flag) + 64 + C;
+    r.hi = static_cast<_Float16*>(xs); r.lo = r.hi + r.M * C;
+    a.N = groups; a.HW = r.M / groups; a.per_sample = groups > 1; a.nsplit = nsplit; a.rows_per_slab = rows_per_slab;
+    a.nslab = nslab; a.ntypes = ntypes; a.P = P; a.colsum = colsum; a.dfix = dfix;
+    hipLaunchKernelGGL(resadd_sample_kernel, dim3((C + kSampCh - 1) / kSampCh), dim3(256), 0, st, r);
+    const size_t lds = 131072 + 512 * 48 + 2 * (size_t)C * 4;
+    const int grid = ((nslab + 7) / 8) * ntypes * 8;
+#define WC_LAUNCH_RX(C_, F_, R_)                                                                                                   \
+    do {                                                                                                                           \
+        static bool attr_set = false;                                                                                              \
+        if (!attr_set) {                                                                                                           \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(resadd_xtx_kernel<C_, F_, R_>),                       \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
+            if (e != hipSuccess) return e;                                                                                         \
+            attr_set = true;                                                                                                       \
+        }                                                                                                                          \
+        hipLaunchKernelGGL((resadd_xtx_kernel<C_, F_, R_>), dim3(grid), dim3(512), lds, st, a);                                    \
+    } while (0)
+    if (C == 256) {
+        if (x32) WC_LAUNCH_RX(256, true, false); else WC_LAUNCH_RX(256, false, false);
+        if (x32) WC_LAUNCH_RX(256, true, true); else WC_LAUNCH_RX(256, false, true);
+    } else {
+        if (x32) WC_LAUNCH_RX(128, true, false); else WC_LAUNCH_RX(128, false, false);
+        if (x32) WC_LAUNCH_RX(128, true, true); else WC_LAUNCH_RX(128, false, true);
+    }
+#undef WC_LAUNCH_RX
     return hipGetLastError();
 }
 

@@ -23,6 +23,9 @@ USE_BWD_BITS = os.environ.get('WC_BWD_BITS', '1') != '0'
 # the backward of a site on pre-split planes reads x from the planes too (wc_bwd_reduce_xsplit_f32 / wc_bwd_apply_xsplit_f32); WC_BWD_XSPLIT=0:
 # from the fp32 sum the producer then writes beside the planes
 USE_BWD_XSPLIT = os.environ.get('WC_BWD_XSPLIT', '1') != '0'
+# the residual add accumulates the next site's covariance partials in its own pass (wc_resadd_stats_split_f32; WC_FUSED_STATS=0: the
+# site runs its K1 on the planes the add wrote, as in round 4)
+USE_FUSED_STATS = os.environ.get('WC_FUSED_STATS', '1') != '0'
 # Test hook (tests/test_producer_gpu.py): {'record': []} collects the one-bit ReLU masks the sites of a pass produce, {'replay': [...]} makes
 # the sites of the next pass SAVE those instead of their own -- two routes whose K3 outputs differ in the last bit then run their backward
 # on identical masks, and their gradients can be compared at rounding level instead of at the level of a few flipped ReLUs.
@@ -64,11 +67,12 @@ class WhitenColorFunction(torch.autograd.Function):
         if st is None:
             x = x.contiguous()
         if st is not None:
+            pre = training and st.moments is not None and st.moments[1] == 1     # the producer accumulated K1's partials in its own pass
             if training and process_group is None:
-                mu, L, W = ops.whiten_split(st, eps, momentum, ddof, mm, moving_cov)
+                mu, L, W = (ops.whiten_presummed if pre else ops.whiten_split)(st, eps, momentum, ddof, mm, moving_cov)
             else:
                 if training:       # sync-WC: the additive moments of all replicas, one collective on K1's own buffer
-                    s, xtx, buf = ops.stats_split(st, flat=True)
+                    s, xtx, buf = (ops.stats_presummed if pre else ops.stats_split)(st, flat=True)
                     dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=process_group)
                     M = M_local * dist.get_world_size(process_group)
                 else:
@@ -293,32 +297,37 @@ class ResidualAddFunction(torch.autograd.Function):
     convolution) -- the result is a handle and the SplitTensor lands in the box (with .x32 when a backward will read fp32)."""
 
     @staticmethod
-    def forward(ctx, h, s, up, box, x32):
+    def forward(ctx, h, s, up, box, x32, stat_groups):
         h = h.contiguous(); s = s.contiguous()
         ctx.up = bool(up)
         if box is None:
             return ops.resadd(h, s, up)
-        st = ops.resadd_split(h, s, up, want_x32=bool(x32) and any(ctx.needs_input_grad[:2]))
+        want32 = bool(x32) and any(ctx.needs_input_grad[:2])
+        if stat_groups and USE_FUSED_STATS and ops.resadd_stats_supported(h.shape, up, stat_groups):
+            st = ops.resadd_stats_split(h, s, up, stat_groups, want_x32=want32)      # ... and K1's partials from the same pass
+        else:
+            st = ops.resadd_split(h, s, up, want_x32=want32)
         box.append(st)
         return _nan_handle(h.shape, h.device)
 
     @staticmethod
     def backward(ctx, g):
         g = g.contiguous()
-        return g, (ops.patch_sum(g) if ctx.up else g), None, None, None
+        return g, (ops.patch_sum(g) if ctx.up else g), None, None, None, None
 
 
-def residual_add(h, s, up, planes=False, x32=True):
+def residual_add(h, s, up, planes=False, x32=True, stat_groups=0):
     """h + (upsample2x of) s.  planes=True (the readers of the sum all have a planes path: layers.WhiteningColoring.takes_split,
     generator.Conv2D.takes_split): a handle carrying the sum as pre-split planes (`split_of(handle)`).  x32=False: no reader's backward
     needs the fp32 sum either (layers.WhiteningColoring.backward_takes_split) -- else it is written beside the planes while a gradient
-    is wanted."""
+    is wanted.  stat_groups > 0: the WC site that reads the sum is in training mode with that many statistic groups -- the add's pass
+    then accumulates that site's covariance partials as well (ops.resadd_stats_split: the site's K1 launch does not exist)."""
     if planes and ops.resadd_split_supported(h.shape):
         box = []
-        out = ResidualAddFunction.apply(h, s, bool(up), box, bool(x32))
+        out = ResidualAddFunction.apply(h, s, bool(up), box, bool(x32), int(stat_groups))
         out._wc_split = box[0]
         return out
-    return ResidualAddFunction.apply(h, s, bool(up), None, False)
+    return ResidualAddFunction.apply(h, s, bool(up), None, False, 0)
 
 
 _SLOT_BASE = {}
@@ -356,7 +365,9 @@ def whiten_color_grouped(x, groups, gamma=None, beta=None, slot=None, moving_mea
     dev = x.device
     mm = moving_mean.view(-1) if moving_mean is not None else None
     if st is not None:
-        mu, L, W = ops.whiten_split(st, eps, momentum, ddof, mm, moving_cov, groups)      # K1 + K2 (wc_whiten_split_f16x2)
+        # K1 + K2 (wc_whiten_split_f16x2) -- or, where the residual add accumulated K1's partials itself, the tail + K2 only
+        pre = st.moments is not None and st.moments[1] == groups
+        mu, L, W = (ops.whiten_presummed if pre else ops.whiten_split)(st, eps, momentum, ddof, mm, moving_cov, groups)
         cs = st.scale
     elif USE_WHITEN:
         mu, L, W, cs = ops.whiten(x.view(M, C), eps, momentum, ddof, mm, moving_cov, groups)      # K1 + K2 (wc_whiten_f32)

@@ -360,7 +360,9 @@ class ResBlockUp(nn.Module):
             # the fp32 sum beside the planes: only while a backward will read it (a site whose K4 / K6 have no planes form)
             x32 = planes and torch.is_grad_enabled() and not all(r.backward_takes_split(h.shape) for r in readers
                                                                   if hasattr(r, 'backward_takes_split'))
-            return residual_add(h, s, self.resample == 'UP', planes=planes, x32=x32)
+            # the WC site among the readers, in training mode: the add's pass accumulates its covariance partials too (no K1 launch there)
+            sg = max([r.wants_moments(h.shape) for r in readers if hasattr(r, 'wants_moments')] + [0]) if planes else 0
+            return residual_add(h, s, self.resample == 'UP', planes=planes, x32=x32, stat_groups=sg)
         if self.resample == 'UP':
             N, H, W, C = s.shape
             return (h.view(N, H, 2, W, 2, C) + s.view(N, H, 1, W, 1, C)).view(N, 2 * H, 2 * W, C)

@@ -457,6 +457,14 @@ class WhiteningColoring(nn.Module):
         """See DecorelationNormalization.takes_split (every coloring variant reduces to one table: no further condition)."""
         return self.npart.takes_split(shape)
 
+    def wants_moments(self, shape):
+        """The statistic groups for which a producer may accumulate this site's covariance partials in its own pass (functional.residual_add's
+        stat_groups), 0 when the site will not take them: training mode on the fused Cholesky route only."""
+        n = self.npart
+        if not n.training or not self.takes_split(shape):
+            return 0
+        return _stat_groups()
+
     def backward_takes_split(self, shape):
         """Will the backward of this site read x from the planes as well (functional.USE_BWD_XSPLIT: K4 / K6 on planes)?  Then the
         producer need not write an fp32 copy of the sum beside them."""

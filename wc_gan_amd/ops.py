@@ -349,11 +349,14 @@ class SplitTensor:
     had to clamp (scales off by more than three decades) -- resadd_split() never clamps: there [0] != 0 says that its gated second
     pass re-ran with the true maxima of the channels whose sampled scale was too tight, and `scale` holds the scales it used."""
 
-    __slots__ = ("planes", "center", "scale", "flag", "shape", "x32")
+    __slots__ = ("planes", "center", "scale", "flag", "shape", "x32", "moments")
 
-    def __init__(self, planes, center, scale, flag, shape, x32=None):
+    def __init__(self, planes, center, scale, flag, shape, x32=None, moments=None):
         self.planes, self.center, self.scale, self.flag, self.shape = planes, center, scale, flag, tuple(shape)
         self.x32 = x32          # the same tensor in fp32, where the producer also wrote it (a reader without a planes path)
+        # (workspace, groups) where the producer also accumulated the covariance partials of the tensor in its own pass
+        # (resadd_stats_split): whiten_presummed / stats_presummed finish K1 from there, no pass over the planes
+        self.moments = moments
 
     @property
     def C(self):
@@ -556,6 +559,78 @@ def resadd_split(h, s, up=False, want_x32=False):
     _lib.check(lib.wc_resadd_split_f32(_ptr(h), _ptr(s), N, H, W, C, 1 if up else 0, _ptr(planes), _ptr(center), _ptr(scale), _ptr(flag),
                                        _ptr(x32), _stream()), "wc_resadd_split_f32")
     return SplitTensor(planes, center, scale, flag, h.shape, x32)
+
+
+def resadd_stats_supported(shape, up, groups=1):
+    """Can the residual add of this NHWC output shape also accumulate the consuming site's covariance partials (resadd_stats_split)?"""
+    N, H, W, C = shape
+    return bool(_lib.load().wc_resadd_stats_supported(int(N), int(H), int(W), int(C), 1 if up else 0, int(groups)))
+
+
+def resadd_stats_split(h, s, up=True, groups=1, want_x32=False):
+    """resadd_split whose pass ALSO accumulates the covariance partials of the sum for the next WC site (wc_resadd_stats_split_f32:
+    the producer feeds K1 literally -- that site's own K1 pass over the planes does not run): -> SplitTensor with .moments = (ws, groups);
+    hand it to whiten_presummed (K1 tail + K2) or stats_presummed (the raw moments).  `groups`: the consuming site's statistic groups."""
+    lib = _lib.load()
+    N, H, W, C = _resadd_args(h, s, up)
+    dev = h.device
+    nb = lib.wc_resadd_stats_workspace_bytes(N, H, W, C, groups)
+    if nb == 0 or not lib.wc_resadd_stats_supported(N, H, W, C, 1 if up else 0, groups):
+        _lib.check(-2, "wc_resadd_stats_split_f32")
+    planes = torch.empty(2, N * H * W, C, dtype=torch.float16, device=dev)
+    center = torch.empty(C, dtype=torch.float32, device=dev)
+    scale = torch.empty(C, dtype=torch.float32, device=dev)
+    flag = torch.empty(SPLIT_FLAG_WORDS, dtype=torch.int32, device=dev)
+    x32 = torch.empty_like(h) if want_x32 else None
+    ws = _workspace(nb, dev)
+    _lib.check(lib.wc_resadd_stats_split_f32(_ptr(h), _ptr(s), N, H, W, C, 1 if up else 0, int(groups), _ptr(planes), _ptr(center), _ptr(scale),
+                                             _ptr(flag), _ptr(x32), _ptr(ws), ws.numel(), _stream()), "wc_resadd_stats_split_f32")
+    return SplitTensor(planes, center, scale, flag, h.shape, x32, moments=(ws, int(groups)))
+
+
+def whiten_presummed(xs, eps, momentum, ddof, moving_mean, moving_cov, groups=1):
+    """K1's tail + K2 for a SplitTensor whose producer left the covariance partials (xs.moments): -> (mu, L, W) as whiten_split(xs, ...)
+    returns them, without the pass over the planes (wc_whiten_presummed_f16x2)."""
+    lib = _lib.load()
+    ws, g = xs.moments
+    if g != groups:
+        raise ValueError(f"the producer accumulated its partials for {g} statistic groups, the site asks for {groups}")
+    M, C = xs.M, xs.C
+    dev = xs.planes.device
+    lead = (groups,) if groups > 1 else ()
+    mu = torch.empty(*lead, C, dtype=torch.float32, device=dev)
+    L = torch.empty(*lead, C, C, dtype=torch.float64, device=dev)
+    W = torch.empty(*lead, C, C, dtype=torch.float64, device=dev)
+    if moving_mean is not None:
+        _need(moving_mean, torch.float32, "moving_mean")
+        _need(moving_cov, torch.float32, "moving_cov", 2)
+    _lib.check(lib.wc_whiten_presummed_f16x2(_ptr(xs.center), M, C, groups, float(eps), float(momentum), int(ddof), _ptr(moving_mean),
+                                             _ptr(moving_cov), _ptr(mu), _ptr(L), _ptr(W), _ptr(ws), ws.numel(), _stream()),
+               "wc_whiten_presummed_f16x2")
+    if CHECK_K2:
+        _check_k2(ws, lib.wc_whiten_presummed_error_offset(M, C, groups), groups, "wc_whiten_presummed_f16x2")
+    return mu, L, W
+
+
+def stats_presummed(xs, groups=1, flat=False):
+    """The raw moments (sum, xtx) of a SplitTensor whose producer left the partials: as stats_split(xs, groups, flat), no pass over the planes."""
+    lib = _lib.load()
+    ws, g = xs.moments
+    if g != groups:
+        raise ValueError(f"the producer accumulated its partials for {g} statistic groups, the site asks for {groups}")
+    M, C = xs.M, xs.C
+    dev = xs.planes.device
+    lead = (groups,) if groups > 1 else ()
+    buf = None
+    if flat and groups == 1:
+        buf = torch.empty(C + C * C, dtype=torch.float64, device=dev)
+        sm, xtx = buf[:C], buf[C:].view(C, C)
+    else:
+        sm = torch.empty(*lead, C, dtype=torch.float64, device=dev)
+        xtx = torch.empty(*lead, C, C, dtype=torch.float64, device=dev)
+    _lib.check(lib.wc_stats_presummed_f16x2(_ptr(xs.center), M, C, groups, _ptr(sm), _ptr(xtx), _ptr(ws), ws.numel(), _stream()),
+               "wc_stats_presummed_f16x2")
+    return (sm, xtx, buf) if buf is not None else (sm, xtx)
 
 
 def patch_sum(g):
