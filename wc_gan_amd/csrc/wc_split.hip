@@ -58,7 +58,10 @@
 #define WC_SPLIT_DEFER 0        // 1: a tile's stores ride in the next tile's MFMA gaps; 0: they follow the tile's own loop
 #endif
 #ifndef WC_SPLIT_ABL
-#define WC_SPLIT_ABL 0       // development ablation bits: 1 no stores, 2 no MFMA, 4 linear (unswizzled) DMA source
+#define WC_SPLIT_ABL 0       // development ablation bits (wrong results, times only; tools/k3_ablations.py): 1 no stores (the hand-counted waits
+                             // adjusted: the DMA waits stay real), 2 no MFMA, 4 linear (unswizzled) DMA source, 8 no table loads (a zero table),
+                             // 16 no mask words (bits not formed, not stored).  (A bit that skipped the epilogue arithmetic HUNG the GPU: the column
+                             // constants arrive by asm loads, and registers nobody reads are handed out again while those loads are in flight.)
 #endif
 
 namespace {
@@ -290,6 +293,12 @@ __global__ __launch_bounds__(512, 1) void apply_split_kernel(SplitApplyArgs a)
     // the lesson of DESIGN.md section 4.9b again).  So with slots the loads are plain loads hipcc tracks itself, drained at once.
     constexpr bool ASYNC_TABLE = !HAS_SLOT;
     auto load_b = [&](int slot) {
+        if (WC_SPLIT_ABL & 8) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) { bhi[s] = f16x8{0, 0, 0, 0, 0, 0, 0, 0}; blo[s] = bhi[s]; }
+            cscale[0] = cscale[1] = 1.f; addv[0] = addv[1] = 0.f; cur_slot = slot;
+            return;
+        }
         const char* ph = reinterpret_cast<const char*>(a.Bhi + (int64_t)slot * a.slot_stride + (int64_t)cg * KS * 512);
         const char* pl = reinterpret_cast<const char*>(a.Blo + (int64_t)slot * a.slot_stride + (int64_t)cg * KS * 512);
         const char* pc = reinterpret_cast<const char*>(a.colscale + (a.slot_stride ? (int64_t)slot * C : 0));
@@ -338,7 +347,7 @@ __global__ __launch_bounds__(512, 1) void apply_split_kernel(SplitApplyArgs a)
     if (ASYNC_TABLE) load_b(0);
     if (n > 1) dma_tile(1);
     if (n > 2) dma_tile(2);
-    if (def_mode && ASYNC_TABLE) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * KS + 4 + 8) : "memory");      // tile 0 only
+    if (def_mode && ASYNC_TABLE) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(((WC_SPLIT_ABL & 8) ? 0 : 2 * KS + 4) + 8) : "memory");      // tile 0 only
     else if (n > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (n > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -380,13 +389,17 @@ __global__ __launch_bounds__(512, 1) void apply_split_kernel(SplitApplyArgs a)
 #endif
     };
     auto store_u32 = [&](const void* base, unsigned off, unsigned v) __attribute__((always_inline)) {      // plain store (planes, mask): the L2 pairs the 64-byte halves of a line
+#if (WC_SPLIT_ABL & 1)
+        asm volatile("" :: "v"(off), "v"(v), "s"(base));
+#else
         asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" :: "v"(off), "v"(v), "s"(base) : "memory");
+#endif
     };
     // PUB_: the hand-counted vmcnt in front of the publication of tile t+1 (-1: no next tile); DMA_: tile t+3 exists;
     // FIRST_: tile 0 in DEF mode (table k-step by k-step); PEND_: the previous tile's stores ride in this loop; DEFER_: this
     // tile's outputs are parked for the next loop
     auto tile_body = [&](int t, auto pub_tag, auto dma_tag, auto first_tag, auto pend_tag, auto defer_tag) {
-        constexpr int PUB_ = decltype(pub_tag)::value;
+        constexpr int PUB_ = (WC_SPLIT_ABL & 1) && decltype(pub_tag)::value > 0 ? decltype(pub_tag)::value % 16 : decltype(pub_tag)::value;      // (no stores: the counts without the 16 per tile)
         constexpr bool DMA_ = decltype(dma_tag)::value;
         constexpr bool FIRST_ = decltype(first_tag)::value;
         constexpr bool PEND_ = decltype(pend_tag)::value;
@@ -477,7 +490,7 @@ __global__ __launch_bounds__(512, 1) void apply_split_kernel(SplitApplyArgs a)
                     v1 = !(v1 <= 0.f) ? v1 : 0.f;
                 }
                 asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(v0), "+v"(v1));
-                if (MASK) {      // after the ReLU a value is +0 or passes: v0 is row 16 rh + r (+ 8 in lanes 32-63), v1 four rows below; column l31
+                if (MASK && !(WC_SPLIT_ABL & 16)) {      // after the ReLU a value is +0 or passes: v0 is row 16 rh + r (+ 8 in lanes 32-63), v1 four rows below; column l31
                     const unsigned b0 = __builtin_bit_cast(unsigned, v0), b1 = __builtin_bit_cast(unsigned, v1);
                     bits |= (b0 < 1u ? b0 : 1u) << (16 * rh + r);
                     bits |= (b1 < 1u ? b1 : 1u) << (16 * rh + r + 4);
@@ -516,7 +529,7 @@ __global__ __launch_bounds__(512, 1) void apply_split_kernel(SplitApplyArgs a)
 #pragma unroll
             for (int i = 0; i < 16; ++i) store_pair(po, i, res[i]);
         }
-        if (MASK) {
+        if (MASK && !(WC_SPLIT_ABL & 16)) {
             // lanes l and l + 32 hold the two halves of column l31's 32 row bits (rows +0..7, +16..23 | +8..15, +24..31); one more
             // store per tile than the schedule's count of 16: a hand-counted wait only gets more conservative by it
             unsigned own = bits, other = bits;
@@ -554,7 +567,7 @@ __global__ __launch_bounds__(512, 1) void apply_split_kernel(SplitApplyArgs a)
 #if !WC_SPLIT_DEFER
         // D0, table, D1, D2 | tile 0: D3, S0 | tile 1: D4, S1 | ... : 8, 20, 36 ... 36, 32
         // (with slots the table is complete before tile 0 and tile 1 is published EARLY in tile 0's loop, ahead of D3: younger than D1 is D2 only)
-        else if (t == 0) { if (ASYNC_TABLE) tile_body(t, P8{}, T_{}, T_{}, F_{}, F_{}); else tile_body(t, P4{}, T_{}, F_{}, F_{}, F_{}); }
+        else if (t == 0) { if (ASYNC_TABLE && !(WC_SPLIT_ABL & 8)) tile_body(t, P8{}, T_{}, T_{}, F_{}, F_{}); else tile_body(t, P4{}, T_{}, F_{}, F_{}, F_{}); }
         else if (t == 1) tile_body(t, P20{}, T_{}, F_{}, F_{}, F_{});
         else if (dma) tile_body(t, P36{}, T_{}, F_{}, F_{}, F_{});
         else if (t + 2 < n) tile_body(t, P36{}, F_{}, F_{}, F_{}, F_{});
