@@ -41,7 +41,18 @@ ops.TRACE = []
 ops.apply_split(xs, None, A, be, None, plan=plan, out=y, folded=True, relu=True, want_mask=True, _mask_out=mk, ws=ws)
 raw = ops.TRACE[0][2]; ops.TRACE = None                             # the raw C-ABI call of the layers' launch
 k = isolated(raw); c = isolated(lambda: ops.stream_copy(x, y2))
-print("K3 min %%5.1f median %%5.1f us | stream copy (same rule, same process) min %%5.1f median %%5.1f us | K3 / copy %%.3f" %% (k[0], k[1], c[0], c[1], k[1] / c[1]))
+def b2b(fn, n=20):           # the same launch n times back to back as ONE hipGraph (bench.py's back_to_back_us), median of 3 replays
+    g_ = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g_):
+        for _ in range(n): fn()
+    g_.replay(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(3):
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(); g_.replay(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) * 1e3 / n)
+    return sorted(ts)[1]
+kb, cb = b2b(raw), b2b(lambda: ops.stream_copy(x, y2))
+print("K3 min %%5.1f median %%5.1f us | stream copy (same rule, same process) min %%5.1f median %%5.1f us | K3 / copy %%.3f | back to back in a graph: K3 %%5.1f copy %%5.1f" %% (k[0], k[1], c[0], c[1], k[1] / c[1], kb, cb))
 ''' % ROOT
 libs = []
 for lib in glob.glob(os.path.join(ROOT, "wc_gan_amd", "csrc", "build", "var", "lib_k3*.so")):

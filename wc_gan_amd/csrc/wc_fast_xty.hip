@@ -51,6 +51,12 @@ constexpr int BW_PLAIN = 3;                // 32x32 blocks per wave
                                // 1.39e-4; 2 stages 1.72e-4; 4 stages 2.19e-4; 16 stages 1.03e-3 -- and SHORTER chains (a flush every 2 k-steps /
                                // every k-step, built and dropped) 1.92e-4 / 3.23e-4: one stage per chain is the optimum of this scheme
 #endif
+#ifndef XTY_LOLO
+#define XTY_LOLO 0      // 1: covariance (K1): the fourth product lo*lo on every block (round 5, VERDICT r4 item 7: the lever named for the non-gaussian families)
+#endif
+#ifndef XTY_SUBFLUSH
+#define XTY_SUBFLUSH 1  // covariance (K1): float64 flushes per stage -- 2 = a flush every KS/2 k-steps (chains of 6 accumulations instead of 12)
+#endif
 template <int C, bool TWO> constexpr bool xty_quad() { return TWO && C == 256; }
 
 // The off-diagonal sums of the covariance kernel come out of the matrix pipe LOW by a nearly constant 8-10 e-10 of sqrt(S_ii S_jj)
@@ -413,11 +419,13 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
         // cancel (measured: mean off-diagonal error -9.7e-10 -> +5e-12 of sqrt(S_ii S_jj), the same on uniform / post-ReLU / Laplace
         // inputs).  The f16 MFMAs have no neg modifier: one v_xor per fragment register with a wave-uniform mask (0 in even stages).
         const unsigned sgn = (XTY_ALT && !TWO && FS == 1 && (st & 1)) ? 0x80008000u : 0u;
+        constexpr int NSUB = (!TWO && XTY_SUBFLUSH > 1 && KS % XTY_SUBFLUSH == 0) ? XTY_SUBFLUSH : 1;
+        int ks_lo = 0, ks_hi = KS;
         auto products = [&](auto ALL_, auto NL_) __attribute__((always_inline)) {
             constexpr bool ALL = decltype(ALL_)::value;
             constexpr int NL = decltype(NL_)::value;          // blocks 0 .. NL-1 (all live when ALL)
 #pragma unroll 4
-            for (int ks = 0; ks < KS; ++ks) {
+            for (int ks = ks_lo; ks < ks_hi; ++ks) {
 #pragma unroll
                 for (int b = 0; b < NL; ++b) {
                     if (!ALL && !live[b]) continue;
@@ -428,6 +436,7 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
                         al = __builtin_bit_cast(f16x8, __builtin_bit_cast(u32x4v_, al) ^ sgn);
                     }
                     const f16x8 bh = frag(b_base[b], ks, 0), bl = frag(b_base[b], ks, 1);
+                    if (XTY_LOLO && !TWO) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bl, acc[b], 0, 0, 0);
                     acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[b], 0, 0, 0);
                     acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[b], 0, 0, 0);
                     acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[b], 0, 0, 0);
@@ -451,13 +460,24 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
                 }
             }
         };
+        const double fsg = sgn ? -1.0 : 1.0;             // (wave-uniform: the chain's sign)
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {
+        if (NSUB > 1) {
+            ks_lo = sub * (KS / NSUB); ks_hi = ks_lo + KS / NSUB;
+            if (sub > 0) {
+#pragma unroll
+                for (int b = 0; b < BW; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+            }
+        }
         if (QUAD) products_quad();
         else if (all_live) products(std::true_type{}, std::integral_constant<int, BW>{});
         else if (two_live) products(std::true_type{}, std::integral_constant<int, 2>{});
         else if (any_live) products(std::false_type{}, std::integral_constant<int, BW>{});
         XS();
         // float64 flush: the fp32 rounding chain never exceeds one stage (3*KS MFMA accumulations)
-        const double fsg = sgn ? -1.0 : 1.0;             // (wave-uniform: the chain's sign)
         if (FS > 1 && st % FS != FS - 1 && st + 1 < nst) {}
         else if (two_live) {
 #pragma unroll
@@ -469,6 +489,7 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
             for (int b = 0; b < BW; ++b)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc64[b][r] = __builtin_fma((double)acc[b][r], fsg, acc64[b][r]);
+        }
         }
         XS();
         // LDS hand-off only (__syncthreads() would also drain vmcnt, i.e. wait for the loads of stage st+2 issued a moment ago)
