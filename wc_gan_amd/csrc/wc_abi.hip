@@ -679,7 +679,7 @@ int wc_resadd_split_f32(const float* h, const float* s, int64_t N, int64_t H, in
 // the producer feeding K1 (ABI 7; resadd_xtx_kernel of wc_resadd.hip): sample + pass with the covariance partials + gate, then the
 // tails of wc_whiten_split_f16x2 / wc_stats_split_f16x2 on those partials
 namespace {
-struct PresumLayout { int nslab, nsplit, ntypes; int64_t rps; double *Sp, *dfix, *P, *sum_scratch, *tmp; float* colsum; };
+struct PresumLayout { int nslab, nsplit, ntypes; int64_t rps; double *Sp, *dfix, *P, *sum_scratch, *tmp; float* colsum; int* wgflag; float* wgmax; };
 // one carve for the producer and both tails (the layout of wc_whiten_split_f16x2's workspace with the fp32-input kernel's slab plan)
 bool presum_layout(int64_t M, int C, int groups, void* ws, size_t ws_bytes, PresumLayout* o)
 {
@@ -692,6 +692,9 @@ bool presum_layout(int64_t M, int C, int groups, void* ws, size_t ws_bytes, Pres
     o->dfix = cv.take<double>((size_t)o->nslab * C);
     o->P = cv.take<double>((size_t)o->nslab * C * C);
     o->sum_scratch = cv.take<double>((size_t)groups * C);
+    const int grid = wc_resadd_xtx_grid(o->nslab, o->ntypes);
+    o->wgflag = cv.take<int>((size_t)grid);                                   // (in front of tmp: tmp stays the LAST block, wc_whiten_presummed_error_offset)
+    o->wgmax = cv.take<float>((size_t)grid * C);
     o->tmp = cv.take<double>((size_t)groups * C * C);
     return true;
 }
@@ -701,8 +704,10 @@ size_t presum_bytes(int64_t M, int C, int groups)
     int nsplit, ntypes; int64_t rps;
     const int nslab = wc_fast_xty_plan(groups, M / groups, C, groups > 1, 0, &nsplit, &rps, &ntypes);
     if (nslab <= 0) return 0;
+    const int grid = wc_resadd_xtx_grid(nslab, ntypes);
     return 256 + slot_bytes((size_t)2 * groups * C, 8) + slot_bytes((size_t)nslab * C, 4) + slot_bytes((size_t)nslab * C, 8) +
-           slot_bytes((size_t)nslab * C * C, 8) + slot_bytes((size_t)groups * C, 8) + slot_bytes((size_t)groups * C * C, 8);
+           slot_bytes((size_t)nslab * C * C, 8) + slot_bytes((size_t)groups * C, 8) + slot_bytes((size_t)grid, 4) + slot_bytes((size_t)grid * C, 4) +
+           slot_bytes((size_t)groups * C * C, 8);
 }
 }  // namespace
 
@@ -729,7 +734,7 @@ int wc_resadd_stats_split_f32(const float* h, const float* s, int64_t N, int64_t
     PresumLayout l;
     if (!presum_layout(N * H * W, C, groups, ws, ws_bytes, &l)) return WC_ERR_SHAPE;
     WC_TRY(wc_launch_resadd_xtx(h, s, N, H, W, C, up, groups, xs, center, scale, flag, x32, l.nsplit, l.rps, l.nslab, l.ntypes,
-                                l.P, l.colsum, l.dfix, static_cast<hipStream_t>(stream)));
+                                l.P, l.colsum, l.dfix, l.wgflag, l.wgmax, static_cast<hipStream_t>(stream)));
     return WC_OK;
 }
 

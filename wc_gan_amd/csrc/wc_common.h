@@ -206,7 +206,9 @@ hipError_t wc_launch_resadd(const float* h, const float* s, int64_t N, int64_t H
 bool wc_resadd_xtx_supported(int64_t N, int64_t H, int64_t W, int C, int up, int groups);
 hipError_t wc_launch_resadd_xtx(const float* h, const float* s, int64_t N, int64_t H, int64_t W, int C, int up, int groups,
                                 void* xs, float* center, float* scale, int* flag, float* x32,
-                                int nsplit, int64_t rows_per_slab, int nslab, int ntypes, double* P, float* colsum, double* dfix, hipStream_t st);
+                                int nsplit, int64_t rows_per_slab, int nslab, int ntypes, double* P, float* colsum, double* dfix,
+                                int* wgflag /*[grid]*/, float* wgmax /*[grid][C]*/, hipStream_t st);
+int wc_resadd_xtx_grid(int nslab, int ntypes);
 hipError_t wc_launch_patch_sum(const float* g, int64_t N, int64_t Hs, int64_t Ws, int C, float* out, hipStream_t st);
 hipError_t wc_launch_fold_channel_scale(const float* w, int64_t so, int64_t sc, int Cout, int Cin, const float* bias,
                                         const float* scale, const float* center, float* wf, float* bf, hipStream_t st);

@@ -30,6 +30,7 @@
 // channel's standard deviation >= max / sqrt(M)).  A non-finite element stays non-finite in the planes (NaN / Inf: loud downstream).
 // fp32 is written too only where a reader without a planes path exists (x32 != NULL: the backward's K4 / K6 at C = 128 today).
 #include "wc_common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -274,13 +275,110 @@ struct ResXtxArgs {
     int64_t rows_per_slab;
     int nslab, ntypes;
     double* P; float* colsum; double* dfix;
+    int sample_inside;                     // 1: every workgroup takes centre / scales from the <= 256 sampled rows itself (no resadd_sample_kernel launch)
+    int* wgflag; float* wgmax;             // [grid], [grid][C]: per-workgroup "an element did not fit" and that workgroup's per-channel maxima (pass 1 -> gate)
 };
+
+// centre / scale of the sum inside the fused kernel: resadd_sample_kernel's statistics, bit for bit (the same rows, the same summation
+// order per row group, the same medians), computed redundantly by every workgroup from the L2-resident sample (256 rows of h and of s:
+// 512 KiB) instead of by a launch of its own in front (12-14 us on 16 small workgroups, a chain of latencies, plus a launch boundary).
+// Leaves scale[C] | -centre scale[C] in LDS; the publishing workgroup also stores centre / scale / scale0 for the consumers.
+template <int C>
+__device__ __forceinline__ void rx_sample(const ResAddArgs& r, char* scratch, float* sc_sh, float* nc_sh, int tid, bool publish)
+{
+    constexpr int C4 = C / 4, RGRP = 512 / C4, NP = 16 / RGRP;          // row groups ("parts") of the sample per thread: 2 (C = 256) | 1 (C = 128)
+    const int c4 = tid % C4, rgrp = tid / C4;
+    float* red = reinterpret_cast<float*>(scratch);                      // [16][C]
+    float* red2 = red + 16 * C;                                          // [16][C]
+    float* cen2 = red2 + 16 * C;                                         // [2][C]: mean | median of the 16 group means
+    const int64_t stride = r.M / 256;                                    // (M >= 20480: always 256 samples)
+    f32x4 v[NP][16];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int p = rgrp + RGRP * q;
+        f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int64_t row = wc_sample_row(p + 16 * i, stride);
+            v[q][i] = *reinterpret_cast<const f32x4*>(r.h + row * C + 4 * c4);
+            v[q][i] += *reinterpret_cast<const f32x4*>(r.s + src_row(r, (unsigned)row) * C + 4 * c4);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sacc += v[q][i];
+        *reinterpret_cast<f32x4*>(red + p * C + 4 * c4) = sacc;
+    }
+    __syncthreads();
+    if (tid < C) {
+        float t = 0.f, pm[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const float ps = red[p * C + tid];
+            t += ps;
+            pm[p] = ps / 16.f;
+        }
+        cen2[tid] = t / 256.f;
+        cen2[C + tid] = wc_median16(pm);
+    }
+    __syncthreads();
+    {
+        const f32x4 mean = *reinterpret_cast<const f32x4*>(cen2 + 4 * c4), med = *reinterpret_cast<const f32x4*>(cen2 + C + 4 * c4);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const int p = rgrp + RGRP * q;
+            f32x4 mx = {0.f, 0.f, 0.f, 0.f}, mx2 = mx;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    mx[j] = fmaxf(mx[j], fabsf(v[q][i][j] - mean[j]));
+                    mx2[j] = fmaxf(mx2[j], fabsf(v[q][i][j] - med[j]));
+                }
+            *reinterpret_cast<f32x4*>(red + p * C + 4 * c4) = mx;
+            *reinterpret_cast<f32x4*>(red2 + p * C + 4 * c4) = mx2;
+        }
+    }
+    __syncthreads();
+    if (tid < C) {
+        float g1[16], g2[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) { g1[p] = red[p * C + tid]; g2[p] = red2[p * C + tid]; }
+        float m = 0.f;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) m = fmaxf(m, g1[p]);
+        const float med1 = wc_median16(g1);
+        const bool outlier = med1 > 0.f && m > 64.f * med1;
+        float centre = cen2[tid];
+        if (outlier) { centre = cen2[C + tid]; m = wc_robust_max16(g2); }
+        float sc = 1.0f;
+        if (m > 0.f && m < 3.0e38f) {
+            int e;
+            frexpf(m, &e);
+            sc = ldexpf(1.0f, 4 - e);
+        }
+        sc_sh[tid] = sc;
+        nc_sh[tid] = -centre * sc;
+        if (publish) { r.center[tid] = centre; r.scale[tid] = sc; r.scale0[tid] = sc; }
+    }
+    __syncthreads();
+}
 
 template <int C, bool F32, bool REDO>
 __global__ __launch_bounds__(512, 1) void resadd_xtx_kernel(ResXtxArgs a)
 {
     static_assert(C == 128 || C == 256, "fused producer: C = 128 or 256");
-    if (REDO && __builtin_nontemporal_load(a.r.flag) != 1) return;
+    // The gate (REDO): did any workgroup of pass 1 meet an element that did not fit?  Pass 1 leaves one word per workgroup (no word that
+    // somebody would have had to clear in front of the launch: the sampling lives inside the kernel now), the gate folds them.
+    __shared__ int any_over;
+    if (REDO) {
+        int mine = 0;
+        for (int i = threadIdx.x; i < (int)gridDim.x; i += 512) mine |= __builtin_nontemporal_load(a.wgflag + i);
+        if (threadIdx.x == 0) any_over = 0;
+        __syncthreads();
+        if (mine) any_over = 1;
+        __syncthreads();
+        if (blockIdx.x == 0 && threadIdx.x == 0) a.r.flag[0] = any_over;      // the status word of the call (informational)
+        if (!any_over) return;
+    }
     constexpr bool BAL = C == 256;                    // 36 blocks as 18 + 18 on the two workgroup types of a slab (wc_fast_xty.hip)
     constexpr int BW = 3;
     constexpr int C4 = C / 4;
@@ -300,13 +398,17 @@ __global__ __launch_bounds__(512, 1) void resadd_xtx_kernel(ResXtxArgs a)
     double* const sq_acc = reinterpret_cast<double*>(aux + 512 * 16);             // [512][4]
     float* const sc_sh = reinterpret_cast<float*>(aux + 512 * 48);                // [C]
     float* const nc_sh = sc_sh + C;                                               // [C]
+    unsigned* const ov_sh = reinterpret_cast<unsigned*>(nc_sh + C);               // [C] pass 1: bits of the largest |scaled element| beyond the guard, per channel | [C]: "any"
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
     const int type = q % a.ntypes;
     const int64_t z = (int64_t)(q / a.ntypes) * 8 + xcd;
-    if (z >= a.nslab) return;
+    if (z >= a.nslab) {
+        if (!REDO && threadIdx.x == 0) a.wgflag[blockIdx.x] = 0;
+        return;
+    }
 
     int64_t r0, r1;
     if (a.per_sample) {
@@ -344,12 +446,26 @@ __global__ __launch_bounds__(512, 1) void resadd_xtx_kernel(ResXtxArgs a)
     const bool any_live = __builtin_amdgcn_readfirstlane(any_ ? 1 : 0) != 0;
 
     const int c4 = tid % C4, rgrp = tid / C4;
-    {
+    if (tid < C) ov_sh[tid] = 0u;
+    if (tid == 0) ov_sh[C] = 0u;
+    if (!REDO && a.sample_inside) {
+        rx_sample<C>(a.r, smem, sc_sh, nc_sh, tid, z == 0 && type == 0);
+        cs_acc[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sq_acc[tid * 4 + j] = 0.0;
+    } else {
         f32x4 scl = *reinterpret_cast<const f32x4*>((REDO ? a.r.scale0 : a.r.scale) + 4 * c4);
         if (REDO) {         // the scales the true maxima ask for (resadd_kernel's rule); the first slab's type-0 workgroup stores them
+            f32x4 gm4 = {0.f, 0.f, 0.f, 0.f};       // the channel's maximum over the workgroups that reported one (rare path: a plain loop)
+            for (int i = 0; i < (int)gridDim.x; ++i)
+                if (a.wgflag[i]) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(a.wgmax + (int64_t)i * C + 4 * c4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) gm4[j] = fmaxf(gm4[j], w[j]);
+                }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float gm = __builtin_bit_cast(float, a.r.gmax[4 * c4 + j]);
+                const float gm = gm4[j];
                 if (gm > 0.f && gm < 3.0e38f) {
                     int e;
                     frexpf(gm, &e);
@@ -423,9 +539,9 @@ __global__ __launch_bounds__(512, 1) void resadd_xtx_kernel(ResXtxArgs a)
                     float mj = 0.f;
 #pragma unroll
                     for (int p = 0; p < 8; ++p) mj = __builtin_fmaxf(mj, fabsf(g[p][j]));
-                    if (mj > kResGuard) atomicMax(a.r.gmax + 4 * c4 + j, __builtin_bit_cast(unsigned, mj));
+                    if (mj > kResGuard) atomicMax(ov_sh + 4 * c4 + j, __builtin_bit_cast(unsigned, mj));      // (LDS: order-independent, deterministic)
                 }
-                *a.r.flag = 1;
+                ov_sh[C] = 1u;
             }
         }
         if (want_csum) {
@@ -586,6 +702,11 @@ __global__ __launch_bounds__(512, 1) void resadd_xtx_kernel(ResXtxArgs a)
             a.dfix[z * C + c] = t / ((double)sc_sh[c] * (double)sc_sh[c]);
         }
     }
+    if (!REDO) {        // this workgroup's word for the gate, and -- only when it met such an element -- its per-channel maxima
+        const bool over = ov_sh[C] != 0u;          // (behind the __syncthreads() above: every wave's last stage_write has happened)
+        if (tid == 0) a.wgflag[blockIdx.x] = over ? 1 : 0;
+        if (over && tid < C) a.wgmax[(int64_t)blockIdx.x * C + tid] = __builtin_bit_cast(float, ov_sh[tid]);
+    }
 }
 
 // gradient of the add with respect to the pre-upsample shortcut: every source pixel collects its 2x2 output patch
@@ -695,9 +816,12 @@ bool wc_resadd_xtx_supported(int64_t N, int64_t H, int64_t W, int C, int up, int
     return wc_fast_xty_plan(groups, (N / groups) * H * W, C, groups > 1, 0, &nsplit, &rps, &ntypes) > 0;
 }
 
+int wc_resadd_xtx_grid(int nslab, int ntypes) { return ((nslab + 7) / 8) * ntypes * 8; }
+
 hipError_t wc_launch_resadd_xtx(const float* h, const float* s, int64_t N, int64_t H, int64_t W, int C, int up, int groups,
                                 void* xs, float* center, float* scale, int* flag, float* x32,
-                                int nsplit, int64_t rows_per_slab, int nslab, int ntypes, double* P, float* colsum, double* dfix, hipStream_t st)
+                                int nsplit, int64_t rows_per_slab, int nslab, int ntypes, double* P, float* colsum, double* dfix,
+                                int* wgflag, float* wgmax, hipStream_t st)
 {
     if (!s || !up) return hipErrorInvalidValue;
     ResXtxArgs a = {};
@@ -713,9 +837,13 @@ hipError_t wc_launch_resadd_xtx(const float* h, const float* s, int64_t N, int64
     r.hi = static_cast<_Float16*>(xs); r.lo = r.hi + r.M * C;
     a.N = groups; a.HW = r.M / groups; a.per_sample = groups > 1; a.nsplit = nsplit; a.rows_per_slab = rows_per_slab;
     a.nslab = nslab; a.ntypes = ntypes; a.P = P; a.colsum = colsum; a.dfix = dfix;
-    hipLaunchKernelGGL(resadd_sample_kernel, dim3((C + kSampCh - 1) / kSampCh), dim3(256), 0, st, r);
-    const size_t lds = 131072 + 512 * 48 + 2 * (size_t)C * 4;
-    const int grid = ((nslab + 7) / 8) * ntypes * 8;
+    a.wgflag = wgflag; a.wgmax = wgmax;
+    // WC_RX_SAMPLE_KERNEL=1 (development, A/B): centre / scales from a launch of resadd_sample_kernel in front, as wc_resadd_split_f32 has it
+    static const bool sample_launch = getenv("WC_RX_SAMPLE_KERNEL") && atoi(getenv("WC_RX_SAMPLE_KERNEL")) != 0;
+    a.sample_inside = sample_launch ? 0 : 1;
+    if (sample_launch) hipLaunchKernelGGL(resadd_sample_kernel, dim3((C + kSampCh - 1) / kSampCh), dim3(256), 0, st, r);
+    const size_t lds = 131072 + 512 * 48 + 2 * (size_t)C * 4 + ((size_t)C + 4) * 4;
+    const int grid = wc_resadd_xtx_grid(nslab, ntypes);
 #define WC_LAUNCH_RX(C_, F_, R_)                                                                                                   \
     do {                                                                                                                           \
         static bool attr_set = false;                                                                                              \
