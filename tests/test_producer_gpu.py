@@ -143,7 +143,7 @@ def _spiky_sum(shape, rng, c0=5, ratio=2.0e4, frac=0.004):
 def test_spiky_channel_through_the_planes_route_meets_the_contract(shape, relu):
     """The same case through the layers' route, default environment: residual_add(planes=True) -> whiten_color (K1 + K2, K3, K4, K5, K6
     all on the rescaled planes), forward + backward against the float64 oracle on the exact sum: 1e-4 (north_star's contract) on y, dh, ds
-    and the coloring gradients.  With round 4's clamp the spikes of channel c0 were cut to 3700 x the sampled maximum: y off by 0.3."""
+    and the coloring gradients.  (Round 4's clamp cut the spikes of channel c0 to 3700 x the sampled maximum and went on.)"""
     from wc_gan_amd.functional import residual_add, split_of, whiten_color
     rng = np.random.default_rng(41)
     N, H, W, C = shape

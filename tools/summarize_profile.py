@@ -28,7 +28,10 @@ tot = sum(sum(v) for v in d.values())
 with open(dst, 'w') as f:
     f.write(f"# rocprofv3 --kernel-trace --stats summary\n\nsource: `{trace}`" +
             ((f", window {window[0]}..{window[1]} s after first dispatch" if window and not after_gap else "") + (", steady-state steps only (after the last pause)" if after_gap else "")) +
-            f"\n\n{len(rows)} dispatches, {tot/1e3:.2f} ms of kernel time\n\n| kernel | calls | total ms | avg us | min us | max us | % |\n|---|---|---|---|---|---|---|\n")
+            f"\n\n{len(rows)} dispatches, {tot/1e3:.2f} ms of kernel time" +
+            "\n\n(The sum of kernel durations is NOT the wall time of the steps: the generator's forward of the update runs on a second stream beside the critic updates and" +
+            " the forward-only passes put each block's shortcut convolution on a side stream, so durations overlap; and kernels run longer under the profiler than in the bench's" +
+            " un-profiled graph replay -- compare with `ms_per_step` of the bench line, not with this total.)\n\n| kernel | calls | total ms | avg us | min us | max us | % |\n|---|---|---|---|---|---|---|\n")
     for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1]))[:45]:
         f.write(f"| `{k[:110]}` | {len(v)} | {sum(v)/1e3:.3f} | {sum(v)/len(v):.1f} | {min(v):.1f} | {max(v):.1f} | {100*sum(v)/tot:.1f} |\n")
 print("wrote", dst)

@@ -57,6 +57,9 @@
 #ifndef WC_SPLIT_DEFER
 #define WC_SPLIT_DEFER 0        // 1: a tile's stores ride in the next tile's MFMA gaps; 0: they follow the tile's own loop
 #endif
+#ifndef WC_SPLIT_PRE3
+#define WC_SPLIT_PRE3 0     // 1 (one table for the launch, >= 6 tiles): tile 3's pieces are requested in the prologue with tiles 0-2 (its buffer is free from the start)
+#endif                      // instead of from tile 0's k-step 1, which waits for the table's first fragments: 128 instead of 96 KiB per CU in flight while the table arrives
 #ifndef WC_SPLIT_ABL
 #define WC_SPLIT_ABL 0       // development ablation bits (wrong results, times only; tools/k3_ablations.py): 1 no stores (the hand-counted waits
                              // adjusted: the DMA waits stay real), 2 no MFMA, 4 linear (unswizzled) DMA source, 8 no table loads (a zero table),
@@ -347,7 +350,9 @@ __global__ __launch_bounds__(512, 1) void apply_split_kernel(SplitApplyArgs a)
     if (ASYNC_TABLE) load_b(0);
     if (n > 1) dma_tile(1);
     if (n > 2) dma_tile(2);
-    if (def_mode && ASYNC_TABLE) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(((WC_SPLIT_ABL & 8) ? 0 : 2 * KS + 4) + 8) : "memory");      // tile 0 only
+    constexpr bool PRE3 = WC_SPLIT_PRE3 && ASYNC_TABLE && !(WC_SPLIT_ABL & 8);
+    if (PRE3 && def_mode) dma_tile(3);             // (def_mode: n >= 6)
+    if (def_mode && ASYNC_TABLE) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(((WC_SPLIT_ABL & 8) ? 0 : 2 * KS + 4) + 8 + (PRE3 ? 4 : 0)) : "memory");      // tile 0 only
     else if (n > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (n > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -430,7 +435,7 @@ __global__ __launch_bounds__(512, 1) void apply_split_kernel(SplitApplyArgs a)
             if (FIRST_) {    // this k-step's four table fragments have landed (younger: the later k-steps', the 4 column constants, the
                 // DMAs of tiles 1 and 2 and, behind step DSTEP, of tile 3).  No "+v" ties: redefining 128 table registers inside one
                 // of the tile bodies cost 60 VGPRs and spills; the scheduling barrier keeps the k-step's MFMAs behind the wait
-                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(12 + 4 * (KS32 - 1 - s) + (s > DSTEP ? 4 : 0)) : "memory");
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"(12 + 4 * (KS32 - 1 - s) + ((PRE3 || s > DSTEP) ? 4 : 0)) : "memory");
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
@@ -567,7 +572,11 @@ __global__ __launch_bounds__(512, 1) void apply_split_kernel(SplitApplyArgs a)
 #if !WC_SPLIT_DEFER
         // D0, table, D1, D2 | tile 0: D3, S0 | tile 1: D4, S1 | ... : 8, 20, 36 ... 36, 32
         // (with slots the table is complete before tile 0 and tile 1 is published EARLY in tile 0's loop, ahead of D3: younger than D1 is D2 only)
-        else if (t == 0) { if (ASYNC_TABLE && !(WC_SPLIT_ABL & 8)) tile_body(t, P8{}, T_{}, T_{}, F_{}, F_{}); else tile_body(t, P4{}, T_{}, F_{}, F_{}, F_{}); }
+        else if (t == 0) {
+            if (PRE3) tile_body(t, P8{}, F_{}, T_{}, F_{}, F_{});          // (D3 went out in the prologue: younger than D1 are D2 and D3, as before)
+            else if (ASYNC_TABLE && !(WC_SPLIT_ABL & 8)) tile_body(t, P8{}, T_{}, T_{}, F_{}, F_{});
+            else tile_body(t, P4{}, T_{}, F_{}, F_{}, F_{});
+        }
         else if (t == 1) tile_body(t, P20{}, T_{}, F_{}, F_{}, F_{});
         else if (dma) tile_body(t, P36{}, T_{}, F_{}, F_{}, F_{});
         else if (t + 2 < n) tile_body(t, P36{}, F_{}, F_{}, F_{}, F_{});
