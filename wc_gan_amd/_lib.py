@@ -134,6 +134,7 @@ SIGNATURES = {
                                     c_void_p, c_void_p, c_int, c_void_p]),
     "wc_spectral_norm_amax_offset": (c_size_t, [c_int, c_int]),
     "wc_spectral_norm_error_offset": (c_size_t, [c_int, c_int]),
+    "wc_conv_split_hist_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "wc_conv_split_colsum_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "wc_conv_wrw_bias_f16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -15,6 +15,7 @@ read back through gfx950's transposing LDS read).  No fallback inside: `supporte
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 
@@ -146,13 +147,45 @@ def _colsum_ok(C):
     return C % 4 == 0 and 256 % (C // 4) == 0
 
 
-def split_planes(x, relu=False, colsum=False):
+# The split's scale from the call before at the same call site (wc_conv_split_hist_f32: one launch instead of absmax + split; nothing clamps,
+# an element that does not fit goes inf = loud).  Training-mode layers only: an eval-mode pass measures every tensor, so that the images of a
+# loaded checkpoint do not depend on what the process ran before.  WC_SPLIT_HIST=0: the measured maximum everywhere, two launches (rounds 1-4).
+SPLIT_HIST = os.environ.get('WC_SPLIT_HIST', '1') != '0'
+HIST_FLOATS = 2 + 512          # include/wc_hip.h WC_CONV_HIST_FLOATS
+
+
+def _site_hist(site, role, device):
+    """[record (HIST_FLOATS floats on the device: the previous call's maximum, a counter, per-workgroup maxima), seeded?] of a call site:
+    `site` is the layer object that owns the convolution (state lives in its __dict__, not in a parameter or buffer: no checkpoint entry --
+    a resumed run measures once), role 'x' (its input) or 'g' (its output gradient).  None for a layer in eval mode, and while a hipGraph is
+    being recorded for a site that has no record yet (no allocation into a graph's private pool; the trainers warm up eagerly first)."""
+    if not getattr(site, 'training', True):
+        return None
+    book = site.__dict__.setdefault('_wc_split_hist', {})
+    h = book.get(role)
+    if h is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        h = book[role] = [torch.zeros(HIST_FLOATS, dtype=torch.float32, device=device), False]
+    return h
+
+
+def split_planes(x, relu=False, colsum=False, site=None, role='x'):
     """fp32 tensor -> (hi, lo, scale): fp16 planes of s*x and the device scalar s.  colsum: also the 512 partial rows of the
-    column sums over the last axis (-> the bias gradient, finished by weight_gradient), returned as a 4th element."""
+    column sums over the last axis (-> the bias gradient, finished by weight_gradient), returned as a 4th element.
+    site (+ role): the layer object this tensor belongs to -- the scale then comes from the previous call of that site (one launch)."""
     lib = _lib.load()
     both = torch.empty((2,) + tuple(x.shape), dtype=torch.float16, device=x.device)
     hi, lo = both[0], both[1]
     scale = torch.empty(1 + 512, dtype=torch.float32, device=x.device)    # [scale | per-workgroup maxima scratch]
+    h = _site_hist(site, role, x.device) if (SPLIT_HIST and site is not None) else None
+    if h is not None:
+        C = x.shape[-1]
+        part = torch.empty((512, C), dtype=torch.float32, device=x.device) if colsum else None
+        _lib.check(lib.wc_conv_split_hist_f32(_ptr(x), x.numel(), 1 if relu else 0, _ptr(hi), _ptr(lo), _ptr(scale), _ptr(part), C if colsum else 0,
+                                              _ptr(h[0]), 0 if h[1] else 1, _stream()), "wc_conv_split_hist_f32")
+        h[1] = True
+        return (hi, lo, scale, part) if colsum else (hi, lo, scale)
     if not colsum:
         _lib.check(lib.wc_conv_split_f32(_ptr(x), x.numel(), 1 if relu else 0, _ptr(hi), _ptr(lo), _ptr(scale),
                                          scale.data_ptr() + 4, _stream()), "wc_conv_split_f32")
@@ -284,11 +317,13 @@ def takes_planes(shape, wshape, kind):
 
 class _FastConv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, kind, plan, relu_input=False, handed=None):
+    def forward(ctx, x, w, bias, kind, plan, relu_input=False, handed=None, site=None):
         gf, kf, nf = plan.fwd
         # handed: x is a K3 handle and these are its planes (already ReLU'd and split by K3's epilogue: no pass here)
         # relu_input: the layer is conv(relu(x)); the ReLU happens in the split
-        planes = handed if handed is not None else split_planes(x, relu=relu_input)
+        # site: the layer object (generator.Conv2D) -- its splits take their scale from the site's previous call (split_planes)
+        planes = handed if handed is not None else split_planes(x, relu=relu_input, site=site, role='x')
+        ctx.site = site
         if ctx.needs_input_grad[0]:                 # the data gradient will want its image too: both in one launch
             img, ctx.bwd_image = weight_image_pair(w, plan.fwd, plan.bwd)
         else:
@@ -306,7 +341,7 @@ class _FastConv(torch.autograd.Function):
         gy = gy.contiguous()
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         fused_db = want_db and ctx.needs_input_grad[1] and _colsum_ok(gy.shape[-1])    # db rides on the split + the dW reduction
-        g_planes = split_planes(gy, colsum=fused_db)
+        g_planes = split_planes(gy, colsum=fused_db, site=ctx.site, role='g')
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             gb, kb, nb = plan.bwd
@@ -322,7 +357,7 @@ class _FastConv(torch.autograd.Function):
                 dw = weight_gradient((xh, xl, xs), g_planes, gf, w, kf, nf, nbytes=plan.wrw_ws)
         if want_db and not fused_db:
             db = gy.sum((0, 1, 2))
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 _ones = {}
@@ -346,8 +381,9 @@ class _SplitConv(torch.autograd.Function):
     weight itself; the weight gradient of wf on the same planes, unfolded (wc_unfold_channel_scale_f32)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, plan, st):
+    def forward(ctx, x, w, bias, plan, st, site=None):
         from . import ops
+        ctx.site = site
         gf, kf, nf = plan.fwd
         wf, bf = ops.fold_channel_scale(w, bias, st.scale, st.center)
         img = weight_image(wf, gf, kf, nf)
@@ -371,7 +407,7 @@ class _SplitConv(torch.autograd.Function):
         need_w = ctx.needs_input_grad[1]
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
         fused_db = need_w and _colsum_ok(gy.shape[-1])       # db rides on the split + the dW reduction (the unfolding needs it anyway)
-        g_planes = split_planes(gy, colsum=fused_db)
+        g_planes = split_planes(gy, colsum=fused_db, site=ctx.site, role='g')
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             gb, kb, nb = plan.bwd
@@ -387,20 +423,21 @@ class _SplitConv(torch.autograd.Function):
             dw = ops.unfold_channel_scale(D, db, scale, center)
         elif need_b:
             db = gy.sum((0, 1, 2))
-        return dx, dw, (db if need_b else None), None, None
+        return dx, dw, (db if need_b else None), None, None, None
 
 
-def split_conv(x, st, w, bias=None):
+def split_conv(x, st, w, bias=None, site=None):
     """conv1x1(x) for a handle x whose data is the ops.SplitTensor st (see _SplitConv).  Raises when the kernel does not take the
     shape -- the producer asks takes_planes() before it writes planes."""
     p = _plan('same', x, w)
     if not (p and p.ok and tuple(w.shape[2:]) == (1, 1) and w.dtype == torch.float32):
         raise _lib.WcHipError(f"split_conv: a pre-split handle reached a convolution without a planes path {tuple(x.shape)} x {tuple(w.shape)}")
-    return _SplitConv.apply(x, w, bias, p, st)
+    return _SplitConv.apply(x, w, bias, p, st, site)
 
 
-def fast_conv_or_none(x, w, bias=None, kind='same', relu_input=False):
-    """fast_conv when the kernel takes the call, else None (the caller's other path).  relu_input: conv(relu(x))."""
+def fast_conv_or_none(x, w, bias=None, kind='same', relu_input=False, site=None):
+    """fast_conv when the kernel takes the call, else None (the caller's other path).  relu_input: conv(relu(x)).
+    site: the layer object that owns this convolution (split_planes keeps the splits' scale history there)."""
     handed = getattr(x, '_wc_planes', None)
     if not supported(x, w, kind):
         if handed is not None:
@@ -409,8 +446,8 @@ def fast_conv_or_none(x, w, bias=None, kind='same', relu_input=False):
     if handed is not None:
         if relu_input:
             raise ValueError("a K3 handle is already ReLU'd")
-        return _FastConv.apply(x, w, bias, kind, _plan(kind, x, w), False, handed)
-    return _FastConv.apply(x, w, bias, kind, _plan(kind, x, w), relu_input)
+        return _FastConv.apply(x, w, bias, kind, _plan(kind, x, w), False, handed, site)
+    return _FastConv.apply(x, w, bias, kind, _plan(kind, x, w), relu_input, None, site)
 
 
 def fast_conv(x, w, bias=None, kind='same'):

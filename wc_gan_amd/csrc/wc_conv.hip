@@ -361,6 +361,90 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const float* __restrict
     }
 }
 
+// ---- the same split in ONE launch, its scale taken from the call before (round 5) ----------------------------------------------------
+// conv_absmax + conv_split run ~240 times per G+D step on the critic's small tensors: two latency-bound launches of 3-8 us each for a
+// pass whose only purpose is one number, the tensor's scale -- and hi + lo carry 22 bits of an element wherever the scaled maximum lies
+// between 2^-5 and fp16's 65504 (an absolute error of 2^-25 / scaled-max of the tensor's maximum below that): twenty binary orders of
+// slack.  So a call site (one convolution's input, or its output gradient) keeps a small record across calls,
+//     hist[0] = max|x| of the previous call      hist[1] = arrival counter (0 between launches)      hist[2 ..] = per-workgroup maxima
+// and a call takes its scale from hist[0] -- the power of two that puts 64 x that maximum into [2^13, 2^14), i.e. the maximum itself
+// into [2^7, 2^8): room for a 255-fold growth from one call to the next before fp16 overflows, a 4000-fold shrink before the absolute
+// error leaves 2^-20 of the maximum.  Every workgroup reads hist[0] first and leaves its own maximum in its slot last; the workgroup
+// that arrives last (a counter; by then every other one has read hist[0]) folds the slots into hist[0] for the next call and clears the
+// counter.  max() is order-free, so the record -- and with it every later scale -- is a function of the sequence of tensors alone:
+// an eager run and a replayed hipGraph of the same calls produce the same bits (no host-side state beyond "has this site been called").
+// NOTHING clamps: an element that does not fit becomes inf in the planes and NaN / inf in the convolution's output -- loud, never
+// quietly wrong.  The first call of a site measures (the two-launch form) and leaves its maximum in the record.
+constexpr float kHistMargin = 64.0f;
+constexpr int kHistHead = 2;                       // floats in front of the per-workgroup slots
+
+__device__ __forceinline__ float scale_for(float amax)
+{
+    if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.0f;
+    int e;
+    (void)frexpf(amax, &e);
+    return ldexpf(1.0f, 14 - e);
+}
+
+__global__ __launch_bounds__(64) void conv_hist_seed_kernel(float* __restrict__ hist)      // the first call: slots (conv_absmax_kernel) -> hist[0]
+{
+    float amax = 0.f;
+    for (int i = threadIdx.x; i < kAmaxBlocks; i += 64) amax = fmaxf(amax, hist[kHistHead + i]);
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    if (threadIdx.x == 0) { hist[0] = amax; reinterpret_cast<unsigned*>(hist)[1] = 0u; }
+}
+
+__global__ __launch_bounds__(256) void conv_split_hist_kernel(const float* __restrict__ x, int64_t n4, int relu, _Float16* __restrict__ hi,
+                                                              _Float16* __restrict__ lo, float* __restrict__ scale_out,
+                                                              float* __restrict__ hist, float* __restrict__ colsum, int c4n)
+{
+    __shared__ float red[4];
+    __shared__ f32x4 red4[256];
+    __shared__ int last;
+    const float s = scale_for(__builtin_nontemporal_load(hist) * kHistMargin);
+    if (blockIdx.x == 0 && threadIdx.x == 0) scale_out[0] = s;
+    float m = 0.f;
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * i);
+        cs += v;                                   // (the bias gradient's column sums are of the tensor as given, as in conv_absmax_kernel)
+        if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        m = fmaxf(fmaxf(m, fabsf(v[0])), fmaxf(fabsf(v[1]), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+        v = v * s;
+        f16x4 h, l;
+        #pragma unroll
+        for (int j = 0; j < 4; ++j) { h[j] = (_Float16)v[j]; l[j] = (_Float16)(v[j] - (float)h[j]); }
+        *reinterpret_cast<f16x4*>(hi + 4 * i) = h;
+        *reinterpret_cast<f16x4*>(lo + 4 * i) = l;
+    }
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    if (colsum) red4[threadIdx.x] = cs;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // the slot through the atomic path (device scope, L2): the last workgroup reads all of them the same way
+        atomicExch(hist + kHistHead + blockIdx.x, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+        __threadfence();
+        last = atomicAdd(reinterpret_cast<unsigned*>(hist) + 1, 1u) == gridDim.x - 1;
+    }
+    if (colsum && (int)threadIdx.x < c4n) {
+        f32x4 t = red4[threadIdx.x];
+        for (int p = threadIdx.x + c4n; p < 256; p += c4n) t += red4[p];
+        *reinterpret_cast<f32x4*>(colsum + (int64_t)blockIdx.x * 4 * c4n + 4 * threadIdx.x) = t;
+    }
+    __syncthreads();
+    if (last && threadIdx.x < 64) {                // every other workgroup has read hist[0] and left its maximum: the next call's record
+        __threadfence();
+        float amax = 0.f;
+        for (int i = threadIdx.x; i < (int)gridDim.x; i += 64) amax = fmaxf(amax, atomicAdd(hist + kHistHead + i, 0.0f));
+        #pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+        if (threadIdx.x == 0) { hist[0] = amax; reinterpret_cast<unsigned*>(hist)[1] = 0u; }
+    }
+}
+
 // ---- weight fragment images ----------------------------------------------------------------------------------------
 struct WeightArgs {
     const float* w; int64_t sk, sn, sr, ss;        // element (k, n, r, s) of the source = w[k*sk + n*sn + r*sr + s*ss]
@@ -779,6 +863,26 @@ int wc_conv_split_colsum_f32(const float* x, int64_t n, int relu, void* hi, void
                        colsum_partials, colsum_partials ? C >> 2 : 0);
     hipLaunchKernelGGL(conv_split_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, x, n / 4, (const float*)amax_scratch, relu,
                        (_Float16*)hi, (_Float16*)lo, scale);
+    return (int)hipGetLastError();
+}
+
+int wc_conv_split_hist_f32(const float* x, int64_t n, int relu, void* hi, void* lo, float* scale, float* colsum_partials, int C,
+                           float* hist, int bootstrap, wc_stream_t stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (!x || !hi || !lo || !scale || !hist || n <= 0 || (n & 3)) return WC_ERR_ARG;
+    if (colsum_partials && (C <= 0 || (C & 3) || 256 % (C >> 2) != 0 || n % C != 0)) return WC_ERR_SHAPE;
+    if (bootstrap) {       // the site's first call: the measured maximum (the two-launch form, bit for bit), left in the record
+        float* slots = hist + kHistHead;
+        hipLaunchKernelGGL(conv_absmax_kernel, dim3(kAmaxBlocks), dim3(256), 0, st, x, n / 4, n, slots, colsum_partials, colsum_partials ? C >> 2 : 0);
+        hipLaunchKernelGGL(conv_split_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, x, n / 4, (const float*)slots, relu, (_Float16*)hi,
+                           (_Float16*)lo, scale);
+        hipLaunchKernelGGL(conv_hist_seed_kernel, dim3(1), dim3(64), 0, st, hist);
+        return (int)hipGetLastError();
+    }
+    // always kAmaxBlocks workgroups: they are the partial rows conv_wrw_reduce_kernel adds up
+    hipLaunchKernelGGL(conv_split_hist_kernel, dim3(kAmaxBlocks), dim3(256), 0, st, x, n / 4, relu, (_Float16*)hi, (_Float16*)lo, scale,
+                       hist, colsum_partials, colsum_partials ? C >> 2 : 0);
     return (int)hipGetLastError();
 }
 

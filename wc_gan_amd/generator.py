@@ -130,7 +130,7 @@ class Conv2D(nn.Module):
         """conv(relu(x)): on the fast path the ReLU happens while the activation is split (one kernel and one pass less)"""
         w = self._weight()
         if FAST_CONV and x.is_cuda:
-            y = fast_conv_mod.fast_conv_or_none(x, w, self.conv.bias, 'same', relu_input=True)
+            y = fast_conv_mod.fast_conv_or_none(x, w, self.conv.bias, 'same', relu_input=True, site=self)
             if y is not None:
                 return y
         return self.forward(F.relu(x), _w=w)
@@ -139,14 +139,14 @@ class Conv2D(nn.Module):
         c = self.conv
         st = split_of(x)
         if st is not None:      # the block input as pre-split planes: the convolution reads those (weight and bias folded)
-            return fast_conv_mod.split_conv(x, st, self._weight() if _w is None else _w, c.bias)
+            return fast_conv_mod.split_conv(x, st, self._weight() if _w is None else _w, c.bias, site=self)
         if (c.out_channels <= 4 and tuple(c.kernel_size) == (3, 3) and not hasattr(c, 'normalized_weight')
                 and x.is_cuda and x.is_contiguous()):
             return _NarrowConv3x3.apply(x, c.weight, c.bias)
         # the weight ONCE per forward: a spectrally normalised layer advances its power iteration in normalized_weight()
         w = self._weight() if _w is None else _w
         if FAST_CONV and x.is_cuda:
-            y = fast_conv_mod.fast_conv_or_none(x, w, c.bias, 'same')      # split-fp16 MFMA implicit GEMM (csrc/wc_conv.hip)
+            y = fast_conv_mod.fast_conv_or_none(x, w, c.bias, 'same', site=self)      # split-fp16 MFMA implicit GEMM (csrc/wc_conv.hip)
             if y is not None:
                 return y
         return to_nhwc(c._conv_forward(to_nchw_view(x), w, c.bias))
@@ -163,7 +163,7 @@ class Conv2D(nn.Module):
         if tuple(w.shape[2:]) != (3, 3):
             return self.forward(upsample2x(x), _w=w)
         if FAST_CONV and x.is_cuda:                 # the 4x4 kernel is formed inside the weight image (csrc/wc_conv.hip)
-            y = fast_conv_mod.fast_conv_or_none(x, w, conv.bias, 'up3')
+            y = fast_conv_mod.fast_conv_or_none(x, w, conv.bias, 'up3', site=self)
             if y is not None:
                 return y
         rows = torch.stack([w[:, :, 2], w[:, :, 1] + w[:, :, 2], w[:, :, 0] + w[:, :, 1], w[:, :, 0]], dim=2)
@@ -180,7 +180,7 @@ def _conv2d_forward_pooled(self, x, relu_input=False):
     conv = self.conv
     w = conv.normalized_weight() if hasattr(conv, 'normalized_weight') else conv.weight
     if FAST_CONV and x.is_cuda and tuple(w.shape[2:]) == (3, 3):
-        y = fast_conv_mod.fast_conv_or_none(x, w, conv.bias, 'down3', relu_input=relu_input)
+        y = fast_conv_mod.fast_conv_or_none(x, w, conv.bias, 'down3', relu_input=relu_input, site=self)
         if y is not None:
             return y
     if relu_input:
