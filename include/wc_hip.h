@@ -537,17 +537,17 @@ int wc_conv_split_colsum_f32(const float* x, int64_t n, int relu, void* hi, void
                              float* colsum_partials, int C, wc_stream_t stream);
 
 /* The same split in ONE launch, its scale taken from the call before at the same call site (ABI 7).  `hist`: WC_CONV_HIST_FLOATS floats
- * that belong to the call site (one convolution's input, or its output gradient), zero-filled once and kept across calls:
- * [0] max|x| of the previous call, [1] an arrival counter (0 between launches), [2 ..] per-workgroup maxima.  The call takes the power of
- * two that puts the PREVIOUS call's maximum into [2^7, 2^8) -- room for a 255-fold growth before fp16 overflows, precision to 2^-20 of the
- * tensor's maximum down to a 4000-fold shrink: hi + lo carry 22 bits wherever the scaled maximum lies in [2^-5, 65504] -- and the
- * workgroup that finishes last leaves this call's maximum in [0].  The record is a function of the sequence of tensors alone, so an
- * eager run and a replayed hipGraph of the same calls give the same bits.  NOTHING clamps: an element that does not fit becomes inf in
- * the planes -- loud downstream, never quietly wrong.  bootstrap != 0 (the site's first call): the two-launch form with the measured
- * maximum, which it leaves in the record.  Calls of one site must be ordered (one stream, or events).  colsum_partials / C as in
- * wc_conv_split_colsum_f32 (nullable).  Replaces the absmax pass of wc_conv_split_f32 (~130 launches of 3-8 us per G+D step on the
- * critic's small tensors; reference call sites: every Conv2D of discriminator.py:41-54 / generator.py:142-158 as in wc_conv_f16x3). */
-#define WC_CONV_HIST_FLOATS (2 + 512)
+ * that belong to the call site (one convolution's input, or its output gradient), zero-filled once and kept across calls: two arrays of
+ * 512 (maximum, tag) pairs.  A call reads both, takes the array whose tags are all equal with the larger tag -- what the previous call
+ * left -- and the power of two that puts THAT maximum into [2^7, 2^8): room for a 255-fold growth before fp16 overflows, precision to
+ * 2^-20 of the tensor's maximum down to a 4000-fold shrink (hi + lo carry 22 bits wherever the scaled maximum lies in [2^-5, 65504]);
+ * each workgroup leaves (its maximum, tag + 1) in the other array.  No atomics, no host-side parity: the record is a function of the
+ * sequence of tensors alone, so an eager run and a replayed hipGraph of the same calls give the same bits.  NOTHING clamps: an element
+ * that does not fit becomes inf in the planes -- loud downstream, never quietly wrong.  bootstrap != 0 (the site's first call): the
+ * two-launch form with the measured maximum, which seeds the record.  Calls of one site must be ordered (one stream, or events).
+ * colsum_partials / C as in wc_conv_split_colsum_f32 (nullable).  Replaces the absmax pass of wc_conv_split_f32 (~130 launches of
+ * 3-30 us per G+D step; reference call sites: every Conv2D of discriminator.py:41-54 / generator.py:142-158 as in wc_conv_f16x3). */
+#define WC_CONV_HIST_FLOATS (4 * 512)
 int wc_conv_split_hist_f32(const float* x, int64_t n, int relu, void* hi, void* lo, float* scale, float* colsum_partials /*nullable*/, int C,
                            float* hist, int bootstrap, wc_stream_t stream);
 

@@ -151,11 +151,11 @@ def _colsum_ok(C):
 # an element that does not fit goes inf = loud).  Training-mode layers only: an eval-mode pass measures every tensor, so that the images of a
 # loaded checkpoint do not depend on what the process ran before.  WC_SPLIT_HIST=0: the measured maximum everywhere, two launches (rounds 1-4).
 SPLIT_HIST = os.environ.get('WC_SPLIT_HIST', '1') != '0'
-HIST_FLOATS = 2 + 512          # include/wc_hip.h WC_CONV_HIST_FLOATS
+HIST_FLOATS = 4 * 512          # include/wc_hip.h WC_CONV_HIST_FLOATS
 
 
 def _site_hist(site, role, device):
-    """[record (HIST_FLOATS floats on the device: the previous call's maximum, a counter, per-workgroup maxima), seeded?] of a call site:
+    """[record (HIST_FLOATS floats on the device: two arrays of per-workgroup (maximum, tag) pairs), seeded?] of a call site:
     `site` is the layer object that owns the convolution (state lives in its __dict__, not in a parameter or buffer: no checkpoint entry --
     a resumed run measures once), role 'x' (its input) or 'g' (its output gradient).  None for a layer in eval mode, and while a hipGraph is
     being recorded for a site that has no record yet (no allocation into a graph's private pool; the trainers warm up eagerly first)."""

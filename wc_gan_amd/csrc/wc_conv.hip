@@ -365,18 +365,22 @@ __global__ __launch_bounds__(256) void conv_split_kernel(const float* __restrict
 // conv_absmax + conv_split run ~240 times per G+D step on the critic's small tensors: two latency-bound launches of 3-8 us each for a
 // pass whose only purpose is one number, the tensor's scale -- and hi + lo carry 22 bits of an element wherever the scaled maximum lies
 // between 2^-5 and fp16's 65504 (an absolute error of 2^-25 / scaled-max of the tensor's maximum below that): twenty binary orders of
-// slack.  So a call site (one convolution's input, or its output gradient) keeps a small record across calls,
-//     hist[0] = max|x| of the previous call      hist[1] = arrival counter (0 between launches)      hist[2 ..] = per-workgroup maxima
-// and a call takes its scale from hist[0] -- the power of two that puts 64 x that maximum into [2^13, 2^14), i.e. the maximum itself
-// into [2^7, 2^8): room for a 255-fold growth from one call to the next before fp16 overflows, a 4000-fold shrink before the absolute
-// error leaves 2^-20 of the maximum.  Every workgroup reads hist[0] first and leaves its own maximum in its slot last; the workgroup
-// that arrives last (a counter; by then every other one has read hist[0]) folds the slots into hist[0] for the next call and clears the
-// counter.  max() is order-free, so the record -- and with it every later scale -- is a function of the sequence of tensors alone:
-// an eager run and a replayed hipGraph of the same calls produce the same bits (no host-side state beyond "has this site been called").
-// NOTHING clamps: an element that does not fit becomes inf in the planes and NaN / inf in the convolution's output -- loud, never
-// quietly wrong.  The first call of a site measures (the two-launch form) and leaves its maximum in the record.
+// slack.  So a call site (one convolution's input, or its output gradient) keeps a small record across calls: TWO arrays of kAmaxBlocks
+// (maximum, tag) pairs, one pair per workgroup.  A launch writes all pairs of one array with one tag; an array whose tags are all equal
+// is COMPLETE.  Every workgroup starts by reading both arrays, takes the complete array with the larger tag -- what the previous call
+// left -- and its maximum: the scale is the power of two that puts 64 x that maximum into [2^13, 2^14), i.e. the maximum itself into
+// [2^7, 2^8): room for a 255-fold growth from one call to the next before fp16 overflows, a 4000-fold shrink before the absolute
+// error leaves 2^-20 of the maximum.  At its end it writes (its own maximum, that tag + 1) into its pair of the OTHER array.  While the
+// launch runs, the other array is a mixture of old and new tags (or still looks old through another XCD's L2): never complete with a
+// larger tag, so a workgroup that starts late makes the same choice as one that started first -- no atomics, no fences, no counters,
+// nothing to clear, and no host-side state beyond "has this site been called": the record is a function of the sequence of tensors
+// alone, an eager run and a replayed hipGraph of the same calls produce the same bits.  (Two forms with an arrival counter were
+// measured first: with a __threadfence every workgroup waits for its plane stores to reach memory, 15.8 us minimum per launch; with
+// relaxed device-scope atomics the 1024 operations on one cache line serialise, 15.4 us against 7.1 for both launches of the measuring
+// form at 128x4x4x256.)  NOTHING clamps: an element that does not fit becomes inf in the planes and NaN / inf in the convolution's
+// output -- loud, never quietly wrong.  The first call of a site measures (the two-launch form) and seeds the record.
 constexpr float kHistMargin = 64.0f;
-constexpr int kHistHead = 2;                       // floats in front of the per-workgroup slots
+constexpr int kHistArray = 2 * kAmaxBlocks;         // floats per array: (maximum, tag) per workgroup
 
 __device__ __forceinline__ float scale_for(float amax)
 {
@@ -386,13 +390,15 @@ __device__ __forceinline__ float scale_for(float amax)
     return ldexpf(1.0f, 14 - e);
 }
 
-__global__ __launch_bounds__(64) void conv_hist_seed_kernel(float* __restrict__ hist)      // the first call: slots (conv_absmax_kernel) -> hist[0]
+// the first call: conv_absmax_kernel's per-workgroup maxima (in the first kAmaxBlocks floats) -> array 0 with tag 1, array 1 with tag 0
+__global__ __launch_bounds__(kAmaxBlocks) void conv_hist_seed_kernel(float* __restrict__ hist)
 {
-    float amax = 0.f;
-    for (int i = threadIdx.x; i < kAmaxBlocks; i += 64) amax = fmaxf(amax, hist[kHistHead + i]);
-    #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
-    if (threadIdx.x == 0) { hist[0] = amax; reinterpret_cast<unsigned*>(hist)[1] = 0u; }
+    const float m = hist[threadIdx.x];
+    __syncthreads();
+    typedef float f32x2h __attribute__((ext_vector_type(2)));
+    f32x2h a = {m, __builtin_bit_cast(float, 1u)}, b = {0.f, __builtin_bit_cast(float, 0u)};
+    *reinterpret_cast<f32x2h*>(hist + 2 * threadIdx.x) = a;
+    *reinterpret_cast<f32x2h*>(hist + kHistArray + 2 * threadIdx.x) = b;
 }
 
 __global__ __launch_bounds__(256) void conv_split_hist_kernel(const float* __restrict__ x, int64_t n4, int relu, _Float16* __restrict__ hi,
@@ -401,8 +407,34 @@ __global__ __launch_bounds__(256) void conv_split_hist_kernel(const float* __res
 {
     __shared__ float red[4];
     __shared__ f32x4 red4[256];
-    __shared__ int last;
-    const float s = scale_for(__builtin_nontemporal_load(hist) * kHistMargin);
+    typedef float f32x2h __attribute__((ext_vector_type(2)));
+    // every wave folds both arrays: the maximum and the smallest / largest tag of each (tags as int: __shfl_xor has no unsigned form --
+    // an unsigned argument travels as a float and comes back rounded)
+    typedef int i32x2h __attribute__((ext_vector_type(2)));
+    float mx[2] = {0.f, 0.f};
+    int tlo[2] = {0x7fffffff, 0x7fffffff}, thi[2] = {0, 0};
+    #pragma unroll
+    for (int arr = 0; arr < 2; ++arr)
+        #pragma unroll
+        for (int i = 0; i < kAmaxBlocks / 64; ++i) {
+            const i32x2h p = *reinterpret_cast<const i32x2h*>(hist + arr * kHistArray + 2 * ((threadIdx.x & 63) + 64 * i));
+            mx[arr] = fmaxf(mx[arr], __builtin_bit_cast(float, p[0]));
+            tlo[arr] = min(tlo[arr], p[1]);
+            thi[arr] = max(thi[arr], p[1]);
+        }
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        #pragma unroll
+        for (int arr = 0; arr < 2; ++arr) {
+            mx[arr] = fmaxf(mx[arr], __shfl_xor(mx[arr], o));
+            tlo[arr] = min(tlo[arr], __shfl_xor(tlo[arr], o));
+            thi[arr] = max(thi[arr], __shfl_xor(thi[arr], o));
+        }
+    const bool ok0 = tlo[0] == thi[0], ok1 = tlo[1] == thi[1];
+    // the complete array with the larger tag (one of the two always is: the launch in flight writes the other one)
+    const int src = (ok1 && (!ok0 || thi[1] > thi[0])) ? 1 : 0;
+    const int tag = (src ? thi[1] : thi[0]) + 1;
+    const float s = scale_for((src ? mx[1] : mx[0]) * kHistMargin);
     if (blockIdx.x == 0 && threadIdx.x == 0) scale_out[0] = s;
     float m = 0.f;
     f32x4 cs = {0.f, 0.f, 0.f, 0.f};
@@ -424,24 +456,13 @@ __global__ __launch_bounds__(256) void conv_split_hist_kernel(const float* __res
     if (colsum) red4[threadIdx.x] = cs;
     __syncthreads();
     if (threadIdx.x == 0) {
-        // the slot through the atomic path (device scope, L2): the last workgroup reads all of them the same way
-        atomicExch(hist + kHistHead + blockIdx.x, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
-        __threadfence();
-        last = atomicAdd(reinterpret_cast<unsigned*>(hist) + 1, 1u) == gridDim.x - 1;
+        const f32x2h p = {fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), __builtin_bit_cast(float, tag)};
+        *reinterpret_cast<f32x2h*>(hist + (1 - src) * kHistArray + 2 * blockIdx.x) = p;       // one 8-byte store: the pair is never torn
     }
     if (colsum && (int)threadIdx.x < c4n) {
         f32x4 t = red4[threadIdx.x];
         for (int p = threadIdx.x + c4n; p < 256; p += c4n) t += red4[p];
         *reinterpret_cast<f32x4*>(colsum + (int64_t)blockIdx.x * 4 * c4n + 4 * threadIdx.x) = t;
-    }
-    __syncthreads();
-    if (last && threadIdx.x < 64) {                // every other workgroup has read hist[0] and left its maximum: the next call's record
-        __threadfence();
-        float amax = 0.f;
-        for (int i = threadIdx.x; i < (int)gridDim.x; i += 64) amax = fmaxf(amax, atomicAdd(hist + kHistHead + i, 0.0f));
-        #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
-        if (threadIdx.x == 0) { hist[0] = amax; reinterpret_cast<unsigned*>(hist)[1] = 0u; }
     }
 }
 
@@ -873,11 +894,10 @@ int wc_conv_split_hist_f32(const float* x, int64_t n, int relu, void* hi, void* 
     if (!x || !hi || !lo || !scale || !hist || n <= 0 || (n & 3)) return WC_ERR_ARG;
     if (colsum_partials && (C <= 0 || (C & 3) || 256 % (C >> 2) != 0 || n % C != 0)) return WC_ERR_SHAPE;
     if (bootstrap) {       // the site's first call: the measured maximum (the two-launch form, bit for bit), left in the record
-        float* slots = hist + kHistHead;
-        hipLaunchKernelGGL(conv_absmax_kernel, dim3(kAmaxBlocks), dim3(256), 0, st, x, n / 4, n, slots, colsum_partials, colsum_partials ? C >> 2 : 0);
-        hipLaunchKernelGGL(conv_split_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, x, n / 4, (const float*)slots, relu, (_Float16*)hi,
+        hipLaunchKernelGGL(conv_absmax_kernel, dim3(kAmaxBlocks), dim3(256), 0, st, x, n / 4, n, hist, colsum_partials, colsum_partials ? C >> 2 : 0);
+        hipLaunchKernelGGL(conv_split_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, x, n / 4, (const float*)hist, relu, (_Float16*)hi,
                            (_Float16*)lo, scale);
-        hipLaunchKernelGGL(conv_hist_seed_kernel, dim3(1), dim3(64), 0, st, hist);
+        hipLaunchKernelGGL(conv_hist_seed_kernel, dim3(1), dim3(kAmaxBlocks), 0, st, hist);
         return (int)hipGetLastError();
     }
     // always kAmaxBlocks workgroups: they are the partial rows conv_wrw_reduce_kernel adds up
