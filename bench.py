@@ -282,7 +282,7 @@ def roofline_apply(dev):
     # HBM bytes per launch: NOT measured in this run -- read from the committed PMC passes of the same kernel
     # (FETCH_SIZE x2 + WRITE_SIZE, collected as MI355X_MICROARCH.md's HBM section prescribes; see the file)
     traffic = src = None
-    cands = (("r4_apply_k3splitmask_pmc.json", "r3_apply_k3split_pmc.json") if "apply_split" in kernel else
+    cands = (("r5_apply_k3splitmask_pmc.json", "r4_apply_k3splitmask_pmc.json", "r3_apply_k3split_pmc.json") if "apply_split" in kernel else
              ("r4_apply_k3mask_pmc.json", "r3_apply_k3_pmc.json", "r2_apply_k3_pmc.json"))
     for name in cands:
         pmc = os.path.join(ROOT, "profiles", name)
