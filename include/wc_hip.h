@@ -585,6 +585,18 @@ int wc_conv_wrw_f16x3(const void* xhi, const void* xlo, const float* xscale, con
                       int64_t stride_n, int64_t stride_r, int64_t stride_s, void* ws, size_t ws_bytes,
                       wc_stream_t stream);
 
+/* Weight and bias gradient of a 'same' convolution (1x1 or 3x3, stride 1) with a handful of INPUT channels, ksize^2 * Cin < 32 -- the
+ * critic's first block on images: Conv2D 3 -> 128 and the 1x1 shortcut 3 -> 128 (discriminator.py:41-54; ABI 7).  x [N,H,W,Cin] and
+ * gy [N,H,W,Cout] in fp32 NHWC, Cout a multiple of 128; one pass over gy on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32, no split, no scales):
+ *     dw[c*stride_k + o*stride_n + r*stride_r + s*stride_s] = sum_p x[p + (r, s) - pad][c] gy[p][o],   db[o] = sum_p gy[p][o]  (nullable)
+ * in a fixed summation order.  `ws`: wc_conv_wrw_narrow_workspace_bytes(...) device bytes.  Replaces MIOpen's fp32 weight-gradient kernels
+ * for these layers (138 / 54 us per critic update at 128x32x32, 0.5 TB/s of gy) and the bias gradient's reduction. */
+int    wc_conv_wrw_narrow_supported(int64_t N, int64_t H, int64_t W, int Cin, int Cout, int ksize);
+size_t wc_conv_wrw_narrow_workspace_bytes(int64_t N, int64_t H, int64_t W, int Cin, int Cout, int ksize);
+int    wc_conv_wrw_narrow_f32(const float* x, const float* gy, int64_t N, int64_t H, int64_t W, int Cin, int Cout, int ksize,
+                              float* dw, int64_t stride_k, int64_t stride_n, int64_t stride_r, int64_t stride_s, float* db /*nullable*/,
+                              void* ws, size_t ws_bytes, wc_stream_t stream);
+
 /* wc_conv_wrw_f16x3 plus the bias gradient db[Cout] = column sums of gy, from the partial rows wc_conv_split_colsum_f32
  * left while gy was split (fixed summation order, no extra launch). */
 int wc_conv_wrw_bias_f16x3(const void* xhi, const void* xlo, const float* xscale, const void* ghi, const void* glo,

@@ -317,3 +317,59 @@ def test_convolution_with_history_scaled_splits_over_several_steps():
         graph.replay()
         torch.cuda.synchronize()
         assert _rel(out[0], _ref(xs, w, b, 'same')) < TOL and _rel(out[1], _ref(xs * 2, w, b, 'same')) < TOL, rep
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 5: weight / bias gradient of the critic's image-reading layers (wc_conv_wrw_narrow_f32)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,cout,k", [((128, 32, 32, 3), 128, 3), ((128, 16, 16, 3), 128, 1), ((5, 12, 12, 1), 256, 3),
+                                          ((3, 48, 48, 3), 128, 3), ((64, 64, 64, 3), 128, 1), ((2, 6, 10, 2), 128, 3)])
+def test_narrow_input_weight_gradient_against_float64(shape, cout, k):
+    """dW, db (and the forward, and dx) of a 'same' convolution on an image-like input through conv.narrow_in_conv against torch in
+    float64: one pass over gy on the fp32 matrix pipe, fixed summation order (two calls give the same bits); weights in channels_last
+    and in contiguous layout."""
+    from wc_gan_amd import conv as C
+    torch.manual_seed(11)
+    N, H, W, Ci = shape
+    x = (torch.randn(*shape, device='cuda') * 0.7 + 0.1).requires_grad_(True)
+    for fmt in (torch.channels_last, torch.contiguous_format):
+        w = (torch.randn(cout, Ci, k, k, device='cuda') / (Ci * k * k) ** 0.5).contiguous(memory_format=fmt).requires_grad_(True)
+        b = (torch.randn(cout, device='cuda') * 0.1).requires_grad_(True)
+        assert C.narrow_wrw_supported(x, w)
+        y = C.narrow_in_conv(x, w, b)
+        gy = torch.randn_like(y)
+        dx, dw, db = torch.autograd.grad(y, (x, w, b), gy)
+        dw2, = torch.autograd.grad(C.narrow_in_conv(x, w, b), (w,), gy)
+        y64 = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), b.double(), padding=k // 2).permute(0, 2, 3, 1)
+        dx64, dw64, db64 = torch.autograd.grad(y64, (x, w, b), gy.double())
+        assert dw.stride() == w.stride() and torch.equal(dw, dw2)
+        assert _rel(y, y64) < 1e-5 and _rel(dx, dx64) < 1e-5
+        assert _rel(dw, dw64) < 2e-6 and _rel(db, db64) < 2e-6, (fmt, _rel(dw, dw64), _rel(db, db64))
+
+
+@pytest.mark.gpu
+def test_critic_first_block_takes_the_narrow_weight_gradient():
+    """generator.Conv2D on a 3-channel input (the critic's conv1 and shortcut): the layer's weight gradient equals MIOpen's route
+    (WC_NARROW_WRW off) to fp32 summation order, with and without spectral normalisation."""
+    from wc_gan_amd import conv as C
+    from wc_gan_amd.generator import Conv2D
+    torch.manual_seed(12)
+    for spectral in (False, True):
+        for k in (3, 1):
+            layer = Conv2D(3, 128, (k, k), spectral=spectral).cuda()
+            x = torch.randn(16, 32, 32, 3, device='cuda')
+            wts = torch.randn(16, 32, 32, 128, device='cuda')         # (random: a sum that cancels to 1e-4 of its terms would compare two fp32 rounding errors)
+            state = {n: v.detach().clone() for n, v in layer.state_dict().items()}
+            outs = []
+            for on in (True, False):
+                layer.load_state_dict(state)
+                C.NARROW_WRW = on
+                try:
+                    y = layer(x)
+                    g = torch.autograd.grad((y * wts).sum(), list(layer.parameters()))
+                finally:
+                    C.NARROW_WRW = True
+                outs.append([y.detach()] + [t.detach() for t in g])
+            for a, b in zip(*outs):
+                assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), (spectral, k)

@@ -18,6 +18,7 @@ import ctypes
 import os
 
 import torch
+import torch.nn.functional as F
 
 from . import _lib, _state
 from .ops import _ptr, _stream
@@ -448,6 +449,62 @@ def fast_conv_or_none(x, w, bias=None, kind='same', relu_input=False, site=None)
             raise ValueError("a K3 handle is already ReLU'd")
         return _FastConv.apply(x, w, bias, kind, _plan(kind, x, w), False, handed, site)
     return _FastConv.apply(x, w, bias, kind, _plan(kind, x, w), relu_input, None, site)
+
+
+# The critic's first block reads images (Conv2D 3 -> 128 and the 1x1 shortcut 3 -> 128): the forward stays with MIOpen, the weight and bias
+# gradients come from ONE pass over gy on the fp32 matrix pipe (wc_conv_wrw_narrow_f32; WC_NARROW_WRW=0: MIOpen's, rounds 1-4)
+NARROW_WRW = os.environ.get('WC_NARROW_WRW', '1') != '0'
+
+
+def narrow_wrw_supported(x, w):
+    """x NHWC fp32 on the GPU, w (Cout, Cin, k, k) with k in (1, 3), k*k*Cin < 32, Cout a multiple of 128"""
+    if not (NARROW_WRW and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.dim() == 4 and w.dim() == 4):
+        return False
+    k = w.shape[2]
+    if w.shape[3] != k or k not in (1, 3) or w.shape[1] != x.shape[3]:
+        return False
+    N, H, W, C = x.shape
+    return bool(_lib.load().wc_conv_wrw_narrow_supported(N, H, W, C, w.shape[0], k))
+
+
+class _NarrowInConv(torch.autograd.Function):
+    """'same' convolution of an image-like input (a handful of channels): forward and data gradient by MIOpen, weight and bias gradient by
+    wc_conv_wrw_narrow_f32 (csrc/wc_conv.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        k = w.shape[2]
+        y = F.conv2d(x.permute(0, 3, 1, 2), w, bias, padding=k // 2).permute(0, 2, 3, 1)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y if y.is_contiguous() else y.contiguous()
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        N, H, W, C = x.shape
+        O, k = w.shape[0], w.shape[2]
+        lib = _lib.load()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.ops.aten.convolution_backward(gy.permute(0, 3, 1, 2), x.permute(0, 3, 1, 2), w, None, [1, 1], [k // 2, k // 2], [1, 1],
+                                                     False, [0, 0], 1, [True, False, False])[0].permute(0, 2, 3, 1)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw = torch.empty_strided(w.shape, w.stride(), dtype=torch.float32, device=w.device)
+            if _storage_extent(dw) != dw.numel():
+                raise ValueError("weight must be dense")
+            db = torch.empty(O, dtype=torch.float32, device=w.device) if ctx.has_bias else None
+            nb = lib.wc_conv_wrw_narrow_workspace_bytes(N, H, W, C, O, k)
+            ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+            xc = x if x.is_contiguous() else x.contiguous()
+            _lib.check(lib.wc_conv_wrw_narrow_f32(_ptr(xc), _ptr(gy), N, H, W, C, O, k, _ptr(dw), dw.stride(1), dw.stride(0), dw.stride(2),
+                                                  dw.stride(3), _ptr(db), _ptr(ws), nb, _stream()), "wc_conv_wrw_narrow_f32")
+        return dx, dw, db
+
+
+def narrow_in_conv(x, w, bias=None):
+    return _NarrowInConv.apply(x, w, bias)
 
 
 def fast_conv(x, w, bias=None, kind='same'):

@@ -832,6 +832,117 @@ __global__ __launch_bounds__(256) void conv_wrw_reduce_kernel(WrwReduceArgs a)
     }
 }
 
+// ---- weight and bias gradient of a convolution with a handful of INPUT channels (round 5) ---------------------------------------------
+// The critic's first block reads images: Conv2D 3 -> 128 (3x3) and the 1x1 shortcut 3 -> 128 (discriminator.py:41-54 with input_image_shape
+// (32, 32, 3)).  Their forward stays with MIOpen (15 us); their weight gradients were MIOpen's too, at 138 and 54 us per critic update for
+// 0.9 GFLOP -- 67 MB of gy read at 0.5 TB/s.  Here it is ONE pass over gy at the stream rate on the fp32 matrix pipe:
+//     D[m][o] = sum_p A[p][m] gy[p][o],   m = tap * Cin + c (< 32):  A[p][m] = x[p + tap][c] (zero padding),  row ntaps * Cin: A = 1  (-> db)
+// as v_mfma_f32_32x32x2_f32 over pixel pairs: lane (i, k) gathers A[p + k][i] (4 bytes out of L1: x is 1.5 MB) and loads 16 bytes of
+// gy[p + k][4 i ..] -- the four floats feed four MFMAs, i.e. output block q holds the channels 4 j + q.  A workgroup of 8 waves takes a pixel
+// range, folds its waves' accumulators in LDS (fixed order) and leaves one partial; conv_wrw_narrow_reduce_kernel adds the partials in a
+// fixed order and scatters into the weight's layout.  fp32 throughout (as MIOpen's kernel): no split, no scales.
+struct NarrowWrwArgs {
+    const float* x; const float* gy; float* partial;
+    int N, H, W, Cin, Cout, ks, nrow;                // ks = 1 | 3 ('same' padding); nrow = ks * ks * Cin (< 32)
+    unsigned magHW, shHW, magW, shW;
+    int64_t M; int64_t pix_per_wave;                 // (even)
+};
+
+__global__ __launch_bounds__(512, 1) void conv_wrw_narrow_kernel(NarrowWrwArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float nw_part[];     // [8 waves][4 q][16 r][64 lanes]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, k = lane >> 5;
+    const int grp = blockIdx.y;                                         // 128 output channels
+    const bool is_tap = i < a.nrow, is_one = i == a.nrow;
+    int dy = 0, dx = 0, c = 0;
+    if (is_tap) {
+        const int tap = i / a.Cin;
+        c = i - tap * a.Cin;
+        dy = tap / a.ks - a.ks / 2; dx = tap % a.ks - a.ks / 2;
+    }
+    const unsigned HW = (unsigned)(a.H * a.W);
+    f32x16 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    const int64_t p0 = ((int64_t)blockIdx.x * 8 + wave) * a.pix_per_wave;
+    int64_t p1 = p0 + a.pix_per_wave;
+    if (p1 > a.M) p1 = a.M;
+    const float* gyc = a.gy + grp * 128 + 4 * i;
+    constexpr int U = 8;
+    for (int64_t p = p0; p < p1; p += 2 * U) {
+        float av[U]; f32x4 bv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t pp = p + 2 * u + k;
+            const bool ok = pp < p1;
+            const unsigned pc = (unsigned)(ok ? pp : a.M - 1);          // clamped, not predicated: the loads stay in flight together
+            const unsigned n = __umulhi(pc, a.magHW) >> a.shHW, rem = pc - n * HW;
+            const unsigned yy = __umulhi(rem, a.magW) >> a.shW, xx = rem - yy * a.W;
+            const int iy = (int)yy + dy, ix = (int)xx + dx;
+            const bool inb = ok && is_tap && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const float xv = a.x[inb ? ((int64_t)(n * a.H + iy) * a.W + ix) * a.Cin + c : 0];
+            av[u] = inb ? xv : ((ok && is_one) ? 1.f : 0.f);
+            bv[u] = *reinterpret_cast<const f32x4*>(gyc + (int64_t)pc * a.Cout);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u][q], acc[q], 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) nw_part[((wave * 4 + q) * 16 + r) * 64 + lane] = acc[q][r];
+    __syncthreads();
+    float* out = a.partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4096;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int e = tid + 512 * m;
+        float sum = nw_part[e];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) sum += nw_part[w * 4096 + e];
+        out[e] = sum;
+    }
+}
+
+// element e = (q, r, lane) of a partial -> row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), output channel 128 grp + 4 (lane & 31) + q.
+// A workgroup = 32 elements x 8 groups of partials (every 8th partial each, 16 loads in flight), folded through LDS in a fixed order.
+__global__ __launch_bounds__(256) void conv_wrw_narrow_reduce_kernel(const float* __restrict__ partial, int nparts, int Cin, int ks, int nrow,
+                                                                     float* __restrict__ dw, int64_t sk, int64_t sn, int64_t sr, int64_t ss,
+                                                                     float* __restrict__ db)
+{
+    __shared__ float red[8][32];
+    const int el = threadIdx.x & 31, pg = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + el;                                 // < 4096
+    const float* p = partial + (int64_t)blockIdx.y * nparts * 4096 + e;
+    float sum = 0.f;
+    int z = pg;
+    for (; z + 8 * 15 < nparts; z += 8 * 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = p[(int64_t)(z + 8 * u) * 4096];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) sum += v[u];
+    }
+    for (; z < nparts; z += 8) sum += p[(int64_t)z * 4096];
+    red[pg][el] = sum;
+    __syncthreads();
+    if (pg != 0) return;
+#pragma unroll
+    for (int g = 1; g < 8; ++g) sum += red[g][el];
+    const int q = e >> 10, r = (e >> 6) & 15, ln = e & 63;
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+    const int o = blockIdx.y * 128 + 4 * (ln & 31) + q;
+    if (row < nrow) {
+        const int tap = row / Cin, c = row - tap * Cin;
+        dw[c * sk + o * sn + (tap / ks) * sr + (tap % ks) * ss] = sum;
+    } else if (row == nrow && db) db[o] = sum;
+}
+
 void magic_u31(unsigned d, unsigned* mag, unsigned* sh)
 {
     // q = umulhi(m, mag) >> sh == m / d for m < 2^31, d >= 2
@@ -1064,6 +1175,57 @@ static int wrw_splits(const wc_conv_geom* g, int* tile)
     if (splits > 64) splits = 64;                   // (the partial sums are splits x the weight size)
     if (splits > nchunks) splits = (int)nchunks;
     return splits < 1 ? 1 : splits;
+}
+
+static int64_t narrow_wrw_parts(int64_t M, int64_t* pix_per_wave)
+{
+    int64_t ppw = (M + 256 * 8 - 1) / (256 * 8);
+    if (ppw < 16) ppw = 16;                          // at least one batch of eight pixel pairs per wave
+    ppw = (ppw + 1) & ~(int64_t)1;
+    *pix_per_wave = ppw;
+    return (M + 8 * ppw - 1) / (8 * ppw);
+}
+
+int wc_conv_wrw_narrow_supported(int64_t N, int64_t H, int64_t W, int Cin, int Cout, int ksize)
+{
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (ksize != 1 && ksize != 3)) return 0;
+    if (ksize * ksize * Cin >= 32 || (Cout & 127)) return 0;
+    return N * H * W < ((int64_t)1 << 31) ? 1 : 0;
+}
+
+size_t wc_conv_wrw_narrow_workspace_bytes(int64_t N, int64_t H, int64_t W, int Cin, int Cout, int ksize)
+{
+    if (!wc_conv_wrw_narrow_supported(N, H, W, Cin, Cout, ksize)) return 0;
+    int64_t ppw;
+    return (size_t)narrow_wrw_parts(N * H * W, &ppw) * (Cout / 128) * 4096 * sizeof(float);
+}
+
+int wc_conv_wrw_narrow_f32(const float* x, const float* gy, int64_t N, int64_t H, int64_t W, int Cin, int Cout, int ksize,
+                           float* dw, int64_t stride_k, int64_t stride_n, int64_t stride_r, int64_t stride_s, float* db,
+                           void* ws, size_t ws_bytes, wc_stream_t stream)
+{
+    if (!x || !gy || !dw || !ws) return WC_ERR_ARG;
+    if (!wc_conv_wrw_narrow_supported(N, H, W, Cin, Cout, ksize)) return WC_ERR_SHAPE;
+    if (ws_bytes < wc_conv_wrw_narrow_workspace_bytes(N, H, W, Cin, Cout, ksize)) return WC_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    NarrowWrwArgs a = {};
+    a.x = x; a.gy = gy; a.partial = (float*)ws;
+    a.N = (int)N; a.H = (int)H; a.W = (int)W; a.Cin = Cin; a.Cout = Cout; a.ks = ksize; a.nrow = ksize * ksize * Cin;
+    magic_u31((unsigned)(H * W), &a.magHW, &a.shHW);
+    magic_u31((unsigned)W, &a.magW, &a.shW);
+    a.M = N * H * W;
+    const int nparts = (int)narrow_wrw_parts(a.M, &a.pix_per_wave);
+    constexpr int lds = 8 * 4096 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wrw_narrow_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv_wrw_narrow_kernel, dim3(nparts, Cout / 128), dim3(512), lds, st, a);
+    hipLaunchKernelGGL(conv_wrw_narrow_reduce_kernel, dim3(128, Cout / 128), dim3(256), 0, st, (const float*)ws, nparts, Cin, ksize, a.nrow,
+                       dw, stride_k, stride_n, stride_r, stride_s, db);
+    return (int)hipGetLastError();
 }
 
 size_t wc_conv_wrw_workspace_bytes(const wc_conv_geom* g)

@@ -149,6 +149,8 @@ class Conv2D(nn.Module):
             y = fast_conv_mod.fast_conv_or_none(x, w, c.bias, 'same', site=self)      # split-fp16 MFMA implicit GEMM (csrc/wc_conv.hip)
             if y is not None:
                 return y
+        if x.is_cuda and torch.is_grad_enabled() and w.requires_grad and fast_conv_mod.narrow_wrw_supported(x, w):
+            return fast_conv_mod.narrow_in_conv(x, w, c.bias)       # an image-like input: the weight / bias gradient in one pass over gy (csrc/wc_conv.hip)
         return to_nhwc(c._conv_forward(to_nchw_view(x), w, c.bias))
 
     def forward_upsampled(self, x):
