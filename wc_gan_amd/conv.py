@@ -467,30 +467,26 @@ def narrow_wrw_supported(x, w):
     return bool(_lib.load().wc_conv_wrw_narrow_supported(N, H, W, C, w.shape[0], k))
 
 
-class _NarrowInConv(torch.autograd.Function):
-    """'same' convolution of an image-like input (a handful of channels): forward and data gradient by MIOpen, weight and bias gradient by
-    wc_conv_wrw_narrow_f32 (csrc/wc_conv.hip)."""
+class _NarrowWrw(torch.autograd.Function):
+    """The weight / bias gradient of a 'same' convolution on an image-like input, attached to the convolution's output: y was computed from
+    DETACHED weight and bias (torch's own convolution, which also owns the data gradient), this node hands gy through and leaves dW, db
+    from wc_conv_wrw_narrow_f32 (csrc/wc_conv.hip)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias):
-        k = w.shape[2]
-        y = F.conv2d(x.permute(0, 3, 1, 2), w, bias, padding=k // 2).permute(0, 2, 3, 1)
+    def forward(ctx, y, x, w, bias):
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
-        return y if y.is_contiguous() else y.contiguous()
+        return y.view_as(y)
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
-        gy = gy.contiguous()
         N, H, W, C = x.shape
         O, k = w.shape[0], w.shape[2]
         lib = _lib.load()
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.ops.aten.convolution_backward(gy.permute(0, 3, 1, 2), x.permute(0, 3, 1, 2), w, None, [1, 1], [k // 2, k // 2], [1, 1],
-                                                     False, [0, 0], 1, [True, False, False])[0].permute(0, 2, 3, 1)
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+        dw = db = None
+        if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
+            g = gy if gy.is_contiguous() else gy.contiguous()
             dw = torch.empty_strided(w.shape, w.stride(), dtype=torch.float32, device=w.device)
             if _storage_extent(dw) != dw.numel():
                 raise ValueError("weight must be dense")
@@ -498,13 +494,17 @@ class _NarrowInConv(torch.autograd.Function):
             nb = lib.wc_conv_wrw_narrow_workspace_bytes(N, H, W, C, O, k)
             ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
             xc = x if x.is_contiguous() else x.contiguous()
-            _lib.check(lib.wc_conv_wrw_narrow_f32(_ptr(xc), _ptr(gy), N, H, W, C, O, k, _ptr(dw), dw.stride(1), dw.stride(0), dw.stride(2),
+            _lib.check(lib.wc_conv_wrw_narrow_f32(_ptr(xc), _ptr(g), N, H, W, C, O, k, _ptr(dw), dw.stride(1), dw.stride(0), dw.stride(2),
                                                   dw.stride(3), _ptr(db), _ptr(ws), nb, _stream()), "wc_conv_wrw_narrow_f32")
-        return dx, dw, db
+        return gy, None, dw, db
 
 
 def narrow_in_conv(x, w, bias=None):
-    return _NarrowInConv.apply(x, w, bias)
+    """y = conv(x, w) + bias for NHWC x with a handful of channels: forward (and dx, if x wants one) by torch / MIOpen exactly as the plain
+    layer call makes them, dW and db by the one-pass kernel."""
+    k = w.shape[2]
+    y = F.conv2d(x.permute(0, 3, 1, 2), w.detach(), None if bias is None else bias.detach(), padding=k // 2).permute(0, 2, 3, 1).contiguous()
+    return _NarrowWrw.apply(y, x.detach(), w, bias)
 
 
 def fast_conv(x, w, bias=None, kind='same'):
