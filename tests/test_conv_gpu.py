@@ -373,3 +373,26 @@ def test_critic_first_block_takes_the_narrow_weight_gradient():
                 outs.append([y.detach()] + [t.detach() for t in g])
             for a, b in zip(*outs):
                 assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), (spectral, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,cout", [((128, 32, 32, 256), 3), ((6, 12, 12, 128), 3), ((4, 8, 8, 128), 1)])
+def test_narrow_output_weight_gradient_against_float64(shape, cout):
+    """The generator's last layer (256 -> 3, generator.py:155-157): its weight gradient by the narrow-input kernel with the operands
+    exchanged and the taps mirrored (conv.narrow_out_weight_gradient), and through generator._NarrowConv3x3, against float64."""
+    from wc_gan_amd import conv as C
+    from wc_gan_amd.generator import _NarrowConv3x3
+    torch.manual_seed(13)
+    N, H, W, Ci = shape
+    x = (torch.randn(*shape, device='cuda') * 0.8).requires_grad_(True)
+    w = (torch.randn(cout, Ci, 3, 3, device='cuda') / (Ci * 9) ** 0.5).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    b = torch.zeros(cout, device='cuda', requires_grad=True)
+    assert C.narrow_out_wrw_supported(x, w)
+    y = _NarrowConv3x3.apply(x, w, b)
+    gy = torch.randn_like(y)
+    dx, dw, db = torch.autograd.grad(y, (x, w, b), gy)
+    y64 = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
+    dx64, dw64, db64 = torch.autograd.grad(y64, (x, w, b), gy.double())
+    assert dw.stride() == w.stride()
+    assert _rel(y, y64) < 1e-5 and _rel(dx, dx64) < 1e-5 and _rel(db, db64) < 1e-5
+    assert _rel(dw, dw64) < 2e-6, _rel(dw, dw64)

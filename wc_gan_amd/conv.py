@@ -507,6 +507,34 @@ def narrow_in_conv(x, w, bias=None):
     return _NarrowWrw.apply(y, x.detach(), w, bias)
 
 
+def narrow_out_weight_gradient(x, gy, w):
+    """dW of a 3x3 'same' convolution with a handful of OUTPUT channels (the generator's last layer, 256 -> 3) by the same one-pass kernel with
+    the operands' roles exchanged: dW[o][c][r][s] = sum_q gy[q - (r-1, s-1)][o] x[q][c] is the narrow-input gradient of a convolution that reads
+    gy (3 channels) and whose output gradient is x (256 channels), with the taps mirrored -- written through negative tap strides.  x, gy NHWC."""
+    lib = _lib.load()
+    N, H, W, C = x.shape
+    O, k = w.shape[0], w.shape[2]
+    dw = torch.empty_strided(w.shape, w.stride(), dtype=torch.float32, device=w.device)
+    if _storage_extent(dw) != dw.numel():
+        raise ValueError("weight must be dense")
+    nb = lib.wc_conv_wrw_narrow_workspace_bytes(N, H, W, O, C, k)
+    ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+    last = dw.data_ptr() + 4 * ((k - 1) * dw.stride(2) + (k - 1) * dw.stride(3))        # tap (k-1, k-1): the mirrored (0, 0)
+    _lib.check(lib.wc_conv_wrw_narrow_f32(_ptr(gy), _ptr(x), N, H, W, O, C, k, ctypes.c_void_p(last), dw.stride(0), dw.stride(1), -dw.stride(2),
+                                          -dw.stride(3), None, _ptr(ws), nb, _stream()), "wc_conv_wrw_narrow_f32")
+    return dw
+
+
+def narrow_out_wrw_supported(x, w):
+    if not (NARROW_WRW and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.dim() == 4 and w.dim() == 4):
+        return False
+    k = w.shape[2]
+    if w.shape[3] != k or k not in (1, 3) or w.shape[1] != x.shape[3]:
+        return False
+    N, H, W, C = x.shape
+    return bool(_lib.load().wc_conv_wrw_narrow_supported(N, H, W, w.shape[0], C, k))
+
+
 def fast_conv(x, w, bias=None, kind='same'):
     """NHWC convolution (see the module docstring) -- raises if the shape is not one the kernel takes."""
     if not supported(x, w, kind):

@@ -75,10 +75,15 @@ class _NarrowConv3x3(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
+        # round 5: the weight gradient in one pass over x on the fp32 matrix pipe (conv.narrow_out_weight_gradient: 256 -> 3 is the
+        # narrow-INPUT gradient with the operands exchanged); MIOpen keeps the data gradient and the 3-element bias gradient
+        own_w = ctx.needs_input_grad[1] and fast_conv_mod.narrow_out_wrw_supported(x, w) and x.is_contiguous()
         gx, gw, gb = torch.ops.aten.convolution_backward(
             g.permute(0, 3, 1, 2), x.permute(0, 3, 1, 2), w, [w.shape[0]] if ctx.has_bias else None,
             [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-            [ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]])
+            [ctx.needs_input_grad[0], ctx.needs_input_grad[1] and not own_w, ctx.has_bias and ctx.needs_input_grad[2]])
+        if own_w:
+            gw = fast_conv_mod.narrow_out_weight_gradient(x, g.contiguous(), w)
         return (gx.permute(0, 2, 3, 1) if gx is not None else None), gw, (gb if ctx.has_bias else None)
 
 
