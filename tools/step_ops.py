@@ -22,5 +22,6 @@ for e in prof.key_averages(group_by_input_shape=True):
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
 print(f"device time {tot / 1e3:.2f} ms")
-for dt, n, k, sh in rows[:70]:
+rows = [r for r in rows if r[2].startswith('aten::') or 'Backward' in r[2] or r[2][0].isupper() or r[2].startswith('_')]
+for dt, n, k, sh in rows[:60]:
     print(f"{dt / 1e3:7.3f} ms {n:4d} x {k[:60]:60s} {sh}")
