@@ -597,6 +597,16 @@ int    wc_conv_wrw_narrow_f32(const float* x, const float* gy, int64_t N, int64_
                               float* dw, int64_t stride_k, int64_t stride_n, int64_t stride_r, int64_t stride_s, float* db /*nullable*/,
                               void* ws, size_t ws_bytes, wc_stream_t stream);
 
+/* Forward of the same kind of layer (ksize^2 * Cin < 32, Cout a multiple of 128; wc_conv_wrw_narrow_supported):
+ *     y[p][o] = bias[o] + sum_{r,s,c} x[p + (r, s) - pad][c] w[c*stride_k + o*stride_n + r*stride_r + s*stride_s]      (relu != 0: max(., 0))
+ * in one launch on the fp32 matrix pipe, the bias as a row of the product (bias nullable).  The strides may be negative: with x := gy of a layer
+ * with a handful of OUTPUT channels, stride_k / stride_n exchanged and the tap strides negated (w pointing at its last tap) this is that
+ * layer's data gradient (the generator's last layer, generator.py:155-157).  Replaces MIOpen's forward + two bias launches for the critic's
+ * first block (discriminator.py:41-54 on images). */
+int    wc_conv_fwd_narrow_f32(const float* x, const float* w, int64_t stride_k, int64_t stride_n, int64_t stride_r, int64_t stride_s,
+                              const float* bias /*nullable*/, int64_t N, int64_t H, int64_t W, int Cin, int Cout, int ksize, int relu,
+                              float* y, wc_stream_t stream);
+
 /* wc_conv_wrw_f16x3 plus the bias gradient db[Cout] = column sums of gy, from the partial rows wc_conv_split_colsum_f32
  * left while gy was split (fixed summation order, no extra launch). */
 int wc_conv_wrw_bias_f16x3(const void* xhi, const void* xlo, const float* xscale, const void* ghi, const void* glo,

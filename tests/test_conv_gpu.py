@@ -350,15 +350,15 @@ def test_narrow_input_weight_gradient_against_float64(shape, cout, k):
 
 @pytest.mark.gpu
 def test_critic_first_block_takes_the_narrow_weight_gradient():
-    """generator.Conv2D on a 3-channel input (the critic's conv1 and shortcut): the layer's weight gradient equals MIOpen's route
-    (WC_NARROW_WRW off) to fp32 summation order, with and without spectral normalisation."""
+    """generator.Conv2D on a 3-channel input (the critic's conv1 and shortcut): the layer's output and gradients equal MIOpen's route
+    (WC_NARROW_WRW off) to fp32 summation order, with and without spectral normalisation; the data gradient too (the generator update)."""
     from wc_gan_amd import conv as C
     from wc_gan_amd.generator import Conv2D
     torch.manual_seed(12)
     for spectral in (False, True):
         for k in (3, 1):
             layer = Conv2D(3, 128, (k, k), spectral=spectral).cuda()
-            x = torch.randn(16, 32, 32, 3, device='cuda')
+            x = torch.randn(16, 32, 32, 3, device='cuda', requires_grad=True)
             wts = torch.randn(16, 32, 32, 128, device='cuda')         # (random: a sum that cancels to 1e-4 of its terms would compare two fp32 rounding errors)
             state = {n: v.detach().clone() for n, v in layer.state_dict().items()}
             outs = []
@@ -367,7 +367,7 @@ def test_critic_first_block_takes_the_narrow_weight_gradient():
                 C.NARROW_WRW = on
                 try:
                     y = layer(x)
-                    g = torch.autograd.grad((y * wts).sum(), list(layer.parameters()))
+                    g = torch.autograd.grad((y * wts).sum(), [x] + list(layer.parameters()))
                 finally:
                     C.NARROW_WRW = True
                 outs.append([y.detach()] + [t.detach() for t in g])

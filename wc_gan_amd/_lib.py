@@ -135,6 +135,8 @@ SIGNATURES = {
     "wc_spectral_norm_amax_offset": (c_size_t, [c_int, c_int]),
     "wc_spectral_norm_error_offset": (c_size_t, [c_int, c_int]),
     "wc_conv_split_hist_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "wc_conv_fwd_narrow_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int,
+                                       c_int, c_void_p, c_void_p]),
     "wc_conv_wrw_narrow_supported": (c_int, [c_int64, c_int64, c_int64, c_int, c_int, c_int]),
     "wc_conv_wrw_narrow_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int, c_int, c_int]),
     "wc_conv_wrw_narrow_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_int64, c_int64, c_int64,

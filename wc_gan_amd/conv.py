@@ -467,16 +467,37 @@ def narrow_wrw_supported(x, w):
     return bool(_lib.load().wc_conv_wrw_narrow_supported(N, H, W, C, w.shape[0], k))
 
 
-class _NarrowWrw(torch.autograd.Function):
-    """The weight / bias gradient of a 'same' convolution on an image-like input, attached to the convolution's output: y was computed from
-    DETACHED weight and bias (torch's own convolution, which also owns the data gradient), this node hands gy through and leaves dW, db
-    from wc_conv_wrw_narrow_f32 (csrc/wc_conv.hip)."""
+def narrow_forward(x, w, bias=None, relu=False, mirrored=False):
+    """wc_conv_fwd_narrow_f32: y = conv(x, w) + bias for NHWC x with a handful of channels, w (Cout, Cin, k, k) in any dense layout.
+    mirrored: w is (Cin, Cout, k, k) of the TRANSPOSED map and its taps are read back to front -- y is then the data gradient of the
+    convolution w belongs to (x = its output gradient)."""
+    lib = _lib.load()
+    N, H, W, C = x.shape
+    k = w.shape[2]
+    if mirrored:
+        O = w.shape[1]
+        ptr = ctypes.c_void_p(w.data_ptr() + 4 * ((k - 1) * w.stride(2) + (k - 1) * w.stride(3)))
+        strides = (w.stride(0), w.stride(1), -w.stride(2), -w.stride(3))
+    else:
+        O = w.shape[0]
+        ptr = _ptr(w)
+        strides = (w.stride(1), w.stride(0), w.stride(2), w.stride(3))
+    y = torch.empty((N, H, W, O), dtype=torch.float32, device=x.device)
+    xc = x if x.is_contiguous() else x.contiguous()
+    _lib.check(lib.wc_conv_fwd_narrow_f32(_ptr(xc), ptr, *strides, _ptr(bias), N, H, W, C, O, k, 1 if relu else 0, _ptr(y), _stream()),
+               "wc_conv_fwd_narrow_f32")
+    return y
+
+
+class _NarrowInConv(torch.autograd.Function):
+    """'same' convolution of an image-like input (k*k*Cin < 32): forward and weight / bias gradient on the fp32 matrix pipe
+    (wc_conv_fwd_narrow_f32, wc_conv_wrw_narrow_f32); the data gradient -- wanted in the generator update only -- by MIOpen."""
 
     @staticmethod
-    def forward(ctx, y, x, w, bias):
+    def forward(ctx, x, w, bias):
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
-        return y.view_as(y)
+        return narrow_forward(x, w, bias)
 
     @staticmethod
     def backward(ctx, gy):
@@ -484,9 +505,12 @@ class _NarrowWrw(torch.autograd.Function):
         N, H, W, C = x.shape
         O, k = w.shape[0], w.shape[2]
         lib = _lib.load()
-        dw = db = None
-        if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
-            g = gy if gy.is_contiguous() else gy.contiguous()
+        dx = dw = db = None
+        g = gy if gy.is_contiguous() else gy.contiguous()
+        if ctx.needs_input_grad[0]:
+            dx = torch.ops.aten.convolution_backward(g.permute(0, 3, 1, 2), x.permute(0, 3, 1, 2), w, None, [1, 1], [k // 2, k // 2], [1, 1],
+                                                     False, [0, 0], 1, [True, False, False])[0].permute(0, 2, 3, 1)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw = torch.empty_strided(w.shape, w.stride(), dtype=torch.float32, device=w.device)
             if _storage_extent(dw) != dw.numel():
                 raise ValueError("weight must be dense")
@@ -496,15 +520,14 @@ class _NarrowWrw(torch.autograd.Function):
             xc = x if x.is_contiguous() else x.contiguous()
             _lib.check(lib.wc_conv_wrw_narrow_f32(_ptr(xc), _ptr(g), N, H, W, C, O, k, _ptr(dw), dw.stride(1), dw.stride(0), dw.stride(2),
                                                   dw.stride(3), _ptr(db), _ptr(ws), nb, _stream()), "wc_conv_wrw_narrow_f32")
-        return gy, None, dw, db
+        return dx, dw, db
 
 
 def narrow_in_conv(x, w, bias=None):
-    """y = conv(x, w) + bias for NHWC x with a handful of channels: forward (and dx, if x wants one) by torch / MIOpen exactly as the plain
-    layer call makes them, dW and db by the one-pass kernel."""
-    k = w.shape[2]
-    y = F.conv2d(x.permute(0, 3, 1, 2), w.detach(), None if bias is None else bias.detach(), padding=k // 2).permute(0, 2, 3, 1).contiguous()
-    return _NarrowWrw.apply(y, x.detach(), w, bias)
+    """y = conv(x, w) + bias for NHWC x with a handful of channels (narrow_wrw_supported)"""
+    if _storage_extent(w) != w.numel():
+        w = w.contiguous()
+    return _NarrowInConv.apply(x, w, bias)
 
 
 def narrow_out_weight_gradient(x, gy, w):

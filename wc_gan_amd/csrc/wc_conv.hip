@@ -943,6 +943,114 @@ __global__ __launch_bounds__(256) void conv_wrw_narrow_reduce_kernel(const float
     } else if (row == nrow && db) db[o] = sum;
 }
 
+// ---- forward of a convolution with a handful of INPUT channels (round 5): y[p][o] = sum_m A[p][m] Wm[m][o],  m = tap * Cin + c ------------
+// The critic's first convolution and shortcut on images (3 -> 128) and -- with the weight read through mirrored tap strides -- the data
+// gradient of the generator's last layer (gy with 3 channels -> dx with 256).  MIOpen's kernel (23 us at 128x32x32, 3 -> 128) is followed by
+// two bias launches (12 + 22 us); here the bias is row k*k*Cin of the product (A = 1) and the pass is bound by the 67 MB it writes.
+// v_mfma_f32_32x32x2_f32 with the 32 PIXELS of a tile as rows: lane (i, k) gathers A[p_i][2 s + k] (4 bytes out of L1) for the KS k-steps,
+// the weight's KS x 4 fragments (128 output channels per wave) stay in registers across the wave's tiles.  fp32 throughout.
+struct NarrowFwdArgs {
+    const float* x; const float* w; const float* bias; float* y;
+    int N, H, W, Cin, Cout, ks, nrow, relu;          // nrow = ks * ks * Cin (< 32)
+    int64_t sk, sn, sr, ss;                          // w[c * sk + o * sn + r * sr + s * ss]
+    unsigned magHW, shHW, magW, shW;
+    int64_t M; int ntiles, tiles_per_wave;
+};
+
+constexpr int kNarrowLd = 32 * 2 + 4;     // floats per pixel row of a wave's LDS tile (16-byte aligned, the two lane halves 16 banks apart)
+constexpr int kNarrowNQ = 2;          // 32-channel output blocks per wave: 64 channels (4 blocks took 316 registers: one wave per SIMD, 35 us)
+template <int KS>
+__global__ __launch_bounds__(256, 2) void conv_fwd_narrow_kernel(NarrowFwdArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float nf_tile[4 * 32 * kNarrowLd];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, k = lane >> 5;
+    const int grp = blockIdx.y;
+    // this lane's KS rows of A: m = 2 s + k -> (dy, dx, c), the bias row, or nothing
+    int dyx[KS]; int cc[KS]; float bw[KS][kNarrowNQ];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int m = 2 * s + k;
+        int tap = 0, c = 0, kind = 2;                // 0: a tap, 1: the bias row, 2: padding of K
+        if (m < a.nrow) { tap = m / a.Cin; c = m - tap * a.Cin; kind = 0; }
+        else if (m == a.nrow) kind = 1;
+        const int dy = tap / a.ks - a.ks / 2, dx = tap % a.ks - a.ks / 2;
+        dyx[s] = (dy & 0xff) | ((dx & 0xff) << 8) | (kind << 16);
+        cc[s] = c;
+#pragma unroll
+        for (int q = 0; q < kNarrowNQ; ++q) {
+            const int o = grp * (32 * kNarrowNQ) + q * 32 + i;
+            float v = 0.f;
+            if (kind == 0) v = a.w[c * a.sk + o * a.sn + (tap / a.ks) * a.sr + (tap % a.ks) * a.ss];
+            else if (kind == 1) v = a.bias ? a.bias[o] : 0.f;
+            bw[s][q] = v;
+        }
+    }
+    const unsigned HW = (unsigned)(a.H * a.W);
+    const int t0 = (blockIdx.x * 4 + wave) * a.tiles_per_wave;
+    int t1 = t0 + a.tiles_per_wave;
+    if (t1 > a.ntiles) t1 = a.ntiles;
+    int off[KS];                                     // (dy W + dx) Cin + c: the tap's element relative to the pixel's own
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int dy = (signed char)(dyx[s] & 0xff), dx = (signed char)((dyx[s] >> 8) & 0xff);
+        off[s] = (dy * a.W + dx) * a.Cin + cc[s];
+    }
+    // the tile's KS values of A for this lane: gathered one tile AHEAD of the MFMAs that use them
+    auto gather = [&](int t, float (&av)[KS]) __attribute__((always_inline)) {
+        const int64_t p = (int64_t)t * 32 + i;
+        const unsigned pc = (unsigned)(p < a.M ? p : a.M - 1);
+        const unsigned n = __umulhi(pc, a.magHW) >> a.shHW, rem = pc - n * HW;
+        const unsigned yy = __umulhi(rem, a.magW) >> a.shW, xx = rem - yy * a.W;
+        const int pb = (int)pc * a.Cin;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int dy = (signed char)(dyx[s] & 0xff), dx = (signed char)((dyx[s] >> 8) & 0xff), kind = dyx[s] >> 16;
+            const bool inb = kind == 0 && (unsigned)((int)yy + dy) < (unsigned)a.H && (unsigned)((int)xx + dx) < (unsigned)a.W;
+            const float xv = a.x[inb ? pb + off[s] : 0];
+            av[s] = inb ? xv : (kind == 1 ? 1.f : 0.f);
+        }
+    };
+    float av[KS], an[KS];
+    if (t0 < t1) gather(t0, av);
+    for (int t = t0; t < t1; ++t) {
+        if (t + 1 < t1) gather(t + 1, an);
+        f32x16 acc[kNarrowNQ];
+#pragma unroll
+        for (int q = 0; q < kNarrowNQ; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int q = 0; q < kNarrowNQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bw[s][q], acc[q], 0, 0, 0);
+        // rows = pixels (r & 3) + 8 (r >> 2) + 4 k of the tile, columns = output channel q * 32 + i of the group: through LDS, so that the
+        // tile leaves as 16 bytes per lane, four whole 256-byte pixel rows per store (4 bytes per lane in 128-byte pieces ran at 2.6 TB/s)
+        float* tl = nf_tile + wave * (32 * kNarrowLd);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * k;
+#pragma unroll
+            for (int q = 0; q < kNarrowNQ; ++q) {
+                float v = acc[q][r];
+                if (a.relu) v = fmaxf(v, 0.f);
+                tl[row * kNarrowLd + q * 32 + i] = v;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);         // lgkmcnt(0): the wave's own writes (no other wave touches its slice)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = 4 * j + (lane >> 4);
+            const int64_t pr = (int64_t)t * 32 + row;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(tl + row * kNarrowLd + 4 * (lane & 15));
+            if (pr < a.M) *reinterpret_cast<f32x4*>(a.y + pr * a.Cout + grp * (32 * kNarrowNQ) + 4 * (lane & 15)) = v;
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) av[s] = an[s];
+    }
+}
+
 void magic_u31(unsigned d, unsigned* mag, unsigned* sh)
 {
     // q = umulhi(m, mag) >> sh == m / d for m < 2^31, d >= 2
@@ -1175,6 +1283,34 @@ static int wrw_splits(const wc_conv_geom* g, int* tile)
     if (splits > 64) splits = 64;                   // (the partial sums are splits x the weight size)
     if (splits > nchunks) splits = (int)nchunks;
     return splits < 1 ? 1 : splits;
+}
+
+int wc_conv_wrw_narrow_supported(int64_t N, int64_t H, int64_t W, int Cin, int Cout, int ksize);
+
+int wc_conv_fwd_narrow_f32(const float* x, const float* w, int64_t stride_k, int64_t stride_n, int64_t stride_r, int64_t stride_s,
+                           const float* bias, int64_t N, int64_t H, int64_t W, int Cin, int Cout, int ksize, int relu, float* y, wc_stream_t stream)
+{
+    if (!x || !w || !y) return WC_ERR_ARG;
+    if (!wc_conv_wrw_narrow_supported(N, H, W, Cin, Cout, ksize) || N * H * W * Cin >= ((int64_t)1 << 31)) return WC_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    NarrowFwdArgs a = {};
+    a.x = x; a.w = w; a.bias = bias; a.y = y;
+    a.N = (int)N; a.H = (int)H; a.W = (int)W; a.Cin = Cin; a.Cout = Cout; a.ks = ksize; a.nrow = ksize * ksize * Cin; a.relu = relu;
+    a.sk = stride_k; a.sn = stride_n; a.sr = stride_r; a.ss = stride_s;
+    magic_u31((unsigned)(H * W), &a.magHW, &a.shHW);
+    magic_u31((unsigned)W, &a.magW, &a.shW);
+    a.M = N * H * W;
+    a.ntiles = (int)((a.M + 31) / 32);
+    a.tiles_per_wave = (a.ntiles + 1023) / 1024;           // x Cout / 64 workgroup columns: ~2 waves per SIMD at Cout = 128
+    if (a.tiles_per_wave < 1) a.tiles_per_wave = 1;
+    const int nwg = (a.ntiles + 4 * a.tiles_per_wave - 1) / (4 * a.tiles_per_wave);
+    const int ks2 = (a.nrow + 2) / 2;                      // k-steps: the taps' rows + the bias row, in pairs
+    dim3 grid(nwg, Cout / (32 * kNarrowNQ));
+    if (ks2 <= 2) hipLaunchKernelGGL(conv_fwd_narrow_kernel<2>, grid, dim3(256), 0, st, a);
+    else if (ks2 <= 5) hipLaunchKernelGGL(conv_fwd_narrow_kernel<5>, grid, dim3(256), 0, st, a);
+    else if (ks2 <= 10) hipLaunchKernelGGL(conv_fwd_narrow_kernel<10>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(conv_fwd_narrow_kernel<16>, grid, dim3(256), 0, st, a);
+    return (int)hipGetLastError();
 }
 
 static int64_t narrow_wrw_parts(int64_t M, int64_t* pix_per_wave)

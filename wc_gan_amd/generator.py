@@ -77,14 +77,20 @@ class _NarrowConv3x3(torch.autograd.Function):
         x, w = ctx.saved_tensors
         # round 5: the weight gradient in one pass over x on the fp32 matrix pipe (conv.narrow_out_weight_gradient: 256 -> 3 is the
         # narrow-INPUT gradient with the operands exchanged); MIOpen keeps the data gradient and the 3-element bias gradient
-        own_w = ctx.needs_input_grad[1] and fast_conv_mod.narrow_out_wrw_supported(x, w) and x.is_contiguous()
+        own = fast_conv_mod.narrow_out_wrw_supported(x, w) and x.is_contiguous()
+        own_w = ctx.needs_input_grad[1] and own
+        own_x = ctx.needs_input_grad[0] and own
         gx, gw, gb = torch.ops.aten.convolution_backward(
             g.permute(0, 3, 1, 2), x.permute(0, 3, 1, 2), w, [w.shape[0]] if ctx.has_bias else None,
             [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-            [ctx.needs_input_grad[0], ctx.needs_input_grad[1] and not own_w, ctx.has_bias and ctx.needs_input_grad[2]])
+            [ctx.needs_input_grad[0] and not own_x, ctx.needs_input_grad[1] and not own_w, ctx.has_bias and ctx.needs_input_grad[2]])
+        gx = gx.permute(0, 2, 3, 1) if gx is not None else None
+        gc = g.contiguous() if (own_w or own_x) else None
         if own_w:
-            gw = fast_conv_mod.narrow_out_weight_gradient(x, g.contiguous(), w)
-        return (gx.permute(0, 2, 3, 1) if gx is not None else None), gw, (gb if ctx.has_bias else None)
+            gw = fast_conv_mod.narrow_out_weight_gradient(x, gc, w)
+        if own_x:       # the data gradient = the narrow-input FORWARD of gy through the mirrored, transposed weight
+            gx = fast_conv_mod.narrow_forward(gc, w, None, mirrored=True)
+        return gx, gw, (gb if ctx.has_bias else None)
 
 
 class Conv2D(nn.Module):
@@ -154,8 +160,8 @@ class Conv2D(nn.Module):
             y = fast_conv_mod.fast_conv_or_none(x, w, c.bias, 'same', site=self)      # split-fp16 MFMA implicit GEMM (csrc/wc_conv.hip)
             if y is not None:
                 return y
-        if x.is_cuda and torch.is_grad_enabled() and w.requires_grad and fast_conv_mod.narrow_wrw_supported(x, w):
-            return fast_conv_mod.narrow_in_conv(x, w, c.bias)       # an image-like input: the weight / bias gradient in one pass over gy (csrc/wc_conv.hip)
+        if x.is_cuda and fast_conv_mod.narrow_wrw_supported(x, w):
+            return fast_conv_mod.narrow_in_conv(x, w, c.bias)       # an image-like input: forward and weight / bias gradient on the fp32 matrix pipe (csrc/wc_conv.hip)
         return to_nhwc(c._conv_forward(to_nchw_view(x), w, c.bias))
 
     def forward_upsampled(self, x):
