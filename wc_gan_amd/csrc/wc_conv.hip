@@ -955,6 +955,7 @@ struct NarrowFwdArgs {
     int64_t sk, sn, sr, ss;                          // w[c * sk + o * sn + r * sr + s * ss]
     unsigned magHW, shHW, magW, shW;
     int64_t M; int ntiles, tiles_per_wave;
+    signed char tdy[32], tdx[32], tch[32], tr[32], ts[32];     // row m of A: tap offsets, input channel, the weight's tap indices (host-made: no divisions on the device)
 };
 
 constexpr int kNarrowLd = 32 * 2 + 4;     // floats per pixel row of a wave's LDS tile (16-byte aligned, the two lane halves 16 banks apart)
@@ -972,17 +973,16 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_narrow_kernel(NarrowFwdArgs a
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         const int m = 2 * s + k;
-        int tap = 0, c = 0, kind = 2;                // 0: a tap, 1: the bias row, 2: padding of K
-        if (m < a.nrow) { tap = m / a.Cin; c = m - tap * a.Cin; kind = 0; }
-        else if (m == a.nrow) kind = 1;
-        const int dy = tap / a.ks - a.ks / 2, dx = tap % a.ks - a.ks / 2;
+        const int kind = m < a.nrow ? 0 : (m == a.nrow ? 1 : 2);     // 0: a tap, 1: the bias row, 2: padding of K
+        const int mm = m < 32 ? m : 31;
+        const int c = a.tch[mm], dy = a.tdy[mm], dx = a.tdx[mm];
         dyx[s] = (dy & 0xff) | ((dx & 0xff) << 8) | (kind << 16);
         cc[s] = c;
 #pragma unroll
         for (int q = 0; q < kNarrowNQ; ++q) {
             const int o = grp * (32 * kNarrowNQ) + q * 32 + i;
             float v = 0.f;
-            if (kind == 0) v = a.w[c * a.sk + o * a.sn + (tap / a.ks) * a.sr + (tap % a.ks) * a.ss];
+            if (kind == 0) v = a.w[c * a.sk + o * a.sn + a.tr[mm] * a.sr + a.ts[mm] * a.ss];
             else if (kind == 1) v = a.bias ? a.bias[o] : 0.f;
             bw[s][q] = v;
         }
@@ -1299,6 +1299,11 @@ int wc_conv_fwd_narrow_f32(const float* x, const float* w, int64_t stride_k, int
     a.sk = stride_k; a.sn = stride_n; a.sr = stride_r; a.ss = stride_s;
     magic_u31((unsigned)(H * W), &a.magHW, &a.shHW);
     magic_u31((unsigned)W, &a.magW, &a.shW);
+    for (int m = 0; m < 32; ++m) {
+        const int tap = m < a.nrow ? m / Cin : 0, c = m < a.nrow ? m % Cin : 0;
+        a.tr[m] = (signed char)(tap / ksize); a.ts[m] = (signed char)(tap % ksize); a.tch[m] = (signed char)c;
+        a.tdy[m] = (signed char)(tap / ksize - ksize / 2); a.tdx[m] = (signed char)(tap % ksize - ksize / 2);
+    }
     a.M = N * H * W;
     a.ntiles = (int)((a.M + 31) / 32);
     a.tiles_per_wave = (a.ntiles + 1023) / 1024;           // x Cout / 64 workgroup columns: ~2 waves per SIMD at Cout = 128
@@ -1309,6 +1314,7 @@ int wc_conv_fwd_narrow_f32(const float* x, const float* w, int64_t stride_k, int
     if (ks2 <= 2) hipLaunchKernelGGL(conv_fwd_narrow_kernel<2>, grid, dim3(256), 0, st, a);
     else if (ks2 <= 5) hipLaunchKernelGGL(conv_fwd_narrow_kernel<5>, grid, dim3(256), 0, st, a);
     else if (ks2 <= 10) hipLaunchKernelGGL(conv_fwd_narrow_kernel<10>, grid, dim3(256), 0, st, a);
+    else if (ks2 <= 14) hipLaunchKernelGGL(conv_fwd_narrow_kernel<14>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(conv_fwd_narrow_kernel<16>, grid, dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }
