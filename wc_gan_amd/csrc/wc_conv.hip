@@ -1306,7 +1306,7 @@ int wc_conv_fwd_narrow_f32(const float* x, const float* w, int64_t stride_k, int
     }
     a.M = N * H * W;
     a.ntiles = (int)((a.M + 31) / 32);
-    a.tiles_per_wave = (a.ntiles + 1023) / 1024;           // x Cout / 64 workgroup columns: ~2 waves per SIMD at Cout = 128
+    a.tiles_per_wave = (a.ntiles + 1023) / 1024;           // x Cout / 64 workgroup columns: ~2 waves per SIMD at Cout = 128 (three, at 166 registers: 32.8 against 30.7 us)
     if (a.tiles_per_wave < 1) a.tiles_per_wave = 1;
     const int nwg = (a.ntiles + 4 * a.tiles_per_wave - 1) / (4 * a.tiles_per_wave);
     const int ks2 = (a.nrow + 2) / 2;                      // k-steps: the taps' rows + the bias row, in pairs
