@@ -288,7 +288,15 @@ __global__ __launch_bounds__(256) void conv_ksplit_reduce_kernel(const float* __
     const float inv = 1.0f / (xscale[0] * wscale[0]);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         f32x4 v = *reinterpret_cast<const f32x4*>(partial + 4 * i);
-        for (int z = 1; z < ksplit; ++z) v += *reinterpret_cast<const f32x4*>(partial + 4 * (z * n4 + i));
+        int z = 1;
+        for (; z + 3 < ksplit; z += 4) {                 // four shares in flight, added in order
+            f32x4 t[4];
+            #pragma unroll
+            for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const f32x4*>(partial + 4 * ((z + u) * n4 + i));
+            #pragma unroll
+            for (int u = 0; u < 4; ++u) v += t[u];
+        }
+        for (; z < ksplit; ++z) v += *reinterpret_cast<const f32x4*>(partial + 4 * (z * n4 + i));
         v = v * inv;
         if (bias) v += *reinterpret_cast<const f32x4*>(bias + (4 * i) % cout);
         if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
@@ -819,7 +827,15 @@ __global__ __launch_bounds__(256) void conv_wrw_reduce_kernel(WrwReduceArgs a)
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         for (int i = 0; i < a.cnt[o]; ++i) {
             const float* src = a.partial + a.slice[o][i] * plane + w;
-            for (int sp = part; sp < a.splits; sp += 4) v += *reinterpret_cast<const f32x4*>(src + sp * per);
+            int sp = part;
+            for (; sp + 28 < a.splits; sp += 32) {      // eight ranges in flight (the additions keep their order: the same bits)
+                f32x4 t[8];
+                #pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const f32x4*>(src + (int64_t)(sp + 4 * u) * per);
+                #pragma unroll
+                for (int u = 0; u < 8; ++u) v += t[u];
+            }
+            for (; sp < a.splits; sp += 4) v += *reinterpret_cast<const f32x4*>(src + sp * per);
         }
         #pragma unroll
         for (int j = 0; j < 4; ++j) { v[j] += __shfl_xor(v[j], 1); v[j] += __shfl_xor(v[j], 2); }
