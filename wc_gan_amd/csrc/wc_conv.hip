@@ -974,6 +974,9 @@ struct NarrowFwdArgs {
     signed char tdy[32], tdx[32], tch[32], tr[32], ts[32];     // row m of A: tap offsets, input channel, the weight's tap indices (host-made: no divisions on the device)
 };
 
+#ifndef WC_NF_ABL
+#define WC_NF_ABL 0      // development (timing only, wrong results): 1 no global stores, 2 no gathers, 4 no MFMAs, 8 no LDS transpose
+#endif
 constexpr int kNarrowLd = 32 * 2 + 4;     // floats per pixel row of a wave's LDS tile (16-byte aligned, the two lane halves 16 banks apart)
 constexpr int kNarrowNQ = 2;          // 32-channel output blocks per wave: 64 channels (4 blocks took 316 registers: one wave per SIMD, 35 us)
 template <int KS>
@@ -984,35 +987,40 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_narrow_kernel(NarrowFwdArgs a
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, k = lane >> 5;
     const int grp = blockIdx.y;
-    // this lane's KS rows of A: m = 2 s + k -> (dy, dx, c), the bias row, or nothing
-    int dyx[KS]; int cc[KS]; float bw[KS][kNarrowNQ];
+    // the workgroup's 32 x 64 slice of the weight (row m = tap * Cin + c, the bias row, zero rows) and the rows' tap tables go through LDS:
+    // eight coalesced loads per thread with wave-uniform row indices (scalar table reads) instead of ~100 dependent gathers per wave
+    __shared__ float nf_w[32][32 * kNarrowNQ];
+    __shared__ int nf_tab[32][2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int m = wave + 4 * j;                                  // wave-uniform
+        const int kind = m < a.nrow ? 0 : (m == a.nrow ? 1 : 2);     // 0: a tap, 1: the bias row, 2: padding of K
+        const int o = grp * (32 * kNarrowNQ) + lane;
+        float v = 0.f;
+        if (kind == 0) v = a.w[a.tch[m] * a.sk + o * a.sn + a.tr[m] * a.sr + a.ts[m] * a.ss];
+        else if (kind == 1) v = a.bias ? a.bias[o] : 0.f;
+        nf_w[m][lane] = v;
+        if (lane == 0) {
+            const int dy = a.tdy[m], dx = a.tdx[m];
+            nf_tab[m][0] = (dy & 0xff) | ((dx & 0xff) << 8) | (kind << 16);
+            nf_tab[m][1] = (dy * a.W + dx) * a.Cin + a.tch[m];
+        }
+    }
+    __syncthreads();
+    // this lane's KS rows of A: m = 2 s + k -> (dy, dx, kind), the element offset of the tap, the weight's fragments
+    int dyx[KS], off[KS]; float bw[KS][kNarrowNQ];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         const int m = 2 * s + k;
-        const int kind = m < a.nrow ? 0 : (m == a.nrow ? 1 : 2);     // 0: a tap, 1: the bias row, 2: padding of K
-        const int mm = m < 32 ? m : 31;
-        const int c = a.tch[mm], dy = a.tdy[mm], dx = a.tdx[mm];
-        dyx[s] = (dy & 0xff) | ((dx & 0xff) << 8) | (kind << 16);
-        cc[s] = c;
+        dyx[s] = nf_tab[m][0];
+        off[s] = nf_tab[m][1];
 #pragma unroll
-        for (int q = 0; q < kNarrowNQ; ++q) {
-            const int o = grp * (32 * kNarrowNQ) + q * 32 + i;
-            float v = 0.f;
-            if (kind == 0) v = a.w[c * a.sk + o * a.sn + a.tr[mm] * a.sr + a.ts[mm] * a.ss];
-            else if (kind == 1) v = a.bias ? a.bias[o] : 0.f;
-            bw[s][q] = v;
-        }
+        for (int q = 0; q < kNarrowNQ; ++q) bw[s][q] = nf_w[m][q * 32 + i];
     }
     const unsigned HW = (unsigned)(a.H * a.W);
     const int t0 = (blockIdx.x * 4 + wave) * a.tiles_per_wave;
     int t1 = t0 + a.tiles_per_wave;
     if (t1 > a.ntiles) t1 = a.ntiles;
-    int off[KS];                                     // (dy W + dx) Cin + c: the tap's element relative to the pixel's own
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        const int dy = (signed char)(dyx[s] & 0xff), dx = (signed char)((dyx[s] >> 8) & 0xff);
-        off[s] = (dy * a.W + dx) * a.Cin + cc[s];
-    }
     // the tile's KS values of A for this lane: gathered one tile AHEAD of the MFMAs that use them
     auto gather = [&](int t, float (&av)[KS]) __attribute__((always_inline)) {
         const int64_t p = (int64_t)t * 32 + i;
@@ -1024,7 +1032,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_narrow_kernel(NarrowFwdArgs a
         for (int s = 0; s < KS; ++s) {
             const int dy = (signed char)(dyx[s] & 0xff), dx = (signed char)((dyx[s] >> 8) & 0xff), kind = dyx[s] >> 16;
             const bool inb = kind == 0 && (unsigned)((int)yy + dy) < (unsigned)a.H && (unsigned)((int)xx + dx) < (unsigned)a.W;
-            const float xv = a.x[inb ? pb + off[s] : 0];
+            const float xv = (WC_NF_ABL & 2) ? 1.f : a.x[inb ? pb + off[s] : 0];
             av[s] = inb ? xv : (kind == 1 ? 1.f : 0.f);
         }
     };
@@ -1040,7 +1048,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_narrow_kernel(NarrowFwdArgs a
 #pragma unroll
         for (int s = 0; s < KS; ++s)
 #pragma unroll
-            for (int q = 0; q < kNarrowNQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bw[s][q], acc[q], 0, 0, 0);
+            for (int q = 0; q < kNarrowNQ; ++q) { if (WC_NF_ABL & 4) acc[q][s & 15] += av[s] * bw[s][q]; else acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bw[s][q], acc[q], 0, 0, 0); }
         // rows = pixels (r & 3) + 8 (r >> 2) + 4 k of the tile, columns = output channel q * 32 + i of the group: through LDS, so that the
         // tile leaves as 16 bytes per lane, four whole 256-byte pixel rows per store (4 bytes per lane in 128-byte pieces ran at 2.6 TB/s)
         float* tl = nf_tile + wave * (32 * kNarrowLd);
@@ -1060,7 +1068,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_narrow_kernel(NarrowFwdArgs a
             const int row = 4 * j + (lane >> 4);
             const int64_t pr = (int64_t)t * 32 + row;
             const f32x4 v = *reinterpret_cast<const f32x4*>(tl + row * kNarrowLd + 4 * (lane & 15));
-            if (pr < a.M) *reinterpret_cast<f32x4*>(a.y + pr * a.Cout + grp * (32 * kNarrowNQ) + 4 * (lane & 15)) = v;
+            if (pr < a.M && (!(WC_NF_ABL & 1) || v[0] == 1.2345f)) *reinterpret_cast<f32x4*>(a.y + pr * a.Cout + grp * (32 * kNarrowNQ) + 4 * (lane & 15)) = v;
         }
 #pragma unroll
         for (int s = 0; s < KS; ++s) av[s] = an[s];
