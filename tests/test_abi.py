@@ -142,3 +142,24 @@ def test_fast_apply_takes_the_grouped_and_conditional_sites(lib):
     assert lib.wc_apply_workspace_bytes(128, 144, 256, 7) > 256       # per-class tables, tiles straddle samples
     assert lib.wc_apply_workspace_bytes(128, 16, 256, 1) > 256        # 2048 rows (the 4x4 site): one planned launch since round 2
     assert lib.wc_apply_workspace_bytes(8, 36, 256, 1) == 256         # 288 rows: below the fast path's minimum
+
+
+def test_round5_harness_entry_points_check_their_arguments(lib):
+    """ABI 7, the harness side (one-launch split with a history record; the narrow-side layers): support predicates, sizes, rejections."""
+    one = ctypes.c_void_p(16)
+    assert lib.wc_conv_split_hist_f32(None, 64, 0, one, one, one, None, 0, one, 1, None) == -5          # (wc_conv.hip's own codes: ARG)
+    assert lib.wc_conv_split_hist_f32(one, 62, 0, one, one, one, None, 0, one, 1, None) == -5           # n % 4
+    assert lib.wc_conv_split_hist_f32(one, 64, 0, one, one, one, None, 0, None, 0, None) == -5          # no record
+    assert lib.wc_conv_split_hist_f32(one, 64, 0, one, one, one, one, 48, one, 0, None) == -2           # column sums: 256 % (C / 4) != 0
+    assert lib.wc_conv_wrw_narrow_supported(128, 32, 32, 3, 128, 3) == 1 and lib.wc_conv_wrw_narrow_supported(128, 16, 16, 3, 256, 1) == 1
+    assert lib.wc_conv_wrw_narrow_supported(128, 32, 32, 4, 128, 3) == 0                                # 36 rows
+    assert lib.wc_conv_wrw_narrow_supported(128, 32, 32, 3, 64, 3) == 0                                 # Cout % 128
+    assert lib.wc_conv_wrw_narrow_supported(128, 32, 32, 3, 128, 5) == 0
+    assert lib.wc_conv_wrw_narrow_workspace_bytes(128, 32, 32, 3, 128, 3) == 256 * 4096 * 4
+    assert lib.wc_conv_wrw_narrow_workspace_bytes(2, 6, 10, 2, 256, 3) == 2 * 4096 * 4                  # one partial per 128 channels
+    assert lib.wc_conv_wrw_narrow_workspace_bytes(128, 32, 32, 3, 64, 3) == 0
+    assert lib.wc_conv_wrw_narrow_f32(None, one, 128, 32, 32, 3, 128, 3, one, 1, 27, 9, 3, None, one, 1 << 30, None) == -5
+    assert lib.wc_conv_wrw_narrow_f32(one, one, 128, 32, 32, 3, 64, 3, one, 1, 27, 9, 3, None, one, 1 << 30, None) == -2
+    assert lib.wc_conv_wrw_narrow_f32(one, one, 128, 32, 32, 3, 128, 3, one, 1, 27, 9, 3, None, one, 16, None) == -4
+    assert lib.wc_conv_fwd_narrow_f32(one, None, 1, 27, 9, 3, None, 128, 32, 32, 3, 128, 3, 0, one, None) == -5
+    assert lib.wc_conv_fwd_narrow_f32(one, one, 1, 27, 9, 3, None, 128, 32, 32, 8, 128, 3, 0, one, None) == -2
