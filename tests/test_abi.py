@@ -163,3 +163,23 @@ def test_round5_harness_entry_points_check_their_arguments(lib):
     assert lib.wc_conv_wrw_narrow_f32(one, one, 128, 32, 32, 3, 128, 3, one, 1, 27, 9, 3, None, one, 16, None) == -4
     assert lib.wc_conv_fwd_narrow_f32(one, None, 1, 27, 9, 3, None, 128, 32, 32, 3, 128, 3, 0, one, None) == -5
     assert lib.wc_conv_fwd_narrow_f32(one, one, 1, 27, 9, 3, None, 128, 32, 32, 8, 128, 3, 0, one, None) == -2
+
+
+def test_round5_producer_entry_points_check_their_arguments(lib):
+    """ABI 7, the producer that feeds K1 (wc_resadd_stats_split_f32) and the K1 tails that read its partials: predicates, sizes, rejections."""
+    one = ctypes.c_void_p(16)
+    assert lib.wc_resadd_stats_supported(128, 32, 32, 256, 1, 1) == 1 and lib.wc_resadd_stats_supported(320, 32, 32, 256, 1, 5) == 1
+    assert lib.wc_resadd_stats_supported(128, 32, 32, 256, 0, 1) == 0           # up = 0: no shortcut rows to add per patch
+    assert lib.wc_resadd_stats_supported(128, 32, 32, 64, 1, 1) == 0            # planes: C = 128 | 256
+    assert lib.wc_resadd_stats_supported(4, 8, 8, 256, 1, 1) == 0               # below the fast reduction's minimum
+    nb = lib.wc_resadd_stats_workspace_bytes(128, 32, 32, 256, 1)
+    assert nb > 36 * 32 * 32 * 8 and lib.wc_resadd_stats_workspace_bytes(4, 8, 8, 256, 1) == 0
+    assert lib.wc_whiten_presummed_error_offset(131072, 256, 1) > 0 and lib.wc_whiten_presummed_error_offset(131072, 64, 1) == 0
+    assert lib.wc_resadd_stats_split_f32(one, None, 128, 32, 32, 256, 1, 1, one, one, one, one, None, one, nb, None) == -1
+    assert lib.wc_resadd_stats_split_f32(one, one, 128, 32, 32, 64, 1, 1, one, one, one, one, None, one, nb, None) == -2
+    assert lib.wc_resadd_stats_split_f32(one, one, 128, 32, 32, 256, 1, 1, one, one, one, one, None, one, 16, None) == -4
+    assert lib.wc_whiten_presummed_f16x2(None, 131072, 256, 1, 1e-3, 0.99, 1, None, None, one, one, one, one, nb, None) == -1
+    assert lib.wc_whiten_presummed_f16x2(one, 131072, 256, 1, 0.0, 0.99, 1, None, None, one, one, one, one, nb, None) == -5
+    assert lib.wc_whiten_presummed_f16x2(one, 131072, 256, 1, 1e-3, 0.99, 1, None, None, one, one, one, one, 16, None) == -4
+    assert lib.wc_stats_presummed_f16x2(one, 131072, 256, 1, None, one, one, nb, None) == -1
+    assert lib.wc_stats_presummed_f16x2(one, 131072, 256, 1, one, one, one, 16, None) == -4
