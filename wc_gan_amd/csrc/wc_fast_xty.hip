@@ -51,6 +51,9 @@ constexpr int BW_PLAIN = 3;                // 32x32 blocks per wave
                                // 1.39e-4; 2 stages 1.72e-4; 4 stages 2.19e-4; 16 stages 1.03e-3 -- and SHORTER chains (a flush every 2 k-steps /
                                // every k-step, built and dropped) 1.92e-4 / 3.23e-4: one stage per chain is the optimum of this scheme
 #endif
+#ifndef XTY_YPL_ABL
+#define XTY_YPL_ABL 0   // development, TIMING ONLY (wrong results): K4 on planes stages the gradient operand from planes as well (it reads x's planes again) --
+#endif                  // what K4 would cost if the gradient arrived pre-masked and pre-split (ranked first for round 6)
 #ifndef XTY_LOLO
 #define XTY_LOLO 0      // 1: covariance (K1): the fourth product lo*lo on every block (round 5, VERDICT r4 item 7: the lever named for the non-gaussian families)
 #endif
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
     f32x4 yr[RELU == 1 ? 8 : 1];
     uint4 ym = {0u, 0u, 0u, 0u};
     const bool y_wave = RELU && __builtin_amdgcn_readfirstlane(op) != 0;       // waves 4-7 stage Y (wave-uniform: a scalar branch)
-    const bool x_wave = XPL && __builtin_amdgcn_readfirstlane(op) == 0;        // waves 0-3 stage X (wave-uniform: a scalar branch)
+    const bool x_wave = XPL && (XTY_YPL_ABL || __builtin_amdgcn_readfirstlane(op) == 0);        // waves 0-3 stage X (wave-uniform: a scalar branch)
     auto stage_load = [&](int st) {
         const int64_t off = (r0 + (int64_t)st * R + rgrp * 8) * C + cbase + 4 * c4;
         if (XPL && x_wave) {        // 4 channels of 8 rows from each plane: xr[p] = (hi word 0, hi word 1, lo word 0, lo word 1) of row p
