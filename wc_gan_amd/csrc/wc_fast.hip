@@ -1239,7 +1239,7 @@ __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
         const float* src = (p & 2) ? a.x : a.gy;
         const int64_t row_ = (int64_t)tile_of(tl) * TR + 2 * wave + (p & 1);
         const char* g = reinterpret_cast<const char*>(src + row_ * C) + lane_ * 16;
-        if (XPL && (p & 2))      // [hi row | lo row]: 512 bytes of each plane
+        if (XPL && ((p & 2) || (WC_K6_ABL & 512)))      // [hi row | lo row]: 512 bytes of each plane  (ABL 512, timing only: the gradient's chunks too)
             g = reinterpret_cast<const char*>(((lane_ >> 5) ? a.xlo : a.xhi) + row_ * C) + (lane_ & 31) * 16;
         const unsigned l = __builtin_amdgcn_readfirstlane(ring_w + slot * 1024);
         unsigned keep;
@@ -1273,7 +1273,7 @@ __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
     u32x4_ mkw = {0u, 0u, 0u, 0u};          // MK: this lane's four channels' mask words of the tile being converted (read once per tile)
     auto mask_words = [&](int tl) { mkw = *reinterpret_cast<const u32x4_*>(mbuf + (tl % 3) * 1024 + lane * 16); };
     auto cv_scale = [&](int p, int tl) {
-        if (XPL && (p & 2)) {       // planes: the chunk IS the image's content; held until its write (craw is the next chunk's by then)
+        if (XPL && ((p & 2) || (WC_K6_ABL & 512))) {       // planes: the chunk IS the image's content; held until its write (craw is the next chunk's by then)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the read has RETURNED before the slot's refill may issue (no arithmetic here would make hipcc wait)
             cg4 = craw;
             return;
@@ -1296,9 +1296,9 @@ __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
         gmax = __builtin_fmaxf(__builtin_fmaxf(gmax, fabsf(cg4[0])), fabsf(cg4[1]));
         gmax = __builtin_fmaxf(__builtin_fmaxf(gmax, fabsf(cg4[2])), fabsf(cg4[3]));
     };
-    auto cv_hi = [&](int p) { if (XPL && (p & 2)) return; chw01 = pk_rne(cg4[0], cg4[1]); chw23 = pk_rne(cg4[2], cg4[3]); };
+    auto cv_hi = [&](int p) { if (XPL && ((p & 2) || (WC_K6_ABL & 512))) return; chw01 = pk_rne(cg4[0], cg4[1]); chw23 = pk_rne(cg4[2], cg4[3]); };
     auto cv_lo = [&](int p) {
-        if (XPL && (p & 2)) return;
+        if (XPL && ((p & 2) || (WC_K6_ABL & 512))) return;
         float r0, r1, r2, r3;
         asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(chw01), "v"(cg4[0]));
         asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(chw01), "v"(cg4[1]));
@@ -1311,8 +1311,8 @@ __global__ __launch_bounds__(512, 1) void onepass_ring_kernel(OnePassArgs a)
     const int woff0 = (2 * wave) * PITCH + lane * 8;
     const int xoff0 = (2 * wave) * PITCH + C * 2 + (lane & 31) * 16 + (lane >> 5) * IMG;      // XPL: this lane's 16 bytes of the x half (hi image | lo image)
     auto cv_write = [&](int fb, int p, int woff0_, int xoff0_) {
-        if (XPL && (p & 2)) {
-            *reinterpret_cast<f32x4*>(fbuf + fb * FBUF + xoff0_ + (p & 1) * PITCH) = cg4;
+        if (XPL && ((p & 2) || (WC_K6_ABL & 512))) {
+            *reinterpret_cast<f32x4*>(fbuf + fb * FBUF + xoff0_ - ((p & 2) ? 0 : C * 2) + (p & 1) * PITCH) = cg4;
             return;
         }
         char* dst = fbuf + fb * FBUF + woff0_ + (p & 1) * PITCH + (p >> 1) * (C * 2);
