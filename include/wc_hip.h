@@ -410,7 +410,9 @@ int wc_bwd_apply_scaled_f32(const float* gy, const float* x, const float* mu, co
  * and its conversion a copy.  (x - mu) = g / scale + (center - mu): K4 adds the rank-one term (center - mu) (sum gy)^T to R, K6 folds
  * (center - mu) S into gmean.  relu_mask (nullable): the site's one-bit ReLU mask, applied by both as in wc_bwd_reduce_bits_f32 /
  * wc_bwd_apply_bits_f32 (gy is then the gradient BEFORE the ReLU).  scales: float[2C]; K4 writes gy's scales to [C, 2C) and K6 reads
- * them there ([0, C) is unused: x's scales are xs_scale).  wc_bwd_xsplit_supported: C = 256, the fast reduction and the one-pass K6,
+ * them there ([0, C) is unused: x's scales are xs_scale).  wc_bwd_xsplit_supported: C = 256 (the fast reduction and the one-pass K6) or, since ABI 7, C = 128 (the plain two-operand
+ * reduction staging x from the planes; K6 as the planes kernel for (x - mu) S - sub followed by the accumulating fp32 kernel for + gy At; relu_mask must be
+ * NULL there: mask gy in front),
  * N*HW a multiple of 32; elsewhere WC_ERR_SHAPE (keep an fp32 x: wc_resadd_split_f32's x32).  Replace the same TF graph gradients as
  * wc_bwd_reduce_f32 / wc_bwd_apply_f32 (run.py:93-94). */
 int    wc_bwd_xsplit_supported(int64_t N, int64_t HW, int C, int has_slot);

@@ -346,12 +346,15 @@ def test_shortcut_convolution_on_the_planes(shape, Cout):
 
 
 @pytest.mark.parametrize("shape,Kc,masked", [((128, 32, 32, 256), 1, True), ((128, 32, 32, 256), 1, False), ((128, 16, 16, 256), 10, True),
-                                             ((64, 32, 32, 256), 1, True)])
+                                             ((64, 32, 32, 256), 1, True),
+                                             ((128, 32, 32, 128), 10, False), ((128, 16, 16, 128), 1, False), ((64, 64, 64, 128), 10, False)])      # round 5: C = 128
 def test_backward_kernels_on_planes_match_the_fp32_kernels(shape, Kc, masked):
     """K4 and K6 reading x from the producer's planes (wc_bwd_reduce_xsplit_f32 / wc_bwd_apply_xsplit_f32) against the same kernels on
     the fp32 tensor (wc_bwd_reduce_bits_f32 / wc_bwd_apply_bits_f32): R, gsum and dx to 2e-6 of their maxima (both hold x to 22 bits;
     kernel-level tolerance of tests/test_fast_gpu.py), with the one-bit ReLU mask, per-class tables, and a gradient element beyond
-    the fp16 range (the gated exact redo, which then also reads x from the planes)."""
+    the fp16 range (the gated exact redo, which then also reads x from the planes).  C = 128 (round 5; the conditional CIFAR-10 and
+    Tiny-ImageNet generators): K4's plain two-operand form stages x from the planes, K6 is the planes kernel for (x - mu) S - sub followed by
+    the accumulating fp32 kernel for + gy At; the bit mask is applied in front by the caller there (no masked form of those kernels)."""
     from wc_gan_amd import ops
     x, G, B, slot = _site(shape, Kc, 31, cond="ill")
     C = shape[-1]

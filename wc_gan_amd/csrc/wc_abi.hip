@@ -932,10 +932,12 @@ int wc_bwd_reduce_bits_f32(const float* x, const float* mu, const float* gy, con
 // ---- K4 / K6 on a pre-split x (ABI 5): the backward of a site whose input the residual add wrote as planes ---------------------
 int wc_bwd_xsplit_supported(int64_t N, int64_t HW, int C, int has_slot)
 {
-    if (N <= 0 || HW <= 0 || C != 256 || ((N * HW) % 32) != 0) return 0;
+    if (N <= 0 || HW <= 0 || (C != 256 && C != 128) || ((N * HW) % 32) != 0) return 0;
     const int per_sample = has_slot != 0;
     const XtyPlan p = plan_xty(per_sample ? N : 1, per_sample ? HW : N * HW, C, per_sample, 0);
-    return (p.fast && wc_fast_affine_supported(N, HW, C, has_slot != 0) && wc_bwd_apply_onepass_supported(N, HW, C)) ? 1 : 0;
+    if (!p.fast || !wc_fast_affine_supported(N, HW, C, has_slot != 0)) return 0;
+    // C = 256: K6 in one pass; C = 128 (round 5): the planes kernel for (x - mu) S - sub, then the accumulating fp32 kernel for + gy At
+    return (C == 256 ? wc_bwd_apply_onepass_supported(N, HW, C) : wc_split_apply_supported(N, HW, C)) ? 1 : 0;
 }
 
 int wc_bwd_reduce_xsplit_f32(const void* xs, const float* xs_center, const float* xs_scale, const float* mu, const float* gy,
@@ -946,6 +948,7 @@ int wc_bwd_reduce_xsplit_f32(const void* xs, const float* xs_center, const float
     if (N <= 0 || HW <= 0 || Kc <= 0 || (!slot && Kc != 1)) return WC_ERR_SHAPE;
     if (bad_channels(C)) return WC_ERR_CHANNELS;
     if (!wc_bwd_xsplit_supported(N, HW, C, slot != nullptr)) return WC_ERR_SHAPE;
+    if (relu_mask && C != 256) return WC_ERR_SHAPE;          // (the masked form of the reduction exists for the quadrant scheme: mask gy in front at C = 128)
     if (ws_bytes < wc_bwd_reduce_workspace_bytes(N, HW, C, Kc, slot != nullptr)) return WC_ERR_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int per_sample = slot != nullptr;
@@ -995,6 +998,17 @@ int wc_bwd_apply_xsplit_f32(const float* gy, const void* relu_mask, const void* 
     float* subf = reinterpret_cast<float*>(w + wc_fast_affine_workspace(C, Kc) + wc_fast_affine_workspace(C, 1));
     // the tables of both halves in one launch: At for gy's scales, S for the planes' scales
     // ... and, in the same launch:  dx = gy At + (x - mu) S - gmean with x - mu = g / scale + (center - mu):  sub = gmean + (mu - center) S
+    if (C != 256) {
+        // C = 128 (round 5): dx = (g / scale) S - sub by the planes kernel (K3's: the additive term carries -sub = -gmean + (center - mu) S),
+        // then dx += gy At by the accumulating fp32 kernel -- x is never needed in fp32, so the producer writes no copy of it
+        if (relu_mask) return WC_ERR_SHAPE;
+        WC_TRY(wc_launch_fast_plan_tables2_bias(At, Kc, plan0, scales + C, S, plan1, xs_scale, C, st, gmean, xs_center, mu, subf, 1));
+        const float *pscale, *pcol; const void *phi, *plo;
+        wc_fast_plan_parts(plan1, C, 1, &pscale, &pcol, &phi, &plo);
+        WC_TRY(wc_launch_apply_split(xs, xs_scale, S, 1, subf, nullptr, N, HW, C, 0, dx, phi, plo, pcol, nullptr, st, nullptr, nullptr, nullptr));
+        WC_TRY(wc_launch_fast_affine_planned(gy, nullptr, At, Kc, false, nullptr, nullptr, slot, N, HW, C, 1, dx, plan0, st, nullptr, nullptr, nullptr));
+        return WC_OK;
+    }
     WC_TRY(wc_launch_fast_plan_tables2_bias(At, Kc, plan0, scales + C, S, plan1, xs_scale, C, st, gmean, mu, xs_center, subf));
     WC_TRY(wc_launch_bwd_apply_onepass(gy, nullptr, mu, At, Kc, S, subf, slot, N, HW, scales, dx, plan0, plan1, st,
                                        static_cast<const unsigned*>(relu_mask), xs, xs_scale));

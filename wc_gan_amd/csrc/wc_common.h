@@ -158,7 +158,7 @@ hipError_t wc_launch_fast_plan_tables_bias(const float* B, int Kc, int C, void* 
                                            const float* bias, const float* center, const float* mu, float* bias_out);
 hipError_t wc_launch_fast_plan_tables2_bias(const float* B0, int Kc0, void* plan0, const float* scale0,
                                             const float* B1, void* plan1, const float* scale1, int C, hipStream_t st,
-                                            const float* bias, const float* center, const float* mu, float* bias_out);
+                                            const float* bias, const float* center, const float* mu, float* bias_out, int neg_bias = 0);
 float* wc_fast_plan_scale(void* plan);
 hipError_t wc_launch_fast_affine_planned(const float* in, const float* center, const float* B, int Kc, bool shared_table,
                                          const float* bias, const float* sub, const int32_t* slot,

@@ -123,7 +123,7 @@ struct SplitJob { const float* B; const float* scale; _Float16* hi; _Float16* lo
 // (round 4) a third, independent job in the same launch: the additive term of an apply on pre-split planes,
 //     out[slot][n] = bias[slot][n] + sum_k (center[k] - mu[k]) A[slot][k][n]          (wc_split.hip's split_bias_kernel)
 // -- it needs A only, as the tables do, and as a launch of its own it cost the forward site 5 us between the tables and K3
-struct BiasJob { const float* A; const float* bias; const float* center; const float* mu; float* out; int slots; };
+struct BiasJob { const float* A; const float* bias; const float* center; const float* mu; float* out; int slots; int neg_bias; };      // neg_bias: out = -bias + ...  (K6's two-pass form on planes)
 __global__ __launch_bounds__(64) void split_table_kernel(SplitJob j0, SplitJob j1, int C, BiasJob bj)
 {
     if ((int)blockIdx.x >= j0.rows + j1.rows) {      // bias job: one workgroup per (slot, 2 columns); thread (q, n) sums the rows k = q mod 32
@@ -146,7 +146,8 @@ __global__ __launch_bounds__(64) void split_table_kernel(SplitJob j0, SplitJob j
             double t = 0.0;
 #pragma unroll
             for (int i = 0; i < 32; ++i) t += red[threadIdx.x + 2 * i];
-            bj.out[(int64_t)slot * C + n] = (float)(t + (bj.bias ? (double)bj.bias[(int64_t)slot * C + n] : 0.0));
+            const double bv = bj.bias ? (double)bj.bias[(int64_t)slot * C + n] : 0.0;
+            bj.out[(int64_t)slot * C + n] = (float)(t + (bj.neg_bias ? -bv : bv));
         }
         return;
     }
@@ -1833,9 +1834,9 @@ hipError_t wc_launch_fast_plan_tables2(const float* B0, int Kc0, void* plan0, co
 // ... and K6 on a pre-split x: gmean folded with (mu - center) S in the same launch (bias job on the second table)
 hipError_t wc_launch_fast_plan_tables2_bias(const float* B0, int Kc0, void* plan0, const float* scale0,
                                             const float* B1, void* plan1, const float* scale1, int C, hipStream_t st,
-                                            const float* bias, const float* center, const float* mu, float* bias_out)
+                                            const float* bias, const float* center, const float* mu, float* bias_out, int neg_bias)
 {
-    BiasJob bj = {B1, bias, center, mu, bias_out, 1};
+    BiasJob bj = {B1, bias, center, mu, bias_out, 1, neg_bias};
     hipLaunchKernelGGL(split_table_kernel, dim3((unsigned)((Kc0 + 1) * C + C / 2)), dim3(64), 0, st,
                        split_job(B0, Kc0, C, plan0, scale0), split_job(B1, 1, C, plan1, scale1), C, bj);
     return hipGetLastError();

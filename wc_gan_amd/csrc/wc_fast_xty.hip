@@ -111,7 +111,7 @@ template <int C, bool TWO, int RELU = 0, bool XPL = false>
 __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
 {
     static_assert(!RELU || xty_quad<C, TWO>(), "the masked form exists for the quadrant scheme only");
-    static_assert(!XPL || xty_quad<C, TWO>(), "X from planes: the quadrant scheme only");
+    static_assert(!XPL || (TWO && (C == 256 || C == 128)), "X from planes: two operands, C = 256 (quadrant scheme) or 128 (round 5: the plain scheme -- same staging: 8 rows x 4 channels per thread, one v_perm per image word)");
     // QUAD (two operands at C = 256): the 8 x 8 blocks are cut into four 4 x 4 quadrants, one workgroup type each.  A
     // quadrant needs only 128 channels of X and 128 of Y, so a workgroup converts HALF of every row (the three types of
     // the plain scheme convert all of it three times), its images hold twice the rows (64 per stage: half the barriers)
@@ -622,8 +622,8 @@ hipError_t wc_launch_fast_xty(const float* X, const float* Y, const float* cx, c
 {
     FastXtyArgs a = {};
     a.Yrelu = yrelu; a.Yout = yout; a.Ymask = ymask;
-    if (xs) {       // X as pre-split planes: the quadrant form (two operands, C = 256) only; sx = the planes' scales, cx = NULL
-        if (C != 256 || yrelu || cx) return hipErrorInvalidValue;
+    if (xs) {       // X as pre-split planes: two operands, C = 256 (quadrant form, with or without the bit mask) or C = 128 (plain form, no mask); sx = the planes' scales, cx = NULL
+        if ((C != 256 && C != 128) || yrelu || cx || (C == 128 && ymask)) return hipErrorInvalidValue;
         a.Xhi = static_cast<const _Float16*>(xs); a.Xlo = a.Xhi + N * HW * C;      // (N * HW = all rows in either slab layout)
     }
     a.dfix = (Y == X) ? dfix : nullptr;
@@ -634,7 +634,9 @@ hipError_t wc_launch_fast_xty(const float* X, const float* Y, const float* cx, c
     switch (C) {
         case 32: return two ? launch_xty_fast<32, true>(a, st) : launch_xty_fast<32, false>(a, st);
         case 64: return two ? launch_xty_fast<64, true>(a, st) : launch_xty_fast<64, false>(a, st);
-        case 128: return two ? launch_xty_fast<128, true>(a, st) : launch_xty_fast<128, false>(a, st);
+        case 128:
+            if (xs) return launch_xty_fast<128, true, 0, true>(a, st);
+            return two ? launch_xty_fast<128, true>(a, st) : launch_xty_fast<128, false>(a, st);
         case 256:
             if (xs) return ymask ? launch_xty_fast<256, true, 2, true>(a, st) : launch_xty_fast<256, true, 0, true>(a, st);
             return two ? (ymask ? launch_xty_fast<256, true, 2>(a, st) : yrelu ? launch_xty_fast<256, true, 1>(a, st) : launch_xty_fast<256, true>(a, st))

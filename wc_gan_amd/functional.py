@@ -116,7 +116,7 @@ class WhitenColorFunction(torch.autograd.Function):
                 y, mask = ops.apply_split(st, None, A, be, slot, plan=plan, relu=True, folded=True, want_mask=True)
             else:
                 y, mask = ops.apply_split(st, None, A, be, slot, plan=plan, relu=relu, folded=True), None
-            # the backward: K4 / K6 read x from the same planes where they can (wc_bwd_*_xsplit_f32: C = 256 fast paths); elsewhere
+            # the backward: K4 / K6 read x from the same planes where they can (wc_bwd_*_xsplit_f32: C = 256 and 128 fast paths); elsewhere
             # from the fp32 sum the producer wrote beside the planes (st.x32), or -- no such copy -- from one made here
             ctx.xsplit = None
             if any(ctx.needs_input_grad[:3]):
@@ -185,6 +185,8 @@ class WhitenColorFunction(torch.autograd.Function):
             # with the bits and a K6 that masks for itself (C = 256 fast paths) K4 writes no masked copy of the gradient at all
             bits_only = rm is not None and share and need_x and USE_BWD_BITS and ops.bwd_bits_supported(x.shape, slot is not None)
             if xs is not None:
+                if rm is not None and gy.shape[-1] != 256:      # the planes forms of K4 / K6 apply the bits themselves at C = 256 only: one masking pass in front
+                    gy, rm = ops.relu_mask_bits(gy, rm), None
                 out = ops.bwd_reduce_xsplit(xs, mu, gy, slot, Kc, relu_mask=rm, flat=ctx.group is not None)
                 R, gsum = out[0], out[1]
                 rbuf = out[2] if ctx.group is not None else None

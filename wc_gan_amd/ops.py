@@ -730,7 +730,7 @@ def bwd_reduce(x, mu, gy, slot, Kc, flat=False, want_scales=False, relu_y=None, 
 
 def bwd_xsplit_supported(shape, has_slot):
     """Can K4 and K6 of a site of this NHWC shape read x from pre-split planes (bwd_reduce_xsplit / bwd_apply_xsplit: C = 256, the fast
-    reduction and the one-pass K6)?  Then no fp32 copy of x has to exist for the backward."""
+    reduction and the one-pass K6; C = 128: the plain reduction and K6 as planes pass + accumulating pass)?  Then no fp32 copy of x has to exist for the backward."""
     N, C = shape[0], shape[-1]
     HW = 1
     for d in shape[1:-1]:
