@@ -183,3 +183,15 @@ def test_round5_producer_entry_points_check_their_arguments(lib):
     assert lib.wc_whiten_presummed_f16x2(one, 131072, 256, 1, 1e-3, 0.99, 1, None, None, one, one, one, one, 16, None) == -4
     assert lib.wc_stats_presummed_f16x2(one, 131072, 256, 1, None, one, one, nb, None) == -1
     assert lib.wc_stats_presummed_f16x2(one, 131072, 256, 1, one, one, one, 16, None) == -4
+
+
+def test_backward_on_planes_takes_both_generator_widths(lib):
+    """ABI 7: wc_bwd_xsplit_supported at C = 128 (the conditional CIFAR-10 / Tiny-ImageNet generators) as at C = 256; the bit-mask forms
+    of K4 / K6 stay with C = 256 (wc_bwd_bits_supported), and the C = 128 planes entries refuse a mask."""
+    one = ctypes.c_void_p(16)
+    assert lib.wc_bwd_xsplit_supported(128, 1024, 256, 0) == 1 and lib.wc_bwd_xsplit_supported(128, 1024, 128, 1) == 1
+    assert lib.wc_bwd_xsplit_supported(64, 4096, 128, 1) == 1 and lib.wc_bwd_xsplit_supported(128, 1024, 64, 0) == 0
+    assert lib.wc_bwd_xsplit_supported(4, 16, 128, 0) == 0                      # below the fast reduction's minimum
+    assert lib.wc_bwd_bits_supported(128, 1024, 128, 0) == 0 and lib.wc_bwd_bits_supported(128, 1024, 256, 0) == 1
+    assert lib.wc_bwd_reduce_xsplit_f32(one, one, one, one, one, one, None, 128, 1024, 128, 1, one, one, one, one, 1 << 30, None) == -2
+    assert lib.wc_bwd_apply_xsplit_f32(one, one, one, one, one, one, one, one, one, None, 128, 1024, 128, 1, one, one, one, 1 << 30, None) == -2
