@@ -164,6 +164,8 @@ def _site_hist(site, role, device):
         return None
     book = site.__dict__.setdefault('_wc_split_hist', {})
     h = book.get(role)
+    if h is not None and h[0].device != device:     # the layer moved to another device: a fresh record there (its first call measures)
+        h = None
     if h is None:
         if torch.cuda.is_current_stream_capturing():
             return None
