@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define WC_ABI_VERSION 7
+#define WC_ABI_VERSION 8
 
 #define WC_OK                 0
 #define WC_ERR_NULL          -1   /* a required pointer is NULL                     */
@@ -544,12 +544,17 @@ int wc_conv_split_colsum_f32(const float* x, int64_t n, int relu, void* hi, void
  * left -- and the power of two that puts THAT maximum into [2^7, 2^8): room for a 255-fold growth before fp16 overflows, precision to
  * 2^-20 of the tensor's maximum down to a 4000-fold shrink (hi + lo carry 22 bits wherever the scaled maximum lies in [2^-5, 65504]);
  * each workgroup leaves (its maximum, tag + 1) in the other array.  No atomics, no host-side parity: the record is a function of the
- * sequence of tensors alone, so an eager run and a replayed hipGraph of the same calls give the same bits.  NOTHING clamps: an element
- * that does not fit becomes inf in the planes -- loud downstream, never quietly wrong.  bootstrap != 0 (the site's first call): the
- * two-launch form with the measured maximum, which seeds the record.  Calls of one site must be ordered (one stream, or events).
+ * sequence of tensors alone, so an eager run and a replayed hipGraph of the same calls give the same bits.  NOTHING clamps.
+ * ABI 8: a gated second launch follows on the same stream; it reads the record (the tensor's own maximum is in it by then) and, when the
+ * scaled maximum fell outside [2^-5, 65504) -- the previous tensor was all zero (a saturated hinge critic), a growth beyond 255-fold, a
+ * shrink beyond 4096-fold -- splits the tensor again with the MEASURED scale (the bits of wc_conv_split_f32) and counts the event in word
+ * WC_CONV_HIST_REDO of `hist`; inside the window it returns at once.  Capturable, no host synchronisation, never quietly wrong.
+ * bootstrap != 0 (the site's first call): the two-launch form with the measured maximum, which seeds the record.  Calls of one site must
+ * be ordered (one stream, or events).
  * colsum_partials / C as in wc_conv_split_colsum_f32 (nullable).  Replaces the absmax pass of wc_conv_split_f32 (~130 launches of
  * 3-30 us per G+D step; reference call sites: every Conv2D of discriminator.py:41-54 / generator.py:142-158 as in wc_conv_f16x3). */
-#define WC_CONV_HIST_FLOATS (4 * 512)
+#define WC_CONV_HIST_FLOATS (4 * 512 + 16)
+#define WC_CONV_HIST_REDO (4 * 512)      /* index of the uint32 count of second passes taken */
 int wc_conv_split_hist_f32(const float* x, int64_t n, int relu, void* hi, void* lo, float* scale, float* colsum_partials /*nullable*/, int C,
                            float* hist, int bootstrap, wc_stream_t stream);
 

@@ -36,7 +36,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_abi_version_and_error_strings(lib):
     from wc_gan_amd import _lib
-    assert lib.wc_abi_version() == _lib.ABI_VERSION == 7
+    assert lib.wc_abi_version() == _lib.ABI_VERSION == 8
     assert b"multiple of 32" in lib.wc_error_string(-3)
     assert lib.wc_error_string(0) == b"ok"
 

@@ -271,20 +271,77 @@ def test_history_scaled_split_gives_the_same_bits_eagerly_and_from_a_graph():
             assert torch.equal(o[0], e[0]) and torch.equal(o[1], e[1]) and torch.equal(o[2][:1], e[2][:1]), (rep, k)
 
 
+def _redo_count(site, role='x'):
+    from wc_gan_amd import conv as C
+    return int(site.__dict__['_wc_split_hist'][role][0].view(torch.int32)[C.HIST_REDO])
+
+
 @pytest.mark.gpu
-def test_history_scaled_split_is_loud_when_the_tensor_outgrows_its_headroom():
-    """Nothing clamps: a tensor that grew more than ~255-fold since the site's previous call does not fit fp16 with the previous call's
-    scale -- its largest elements become inf in the planes (and NaN / inf in any convolution of them) instead of a quietly wrong number;
-    the call after that is exact again (it has seen the new maximum)."""
+def test_history_scaled_split_outside_its_window_is_split_again_with_the_measured_scale():
+    """Round 6: the previous call's maximum can be wrong in three ways -- the tensor grew more than 255-fold
+    (round 5: inf in the planes, NaN in the weights one optimizer step later, no redo), it shrank more than 4096-fold (round 5: the lo plane
+    in fp16's subnormals, quietly fewer bits), or the previous tensor was ALL ZERO (round 5: scale 1.0, whatever the next tensor is -- a
+    hinge critic whose margins are all met hands back exactly-zero gradients).  The gated second launch sees the tensor's own maximum in
+    the record and splits again with the measured scale: the planes are then the two-launch form's, bit for bit, and the site's counter
+    says the second pass ran.  Inside the window it does not run."""
     from wc_gan_amd import conv as C
     torch.manual_seed(4)
     site = _Site()
     x = torch.randn(8, 16, 16, 128, device='cuda')
     C.split_planes(x, site=site)
-    big = C.split_planes(x * 3000.0, site=site)
-    assert not bool(torch.isfinite(big[0].float()).all())
-    again = C.split_planes(x * 3000.0, site=site)
-    assert float((_back(again) - (x * 3000.0).double()).abs().max() / (x * 3000.0).abs().max()) < 2.0 ** -20
+    assert _redo_count(site) == 0
+    ok = C.split_planes(x * 4.0, site=site)                        # inside the window: history scale, no second pass
+    assert _redo_count(site) == 0 and float(ok[2][0]) != float(C.split_planes(x * 4.0)[2][0])
+    def exact(t, got):
+        ref = C.split_planes(t)
+        return torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]) and torch.equal(got[2][:1], ref[2][:1])
+    big = C.split_planes(x * 12000.0, site=site)                    # x 3000 from one call to the next
+    assert bool(torch.isfinite(big[0].float()).all()) and exact(x * 12000.0, big) and _redo_count(site) == 1
+    small = C.split_planes(x * 0.12, site=site)                     # / 100000
+    assert exact(x * 0.12, small) and _redo_count(site) == 2
+    assert float((_back(small) - (x * 0.12).double()).abs().max() / (x * 0.12).abs().max()) < 2.0 ** -20
+    # zeros, then a tensor of size 1e-4: 2^-20 of its maximum
+    z = C.split_planes(torch.zeros_like(x), site=site)
+    assert _redo_count(site) == 2 and not bool(z[0].any()) and not bool(z[1].any())
+    z2 = C.split_planes(torch.zeros_like(x), site=site)            # zeros after zeros: nothing to redo either
+    assert _redo_count(site) == 2 and not bool(z2[0].any())
+    tiny = x * 1.0e-4
+    got = C.split_planes(tiny, site=site)
+    assert exact(tiny, got) and _redo_count(site) == 3
+    assert float((_back(got) - tiny.double()).abs().max() / tiny.abs().max()) < 2.0 ** -20
+    nxt = C.split_planes(tiny * 2.0, site=site)                    # the record now holds the measured maximum: history again
+    assert _redo_count(site) == 3
+    assert float((_back(nxt) - (tiny * 2.0).double()).abs().max() / (tiny * 2.0).abs().max()) < 2.0 ** -20
+    # with the ReLU in the split: the maximum that counts is the one of what is split (a tensor whose positive part is tiny)
+    site2 = _Site()
+    y = torch.where(x > 0, x * 1.0e-5, x * 50.0)
+    C.split_planes(x, relu=True, site=site2)
+    gr = C.split_planes(y, relu=True, site=site2)
+    ref = C.split_planes(y, relu=True)
+    assert torch.equal(gr[0], ref[0]) and torch.equal(gr[1], ref[1]) and _redo_count(site2) == 1
+
+
+@pytest.mark.gpu
+def test_history_scaled_split_second_pass_inside_a_graph():
+    """The gate is on the device: a captured sequence takes the second pass on exactly the replays whose tensors need it."""
+    from wc_gan_amd import conv as C
+    torch.manual_seed(8)
+    site = _Site()
+    x = torch.randn(8, 16, 16, 128, device='cuda')
+    C.split_planes(x, site=site)
+    buf = torch.empty_like(x)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = C.split_planes(buf, site=site)
+    for factor, redo in ((2.0, 0), (0.0, 0), (1.0e-3, 1), (3.0e-3, 0), (40.0, 1), (40.0, 0)):
+        before = _redo_count(site)
+        buf.copy_(x * factor)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert _redo_count(site) - before == redo, (factor, redo)
+        if factor:
+            assert float((_back(out) - buf.double()).abs().max() / buf.abs().max()) < 2.0 ** -20, factor
+            assert bool(torch.isfinite(out[0].float()).all())
 
 
 @pytest.mark.gpu

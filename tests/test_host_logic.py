@@ -216,6 +216,31 @@ def test_keras_named_checkpoint_covers_embedding_batchnorm_and_any_dense_index()
         load_keras_named(G2, st)
 
 
+def test_keras_named_checkpoint_loads_the_legacy_sn_embedding_spelling():
+    """rounds 3-4 of this build wrote a spectrally normalised embedding as `sn_embedding_<n>` (two d); upstream's class is
+    SNEmbeding and Keras names it `sn_embeding_<n>`, which is what _entries emits since round 5.  A file with the old spelling -- and any
+    index -- must still load (it raised `missing weight`, or loaded nothing with strict=False)."""
+    from wc_gan_amd.checkpoint import keras_named_state, load_keras_named
+    from wc_gan_amd.spectral import SNEmbedding
+
+    class D(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.emb = SNEmbedding(7, 12)
+
+    torch.manual_seed(2)
+    a, b = D(), D()
+    st = keras_named_state(a)
+    assert any(k.startswith('sn_embeding_1/') for k in st) and not any(k.startswith('sn_embedding_') for k in st)
+    legacy = {k.replace('sn_embeding_1/', 'sn_embedding_5/'): v for k, v in st.items()}
+    seen = load_keras_named(b, legacy)
+    assert len(seen) == len(st)
+    for k, v in keras_named_state(b).items():
+        assert np.array_equal(v, st[k]), k
+    c = D()
+    assert len(load_keras_named(c, legacy, strict=False)) == len(st) and torch.equal(c.emb.weight, a.emb.weight)
+
+
 def test_h5_converter_round_trip_when_h5py_is_available(tmp_path):
     """tools/h5_to_npz.py (runs wherever h5py exists; skipped here when it does not)."""
     pytest.importorskip("h5py")

@@ -22,3 +22,12 @@ t0 = min(int(r[0]) for r in st if int(r[127]) > 0)
 for w, row in enumerate(st):
     n = int(row[127]); t = (row[:n].astype(np.int64) - t0)
     print("wave %2d (SIMD %d): " % (w, w & 3) + " ".join("%d>%d" % (t[k], t[k + 1]) for k in range(0, min(n - 1, 24), 2)))
+
+# wave 0's phases per step j >= 1 (slots 40 + 5 j + {0: next diagonal block solved + updated, in LDS; 1: its 16 columns loaded;
+# 2: factored + inverted; 3: stores issued}), relative to the release of barrier (A) of step j - 1
+row = st[0]; n = int(row[127]); t = row[:n].astype(np.int64) - t0
+for j in range(1, min(C // 16, 16)):
+    if 2 * (j - 1) + 1 >= n: break
+    rel = int(t[2 * (j - 1) + 1]); ph = [int(row[40 + 5 * j + q]) - t0 - rel for q in range(4)]
+    arrive = int(t[2 * j]) - rel if 2 * j < n else -1
+    print("step %2d: update done +%d, columns loaded +%d, leaf done +%d, stores issued +%d, at barrier +%d" % (j, ph[0], ph[1], ph[2], ph[3], arrive))

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwc_hip.so")
 
 WC_OK = 0
-ABI_VERSION = 7          # WC_ABI_VERSION of include/wc_hip.h
+ABI_VERSION = 8          # WC_ABI_VERSION of include/wc_hip.h
 ERRORS = {-1: "WC_ERR_NULL", -2: "WC_ERR_SHAPE", -3: "WC_ERR_CHANNELS", -4: "WC_ERR_WORKSPACE", -5: "WC_ERR_ARG"}
 
 # name -> (restype, argtypes); mirrors include/wc_hip.h one to one

@@ -144,27 +144,35 @@ OPTIONAL_SUFFIXES = ("/v:0",)        # this build's additions: an upstream file 
 _AUTO_NAME = re.compile(r"^(dense|sn_dense|embedding|sn_embeding|sn_embedding)_(\d+)/(.+)$")     # (sn_embedding: files written by rounds 3-4 of this build)
 
 
+_LEGACY_KINDS = {'sn_embedding': 'sn_embeding'}
+
+
 def _renumber_auto_names(module, state):
     """Keras numbers unnamed layers with a process-global counter (`dense_1`, `dense_7` ... depending on what was built before the
     generator), so a file's `dense_N` need not be this build's `dense_1`: the n-th distinct index of a kind in the file (ascending)
     is taken for the n-th such layer of the module."""
+    # the kind as THIS build spells it: rounds 3-4 wrote `sn_embedding_N`, upstream's class SNEmbeding snake-cases to `sn_embeding_N`
+    # (ADVICE r5: the legacy spelling matched _AUTO_NAME but was never rewritten, so such a file failed with `missing weight` or, with
+    # strict=False, loaded nothing)
+    canon = lambda kind: _LEGACY_KINDS.get(kind, kind)
     want = {}
     for k, _, _, _ in _entries(module):
         m = _AUTO_NAME.match(k)
         if m:
-            want.setdefault(m.group(1), set()).add(int(m.group(2)))
+            want.setdefault(canon(m.group(1)), set()).add(int(m.group(2)))
     have = {}
     for k in state:
         m = _AUTO_NAME.match(k)
         if m:
-            have.setdefault(m.group(1), set()).add(int(m.group(2)))
+            have.setdefault(canon(m.group(1)), set()).add(int(m.group(2)))
     out = {}
     for k, v in state.items():
         m = _AUTO_NAME.match(k)
-        if m and m.group(1) in want and sorted(have[m.group(1)]) != sorted(want[m.group(1)]) \
-                and len(have[m.group(1)]) == len(want[m.group(1)]):
-            idx = sorted(want[m.group(1)])[sorted(have[m.group(1)]).index(int(m.group(2)))]
-            k = f"{m.group(1)}_{idx}/{m.group(3)}"
+        if m:
+            kind, idx = canon(m.group(1)), int(m.group(2))
+            if kind in want and sorted(have[kind]) != sorted(want[kind]) and len(have[kind]) == len(want[kind]):
+                idx = sorted(want[kind])[sorted(have[kind]).index(idx)]
+            k = f"{kind}_{idx}/{m.group(3)}"
         out[k] = v
     return out
 

@@ -152,7 +152,8 @@ def _colsum_ok(C):
 # an element that does not fit goes inf = loud).  Training-mode layers only: an eval-mode pass measures every tensor, so that the images of a
 # loaded checkpoint do not depend on what the process ran before.  WC_SPLIT_HIST=0: the measured maximum everywhere, two launches (rounds 1-4).
 SPLIT_HIST = os.environ.get('WC_SPLIT_HIST', '1') != '0'
-HIST_FLOATS = 4 * 512          # include/wc_hip.h WC_CONV_HIST_FLOATS
+HIST_FLOATS = 4 * 512 + 16     # include/wc_hip.h WC_CONV_HIST_FLOATS
+HIST_REDO = 4 * 512            # WC_CONV_HIST_REDO: uint32 count of the gated second passes a site has taken
 
 
 def _site_hist(site, role, device):

@@ -474,6 +474,62 @@ __global__ __launch_bounds__(256) void conv_split_hist_kernel(const float* __res
     }
 }
 
+// ---- the history-scaled split's gated second pass (round 6) ---------------------------------------------------------------------------
+// The launch above trusts the previous call's maximum.  Three things can make that wrong: the previous tensor was all zero (nothing to
+// go by: a saturated hinge loss gives the critic exactly-zero gradients), the tensor grew more than 255-fold (inf in the planes), or it
+// shrank more than 4096-fold (the lo plane sinks into fp16's subnormals: fewer than 20 bits of the maximum, quietly).  This launch
+// follows the split on the same stream: both arrays of the record are complete and at rest now -- the one with the larger tag holds the
+// maximum of THIS tensor, the other one what the split assumed -- so every workgroup reaches the same verdict from the same 8 KB
+// without a flag, a fence or a counter: inside the window it returns (the usual case: a launch of ~2 us that reads 8 KB), outside it
+// splits the tensor again with the measured scale, exactly as conv_split_kernel would have (same bits as the two-launch form).
+// hist[WC_CONV_HIST_REDO] counts the second passes taken (tests, long-run logs).  Capturable; no host synchronisation.
+constexpr int kHistRedoWord = 2 * kHistArray;
+__global__ __launch_bounds__(256) void conv_split_redo_kernel(const float* __restrict__ x, int64_t n4, int relu, _Float16* __restrict__ hi,
+                                                              _Float16* __restrict__ lo, float* __restrict__ scale_out,
+                                                              float* __restrict__ hist)
+{
+    typedef int i32x2h __attribute__((ext_vector_type(2)));
+    float mx[2] = {0.f, 0.f};
+    int tg[2] = {0, 0};
+    #pragma unroll
+    for (int arr = 0; arr < 2; ++arr)
+        #pragma unroll
+        for (int i = 0; i < kAmaxBlocks / 64; ++i) {
+            const i32x2h p = *reinterpret_cast<const i32x2h*>(hist + arr * kHistArray + 2 * ((threadIdx.x & 63) + 64 * i));
+            mx[arr] = fmaxf(mx[arr], __builtin_bit_cast(float, p[0]));
+            tg[arr] = max(tg[arr], p[1]);
+        }
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        #pragma unroll
+        for (int arr = 0; arr < 2; ++arr) {
+            mx[arr] = fmaxf(mx[arr], __shfl_xor(mx[arr], o));
+            tg[arr] = max(tg[arr], __shfl_xor(tg[arr], o));
+        }
+    const int now = tg[1] > tg[0] ? 1 : 0;
+    const float own = mx[now], assumed = mx[1 - now];
+    const float s_used = scale_for(assumed * kHistMargin);
+    const float top = own * s_used;                // the scaled maximum the planes were written with
+    // (a NaN maximum never reaches here: fmaxf drops NaN operands; a tensor holding inf has own = inf -> no finite scale exists, leave it loud)
+    const bool fine = !(own > 0.f) || !(own < 3.0e38f) || (top >= 0.03125f && top < 65504.0f);
+    if (fine) return;
+    const float s = scale_for(own);                // the measured form's scale: the maximum into [2^13, 2^14)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        scale_out[0] = s;
+        reinterpret_cast<unsigned*>(hist)[kHistRedoWord] += 1u;
+    }
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * i);
+        if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        v = v * s;
+        f16x4 h, l;
+        #pragma unroll
+        for (int j = 0; j < 4; ++j) { h[j] = (_Float16)v[j]; l[j] = (_Float16)(v[j] - (float)h[j]); }
+        *reinterpret_cast<f16x4*>(hi + 4 * i) = h;
+        *reinterpret_cast<f16x4*>(lo + 4 * i) = l;
+    }
+}
+
 // ---- weight fragment images ----------------------------------------------------------------------------------------
 struct WeightArgs {
     const float* w; int64_t sk, sn, sr, ss;        // element (k, n, r, s) of the source = w[k*sk + n*sn + r*sr + s*ss]
@@ -1146,6 +1202,10 @@ int wc_conv_split_hist_f32(const float* x, int64_t n, int relu, void* hi, void* 
     // always kAmaxBlocks workgroups: they are the partial rows conv_wrw_reduce_kernel adds up
     hipLaunchKernelGGL(conv_split_hist_kernel, dim3(kAmaxBlocks), dim3(256), 0, st, x, n / 4, relu, (_Float16*)hi, (_Float16*)lo, scale,
                        hist, colsum_partials, colsum_partials ? C >> 2 : 0);
+    static const bool redo = !(getenv("WC_SPLIT_HIST_REDO") && getenv("WC_SPLIT_HIST_REDO")[0] == '0');      // development A/B only: "0" = round 5's unguarded form
+    if (redo)
+        hipLaunchKernelGGL(conv_split_redo_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, x, n / 4, relu, (_Float16*)hi, (_Float16*)lo,
+                           scale, hist);
     return (int)hipGetLastError();
 }
 

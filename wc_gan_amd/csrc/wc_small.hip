@@ -866,8 +866,11 @@ __global__ __launch_bounds__(1024) void cholesky_fused_kernel(double* __restrict
     }
     unsigned* rowflag = rows ? rows + 16 * blockIdx.x : nullptr;
     double* Praw = sm;                          // [2][C][17]  the current / next panel as its owners hold it (row-major)
-    double* Pn = Praw + 2 * C * 17;             // [16][ldp]   solved panel, column-major: the update's MFMA operands
-    double* Dinv = Pn + 16 * ldp;               // [2][16][17] INVERSE of the factored diagonal block (even / odd steps)
+    double* Pn = Praw + 2 * C * 17;             // [C][17]     solved panel, row-major like Praw: the update's MFMA operands.  (Round 6: it was
+                                                // [16][C + 2] column-major -- lanes (li, lq) and (li + 2, lq - 1) of an operand read met in one bank,
+                                                // every read ran twice: 95 cycles per f64 MFMA against the instruction's own 64,
+                                                // tools/probe/mfma_f64_rate.hip)
+    double* Dinv = Pn + C * 17;                 // [2][16][17] INVERSE of the factored diagonal block (even / odd steps)
     double* Dpre = Dinv + 2 * 16 * 17;          // [2][16][17] diagonal block (b, b) with every update but the last one, b even / odd
     volatile int* const cntB = reinterpret_cast<volatile int*>(Dpre + 2 * 16 * 17);      // CF_SPLIT_B: owner waves through the panel solve (running count)
     const unsigned cntB_lds = (unsigned)(size_t)((__attribute__((address_space(3))) char*)(Dpre + 2 * 16 * 17));
@@ -978,13 +981,13 @@ __global__ __launch_bounds__(1024) void cholesky_fused_kernel(double* __restrict
             }
 #else
             CF_BARRIER();                                          // (B) the others have solved panel j
-            const double* px = Pn + lq * ldp + 16 * (j + 1) + li;
+            const double* px = Pn + (16 * (j + 1) + li) * 17 + lq;
 #pragma unroll
             for (int r = 0; r < 4; ++r) d4[r] = dp[(lq + 4 * r) * 17 + li];
             d4 = __builtin_amdgcn_mfma_f64_16x16x4f64(-px[0], px[0], d4, 0, 0, 0);
-            d5 = __builtin_amdgcn_mfma_f64_16x16x4f64(-px[4 * ldp], px[4 * ldp], d5, 0, 0, 0);
-            d4 = __builtin_amdgcn_mfma_f64_16x16x4f64(-px[8 * ldp], px[8 * ldp], d4, 0, 0, 0);
-            d5 = __builtin_amdgcn_mfma_f64_16x16x4f64(-px[12 * ldp], px[12 * ldp], d5, 0, 0, 0);
+            d5 = __builtin_amdgcn_mfma_f64_16x16x4f64(-px[4], px[4], d5, 0, 0, 0);
+            d4 = __builtin_amdgcn_mfma_f64_16x16x4f64(-px[8], px[8], d4, 0, 0, 0);
+            d5 = __builtin_amdgcn_mfma_f64_16x16x4f64(-px[12], px[12], d5, 0, 0, 0);
 #endif
             d4 += d5;
 #pragma unroll
@@ -1018,11 +1021,11 @@ __global__ __launch_bounds__(1024) void cholesky_fused_kernel(double* __restrict
         auto update = [&](auto Q) __attribute__((always_inline)) {
             constexpr int q = decltype(Q)::value;
             const int bc = bc_[q];
-            const double* pa = Pn + lq_t * ldp + 16 * (bc >> 8) + li_t;
-            const double* pb = Pn + lq_t * ldp + 16 * (bc & 255) + li_t;
+            const double* pa = Pn + (16 * (bc >> 8) + li_t) * 17 + lq_t;
+            const double* pb = Pn + (16 * (bc & 255) + li_t) * 17 + lq_t;
             double av[4], bv[4];
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) { av[kk] = -pa[4 * kk * ldp]; bv[kk] = pb[4 * kk * ldp]; }
+            for (int kk = 0; kk < 4; ++kk) { av[kk] = -pa[4 * kk]; bv[kk] = pb[4 * kk]; }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) blk[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], blk[q], 0, 0, 0);
         };
@@ -1057,7 +1060,7 @@ __global__ __launch_bounds__(1024) void cholesky_fused_kernel(double* __restrict
                     for (int e = 0; e < 4; ++e) {
                         const int r = row0 + lq_t + 4 * e;
                         st_sc1(T + (int64_t)r * C + j0 + li_t, x[e]);      // write-through: the inverse role reads it in this launch
-                        Pn[li_t * ldp + r] = x[e];
+                        Pn[r * 17 + li_t] = x[e];
                     }
                 }
             }
@@ -1577,8 +1580,8 @@ hipError_t wc_launch_stats_prepare(const double* P, const float* colsum, const f
 
 hipError_t wc_launch_factor_fused(double* T, double* W, double* tmp, int C, int groups, hipStream_t st)
 {
-    const int nb = C >> 4, ldp = C + 2;
-    size_t lds = (size_t)(2 * C * 17 + 16 * ldp + 4 * 16 * 17 + 2) * sizeof(double);      // (+ the owners' panel counter)
+    const int nb = C >> 4, ldp = 17;
+    size_t lds = (size_t)(2 * C * 17 + C * 17 + 4 * 16 * 17 + 2) * sizeof(double);      // (+ the owners' panel counter)
     const bool one = factor_one_launch(C, groups);
     static const bool split = getenv("WC_K2_SPLIT") != nullptr;         // development: the four-waves-per-column inverse as a launch of its own
     const size_t lds_role = ti_role_lds_doubles(C) * sizeof(double);
