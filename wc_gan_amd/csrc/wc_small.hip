@@ -1125,6 +1125,405 @@ __global__ __launch_bounds__(1024) void cholesky_fused_kernel(double* __restrict
     // were written whole
 }
 
+// =================================================================================================================================
+// K2 in PHASES with helper workgroups (round 6; VERDICT r5 item 1: "take the small-matrix stage off one CU").
+//
+// What the stamps of cholesky_fused_kernel said at C = 256 (profiles/r6_k2_timeline.txt): the kernel is the sum over its 16 steps of
+// max(wave 0's chain, the owners' panel solve + trailing update).  Wave 0 needs 6 300 - 7 700 cycles per step (3 100 - 5 700 of them the
+// 16 x 16 leaf, 1 200 - 2 000 the 48 stores behind it); the owners need 14 900 / 13 700 / 13 100 / 12 000 / 10 100 ... cycles in steps
+// 0 .. 4 for work whose f64-MFMA floor on one CU is 8 600 / 7 600 / 6 700 / 5 800 / 4 900: the first eight steps are bound by ONE CU's
+// matrix pipe, the last eight by wave 0.  Spreading every step's update over several CUs puts a cross-CU hand-off (~1 us each way) into
+// every step's critical path -- longer than the step; that is what killed the forms of DESIGN 4.7 / 8.  The split here is by COLUMNS
+// and by TIME instead:
+//   phase 1: the factorising workgroup (F) owns block columns 0 .. split-1 only (C = 256: split = 6, 65 trailing blocks instead of
+//            120) and runs the look-ahead algorithm on them unchanged -- every row of every panel is solved by F (the panel is F's own
+//            column) and leaves for global memory write-through, as it always did for the inverse role;
+//            CP_NH helper workgroups (H) own the trailing blocks of columns >= split (55 blocks, one per wave).  They follow F through
+//            a counter of complete panels, a step or two BEHIND it: fetch rows >= 16 split of panel j (20 KB), apply it to their
+//            blocks (four MFMAs per wave), wait for the next one.  Nothing F does in phase 1 waits for them.
+//   boundary: after panel split-1 the helpers store their blocks (write-through) and count themselves done; F picks the trailing matrix
+//            up again -- the same loads as at kernel start, from the helpers' output -- and
+//   phase 2: factors columns split .. nb-1 as it would a matrix of that size.
+// One hand-off per launch instead of one per step; F's owner waves hold 5 blocks each instead of 8 (40 VGPRs: the register file is no
+// longer at its limit, which is what let the publisher below in without spills).
+// Also new on F's side: (a) wave 0 leaves the factored block and its inverse in LDS only; owner wave 1 copies them to global memory behind
+// barrier (A) (publish_diag) and counts the complete row blocks for the inverse role; (b) the panel solve's row blocks go to the twelve
+// owners that do not share wave 0's SIMD; (c) no workgroup barrier in front of the first step: wave 0 takes its block straight from
+// global memory while the others stage the panel.
+// Hand-off protocol (MI355X_MICROARCH.md, "Valid forms": all payload bytes sc1 stores / sc1 loads, every storing wave's vmcnt(0), a
+// workgroup barrier, ONE lane's sc1 flag store or agent-scope add; the consumer's polling wave loads behind its own poll, the others
+// behind a barrier).  Every workgroup of the launch must be resident at once, as for tri_inverse_role: groups * (1 + TI_WG + CP_NH) <= 72.
+// sync words of matrix g (zeroed by the prepare launch): sync[16 g] complete row blocks, +1 error bits, +2 complete panels, +3 helpers done.
+// =================================================================================================================================
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+constexpr int CP_NH = 4;                    // helper workgroups per matrix
+constexpr int CP_SLOTS = 5;                 // trailing blocks per owner wave of F
+constexpr int CP_MAXB = 15 * CP_SLOTS;      // ... so a phase holds at most 75 blocks
+__host__ __device__ constexpr int cp_colblocks(int c, int c1, int nb)          // blocks (bi >= bj) of the block columns c .. c1-1
+{ return c1 > c ? (c1 - c) * (2 * nb - c - c1 + 1) / 2 : 0; }
+// the block column where the helpers' part begins (nb: no helpers, one phase)
+__host__ __device__ constexpr int cp_split(int nb) { return nb >= 12 ? nb - 10 : nb; }
+__host__ __device__ constexpr size_t cp_factor_lds_doubles(int C) { return (size_t)3 * C * 17 + 6 * 16 * 18 + 2; }
+__host__ __device__ constexpr size_t cp_helper_lds_doubles(int C) { return (size_t)2 * 160 * 17 + 2; }
+
+__device__ __forceinline__ bool cp_wait_word(const unsigned* w, unsigned target)
+{
+    unsigned spins = 0;              // bounded: a lost producer must not hang the device
+    while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(2);
+    return spins < (1u << 22);
+}
+
+__device__ __forceinline__ void cp_helper_role(double* __restrict__ T, int C, unsigned* sync, int split, int h, double* sm)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lq = lane >> 4;
+    const int nb = C >> 4, nreg = nb - split, row0 = 16 * split;
+    double* Pn = sm;                                   // [2][nreg * 16][17]  rows >= 16 split of panel j, even / odd j
+    unsigned* ok = reinterpret_cast<unsigned*>(sm + 2 * 160 * 17);
+    // this wave's block: rank h*16 + wave over the region's columns, LAST column first (as F deals its own)
+    const int r = h * 16 + wave;
+    int bi = 0, bj = 0;
+    bool has = false;
+    {
+        int m = 0;
+        while ((m + 1) * (m + 2) / 2 <= r) ++m;         // column nb-1-m holds m+1 blocks
+        if (m < nreg) { has = true; bj = nb - 1 - m; bi = bj + (r - m * (m + 1) / 2); }
+    }
+    f64x4 blk = {0.0, 0.0, 0.0, 0.0};
+    if (has) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) blk[e] = T[(int64_t)(16 * bi + lq + 4 * e) * C + 16 * bj + li];
+    }
+    if (tid == 0) *ok = 1u;
+    const double* pa0 = Pn + (16 * (bi - split) + li) * 17 + lq;
+    const double* pb0 = Pn + (16 * (bj - split) + li) * 17 + lq;
+#pragma unroll 1
+    for (int j = 0; j < split; ++j) {
+        if (tid == 0 && !cp_wait_word(sync + 2, (unsigned)j + 1)) *ok = 0u;
+        __syncthreads();
+        double* pn = Pn + (j & 1) * (160 * 17);
+        for (int e = tid; e < nreg * 256; e += 1024)
+            pn[(e >> 4) * 17 + (e & 15)] = ld_sc1(T + (int64_t)(row0 + (e >> 4)) * C + 16 * j + (e & 15));
+        __syncthreads();
+        if (has) {
+            const double* pa = pa0 + (j & 1) * (160 * 17);
+            const double* pb = pb0 + (j & 1) * (160 * 17);
+            double av[4], bv[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) { av[kk] = -pa[4 * kk]; bv[kk] = pb[4 * kk]; }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) blk = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], blk, 0, 0, 0);
+        }
+    }
+    if (has) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) st_sc1(T + (int64_t)(16 * bi + lq + 4 * e) * C + 16 * bj + li, blk[e]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        if (*ok == 0u) atomicOr(sync + 1, 2u);          // a wait ran out: the host reads the error word (wc_factor_error_offset)
+        __hip_atomic_fetch_add(sync + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+#define CP_BARRIER() do { if (CF_STAMPS && stamp_ok && nstamp < 100) stamps[nstamp++] = __builtin_amdgcn_s_memtime();              \
+                          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                          \
+                          if (CF_STAMPS && stamp_ok && nstamp < 100) stamps[nstamp++] = __builtin_amdgcn_s_memtime(); } while (0)
+
+__device__ __forceinline__ void cp_factor_role(double* __restrict__ T, double* __restrict__ Linv, int C, unsigned* sync, int split, double* sm,
+                                               unsigned long long* stamp_base)
+{
+    double* Praw = sm;                          // [2][C][17]  the current / next panel as its owners hold it (row-major)
+    double* Pn = Praw + 2 * C * 17;             // [C][17]     solved panel: the update's MFMA operands
+    // the three 16 x 16 hand-off blocks have rows of 18 doubles: 16-byte aligned, so wave 0 moves them with 128-bit LDS accesses
+    // (16 writes + 8 reads per step instead of 32 + 16: ~600 cycles of its chain), conflict-free for the MFMA operand reads
+    double* DinvT = Pn + C * 17;                // [2][16][18] INVERSE of the factored diagonal block, TRANSPOSED: [c][i] = Linv[i][c] (even / odd steps)
+    double* Dpre = DinvT + 2 * 16 * 18;         // [2][16][18] diagonal block (b, b) with every update but the last one, b even / odd
+    double* Ldg = Dpre + 2 * 16 * 18;           // [2][16][18] the factored diagonal block on its way to global memory (even / odd steps)
+    const unsigned cntB_lds = (unsigned)(size_t)((__attribute__((address_space(3))) char*)(Ldg + 2 * 16 * 18));
+    volatile int* const cntB = reinterpret_cast<volatile int*>(Ldg + 2 * 16 * 18);      // owner waves through the panel solve (running count)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lq = lane >> 4;
+    const int nb = C >> 4;
+    const int nph = split < nb ? 2 : 1;
+    const bool stamp_ok = CF_STAMPS && lane == 0 && blockIdx.x == 0;
+    unsigned long long* stamps = stamp_base + wave * 128;
+    int nstamp = 0;
+    (void)stamps; (void)nstamp; (void)stamp_ok;
+    if (tid == 0) cntB[0] = 0;
+
+    if (wave == 0) {
+        // ---- wave 0: the diagonal blocks.  Factor + invert block (j, j) [lane = row / column, all four 16-lane rows do the same work],
+        //      results into LDS; the look-ahead between two barriers (A) as in cholesky_fused_kernel.
+        __builtin_amdgcn_s_setprio(3);
+        auto factor = [&](int j, const double* src) __attribute__((always_inline)) {
+            double a[16], w[16];
+            if (src) {
+#pragma unroll
+                for (int c = 0; c < 16; c += 2) {
+                    const f64x2 v = *reinterpret_cast<const f64x2*>(src + li * 18 + c);
+                    a[c] = v[0]; a[c + 1] = v[1];
+                }
+            } else {                            // the first block of a phase: from global memory (the helpers' output in phase 2)
+#pragma unroll
+                for (int c = 0; c < 16; ++c) a[c] = ld_sc1(T + (int64_t)(16 * j + li) * C + 16 * j + c);
+            }
+            if (CF_STAMPS && stamp_ok) { if (src) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                                         stamps[40 + 5 * j + 1] = __builtin_amdgcn_s_memtime(); }
+            static_for<0, 16>([&](auto J) {
+                constexpr int jj = decltype(J)::value;
+                const double p = row_bcast<jj>(a[jj]);
+                double rd = __builtin_amdgcn_rsq(p);
+                rd = rd * (1.5 - 0.5 * p * rd * rd);
+                a[jj] = a[jj] * rd;                                     // (lane jj's a[jj] IS the pivot)
+                dpp_settle(a[jj]);
+                const double nj = -a[jj];
+                static_for<jj + 1, 16>([&](auto K) {
+                    constexpr int k = decltype(K)::value;
+                    fmac_bcast<k>(a[k], a[jj], nj);                    // a[li][k] -= l[k][jj] * l[li][jj]
+                });
+                double acc = (li == jj) ? -1.0 : 0.0;                  // lane jj: w = rd; lanes above jj: the sum is zero by itself
+                static_for<0, jj>([&](auto K) {
+                    constexpr int k = decltype(K)::value;
+                    fmac_bcast<jj>(acc, a[k], w[k]);                   // acc += l[jj][k] * w[k][c]
+                });
+                w[jj] = -acc * rd;
+            });
+            if (CF_STAMPS && stamp_ok) { asm volatile("" :: "v"(a[15]), "v"(w[15])); stamps[40 + 5 * j + 2] = __builtin_amdgcn_s_memtime(); }
+            if (lane < 16) {
+                double* lg = Ldg + (j & 1) * (16 * 18);
+                double* dv = DinvT + (j & 1) * (16 * 18);
+#pragma unroll
+                for (int c = 0; c < 16; c += 2) *reinterpret_cast<f64x2*>(lg + lane * 18 + c) = f64x2{a[c], a[c + 1]};     // (publish_diag zeroes what lies above the diagonal)
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) *reinterpret_cast<f64x2*>(dv + lane * 18 + i) = f64x2{w[i], w[i + 1]};     // [c][i], zero where i < c
+            }
+            if (CF_STAMPS && stamp_ok) stamps[40 + 5 * j + 3] = __builtin_amdgcn_s_memtime();
+        };
+#pragma unroll 1
+        for (int ph = 0; ph < nph; ++ph) {
+            const int c0 = ph ? split : 0, c1 = (ph || nph == 1) ? nb : split;
+            if (ph) {
+                bool good = true;
+                if (lane == 0) good = cp_wait_word(sync + 3, (unsigned)CP_NH);
+                if (!__builtin_amdgcn_readfirstlane((int)good) && lane == 0) atomicOr(sync + 1, 4u);
+            }
+            factor(c0, nullptr);
+#pragma unroll 1
+            for (int j = c0; j < c1; ++j) {
+                CP_BARRIER();                                          // (A)
+                if (j + 1 >= c1) break;                                // the phase's (or the matrix') last panel: nothing to look ahead to
+                // the next diagonal block: its 16 rows of panel j solved here, its last update, through LDS into the lane = row layout
+                double* dp = Dpre + ((j + 1) & 1) * (16 * 18);
+                f64x4 d4, d5 = {0.0, 0.0, 0.0, 0.0};
+                {
+                    const double* pr = Praw + (j & 1) * (C * 17) + (16 * (j + 1) + li) * 17 + lq;
+                    const double* dv0 = DinvT + (j & 1) * (16 * 18) + lq * 18 + li;        // Linv[li][lq + 4 kk] = DinvT[lq + 4 kk][li]
+                    f64x4 xa = {0.0, 0.0, 0.0, 0.0}, xb = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) d4[r] = dp[(lq + 4 * r) * 18 + li];
+                    xa = __builtin_amdgcn_mfma_f64_16x16x4f64(dv0[0], pr[0], xa, 0, 0, 0);
+                    xb = __builtin_amdgcn_mfma_f64_16x16x4f64(dv0[4 * 18], pr[4], xb, 0, 0, 0);
+                    xa = __builtin_amdgcn_mfma_f64_16x16x4f64(dv0[8 * 18], pr[8], xa, 0, 0, 0);
+                    xb = __builtin_amdgcn_mfma_f64_16x16x4f64(dv0[12 * 18], pr[12], xb, 0, 0, 0);
+                    xa += xb;
+                    d4 = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[0], xa[0], d4, 0, 0, 0);
+                    d5 = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[1], xa[1], d5, 0, 0, 0);
+                    d4 = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[2], xa[2], d4, 0, 0, 0);
+                    d5 = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[3], xa[3], d5, 0, 0, 0);
+                }
+                d4 += d5;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dp[(lq + 4 * r) * 18 + li] = d4[r];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // own LDS writes before own reads (one wave: no barrier needed)
+                if (CF_STAMPS && stamp_ok) stamps[40 + 5 * (j + 1)] = __builtin_amdgcn_s_memtime();
+                factor(j + 1, dp);
+            }
+        }
+    } else {
+        // ---- waves 1 .. 15: the panel solve and the trailing update of the phase's block columns
+        const int ow = wave - 1;
+        const bool publisher = wave == 4;                 // (on wave 0's SIMD: it has no row block to solve)
+        const bool solver = (wave & 3) != 0;               // not on wave 0's SIMD
+        const int sv = ow - (wave >> 2);                   // 0 .. 11 among the solvers
+        int bc_[CP_SLOTS];
+        f64x4 blk[CP_SLOTS];
+        int li_t = li, lq_t = lq;       // per-step opaque copies of the lane constants (nothing built from them may be hoisted out of the step loop)
+        auto update = [&](auto Q) __attribute__((always_inline)) {
+            constexpr int q = decltype(Q)::value;
+            const int bc = bc_[q];
+            const double* pa = Pn + (16 * (bc >> 8) + li_t) * 17 + lq_t;
+            const double* pb = Pn + (16 * (bc & 255) + li_t) * 17 + lq_t;
+            double av[4], bv[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) { av[kk] = -pa[4 * kk]; bv[kk] = pb[4 * kk]; }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) blk[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], blk[q], 0, 0, 0);
+        };
+        // the diagonal block of step j and its inverse, from wave 0's LDS copies to global memory (off wave 0's chain)
+        auto publish_diag = [&](int j) __attribute__((always_inline)) {
+            const double* lg = Ldg + (j & 1) * (16 * 18);
+            const double* dv = DinvT + (j & 1) * (16 * 18);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int r = lq_t + 4 * t, c = li_t;
+                T[(int64_t)(16 * j + r) * C + 16 * j + c] = c <= r ? lg[r * 18 + c] : 0.0;
+                st_sc1(Linv + j * 256 + 16 * r + c, dv[c * 18 + r]);
+            }
+        };
+        int nB = 0;                     // meetings (B) so far
+#pragma unroll 1
+        for (int ph = 0; ph < nph; ++ph) {
+            const int c0 = ph ? split : 0, c1 = (ph || nph == 1) ? nb : split;
+            if (ph) {
+                bool good = true;
+                if (lane == 0) good = cp_wait_word(sync + 3, (unsigned)CP_NH);
+                if (!__builtin_amdgcn_readfirstlane((int)good) && lane == 0) atomicOr(sync + 1, 4u);
+            }
+            // the phase's first panel (block column c0 below its diagonal block) and block (c0+1, c0+1) as they stand -> LDS
+            {
+                double* pw = Praw + (c0 & 1) * (C * 17);
+                const int r0 = 16 * (c0 + 1);
+                for (int e = tid - 64; e < (C - r0) * 16; e += 960)
+                    pw[(r0 + (e >> 4)) * 17 + (e & 15)] = ld_sc1(T + (int64_t)(r0 + (e >> 4)) * C + 16 * c0 + (e & 15));
+                if (c0 + 1 < nb)
+                    for (int e = tid - 64; e < 256; e += 960)
+                        Dpre[((c0 + 1) & 1) * (16 * 18) + (e >> 4) * 18 + (e & 15)] = ld_sc1(T + (int64_t)(r0 + (e >> 4)) * C + r0 + (e & 15));
+            }
+            // this wave's trailing blocks of the phase: ranked by block column, LAST column first, the diagonal block first within a
+            // column, dealt round-robin -- the blocks still active at a step are a prefix of every wave's slots
+            const int nblk = cp_colblocks(c0 + 1, c1, nb);
+#pragma unroll
+            for (int q = 0; q < CP_SLOTS; ++q) {
+                const int r = ow + 15 * q;
+                bc_[q] = 0;
+                blk[q] = f64x4{0.0, 0.0, 0.0, 0.0};
+                if (r < nblk) {
+                    int bj = c1 - 1;
+                    while (cp_colblocks(bj, c1, nb) <= r) --bj;       // column bj holds the ranks [blocks right of it, blocks from it on)
+                    const int bi = bj + (r - cp_colblocks(bj + 1, c1, nb));
+                    bc_[q] = (bi << 8) | bj;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) blk[q][e] = ld_sc1(T + (int64_t)(16 * bi + lq + 4 * e) * C + 16 * bj + li);
+                }
+            }
+#pragma unroll 1
+            for (int j = c0; j < c1; ++j) {
+                // every store of the step before has landed (the solved panel's rows; the publisher's copy of diagonal block j-1), and
+                // every owner passed this wait before barrier (A) of step j-1 with its rows of the panels before: row blocks 0..j-1 and
+                // panels 0..j-1 are complete in global memory once the barrier below is behind us
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                CP_BARRIER();                                          // (A) the inverse of L_jj and panel j are in LDS
+                asm volatile("" : "+v"(li_t), "+v"(lq_t));
+                if (publisher && lane == 0 && j > 0) {
+                    __hip_atomic_store(sync, (unsigned)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (ph == 0 && nph == 2) __hip_atomic_store(sync + 2, (unsigned)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (publisher) publish_diag(j);
+                const int j0 = 16 * j, g0 = j0 + 16, rows = C - g0;
+                if (rows <= 0) {
+                    if (publisher) {                                   // the last block and its inverse have landed: L is complete
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (lane == 0) __hip_atomic_store(sync, (unsigned)nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    break;
+                }
+                const double* pan = Praw + (j & 1) * (C * 17);
+                double* nxt = Praw + ((j + 1) & 1) * (C * 17);
+                // (S2) panel solve X = P L_jj^-T as a product with the inverted diagonal block, one 16-row block per solver wave and turn
+                if (solver) {
+                    const double* dv = DinvT + (j & 1) * (16 * 18);        // B operand Linv[c = li][k = lq + 4 kk] = DinvT[k][li]
+                    for (int rb = sv; 16 * rb < rows; rb += 12) {
+                        const int row0 = g0 + 16 * rb;
+                        f64x4 x = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int kk = 0; kk < 4; kk += 2) {
+                            x = __builtin_amdgcn_mfma_f64_16x16x4f64(pan[(row0 + li_t) * 17 + 4 * kk + lq_t], dv[(4 * kk + lq_t) * 18 + li_t], x, 0, 0, 0);
+                            x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(pan[(row0 + li_t) * 17 + 4 * kk + 4 + lq_t], dv[(4 * kk + 4 + lq_t) * 18 + li_t], x1, 0, 0, 0);
+                        }
+                        x += x1;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int r = row0 + lq_t + 4 * e;
+                            st_sc1(T + (int64_t)r * C + j0 + li_t, x[e]);      // write-through: the inverse role and the helpers read it in this launch
+                            Pn[r * 17 + li_t] = x[e];
+                        }
+                    }
+                }
+                const bool last_of_phase = j + 1 >= c1;                 // (and not the matrix' last panel: rows > 0)
+                if (last_of_phase) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the meeting below then says: panel j is complete in memory
+                {   // (B) among the owners: every owner's rows of the solved panel are in LDS
+                    if (CF_STAMPS && stamp_ok && nstamp < 100) stamps[nstamp++] = __builtin_amdgcn_s_memtime();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (lane == 0) { const unsigned one = 1u; asm volatile("ds_add_u32 %0, %1" :: "v"(cntB_lds), "v"(one) : "memory"); }
+                    const int target = 15 * (++nB);
+                    for (;;) {
+                        int v;
+                        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(cntB_lds) : "memory");
+                        if (__builtin_amdgcn_readfirstlane(v) >= target) break;
+                    }
+                    if (CF_STAMPS && stamp_ok && nstamp < 100) stamps[nstamp++] = __builtin_amdgcn_s_memtime();
+                }
+                if (last_of_phase) {
+                    // the helpers' last panel.  (Its diagonal block is not needed by them; the row counter follows at the next barrier.)
+                    if (publisher && lane == 0) __hip_atomic_store(sync + 2, (unsigned)j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                // (S4) this wave's active slots are [0, n34): ranks below R4 lie right of the next panel, the next ranks ARE the next panel
+                // (column j+1).  The next panel's blocks go first and leave for the other panel buffer -- except the diagonal one, which
+                // wave 0 updates and factors itself.  The diagonal block after that, (j+2, j+2), leaves a copy behind once it has this
+                // step's update: wave 0's input at the next step.
+                const int R4 = cp_colblocks(j + 2, c1, nb), R3 = cp_colblocks(j + 1, c1, nb);
+                const int n4 = R4 > ow ? (R4 - ow + 14) / 15 : 0;
+                const int n34 = R3 > ow ? (R3 - ow + 14) / 15 : 0;
+                const int R5 = cp_colblocks(j + 3, c1, nb);            // rank of block (j+2, j+2), the first of its column
+                const int qd = (j + 2 < c1 && R5 % 15 == ow) ? R5 / 15 : -1;
+                static_for<0, CP_SLOTS>([&](auto Q) {                  // next panel first (the highest active slots)
+                    constexpr int q = CP_SLOTS - 1 - decltype(Q)::value;
+                    if (q >= n4 && q < n34 && (bc_[q] >> 8) != (bc_[q] & 255)) {
+                        update(std::integral_constant<int, q>{});
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) nxt[(16 * (bc_[q] >> 8) + lq_t + 4 * e) * 17 + li_t] = blk[q][e];
+                    }
+                });
+                static_for<0, CP_SLOTS>([&](auto Q) {
+                    constexpr int q = decltype(Q)::value;
+                    if (q < n4) {
+                        update(std::integral_constant<int, q>{});
+                        if (q == qd) {
+                            double* dp = Dpre + (j & 1) * (16 * 18);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) dp[(lq_t + 4 * e) * 18 + li_t] = blk[q][e];
+                        }
+                    }
+                });
+            }
+        }
+    }
+    if (CF_STAMPS && stamp_ok) { if (nstamp < 100) stamps[nstamp++] = __builtin_amdgcn_s_memtime(); stamps[127] = nstamp; }
+}
+
+// grid: [0, groups) factorising, [groups, groups (1 + TI_WG)) inverse, [groups (1 + TI_WG), groups (1 + TI_WG + CP_NH)) helpers (when split < nb)
+__global__ __launch_bounds__(1024) void cholesky_phased_kernel(double* __restrict__ T, double* __restrict__ Linv, int C, double* __restrict__ Winv,
+                                                               unsigned* __restrict__ sync, int groups, int split)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int b = (int)blockIdx.x;
+    if (b < groups) {
+        cp_factor_role(T + (int64_t)b * C * C, Linv + (int64_t)b * C * 16, C, sync + 16 * b, split, sm,
+                       reinterpret_cast<unsigned long long*>(Linv + 8192));
+    } else if (b < groups * (1 + TI_WG)) {
+        const int idx = b - groups, g = idx / TI_WG;
+        tri_inverse_role(T + (int64_t)g * C * C, Linv + (int64_t)g * C * 16, Winv + (int64_t)g * C * C, C, idx % TI_WG, sync + 16 * g, sm);
+    } else {
+        const int idx = b - groups * (1 + TI_WG), g = idx / CP_NH;
+        cp_helper_role(T + (int64_t)g * C * C, C, sync + 16 * g, split, idx % CP_NH, sm);
+    }
+}
+
 // W = L^-1 from L and the inverses of its 16 x 16 diagonal blocks, one WAVE per block column j:
 //   X_j = Linv_jj;   X_i = -Linv_ii sum_{k=j}^{i-1} L_ik X_k   (i > j),   W[i][j] = X_i.
 // The X blocks of a column stay in its wave's registers in the MFMA accumulator layout, which is at the same time a valid
@@ -1591,6 +1990,26 @@ hipError_t wc_launch_factor_fused(double* T, double* W, double* tmp, int C, int 
     if (e != hipSuccess) return e;
     if (one) {
         unsigned* rows = reinterpret_cast<unsigned*>(tmp + (size_t)groups * C * 16);     // zeroed by factor_prepare_kernel
+        static const bool old_one = getenv("WC_K2_FUSED_R5") != nullptr;     // development A/B: round 5's one-workgroup factorisation
+        if (!old_one) {
+            static const int split_env = getenv("WC_K2_PHASE_SPLIT") ? atoi(getenv("WC_K2_PHASE_SPLIT")) : -1;      // development: nb = no helpers
+            int split = cp_split(nb);
+            if (split_env >= 1 && split_env <= nb) split = split_env;
+            // what a phase may hold (the owners' slots, the helpers' one block per wave); anything else runs in one phase, or on round 5's kernel
+            const bool fits2 = split < nb && cp_colblocks(1, split, nb) <= CP_MAXB && cp_colblocks(split + 1, nb, nb) <= CP_MAXB &&
+                               cp_colblocks(split, nb, nb) <= CP_NH * 16 && nb - split <= 10;
+            if (!fits2) split = nb;
+            if (split < nb || cp_colblocks(1, nb, nb) <= CP_MAXB) {
+                size_t l2 = cp_factor_lds_doubles(C) * sizeof(double);
+                if (lds_role > l2) l2 = lds_role;
+                if (cp_helper_lds_doubles(C) * sizeof(double) > l2) l2 = cp_helper_lds_doubles(C) * sizeof(double);
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(cholesky_phased_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+                if (e != hipSuccess) return e;
+                const int nwg = groups * (1 + TI_WG + (split < nb ? CP_NH : 0));
+                hipLaunchKernelGGL(cholesky_phased_kernel, dim3(nwg), dim3(1024), l2, st, T, tmp, C, W, rows, groups, split);
+                return hipGetLastError();
+            }
+        }
         hipLaunchKernelGGL(cholesky_fused_kernel, dim3(groups * (1 + TI_WG)), dim3(1024), lds, st, T, tmp, C, ldp, W, rows, groups);
         return hipGetLastError();
     }
