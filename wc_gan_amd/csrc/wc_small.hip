@@ -1162,28 +1162,70 @@ constexpr int CP_MAXB = 15 * CP_SLOTS;      // ... so a phase holds at most 75 b
 __host__ __device__ constexpr int cp_colblocks(int c, int c1, int nb)          // blocks (bi >= bj) of the block columns c .. c1-1
 { return c1 > c ? (c1 - c) * (2 * nb - c - c1 + 1) / 2 : 0; }
 // the block column where the helpers' part begins (nb: no helpers, one phase)
-__host__ __device__ constexpr int cp_split(int nb) { return nb >= 12 ? nb - 10 : nb; }
-__host__ __device__ constexpr size_t cp_factor_lds_doubles(int C) { return (size_t)3 * C * 17 + 6 * 16 * 18 + 2; }
-__host__ __device__ constexpr size_t cp_helper_lds_doubles(int C) { return (size_t)2 * 160 * 17 + 2; }
+__host__ __device__ constexpr int cp_split(int nb) { return nb >= 14 ? nb - 10 : nb; }       // (the helpers apply panels 0 .. split-3: below 14 block columns there is nothing for them to do)
+__host__ __device__ constexpr size_t cp_factor_lds_doubles(int C) { return (size_t)3 * C * 17 + 6 * 16 * 18 + 160 * 17 + 2; }
+__host__ __device__ constexpr size_t cp_helper_lds_doubles(int C) { return (size_t)2 * 160 * 18 + 2; }
 
 __device__ __forceinline__ bool cp_wait_word(const unsigned* w, unsigned target)
 {
     unsigned spins = 0;              // bounded: a lost producer must not hang the device
-    while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(2);
+    while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(1);
     return spins < (1u << 22);
 }
 
-__device__ __forceinline__ void cp_helper_role(double* __restrict__ T, int C, unsigned* sync, int split, int h, double* sm)
+// ---- 16-byte write-through stores / L1-bypassing loads -------------------------------------------------------------------------
+// The 8-byte agent-scope atomics ld_sc1 / st_sc1 are ONE FABRIC TRANSACTION PER LANE (MI355X_MICROARCH.md: "scalar sc1 stores are one
+// fabric write each: dwordx2 2.7x ... the dwordx4 time per byte"): a 16 x 16 block costs a wave 256 of them, a helper workgroup's panel
+// round 8 192 -- the stamps of the first helper version showed its sixteen waves 12 000 - 15 000 cycles apart behind that queue, and the
+// takeover waiting for the last of them.  A dwordx4 access with the sc1 bit coalesces like a plain one; as raw-buffer builtins (not inline
+// asm) the compiler keeps the vmcnt bookkeeping -- an asm load's destination is a register the allocator may copy or spill before it lands.
+typedef unsigned int cp_u32x4 __attribute__((ext_vector_type(4)));
+// a raw buffer over one matrix (element offsets below are in doubles); aux 16 = the sc1 bit on gfx940+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t cp_rsrc(const double* p)
+{ return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p), 0, 0x7fffffff, 0x00020000); }
+__device__ __forceinline__ void st_sc1_x2(__amdgpu_buffer_rsrc_t r, int elem, f64x2 v)
+{ __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(cp_u32x4, v), r, elem * 8, 0, 16); }
+__device__ __forceinline__ f64x2 ld_sc1_x2(__amdgpu_buffer_rsrc_t r, int elem)
+{ return __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(r, elem * 8, 0, 16)); }
+// the value of lane ^ 1
+__device__ __forceinline__ double cp_swap1(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xf, 0xf, false);      // quad_perm [1, 0, 3, 2]
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// A 16 x 16 block in the f64 MFMA accumulator layout (register e of lane (li, lq) = element [lq + 4 e][li]) to / from the matrix behind
+// `r` at element offset `b` (leading dimension ld) in 16-byte pieces: neighbouring lanes trade halves, an even lane moves rows lq, lq + 4
+// (two columns each), an odd lane rows lq + 8, lq + 12.
+__device__ __forceinline__ void cp_store_block_sc1(__amdgpu_buffer_rsrc_t r, int b, int ld, const f64x4& x, int li, int lq)
+{
+    const bool odd = li & 1;
+    const double r0 = cp_swap1(odd ? x[0] : x[2]), r1 = cp_swap1(odd ? x[1] : x[3]);
+    const int p = b + (lq + (odd ? 8 : 0)) * ld + (li & ~1);
+    st_sc1_x2(r, p, odd ? f64x2{r0, x[2]} : f64x2{x[0], r0});
+    st_sc1_x2(r, p + 4 * ld, odd ? f64x2{r1, x[3]} : f64x2{x[1], r1});
+}
+__device__ __forceinline__ f64x4 cp_load_block_sc1(__amdgpu_buffer_rsrc_t r, int b, int ld, int li, int lq)
+{
+    const bool odd = li & 1;
+    const int p = b + (lq + (odd ? 8 : 0)) * ld + (li & ~1);
+    const f64x2 v0 = ld_sc1_x2(r, p), v1 = ld_sc1_x2(r, p + 4 * ld);
+    const double r0 = cp_swap1(odd ? v0[0] : v0[1]), r1 = cp_swap1(odd ? v1[0] : v1[1]);
+    return odd ? f64x4{r0, r1, v0[1], v1[1]} : f64x4{v0[0], v1[0], r0, r1};
+}
+
+__device__ __forceinline__ void cp_helper_role(double* __restrict__ T, int C, unsigned* sync, int split, int h, double* sm, unsigned long long* hst)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lq = lane >> 4;
     const int nb = C >> 4, nreg = nb - split, row0 = 16 * split;
-    double* Pn = sm;                                   // [2][nreg * 16][17]  rows >= 16 split of panel j, even / odd j
-    unsigned* ok = reinterpret_cast<unsigned*>(sm + 2 * 160 * 17);
+    double* Pn = sm;                                   // [2][nreg * 16][18]  rows >= 16 split of panel j, even / odd j
+    const __amdgpu_buffer_rsrc_t rT = cp_rsrc(T);
+    unsigned* ok = reinterpret_cast<unsigned*>(sm + 2 * 160 * 18);
     // this wave's block: rank h*16 + wave over the region's columns, LAST column first (as F deals its own)
     const int r = h * 16 + wave;
-    int bi = 0, bj = 0;
+    int bi = split, bj = split;
     bool has = false;
     {
         int m = 0;
@@ -1196,19 +1238,29 @@ __device__ __forceinline__ void cp_helper_role(double* __restrict__ T, int C, un
         for (int e = 0; e < 4; ++e) blk[e] = T[(int64_t)(16 * bi + lq + 4 * e) * C + 16 * bj + li];
     }
     if (tid == 0) *ok = 1u;
-    const double* pa0 = Pn + (16 * (bi - split) + li) * 17 + lq;
-    const double* pb0 = Pn + (16 * (bj - split) + li) * 17 + lq;
+    const double* pa0 = Pn + (16 * (bi - split) + li) * 18 + lq;
+    const double* pb0 = Pn + (16 * (bj - split) + li) * 18 + lq;
 #pragma unroll 1
-    for (int j = 0; j < split; ++j) {
+    for (int j = 0; j + 2 < split; ++j) {          // panels 0 .. split-3: F applies the two after them itself (the takeover step)
+        if (CF_STAMPS && hst && lane == 0) hst[4 * j] = __builtin_amdgcn_s_memtime();
         if (tid == 0 && !cp_wait_word(sync + 2, (unsigned)j + 1)) *ok = 0u;
         __syncthreads();
-        double* pn = Pn + (j & 1) * (160 * 17);
-        for (int e = tid; e < nreg * 256; e += 1024)
-            pn[(e >> 4) * 17 + (e & 15)] = ld_sc1(T + (int64_t)(row0 + (e >> 4)) * C + 16 * j + (e & 15));
+        if (CF_STAMPS && hst && lane == 0) hst[4 * j + 1] = __builtin_amdgcn_s_memtime();
+        // rows >= 16 split of panel j -> LDS, 16 bytes per thread and load (nreg * 128 pieces: at most two per thread)
+        double* pn = Pn + (j & 1) * (160 * 18);
+        {
+            const int e0 = tid, e1 = tid + 1024, n16 = nreg * 128;
+            f64x2 v0 = {0.0, 0.0}, v1 = {0.0, 0.0};
+            if (e0 < n16) v0 = ld_sc1_x2(rT, (row0 + (e0 >> 3)) * C + 16 * j + 2 * (e0 & 7));
+            if (e1 < n16) v1 = ld_sc1_x2(rT, (row0 + (e1 >> 3)) * C + 16 * j + 2 * (e1 & 7));
+            if (e0 < n16) *reinterpret_cast<f64x2*>(pn + (e0 >> 3) * 18 + 2 * (e0 & 7)) = v0;
+            if (e1 < n16) *reinterpret_cast<f64x2*>(pn + (e1 >> 3) * 18 + 2 * (e1 & 7)) = v1;
+        }
         __syncthreads();
+        if (CF_STAMPS && hst && lane == 0) hst[4 * j + 2] = __builtin_amdgcn_s_memtime();
         if (has) {
-            const double* pa = pa0 + (j & 1) * (160 * 17);
-            const double* pb = pb0 + (j & 1) * (160 * 17);
+            const double* pa = pa0 + (j & 1) * (160 * 18);
+            const double* pb = pb0 + (j & 1) * (160 * 18);
             double av[4], bv[4];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) { av[kk] = -pa[4 * kk]; bv[kk] = pb[4 * kk]; }
@@ -1216,15 +1268,15 @@ __device__ __forceinline__ void cp_helper_role(double* __restrict__ T, int C, un
             for (int kk = 0; kk < 4; ++kk) blk = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], blk, 0, 0, 0);
         }
     }
-    if (has) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) st_sc1(T + (int64_t)(16 * bi + lq + 4 * e) * C + 16 * bj + li, blk[e]);
-    }
+    if (has) cp_store_block_sc1(rT, 16 * bi * C + 16 * bj, C, blk, li, lq);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (CF_STAMPS && hst && lane == 0) hst[60] = __builtin_amdgcn_s_memtime();
     __syncthreads();
+    if (CF_STAMPS && hst && lane == 0) hst[61] = __builtin_amdgcn_s_memtime();
     if (tid == 0) {
         if (*ok == 0u) atomicOr(sync + 1, 2u);          // a wait ran out: the host reads the error word (wc_factor_error_offset)
-        __hip_atomic_fetch_add(sync + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned was = __hip_atomic_fetch_add(sync + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (CF_STAMPS && hst) { hst[62] = __builtin_amdgcn_s_memtime(); hst[63] = was; }
     }
 }
 
@@ -1242,13 +1294,14 @@ __device__ __forceinline__ void cp_factor_role(double* __restrict__ T, double* _
     double* DinvT = Pn + C * 17;                // [2][16][18] INVERSE of the factored diagonal block, TRANSPOSED: [c][i] = Linv[i][c] (even / odd steps)
     double* Dpre = DinvT + 2 * 16 * 18;         // [2][16][18] diagonal block (b, b) with every update but the last one, b even / odd
     double* Ldg = Dpre + 2 * 16 * 18;           // [2][16][18] the factored diagonal block on its way to global memory (even / odd steps)
-    const unsigned cntB_lds = (unsigned)(size_t)((__attribute__((address_space(3))) char*)(Ldg + 2 * 16 * 18));
-    volatile int* const cntB = reinterpret_cast<volatile int*>(Ldg + 2 * 16 * 18);      // owner waves through the panel solve (running count)
+    double* Psave = Ldg + 2 * 16 * 18;          // [160][17]   rows >= 16 split of the solved panel split-2: the takeover step applies it to the helpers' blocks
+    const unsigned cntB_lds = (unsigned)(size_t)((__attribute__((address_space(3))) char*)(Psave + 160 * 17));
+    volatile int* const cntB = reinterpret_cast<volatile int*>(Psave + 160 * 17);      // owner waves through the panel solve (running count)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lq = lane >> 4;
     const int nb = C >> 4;
-    const int nph = split < nb ? 2 : 1;
+    const __amdgpu_buffer_rsrc_t rT = cp_rsrc(T), rLinv = cp_rsrc(Linv);
     const bool stamp_ok = CF_STAMPS && lane == 0 && blockIdx.x == 0;
     unsigned long long* stamps = stamp_base + wave * 128;
     int nstamp = 0;
@@ -1269,7 +1322,7 @@ __device__ __forceinline__ void cp_factor_role(double* __restrict__ T, double* _
                 }
             } else {                            // the first block of a phase: from global memory (the helpers' output in phase 2)
 #pragma unroll
-                for (int c = 0; c < 16; ++c) a[c] = ld_sc1(T + (int64_t)(16 * j + li) * C + 16 * j + c);
+                for (int c = 0; c < 16; ++c) a[c] = T[(int64_t)(16 * j + li) * C + 16 * j + c];      // (block (0, 0): the launch before wrote it)
             }
             if (CF_STAMPS && stamp_ok) { if (src) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                                          stamps[40 + 5 * j + 1] = __builtin_amdgcn_s_memtime(); }
@@ -1303,45 +1356,52 @@ __device__ __forceinline__ void cp_factor_role(double* __restrict__ T, double* _
             }
             if (CF_STAMPS && stamp_ok) stamps[40 + 5 * j + 3] = __builtin_amdgcn_s_memtime();
         };
+        factor(0, nullptr);
 #pragma unroll 1
-        for (int ph = 0; ph < nph; ++ph) {
-            const int c0 = ph ? split : 0, c1 = (ph || nph == 1) ? nb : split;
-            if (ph) {
+        for (int j = 0; j < nb; ++j) {
+            CP_BARRIER();                                          // (A)
+            if (j + 1 >= nb) break;                                // the last panel: nothing to look ahead to
+            // the next diagonal block: its 16 rows of panel j solved here, its last update, through LDS into the lane = row layout
+            double* dp = Dpre + ((j + 1) & 1) * (16 * 18);
+            f64x4 d4, d5 = {0.0, 0.0, 0.0, 0.0};
+            if (j + 1 == split) {
+                // the takeover step: block (split, split) comes from the helpers, with every update but panel j's
                 bool good = true;
                 if (lane == 0) good = cp_wait_word(sync + 3, (unsigned)CP_NH);
                 if (!__builtin_amdgcn_readfirstlane((int)good) && lane == 0) atomicOr(sync + 1, 4u);
-            }
-            factor(c0, nullptr);
-#pragma unroll 1
-            for (int j = c0; j < c1; ++j) {
-                CP_BARRIER();                                          // (A)
-                if (j + 1 >= c1) break;                                // the phase's (or the matrix') last panel: nothing to look ahead to
-                // the next diagonal block: its 16 rows of panel j solved here, its last update, through LDS into the lane = row layout
-                double* dp = Dpre + ((j + 1) & 1) * (16 * 18);
-                f64x4 d4, d5 = {0.0, 0.0, 0.0, 0.0};
-                {
-                    const double* pr = Praw + (j & 1) * (C * 17) + (16 * (j + 1) + li) * 17 + lq;
-                    const double* dv0 = DinvT + (j & 1) * (16 * 18) + lq * 18 + li;        // Linv[li][lq + 4 kk] = DinvT[lq + 4 kk][li]
-                    f64x4 xa = {0.0, 0.0, 0.0, 0.0}, xb = {0.0, 0.0, 0.0, 0.0};
+                if (CF_STAMPS && stamp_ok) stamps[124] = __builtin_amdgcn_s_memtime();
+                d4 = cp_load_block_sc1(rT, 16 * (j + 1) * C + 16 * (j + 1), C, li, lq);
+                if (CF_STAMPS && stamp_ok) stamps[125] = __builtin_amdgcn_s_memtime();
+                // ... and with every update but the last TWO: panel j-1's rows of this block row wait in Psave (rows 0..15)
+                const double* ps = Psave + li * 17 + lq;
+                d4 = __builtin_amdgcn_mfma_f64_16x16x4f64(-ps[0], ps[0], d4, 0, 0, 0);
+                d5 = __builtin_amdgcn_mfma_f64_16x16x4f64(-ps[4], ps[4], d5, 0, 0, 0);
+                d4 = __builtin_amdgcn_mfma_f64_16x16x4f64(-ps[8], ps[8], d4, 0, 0, 0);
+                d5 = __builtin_amdgcn_mfma_f64_16x16x4f64(-ps[12], ps[12], d5, 0, 0, 0);
+            } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) d4[r] = dp[(lq + 4 * r) * 18 + li];
-                    xa = __builtin_amdgcn_mfma_f64_16x16x4f64(dv0[0], pr[0], xa, 0, 0, 0);
-                    xb = __builtin_amdgcn_mfma_f64_16x16x4f64(dv0[4 * 18], pr[4], xb, 0, 0, 0);
-                    xa = __builtin_amdgcn_mfma_f64_16x16x4f64(dv0[8 * 18], pr[8], xa, 0, 0, 0);
-                    xb = __builtin_amdgcn_mfma_f64_16x16x4f64(dv0[12 * 18], pr[12], xb, 0, 0, 0);
-                    xa += xb;
-                    d4 = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[0], xa[0], d4, 0, 0, 0);
-                    d5 = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[1], xa[1], d5, 0, 0, 0);
-                    d4 = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[2], xa[2], d4, 0, 0, 0);
-                    d5 = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[3], xa[3], d5, 0, 0, 0);
-                }
-                d4 += d5;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) dp[(lq + 4 * r) * 18 + li] = d4[r];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // own LDS writes before own reads (one wave: no barrier needed)
-                if (CF_STAMPS && stamp_ok) stamps[40 + 5 * (j + 1)] = __builtin_amdgcn_s_memtime();
-                factor(j + 1, dp);
+                for (int r = 0; r < 4; ++r) d4[r] = dp[(lq + 4 * r) * 18 + li];
             }
+            {
+                const double* pr = Praw + (j & 1) * (C * 17) + (16 * (j + 1) + li) * 17 + lq;
+                const double* dv0 = DinvT + (j & 1) * (16 * 18) + lq * 18 + li;        // Linv[li][lq + 4 kk] = DinvT[lq + 4 kk][li]
+                f64x4 xa = {0.0, 0.0, 0.0, 0.0}, xb = {0.0, 0.0, 0.0, 0.0};
+                xa = __builtin_amdgcn_mfma_f64_16x16x4f64(dv0[0], pr[0], xa, 0, 0, 0);
+                xb = __builtin_amdgcn_mfma_f64_16x16x4f64(dv0[4 * 18], pr[4], xb, 0, 0, 0);
+                xa = __builtin_amdgcn_mfma_f64_16x16x4f64(dv0[8 * 18], pr[8], xa, 0, 0, 0);
+                xb = __builtin_amdgcn_mfma_f64_16x16x4f64(dv0[12 * 18], pr[12], xb, 0, 0, 0);
+                xa += xb;
+                d4 = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[0], xa[0], d4, 0, 0, 0);
+                d5 = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[1], xa[1], d5, 0, 0, 0);
+                d4 = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[2], xa[2], d4, 0, 0, 0);
+                d5 = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa[3], xa[3], d5, 0, 0, 0);
+            }
+            d4 += d5;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dp[(lq + 4 * r) * 18 + li] = d4[r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // own LDS writes before own reads (one wave: no barrier needed)
+            if (CF_STAMPS && stamp_ok) stamps[40 + 5 * (j + 1)] = __builtin_amdgcn_s_memtime();
+            factor(j + 1, dp);
         }
     } else {
         // ---- waves 1 .. 15: the panel solve and the trailing update of the phase's block columns
@@ -1368,139 +1428,166 @@ __device__ __forceinline__ void cp_factor_role(double* __restrict__ T, double* _
             const double* lg = Ldg + (j & 1) * (16 * 18);
             const double* dv = DinvT + (j & 1) * (16 * 18);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int r = lq_t + 4 * t, c = li_t;
-                T[(int64_t)(16 * j + r) * C + 16 * j + c] = c <= r ? lg[r * 18 + c] : 0.0;
-                st_sc1(Linv + j * 256 + 16 * r + c, dv[c * 18 + r]);
+            for (int t = 0; t < 2; ++t) {       // 128 pairs of neighbouring columns: 16 bytes per lane and store
+                const int r = 2 * lq_t + (li_t >> 3) + 8 * t, c = 2 * (li_t & 7);
+                const f64x2 l2 = *reinterpret_cast<const f64x2*>(lg + r * 18 + c);
+                *reinterpret_cast<f64x2*>(T + (int64_t)(16 * j + r) * C + 16 * j + c) = f64x2{c <= r ? l2[0] : 0.0, c + 1 <= r ? l2[1] : 0.0};
+                st_sc1_x2(rLinv, j * 256 + 16 * r + c, f64x2{dv[c * 18 + r], dv[(c + 1) * 18 + r]});
             }
         };
         int nB = 0;                     // meetings (B) so far
-#pragma unroll 1
-        for (int ph = 0; ph < nph; ++ph) {
-            const int c0 = ph ? split : 0, c1 = (ph || nph == 1) ? nb : split;
-            if (ph) {
-                bool good = true;
-                if (lane == 0) good = cp_wait_word(sync + 3, (unsigned)CP_NH);
-                if (!__builtin_amdgcn_readfirstlane((int)good) && lane == 0) atomicOr(sync + 1, 4u);
-            }
-            // the phase's first panel (block column c0 below its diagonal block) and block (c0+1, c0+1) as they stand -> LDS
-            {
-                double* pw = Praw + (c0 & 1) * (C * 17);
-                const int r0 = 16 * (c0 + 1);
-                for (int e = tid - 64; e < (C - r0) * 16; e += 960)
-                    pw[(r0 + (e >> 4)) * 17 + (e & 15)] = ld_sc1(T + (int64_t)(r0 + (e >> 4)) * C + 16 * c0 + (e & 15));
-                if (c0 + 1 < nb)
-                    for (int e = tid - 64; e < 256; e += 960)
-                        Dpre[((c0 + 1) & 1) * (16 * 18) + (e >> 4) * 18 + (e & 15)] = ld_sc1(T + (int64_t)(r0 + (e >> 4)) * C + r0 + (e & 15));
-            }
-            // this wave's trailing blocks of the phase: ranked by block column, LAST column first, the diagonal block first within a
-            // column, dealt round-robin -- the blocks still active at a step are a prefix of every wave's slots
-            const int nblk = cp_colblocks(c0 + 1, c1, nb);
+        // this wave's trailing blocks of the block columns [cb, ce): ranked by block column, LAST column first, the diagonal block first
+        // within a column, dealt round-robin -- the blocks still active at a step are a prefix of every wave's slots
+        auto load_blocks = [&](int cb, int ce, bool fresh) __attribute__((always_inline)) {
+            const int nblk = cp_colblocks(cb, ce, nb);
 #pragma unroll
             for (int q = 0; q < CP_SLOTS; ++q) {
                 const int r = ow + 15 * q;
                 bc_[q] = 0;
-                blk[q] = f64x4{0.0, 0.0, 0.0, 0.0};
                 if (r < nblk) {
-                    int bj = c1 - 1;
-                    while (cp_colblocks(bj, c1, nb) <= r) --bj;       // column bj holds the ranks [blocks right of it, blocks from it on)
-                    const int bi = bj + (r - cp_colblocks(bj + 1, c1, nb));
+                    int bj = ce - 1;
+                    while (cp_colblocks(bj, ce, nb) <= r) --bj;       // column bj holds the ranks [blocks right of it, blocks from it on)
+                    const int bi = bj + (r - cp_colblocks(bj + 1, ce, nb));
                     bc_[q] = (bi << 8) | bj;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) blk[q][e] = ld_sc1(T + (int64_t)(16 * bi + lq + 4 * e) * C + 16 * bj + li);
                 }
             }
+            if (fresh) {
+                // the helpers' output, 16-byte sc1 loads.  No branch between the slots' loads (an empty slot reads block (cb, cb) for
+                // nothing): one basic block, every load in flight before the first lane swap waits for its data
+#pragma unroll
+                for (int q = 0; q < CP_SLOTS; ++q) {
+                    const int bc = bc_[q] ? bc_[q] : ((cb << 8) | cb);
+                    blk[q] = cp_load_block_sc1(rT, 16 * (bc >> 8) * C + 16 * (bc & 255), C, li, lq);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < CP_SLOTS; ++q) {
+                    blk[q] = f64x4{0.0, 0.0, 0.0, 0.0};
+                    if (bc_[q]) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) blk[q][e] = T[(int64_t)(16 * (bc_[q] >> 8) + lq + 4 * e) * C + 16 * (bc_[q] & 255) + li];
+                    }
+                }
+            }
+        };
+        // panel 0 (block column 0 below its diagonal block) and block (1, 1) as they stand -> LDS
+        for (int e = tid - 64; e < (C - 16) * 16; e += 960)
+            Praw[(16 + (e >> 4)) * 17 + (e & 15)] = T[(int64_t)(16 + (e >> 4)) * C + (e & 15)];
+        if (nb > 1)
+            for (int e = tid - 64; e < 256; e += 960)
+                Dpre[16 * 18 + (e >> 4) * 18 + (e & 15)] = T[(int64_t)(16 + (e >> 4)) * C + 16 + (e & 15)];
+        load_blocks(1, split, false);   // (split == nb: every block column is F's own)
 #pragma unroll 1
-            for (int j = c0; j < c1; ++j) {
-                // every store of the step before has landed (the solved panel's rows; the publisher's copy of diagonal block j-1), and
-                // every owner passed this wait before barrier (A) of step j-1 with its rows of the panels before: row blocks 0..j-1 and
-                // panels 0..j-1 are complete in global memory once the barrier below is behind us
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                CP_BARRIER();                                          // (A) the inverse of L_jj and panel j are in LDS
-                asm volatile("" : "+v"(li_t), "+v"(lq_t));
-                if (publisher && lane == 0 && j > 0) {
-                    __hip_atomic_store(sync, (unsigned)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (ph == 0 && nph == 2) __hip_atomic_store(sync + 2, (unsigned)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int j = 0; j < nb; ++j) {
+            // every store of the step before has landed (the solved panel's rows; the publisher's copy of diagonal block j-1), and
+            // every owner passed this wait before barrier (A) of step j-1 with its rows of the panels before: row blocks 0..j-1 and
+            // panels 0..j-1 are complete in global memory once the barrier below is behind us
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            CP_BARRIER();                                          // (A) the inverse of L_jj and panel j are in LDS
+            asm volatile("" : "+v"(li_t), "+v"(lq_t));
+            if (publisher && lane == 0 && j > 0) {
+                __hip_atomic_store(sync, (unsigned)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (j + 1 < split && split < nb) __hip_atomic_store(sync + 2, (unsigned)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (publisher) publish_diag(j);
+            const int j0 = 16 * j, g0 = j0 + 16, rows = C - g0;
+            if (rows <= 0) {
+                if (publisher) {                                   // the last block and its inverse have landed: L is complete
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_store(sync, (unsigned)nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                if (publisher) publish_diag(j);
-                const int j0 = 16 * j, g0 = j0 + 16, rows = C - g0;
-                if (rows <= 0) {
-                    if (publisher) {                                   // the last block and its inverse have landed: L is complete
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        if (lane == 0) __hip_atomic_store(sync, (unsigned)nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    break;
-                }
-                const double* pan = Praw + (j & 1) * (C * 17);
-                double* nxt = Praw + ((j + 1) & 1) * (C * 17);
-                // (S2) panel solve X = P L_jj^-T as a product with the inverted diagonal block, one 16-row block per solver wave and turn
-                if (solver) {
-                    const double* dv = DinvT + (j & 1) * (16 * 18);        // B operand Linv[c = li][k = lq + 4 kk] = DinvT[k][li]
-                    for (int rb = sv; 16 * rb < rows; rb += 12) {
-                        const int row0 = g0 + 16 * rb;
-                        f64x4 x = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
+                break;
+            }
+            const double* pan = Praw + (j & 1) * (C * 17);
+            double* nxt = Praw + ((j + 1) & 1) * (C * 17);
+            // (S2) panel solve X = P L_jj^-T as a product with the inverted diagonal block, one 16-row block per solver wave and turn
+            if (solver) {
+                const double* dv = DinvT + (j & 1) * (16 * 18);        // B operand Linv[c = li][k = lq + 4 kk] = DinvT[k][li]
+                for (int rb = sv; 16 * rb < rows; rb += 12) {
+                    const int row0 = g0 + 16 * rb;
+                    f64x4 x = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                        for (int kk = 0; kk < 4; kk += 2) {
-                            x = __builtin_amdgcn_mfma_f64_16x16x4f64(pan[(row0 + li_t) * 17 + 4 * kk + lq_t], dv[(4 * kk + lq_t) * 18 + li_t], x, 0, 0, 0);
-                            x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(pan[(row0 + li_t) * 17 + 4 * kk + 4 + lq_t], dv[(4 * kk + 4 + lq_t) * 18 + li_t], x1, 0, 0, 0);
-                        }
-                        x += x1;
+                    for (int kk = 0; kk < 4; kk += 2) {
+                        x = __builtin_amdgcn_mfma_f64_16x16x4f64(pan[(row0 + li_t) * 17 + 4 * kk + lq_t], dv[(4 * kk + lq_t) * 18 + li_t], x, 0, 0, 0);
+                        x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(pan[(row0 + li_t) * 17 + 4 * kk + 4 + lq_t], dv[(4 * kk + 4 + lq_t) * 18 + li_t], x1, 0, 0, 0);
+                    }
+                    x += x1;
+                    cp_store_block_sc1(rT, row0 * C + j0, C, x, li_t, lq_t);      // write-through: the inverse role and the helpers read it in this launch
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int r = row0 + lq_t + 4 * e;
-                            st_sc1(T + (int64_t)r * C + j0 + li_t, x[e]);      // write-through: the inverse role and the helpers read it in this launch
-                            Pn[r * 17 + li_t] = x[e];
-                        }
-                    }
-                }
-                const bool last_of_phase = j + 1 >= c1;                 // (and not the matrix' last panel: rows > 0)
-                if (last_of_phase) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the meeting below then says: panel j is complete in memory
-                {   // (B) among the owners: every owner's rows of the solved panel are in LDS
-                    if (CF_STAMPS && stamp_ok && nstamp < 100) stamps[nstamp++] = __builtin_amdgcn_s_memtime();
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    if (lane == 0) { const unsigned one = 1u; asm volatile("ds_add_u32 %0, %1" :: "v"(cntB_lds), "v"(one) : "memory"); }
-                    const int target = 15 * (++nB);
-                    for (;;) {
-                        int v;
-                        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(cntB_lds) : "memory");
-                        if (__builtin_amdgcn_readfirstlane(v) >= target) break;
-                    }
-                    if (CF_STAMPS && stamp_ok && nstamp < 100) stamps[nstamp++] = __builtin_amdgcn_s_memtime();
-                }
-                if (last_of_phase) {
-                    // the helpers' last panel.  (Its diagonal block is not needed by them; the row counter follows at the next barrier.)
-                    if (publisher && lane == 0) __hip_atomic_store(sync + 2, (unsigned)j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-                // (S4) this wave's active slots are [0, n34): ranks below R4 lie right of the next panel, the next ranks ARE the next panel
-                // (column j+1).  The next panel's blocks go first and leave for the other panel buffer -- except the diagonal one, which
-                // wave 0 updates and factors itself.  The diagonal block after that, (j+2, j+2), leaves a copy behind once it has this
-                // step's update: wave 0's input at the next step.
-                const int R4 = cp_colblocks(j + 2, c1, nb), R3 = cp_colblocks(j + 1, c1, nb);
-                const int n4 = R4 > ow ? (R4 - ow + 14) / 15 : 0;
-                const int n34 = R3 > ow ? (R3 - ow + 14) / 15 : 0;
-                const int R5 = cp_colblocks(j + 3, c1, nb);            // rank of block (j+2, j+2), the first of its column
-                const int qd = (j + 2 < c1 && R5 % 15 == ow) ? R5 / 15 : -1;
-                static_for<0, CP_SLOTS>([&](auto Q) {                  // next panel first (the highest active slots)
-                    constexpr int q = CP_SLOTS - 1 - decltype(Q)::value;
-                    if (q >= n4 && q < n34 && (bc_[q] >> 8) != (bc_[q] & 255)) {
-                        update(std::integral_constant<int, q>{});
+                    for (int e = 0; e < 4; ++e) Pn[(row0 + lq_t + 4 * e) * 17 + li_t] = x[e];
+                    if (j + 2 == split && row0 >= 16 * split) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) nxt[(16 * (bc_[q] >> 8) + lq_t + 4 * e) * 17 + li_t] = blk[q][e];
+                        for (int e = 0; e < 4; ++e) Psave[(row0 - 16 * split + lq_t + 4 * e) * 17 + li_t] = x[e];
                     }
-                });
+                }
+            }
+            {   // (B) among the owners: every owner's rows of the solved panel are in LDS
+                if (CF_STAMPS && stamp_ok && nstamp < 100) stamps[nstamp++] = __builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) { const unsigned one = 1u; asm volatile("ds_add_u32 %0, %1" :: "v"(cntB_lds), "v"(one) : "memory"); }
+                const int target = 15 * (++nB);
+                for (;;) {
+                    int v;
+                    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(cntB_lds) : "memory");
+                    if (__builtin_amdgcn_readfirstlane(v) >= target) break;
+                }
+                if (CF_STAMPS && stamp_ok && nstamp < 100) stamps[nstamp++] = __builtin_amdgcn_s_memtime();
+            }
+            // the block columns this step's ranks run over: F's own up to the takeover step, the helpers' from it on
+            const bool took = j + 1 >= split;
+            const int c1 = took ? nb : split;
+            if (j + 1 == split && split < nb) {
+                // the takeover step: the helpers' blocks (every panel but this one applied) become this workgroup's trailing blocks
+                bool good = true;
+                if (lane == 0) good = cp_wait_word(sync + 3, (unsigned)CP_NH);
+                if (!__builtin_amdgcn_readfirstlane((int)good) && lane == 0) atomicOr(sync + 1, 4u);
+                if (CF_STAMPS && stamp_ok) stamps[100] = __builtin_amdgcn_s_memtime();
+                load_blocks(split, nb, true);
+                if (CF_STAMPS && stamp_ok) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamps[101] = __builtin_amdgcn_s_memtime(); }
+                // every panel but the last two applied: panel j-1 from Psave here, panel j with the step's own update below
                 static_for<0, CP_SLOTS>([&](auto Q) {
                     constexpr int q = decltype(Q)::value;
-                    if (q < n4) {
-                        update(std::integral_constant<int, q>{});
-                        if (q == qd) {
-                            double* dp = Dpre + (j & 1) * (16 * 18);
+                    if (ow + 15 * q < cp_colblocks(split, nb, nb)) {
+                        const int bc = bc_[q];
+                        const double* pa = Psave + (16 * ((bc >> 8) - split) + li_t) * 17 + lq_t;
+                        const double* pb = Psave + (16 * ((bc & 255) - split) + li_t) * 17 + lq_t;
+                        double av[4], bv[4];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) dp[(lq_t + 4 * e) * 18 + li_t] = blk[q][e];
-                        }
+                        for (int kk = 0; kk < 4; ++kk) { av[kk] = -pa[4 * kk]; bv[kk] = pb[4 * kk]; }
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) blk[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], blk[q], 0, 0, 0);
                     }
                 });
+                if (CF_STAMPS && stamp_ok) stamps[102] = __builtin_amdgcn_s_memtime();
             }
+            // (S4) this wave's active slots are [0, n34): ranks below R4 lie right of the next panel, the next ranks ARE the next panel
+            // (column j+1).  The next panel's blocks go first and leave for the other panel buffer -- except the diagonal one, which
+            // wave 0 updates and factors itself.  The diagonal block after that, (j+2, j+2), leaves a copy behind once it has this
+            // step's update: wave 0's input at the next step.
+            const int R4 = cp_colblocks(j + 2, c1, nb), R3 = cp_colblocks(j + 1, c1, nb);
+            const int n4 = R4 > ow ? (R4 - ow + 14) / 15 : 0;
+            const int n34 = R3 > ow ? (R3 - ow + 14) / 15 : 0;
+            const int R5 = cp_colblocks(j + 3, c1, nb);            // rank of block (j+2, j+2), the first of its column
+            const int qd = (j + 2 < c1 && R5 % 15 == ow) ? R5 / 15 : -1;
+            static_for<0, CP_SLOTS>([&](auto Q) {                  // next panel first (the highest active slots)
+                constexpr int q = CP_SLOTS - 1 - decltype(Q)::value;
+                if (q >= n4 && q < n34 && (bc_[q] >> 8) != (bc_[q] & 255)) {
+                    update(std::integral_constant<int, q>{});
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) nxt[(16 * (bc_[q] >> 8) + lq_t + 4 * e) * 17 + li_t] = blk[q][e];
+                }
+            });
+            static_for<0, CP_SLOTS>([&](auto Q) {
+                constexpr int q = decltype(Q)::value;
+                if (q < n4) {
+                    update(std::integral_constant<int, q>{});
+                    if (q == qd) {
+                        double* dp = Dpre + (j & 1) * (16 * 18);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dp[(lq_t + 4 * e) * 18 + li_t] = blk[q][e];
+                    }
+                }
+            });
         }
     }
     if (CF_STAMPS && stamp_ok) { if (nstamp < 100) stamps[nstamp++] = __builtin_amdgcn_s_memtime(); stamps[127] = nstamp; }
@@ -1520,7 +1607,9 @@ __global__ __launch_bounds__(1024) void cholesky_phased_kernel(double* __restric
         tri_inverse_role(T + (int64_t)g * C * C, Linv + (int64_t)g * C * 16, Winv + (int64_t)g * C * C, C, idx % TI_WG, sync + 16 * g, sm);
     } else {
         const int idx = b - groups * (1 + TI_WG), g = idx / CP_NH;
-        cp_helper_role(T + (int64_t)g * C * C, C, sync + 16 * g, split, idx % CP_NH, sm);
+        // (development stamps: 64 words per helper wave behind the factorising workgroup's 16 x 128)
+        cp_helper_role(T + (int64_t)g * C * C, C, sync + 16 * g, split, idx % CP_NH, sm,
+                       (CF_STAMPS && g == 0) ? reinterpret_cast<unsigned long long*>(Linv + 8192) + 16 * 128 + ((idx % CP_NH) * 16 + (threadIdx.x >> 6)) * 64 : nullptr);
     }
 }
 
