@@ -1126,7 +1126,7 @@ __global__ __launch_bounds__(1024) void cholesky_fused_kernel(double* __restrict
 }
 
 // =================================================================================================================================
-// K2 in PHASES with helper workgroups (round 6; VERDICT r5 item 1: "take the small-matrix stage off one CU").
+// K2 as a RELAY of two factorising workgroups (round 6; VERDICT r5 item 1: "take the small-matrix stage off one CU").
 //
 // What the stamps of cholesky_fused_kernel said at C = 256 (profiles/r6_k2_timeline.txt): the kernel is the sum over its 16 steps of
 // max(wave 0's chain, the owners' panel solve + trailing update).  Wave 0 needs 6 300 - 7 700 cycles per step (3 100 - 5 700 of them the
@@ -1135,36 +1135,37 @@ __global__ __launch_bounds__(1024) void cholesky_fused_kernel(double* __restrict
 // matrix pipe, the last eight by wave 0.  Spreading every step's update over several CUs puts a cross-CU hand-off (~1 us each way) into
 // every step's critical path -- longer than the step; that is what killed the forms of DESIGN 4.7 / 8.  The split here is by COLUMNS
 // and by TIME instead:
-//   phase 1: the factorising workgroup (F) owns block columns 0 .. split-1 only (C = 256: split = 6, 65 trailing blocks instead of
-//            120) and runs the look-ahead algorithm on them unchanged -- every row of every panel is solved by F (the panel is F's own
-//            column) and leaves for global memory write-through, as it always did for the inverse role;
-//            CP_NH helper workgroups (H) own the trailing blocks of columns >= split (55 blocks, one per wave).  They follow F through
-//            a counter of complete panels, a step or two BEHIND it: fetch rows >= 16 split of panel j (20 KB), apply it to their
-//            blocks (four MFMAs per wave), wait for the next one.  Nothing F does in phase 1 waits for them.
-//   boundary: after panel split-1 the helpers store their blocks (write-through) and count themselves done; F picks the trailing matrix
-//            up again -- the same loads as at kernel start, from the helpers' output -- and
-//   phase 2: factors columns split .. nb-1 as it would a matrix of that size.
-// One hand-off per launch instead of one per step; F's owner waves hold 5 blocks each instead of 8 (40 VGPRs: the register file is no
-// longer at its limit, which is what let the publisher below in without spills).
-// Also new on F's side: (a) wave 0 leaves the factored block and its inverse in LDS only; owner wave 1 copies them to global memory behind
-// barrier (A) (publish_diag) and counts the complete row blocks for the inverse role; (b) the panel solve's row blocks go to the twelve
-// owners that do not share wave 0's SIMD; (c) no workgroup barrier in front of the first step: wave 0 takes its block straight from
-// global memory while the others stage the panel.
+//   F1 owns block columns 0 .. split-1 only (C = 256: split = 6, 65 trailing blocks instead of 120) and runs the look-ahead algorithm on
+//      them unchanged, steps 0 .. split-1 -- every row of every panel is solved by F1 (the panel is its own column) and leaves for global
+//      memory write-through, as it always did for the inverse role.  Then it is done.
+//   F2 holds the trailing blocks of the columns >= split (55 blocks) from the start.  While F1 factors, F2 is PASSIVE: it follows a
+//      counter of complete panels, fetches rows >= 16 split of panel j (20 KB) into LDS and applies it to its blocks -- a step or so
+//      behind F1, which never waits for it.  After panel split-1 it has the trailing matrix of step split in its registers, the next
+//      panel in LDS and the next diagonal block factored: it IS the factoriser from there on, steps split .. nb-1.
+// One hand-off per launch, and it moves 20 KB (the last panel), not the trailing matrix.  Three forms that moved the trailing blocks
+// instead were built and measured first (four helper workgroups, F taking the blocks back at a takeover step; C = 256, K2 per call):
+// helpers through LDS with a boundary wait 67.6 us; helpers fed by 8-byte sc1 loads 70.7 (one fabric transaction per LANE: their waves
+// ran 12 000 - 15 000 cycles apart); 16-byte sc1 accesses + the last two panels applied by F itself 64.5 -- there the takeover alone
+// was 22 000 cycles, 12 000 of them F fetching 110 KB that write-through stores had dropped from every L2 (profiles/r6_k2_timeline.txt).
+// Each factoriser's owner waves hold 5 blocks instead of 8 (40 VGPRs: the register file is no longer at its limit, which is what let
+// the publisher below in without spills).
+// Also new on the factorisers' side: (a) wave 0 leaves the factored block and its inverse in LDS only, in 128-bit accesses; an owner wave
+// that solves nothing copies them to global memory behind barrier (A) (publish_diag) and counts the complete row blocks for the inverse
+// role; (b) the panel solve's row blocks go to the twelve owners that do not share wave 0's SIMD; (c) no workgroup barrier in front of
+// the first step: wave 0 takes its block straight from global memory while the others stage the panel.
 // Hand-off protocol (MI355X_MICROARCH.md, "Valid forms": all payload bytes sc1 stores / sc1 loads, every storing wave's vmcnt(0), a
-// workgroup barrier, ONE lane's sc1 flag store or agent-scope add; the consumer's polling wave loads behind its own poll, the others
-// behind a barrier).  Every workgroup of the launch must be resident at once, as for tri_inverse_role: groups * (1 + TI_WG + CP_NH) <= 72.
-// sync words of matrix g (zeroed by the prepare launch): sync[16 g] complete row blocks, +1 error bits, +2 complete panels, +3 helpers done.
+// workgroup barrier, ONE lane's sc1 flag store; the consumer's polling wave joins a workgroup barrier, the others load behind it).
+// Every workgroup of the launch must be resident at once, as for tri_inverse_role: groups * (2 + TI_WG) <= 48.
+// sync words of matrix g (zeroed by the prepare launch): sync[16 g] complete row blocks, +1 error bits, +2 complete panels.
 // =================================================================================================================================
 typedef double f64x2 __attribute__((ext_vector_type(2)));
-constexpr int CP_NH = 4;                    // helper workgroups per matrix
 constexpr int CP_SLOTS = 5;                 // trailing blocks per owner wave of F
 constexpr int CP_MAXB = 15 * CP_SLOTS;      // ... so a phase holds at most 75 blocks
 __host__ __device__ constexpr int cp_colblocks(int c, int c1, int nb)          // blocks (bi >= bj) of the block columns c .. c1-1
 { return c1 > c ? (c1 - c) * (2 * nb - c - c1 + 1) / 2 : 0; }
 // the block column where the helpers' part begins (nb: no helpers, one phase)
 __host__ __device__ constexpr int cp_split(int nb) { return nb >= 14 ? nb - 10 : nb; }       // (the helpers apply panels 0 .. split-3: below 14 block columns there is nothing for them to do)
-__host__ __device__ constexpr size_t cp_factor_lds_doubles(int C) { return (size_t)3 * C * 17 + 6 * 16 * 18 + 160 * 17 + 2; }
-__host__ __device__ constexpr size_t cp_helper_lds_doubles(int C) { return (size_t)2 * 160 * 18 + 2; }
+__host__ __device__ constexpr size_t cp_factor_lds_doubles(int C) { return (size_t)3 * C * 17 + 6 * 16 * 18 + 2; }
 
 __device__ __forceinline__ bool cp_wait_word(const unsigned* w, unsigned target)
 {
@@ -1214,78 +1215,18 @@ __device__ __forceinline__ f64x4 cp_load_block_sc1(__amdgpu_buffer_rsrc_t r, int
     return odd ? f64x4{r0, r1, v0[1], v1[1]} : f64x4{v0[0], v1[0], r0, r1};
 }
 
-__device__ __forceinline__ void cp_helper_role(double* __restrict__ T, int C, unsigned* sync, int split, int h, double* sm, unsigned long long* hst)
-{
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 15, lq = lane >> 4;
-    const int nb = C >> 4, nreg = nb - split, row0 = 16 * split;
-    double* Pn = sm;                                   // [2][nreg * 16][18]  rows >= 16 split of panel j, even / odd j
-    const __amdgpu_buffer_rsrc_t rT = cp_rsrc(T);
-    unsigned* ok = reinterpret_cast<unsigned*>(sm + 2 * 160 * 18);
-    // this wave's block: rank h*16 + wave over the region's columns, LAST column first (as F deals its own)
-    const int r = h * 16 + wave;
-    int bi = split, bj = split;
-    bool has = false;
-    {
-        int m = 0;
-        while ((m + 1) * (m + 2) / 2 <= r) ++m;         // column nb-1-m holds m+1 blocks
-        if (m < nreg) { has = true; bj = nb - 1 - m; bi = bj + (r - m * (m + 1) / 2); }
-    }
-    f64x4 blk = {0.0, 0.0, 0.0, 0.0};
-    if (has) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) blk[e] = T[(int64_t)(16 * bi + lq + 4 * e) * C + 16 * bj + li];
-    }
-    if (tid == 0) *ok = 1u;
-    const double* pa0 = Pn + (16 * (bi - split) + li) * 18 + lq;
-    const double* pb0 = Pn + (16 * (bj - split) + li) * 18 + lq;
-#pragma unroll 1
-    for (int j = 0; j + 2 < split; ++j) {          // panels 0 .. split-3: F applies the two after them itself (the takeover step)
-        if (CF_STAMPS && hst && lane == 0) hst[4 * j] = __builtin_amdgcn_s_memtime();
-        if (tid == 0 && !cp_wait_word(sync + 2, (unsigned)j + 1)) *ok = 0u;
-        __syncthreads();
-        if (CF_STAMPS && hst && lane == 0) hst[4 * j + 1] = __builtin_amdgcn_s_memtime();
-        // rows >= 16 split of panel j -> LDS, 16 bytes per thread and load (nreg * 128 pieces: at most two per thread)
-        double* pn = Pn + (j & 1) * (160 * 18);
-        {
-            const int e0 = tid, e1 = tid + 1024, n16 = nreg * 128;
-            f64x2 v0 = {0.0, 0.0}, v1 = {0.0, 0.0};
-            if (e0 < n16) v0 = ld_sc1_x2(rT, (row0 + (e0 >> 3)) * C + 16 * j + 2 * (e0 & 7));
-            if (e1 < n16) v1 = ld_sc1_x2(rT, (row0 + (e1 >> 3)) * C + 16 * j + 2 * (e1 & 7));
-            if (e0 < n16) *reinterpret_cast<f64x2*>(pn + (e0 >> 3) * 18 + 2 * (e0 & 7)) = v0;
-            if (e1 < n16) *reinterpret_cast<f64x2*>(pn + (e1 >> 3) * 18 + 2 * (e1 & 7)) = v1;
-        }
-        __syncthreads();
-        if (CF_STAMPS && hst && lane == 0) hst[4 * j + 2] = __builtin_amdgcn_s_memtime();
-        if (has) {
-            const double* pa = pa0 + (j & 1) * (160 * 18);
-            const double* pb = pb0 + (j & 1) * (160 * 18);
-            double av[4], bv[4];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) { av[kk] = -pa[4 * kk]; bv[kk] = pb[4 * kk]; }
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) blk = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], blk, 0, 0, 0);
-        }
-    }
-    if (has) cp_store_block_sc1(rT, 16 * bi * C + 16 * bj, C, blk, li, lq);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (CF_STAMPS && hst && lane == 0) hst[60] = __builtin_amdgcn_s_memtime();
-    __syncthreads();
-    if (CF_STAMPS && hst && lane == 0) hst[61] = __builtin_amdgcn_s_memtime();
-    if (tid == 0) {
-        if (*ok == 0u) atomicOr(sync + 1, 2u);          // a wait ran out: the host reads the error word (wc_factor_error_offset)
-        const unsigned was = __hip_atomic_fetch_add(sync + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (CF_STAMPS && hst) { hst[62] = __builtin_amdgcn_s_memtime(); hst[63] = was; }
-    }
-}
-
+#ifndef CP_SKIP
+#define CP_SKIP 0        // development ablations (WRONG results): 1 no update MFMAs, 2 no trailing update at all, 4 no panel-solve MFMAs, 8 no pivots in the leaf, 16 no panel stores to global memory
+#endif
 #define CP_BARRIER() do { if (CF_STAMPS && stamp_ok && nstamp < 100) stamps[nstamp++] = __builtin_amdgcn_s_memtime();              \
                           asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                          \
                           if (CF_STAMPS && stamp_ok && nstamp < 100) stamps[nstamp++] = __builtin_amdgcn_s_memtime(); } while (0)
 
-__device__ __forceinline__ void cp_factor_role(double* __restrict__ T, double* __restrict__ Linv, int C, unsigned* sync, int split, double* sm,
-                                               unsigned long long* stamp_base)
+// part 0: the first factoriser (steps 0 .. split-1; every step when split == nb).  part 1: the second one -- it holds the trailing blocks
+// of the block columns >= split from the start, applies panels 0 .. split-1 to them as the first one publishes them (the PASSIVE steps:
+// fetch rows >= 16 split of the solved panel, update) and is the factoriser from step split on.
+__device__ __forceinline__ void cp_factor_role(double* __restrict__ T, double* __restrict__ Linv, int C, unsigned* sync, int split, int part,
+                                               double* sm, unsigned long long* stamp_base)
 {
     double* Praw = sm;                          // [2][C][17]  the current / next panel as its owners hold it (row-major)
     double* Pn = Praw + 2 * C * 17;             // [C][17]     solved panel: the update's MFMA operands
@@ -1294,19 +1235,29 @@ __device__ __forceinline__ void cp_factor_role(double* __restrict__ T, double* _
     double* DinvT = Pn + C * 17;                // [2][16][18] INVERSE of the factored diagonal block, TRANSPOSED: [c][i] = Linv[i][c] (even / odd steps)
     double* Dpre = DinvT + 2 * 16 * 18;         // [2][16][18] diagonal block (b, b) with every update but the last one, b even / odd
     double* Ldg = Dpre + 2 * 16 * 18;           // [2][16][18] the factored diagonal block on its way to global memory (even / odd steps)
-    double* Psave = Ldg + 2 * 16 * 18;          // [160][17]   rows >= 16 split of the solved panel split-2: the takeover step applies it to the helpers' blocks
-    const unsigned cntB_lds = (unsigned)(size_t)((__attribute__((address_space(3))) char*)(Psave + 160 * 17));
-    volatile int* const cntB = reinterpret_cast<volatile int*>(Psave + 160 * 17);      // owner waves through the panel solve (running count)
+    const unsigned cntB_lds = (unsigned)(size_t)((__attribute__((address_space(3))) char*)(Ldg + 2 * 16 * 18));
+    volatile int* const cntB = reinterpret_cast<volatile int*>(Ldg + 2 * 16 * 18);      // owner waves through the panel solve (running count)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lq = lane >> 4;
     const int nb = C >> 4;
+    const int jbeg = part ? split : 0, jend = part ? nb : split;        // the active steps
     const __amdgpu_buffer_rsrc_t rT = cp_rsrc(T), rLinv = cp_rsrc(Linv);
-    const bool stamp_ok = CF_STAMPS && lane == 0 && blockIdx.x == 0;
+    const bool stamp_ok = CF_STAMPS && lane == 0 && stamp_base != nullptr;
     unsigned long long* stamps = stamp_base + wave * 128;
     int nstamp = 0;
     (void)stamps; (void)nstamp; (void)stamp_ok;
     if (tid == 0) cntB[0] = 0;
+    // a passive step's fetch: rows >= 16 split of the solved panel j -> Pn, 16 bytes per thread and load (all 16 waves)
+    auto stage_panel = [&](int j) __attribute__((always_inline)) {
+        const int row0 = 16 * split, n16 = (nb - split) * 128;
+        const int e0 = tid, e1 = tid + 1024;
+        f64x2 v0 = {0.0, 0.0}, v1 = {0.0, 0.0};
+        if (e0 < n16) v0 = ld_sc1_x2(rT, (row0 + (e0 >> 3)) * C + 16 * j + 2 * (e0 & 7));
+        if (e1 < n16) v1 = ld_sc1_x2(rT, (row0 + (e1 >> 3)) * C + 16 * j + 2 * (e1 & 7));
+        if (e0 < n16) { double* d = Pn + (row0 + (e0 >> 3)) * 17 + 2 * (e0 & 7); d[0] = v0[0]; d[1] = v0[1]; }
+        if (e1 < n16) { double* d = Pn + (row0 + (e1 >> 3)) * 17 + 2 * (e1 & 7); d[0] = v1[0]; d[1] = v1[1]; }
+    };
 
     if (wave == 0) {
         // ---- wave 0: the diagonal blocks.  Factor + invert block (j, j) [lane = row / column, all four 16-lane rows do the same work],
@@ -1320,14 +1271,15 @@ __device__ __forceinline__ void cp_factor_role(double* __restrict__ T, double* _
                     const f64x2 v = *reinterpret_cast<const f64x2*>(src + li * 18 + c);
                     a[c] = v[0]; a[c + 1] = v[1];
                 }
-            } else {                            // the first block of a phase: from global memory (the helpers' output in phase 2)
+            } else {                            // block (0, 0): straight from global memory (the launch before wrote it), nothing is in LDS yet
 #pragma unroll
-                for (int c = 0; c < 16; ++c) a[c] = T[(int64_t)(16 * j + li) * C + 16 * j + c];      // (block (0, 0): the launch before wrote it)
+                for (int c = 0; c < 16; ++c) a[c] = T[(int64_t)(16 * j + li) * C + 16 * j + c];
             }
             if (CF_STAMPS && stamp_ok) { if (src) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                                         stamps[40 + 5 * j + 1] = __builtin_amdgcn_s_memtime(); }
+                                         stamps[40 + 5 * (j - jbeg) + 1] = __builtin_amdgcn_s_memtime(); }
             static_for<0, 16>([&](auto J) {
                 constexpr int jj = decltype(J)::value;
+                if (CP_SKIP & 8) { w[jj] = a[jj]; return; }
                 const double p = row_bcast<jj>(a[jj]);
                 double rd = __builtin_amdgcn_rsq(p);
                 rd = rd * (1.5 - 0.5 * p * rd * rd);
@@ -1345,7 +1297,7 @@ __device__ __forceinline__ void cp_factor_role(double* __restrict__ T, double* _
                 });
                 w[jj] = -acc * rd;
             });
-            if (CF_STAMPS && stamp_ok) { asm volatile("" :: "v"(a[15]), "v"(w[15])); stamps[40 + 5 * j + 2] = __builtin_amdgcn_s_memtime(); }
+            if (CF_STAMPS && stamp_ok) { asm volatile("" :: "v"(a[15]), "v"(w[15])); stamps[40 + 5 * (j - jbeg) + 2] = __builtin_amdgcn_s_memtime(); }
             if (lane < 16) {
                 double* lg = Ldg + (j & 1) * (16 * 18);
                 double* dv = DinvT + (j & 1) * (16 * 18);
@@ -1354,38 +1306,48 @@ __device__ __forceinline__ void cp_factor_role(double* __restrict__ T, double* _
 #pragma unroll
                 for (int i = 0; i < 16; i += 2) *reinterpret_cast<f64x2*>(dv + lane * 18 + i) = f64x2{w[i], w[i + 1]};     // [c][i], zero where i < c
             }
-            if (CF_STAMPS && stamp_ok) stamps[40 + 5 * j + 3] = __builtin_amdgcn_s_memtime();
+            if (CF_STAMPS && stamp_ok) stamps[40 + 5 * (j - jbeg) + 3] = __builtin_amdgcn_s_memtime();
         };
-        factor(0, nullptr);
+        if (part == 0) factor(0, nullptr);
+        else {
 #pragma unroll 1
-        for (int j = 0; j < nb; ++j) {
+            for (int j = 0; j < split; ++j) {
+                CP_BARRIER();                                          // (P1) panel j is complete in global memory
+                stage_panel(j);
+                CP_BARRIER();                                          // (P2) ... and its rows >= 16 split in Pn
+                if (j + 1 == split) {
+                    // the look-ahead into the first active step: block (split, split) with every update but panel j's waits in Dpre (the
+                    // passive step before left it there), its 16 rows of panel j are SOLVED already (the first factoriser's work)
+                    double* dp = Dpre + (split & 1) * (16 * 18);
+                    const double* px = Pn + (16 * split + li) * 17 + lq;
+                    f64x4 d4, d5 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) d4[r] = dp[(lq + 4 * r) * 18 + li];
+                    d4 = __builtin_amdgcn_mfma_f64_16x16x4f64(-px[0], px[0], d4, 0, 0, 0);
+                    d5 = __builtin_amdgcn_mfma_f64_16x16x4f64(-px[4], px[4], d5, 0, 0, 0);
+                    d4 = __builtin_amdgcn_mfma_f64_16x16x4f64(-px[8], px[8], d4, 0, 0, 0);
+                    d5 = __builtin_amdgcn_mfma_f64_16x16x4f64(-px[12], px[12], d5, 0, 0, 0);
+                    d4 += d5;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dp[(lq + 4 * r) * 18 + li] = d4[r];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    factor(split, dp);
+                }
+            }
+        }
+#pragma unroll 1
+        for (int j = jbeg; j < jend; ++j) {
             CP_BARRIER();                                          // (A)
-            if (j + 1 >= nb) break;                                // the last panel: nothing to look ahead to
+            if (j + 1 >= jend) break;                              // this factoriser's last panel: nothing to look ahead to
             // the next diagonal block: its 16 rows of panel j solved here, its last update, through LDS into the lane = row layout
             double* dp = Dpre + ((j + 1) & 1) * (16 * 18);
             f64x4 d4, d5 = {0.0, 0.0, 0.0, 0.0};
-            if (j + 1 == split) {
-                // the takeover step: block (split, split) comes from the helpers, with every update but panel j's
-                bool good = true;
-                if (lane == 0) good = cp_wait_word(sync + 3, (unsigned)CP_NH);
-                if (!__builtin_amdgcn_readfirstlane((int)good) && lane == 0) atomicOr(sync + 1, 4u);
-                if (CF_STAMPS && stamp_ok) stamps[124] = __builtin_amdgcn_s_memtime();
-                d4 = cp_load_block_sc1(rT, 16 * (j + 1) * C + 16 * (j + 1), C, li, lq);
-                if (CF_STAMPS && stamp_ok) stamps[125] = __builtin_amdgcn_s_memtime();
-                // ... and with every update but the last TWO: panel j-1's rows of this block row wait in Psave (rows 0..15)
-                const double* ps = Psave + li * 17 + lq;
-                d4 = __builtin_amdgcn_mfma_f64_16x16x4f64(-ps[0], ps[0], d4, 0, 0, 0);
-                d5 = __builtin_amdgcn_mfma_f64_16x16x4f64(-ps[4], ps[4], d5, 0, 0, 0);
-                d4 = __builtin_amdgcn_mfma_f64_16x16x4f64(-ps[8], ps[8], d4, 0, 0, 0);
-                d5 = __builtin_amdgcn_mfma_f64_16x16x4f64(-ps[12], ps[12], d5, 0, 0, 0);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) d4[r] = dp[(lq + 4 * r) * 18 + li];
-            }
             {
                 const double* pr = Praw + (j & 1) * (C * 17) + (16 * (j + 1) + li) * 17 + lq;
                 const double* dv0 = DinvT + (j & 1) * (16 * 18) + lq * 18 + li;        // Linv[li][lq + 4 kk] = DinvT[lq + 4 kk][li]
                 f64x4 xa = {0.0, 0.0, 0.0, 0.0}, xb = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d4[r] = dp[(lq + 4 * r) * 18 + li];
                 xa = __builtin_amdgcn_mfma_f64_16x16x4f64(dv0[0], pr[0], xa, 0, 0, 0);
                 xb = __builtin_amdgcn_mfma_f64_16x16x4f64(dv0[4 * 18], pr[4], xb, 0, 0, 0);
                 xa = __builtin_amdgcn_mfma_f64_16x16x4f64(dv0[8 * 18], pr[8], xa, 0, 0, 0);
@@ -1400,28 +1362,76 @@ __device__ __forceinline__ void cp_factor_role(double* __restrict__ T, double* _
 #pragma unroll
             for (int r = 0; r < 4; ++r) dp[(lq + 4 * r) * 18 + li] = d4[r];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // own LDS writes before own reads (one wave: no barrier needed)
-            if (CF_STAMPS && stamp_ok) stamps[40 + 5 * (j + 1)] = __builtin_amdgcn_s_memtime();
+            if (CF_STAMPS && stamp_ok) stamps[40 + 5 * (j + 1 - jbeg)] = __builtin_amdgcn_s_memtime();
             factor(j + 1, dp);
         }
     } else {
-        // ---- waves 1 .. 15: the panel solve and the trailing update of the phase's block columns
+        // ---- waves 1 .. 15: the panel solve and the trailing update of this factoriser's block columns
         const int ow = wave - 1;
         const bool publisher = wave == 4;                 // (on wave 0's SIMD: it has no row block to solve)
         const bool solver = (wave & 3) != 0;               // not on wave 0's SIMD
         const int sv = ow - (wave >> 2);                   // 0 .. 11 among the solvers
+        const int cb = part ? split : 1, ce = jend;        // this factoriser's trailing block columns [cb, ce)
         int bc_[CP_SLOTS];
         f64x4 blk[CP_SLOTS];
         int li_t = li, lq_t = lq;       // per-step opaque copies of the lane constants (nothing built from them may be hoisted out of the step loop)
-        auto update = [&](auto Q) __attribute__((always_inline)) {
-            constexpr int q = decltype(Q)::value;
-            const int bc = bc_[q];
-            const double* pa = Pn + (16 * (bc >> 8) + li_t) * 17 + lq_t;
-            const double* pb = Pn + (16 * (bc & 255) + li_t) * 17 + lq_t;
-            double av[4], bv[4];
+        // (S4) the trailing update of step j: block (bi, bj) -= P[bi] P[bj]^T, operands from the solved panel in LDS.  This wave's active
+        // slots are [0, n34): ranks below R4 lie right of the next panel, the next ranks ARE the next panel (column j+1).  The slots run from
+        // the highest down, so the next panel's blocks go first; they leave for the other panel buffer -- except the diagonal one, which
+        // wave 0 updates and factors itself.  The diagonal block after that, (j+2, j+2), leaves a copy behind once it has this step's
+        // update: wave 0's input at the next step.  (Columns left of cb do not exist here: a passive step's ranks.)
+        // Round 6: software-pipelined.  A block used to be eight LDS reads, a wait, four dependent MFMAs, and (next panel) four LDS writes
+        // that wait for the last MFMA -- with every wave of a SIMD in the same phase of that at the same time its matrix pipe was idle half
+        // of the update (stamps: the youngest wave of a SIMD finished 2 700 cycles behind the oldest).  Now the next slot's operands are on
+        // their way while this slot's MFMAs run, and a slot's LDS writes follow the NEXT slot's MFMAs.
+        auto trailing = [&](int j) __attribute__((always_inline)) {
+            const int c3 = j + 1 > cb ? j + 1 : cb, c4 = j + 2 > cb ? j + 2 : cb, c5 = j + 3 > cb ? j + 3 : cb;
+            const int R4 = cp_colblocks(c4, ce, nb), R3 = cp_colblocks(c3, ce, nb);
+            const int n4 = R4 > ow ? (R4 - ow + 14) / 15 : 0;
+            const int n34 = R3 > ow ? (R3 - ow + 14) / 15 : 0;
+            const int R5 = cp_colblocks(c5, ce, nb);               // rank of block (j+2, j+2), the first of its column
+            const int qd = (j + 2 >= cb && j + 2 < ce && R5 % 15 == ow) ? R5 / 15 : -1;
+            double* nxt = Praw + ((j + 1) & 1) * (C * 17);
+            double* dpq = Dpre + (j & 1) * (16 * 18);
+            double av[2][4], bv[2][4];
+            auto fetch = [&](auto Q) __attribute__((always_inline)) {
+                constexpr int q = decltype(Q)::value;
+                const int bc = bc_[q];
+                const double* pa = Pn + (16 * (bc >> 8) + li_t) * 17 + lq_t;
+                const double* pb = Pn + (16 * (bc & 255) + li_t) * 17 + lq_t;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) { av[kk] = -pa[4 * kk]; bv[kk] = pb[4 * kk]; }
+                for (int kk = 0; kk < 4; ++kk) { av[q & 1][kk] = -pa[4 * kk]; bv[q & 1][kk] = pb[4 * kk]; }
+            };
+            auto leave = [&](auto Q) __attribute__((always_inline)) {      // what a finished slot leaves in LDS
+                constexpr int q = decltype(Q)::value;
+                if (q >= n4 && (bc_[q] >> 8) != (bc_[q] & 255)) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) blk[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], blk[q], 0, 0, 0);
+                    for (int e = 0; e < 4; ++e) nxt[(16 * (bc_[q] >> 8) + lq_t + 4 * e) * 17 + li_t] = blk[q][e];
+                }
+                if (q == qd) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dpq[(lq_t + 4 * e) * 18 + li_t] = blk[q][e];
+                }
+            };
+            static_for<0, CP_SLOTS>([&](auto Q) {
+                constexpr int q = CP_SLOTS - 1 - decltype(Q)::value;
+                if (q < n34) {
+                    if (CF_STAMPS && stamp_ok && j == jbeg) stamps[100 + q] = __builtin_amdgcn_s_memtime();
+                    if (q == n34 - 1) fetch(std::integral_constant<int, q>{});
+                    if constexpr (q > 0) fetch(std::integral_constant<int, q - 1>{});
+                    // (a next-panel slot that holds the diagonal block takes no update here: wave 0 gives it its last one)
+                    if (!(q >= n4 && (bc_[q] >> 8) == (bc_[q] & 255))) {
+                        if (CP_SKIP & 1) { blk[q][0] += av[q & 1][0] * bv[q & 1][1] + av[q & 1][2] * bv[q & 1][3] + av[q & 1][1] * bv[q & 1][0] + av[q & 1][3] * bv[q & 1][2]; }
+                        else {
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) blk[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q & 1][kk], bv[q & 1][kk], blk[q], 0, 0, 0);
+                        }
+                    }
+                    if constexpr (q + 1 < CP_SLOTS) { if (q + 1 < n34) leave(std::integral_constant<int, q + 1>{}); }
+                }
+            });
+            if (n34 > 0) leave(std::integral_constant<int, 0>{});
+            if (CF_STAMPS && stamp_ok && j == jbeg) { stamps[106] = __builtin_amdgcn_s_memtime(); asm volatile("s_nop 0" :: "v"(blk[0])); stamps[107] = __builtin_amdgcn_s_memtime(); }
         };
         // the diagonal block of step j and its inverse, from wave 0's LDS copies to global memory (off wave 0's chain)
         auto publish_diag = [&](int j) __attribute__((always_inline)) {
@@ -1435,59 +1445,59 @@ __device__ __forceinline__ void cp_factor_role(double* __restrict__ T, double* _
                 st_sc1_x2(rLinv, j * 256 + 16 * r + c, f64x2{dv[c * 18 + r], dv[(c + 1) * 18 + r]});
             }
         };
-        int nB = 0;                     // meetings (B) so far
-        // this wave's trailing blocks of the block columns [cb, ce): ranked by block column, LAST column first, the diagonal block first
-        // within a column, dealt round-robin -- the blocks still active at a step are a prefix of every wave's slots
-        auto load_blocks = [&](int cb, int ce, bool fresh) __attribute__((always_inline)) {
+        // this wave's trailing blocks: ranked by block column, LAST column first, the diagonal block first within a column, dealt
+        // round-robin -- the blocks still active at a step are a prefix of every wave's slots.  (As the launch before left them.)
+        {
             const int nblk = cp_colblocks(cb, ce, nb);
 #pragma unroll
             for (int q = 0; q < CP_SLOTS; ++q) {
                 const int r = ow + 15 * q;
                 bc_[q] = 0;
+                blk[q] = f64x4{0.0, 0.0, 0.0, 0.0};
                 if (r < nblk) {
                     int bj = ce - 1;
                     while (cp_colblocks(bj, ce, nb) <= r) --bj;       // column bj holds the ranks [blocks right of it, blocks from it on)
                     const int bi = bj + (r - cp_colblocks(bj + 1, ce, nb));
                     bc_[q] = (bi << 8) | bj;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) blk[q][e] = T[(int64_t)(16 * bi + lq + 4 * e) * C + 16 * bj + li];
                 }
             }
-            if (fresh) {
-                // the helpers' output, 16-byte sc1 loads.  No branch between the slots' loads (an empty slot reads block (cb, cb) for
-                // nothing): one basic block, every load in flight before the first lane swap waits for its data
-#pragma unroll
-                for (int q = 0; q < CP_SLOTS; ++q) {
-                    const int bc = bc_[q] ? bc_[q] : ((cb << 8) | cb);
-                    blk[q] = cp_load_block_sc1(rT, 16 * (bc >> 8) * C + 16 * (bc & 255), C, li, lq);
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < CP_SLOTS; ++q) {
-                    blk[q] = f64x4{0.0, 0.0, 0.0, 0.0};
-                    if (bc_[q]) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) blk[q][e] = T[(int64_t)(16 * (bc_[q] >> 8) + lq + 4 * e) * C + 16 * (bc_[q] & 255) + li];
-                    }
-                }
-            }
-        };
-        // panel 0 (block column 0 below its diagonal block) and block (1, 1) as they stand -> LDS
-        for (int e = tid - 64; e < (C - 16) * 16; e += 960)
-            Praw[(16 + (e >> 4)) * 17 + (e & 15)] = T[(int64_t)(16 + (e >> 4)) * C + (e & 15)];
-        if (nb > 1)
-            for (int e = tid - 64; e < 256; e += 960)
-                Dpre[16 * 18 + (e >> 4) * 18 + (e & 15)] = T[(int64_t)(16 + (e >> 4)) * C + 16 + (e & 15)];
-        load_blocks(1, split, false);   // (split == nb: every block column is F's own)
+        }
+        if (part == 0) {
+            // panel 0 (block column 0 below its diagonal block) and block (1, 1) as they stand -> LDS
+            for (int e = tid - 64; e < (C - 16) * 16; e += 960)
+                Praw[(16 + (e >> 4)) * 17 + (e & 15)] = T[(int64_t)(16 + (e >> 4)) * C + (e & 15)];
+            if (nb > 1)
+                for (int e = tid - 64; e < 256; e += 960)
+                    Dpre[16 * 18 + (e >> 4) * 18 + (e & 15)] = T[(int64_t)(16 + (e >> 4)) * C + 16 + (e & 15)];
+        } else {
 #pragma unroll 1
-        for (int j = 0; j < nb; ++j) {
+            for (int j = 0; j < split; ++j) {
+                if (wave == 1) {
+                    bool good = true;
+                    if (lane == 0) good = cp_wait_word(sync + 2, (unsigned)j + 1);
+                    if (!__builtin_amdgcn_readfirstlane((int)good) && lane == 0) atomicOr(sync + 1, 2u);     // a wait ran out: the host reads the error word
+                }
+                CP_BARRIER();                                      // (P1) panel j is complete in global memory
+                asm volatile("" : "+v"(li_t), "+v"(lq_t));
+                stage_panel(j);
+                CP_BARRIER();                                      // (P2) ... and its rows >= 16 split in Pn
+                trailing(j);
+            }
+        }
+        int nB = 0;                     // meetings (B) so far
+#pragma unroll 1
+        for (int j = jbeg; j < jend; ++j) {
             // every store of the step before has landed (the solved panel's rows; the publisher's copy of diagonal block j-1), and
             // every owner passed this wait before barrier (A) of step j-1 with its rows of the panels before: row blocks 0..j-1 and
             // panels 0..j-1 are complete in global memory once the barrier below is behind us
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             CP_BARRIER();                                          // (A) the inverse of L_jj and panel j are in LDS
             asm volatile("" : "+v"(li_t), "+v"(lq_t));
-            if (publisher && lane == 0 && j > 0) {
+            if (publisher && lane == 0 && j > jbeg) {
                 __hip_atomic_store(sync, (unsigned)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (j + 1 < split && split < nb) __hip_atomic_store(sync + 2, (unsigned)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (part == 0 && split < nb) __hip_atomic_store(sync + 2, (unsigned)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (publisher) publish_diag(j);
             const int j0 = 16 * j, g0 = j0 + 16, rows = C - g0;
@@ -1499,7 +1509,6 @@ __device__ __forceinline__ void cp_factor_role(double* __restrict__ T, double* _
                 break;
             }
             const double* pan = Praw + (j & 1) * (C * 17);
-            double* nxt = Praw + ((j + 1) & 1) * (C * 17);
             // (S2) panel solve X = P L_jj^-T as a product with the inverted diagonal block, one 16-row block per solver wave and turn
             if (solver) {
                 const double* dv = DinvT + (j & 1) * (16 * 18);        // B operand Linv[c = li][k = lq + 4 kk] = DinvT[k][li]
@@ -1508,19 +1517,18 @@ __device__ __forceinline__ void cp_factor_role(double* __restrict__ T, double* _
                     f64x4 x = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                     for (int kk = 0; kk < 4; kk += 2) {
+                        if (CP_SKIP & 4) { x[kk] += pan[(row0 + li_t) * 17 + 4 * kk + lq_t] * dv[(4 * kk + lq_t) * 18 + li_t]; x1[kk] += pan[(row0 + li_t) * 17 + 4 * kk + 4 + lq_t] * dv[(4 * kk + 4 + lq_t) * 18 + li_t]; continue; }
                         x = __builtin_amdgcn_mfma_f64_16x16x4f64(pan[(row0 + li_t) * 17 + 4 * kk + lq_t], dv[(4 * kk + lq_t) * 18 + li_t], x, 0, 0, 0);
                         x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(pan[(row0 + li_t) * 17 + 4 * kk + 4 + lq_t], dv[(4 * kk + 4 + lq_t) * 18 + li_t], x1, 0, 0, 0);
                     }
                     x += x1;
-                    cp_store_block_sc1(rT, row0 * C + j0, C, x, li_t, lq_t);      // write-through: the inverse role and the helpers read it in this launch
+                    if (!(CP_SKIP & 16)) cp_store_block_sc1(rT, row0 * C + j0, C, x, li_t, lq_t);      // write-through: the inverse role and the second factoriser read it in this launch
 #pragma unroll
                     for (int e = 0; e < 4; ++e) Pn[(row0 + lq_t + 4 * e) * 17 + li_t] = x[e];
-                    if (j + 2 == split && row0 >= 16 * split) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) Psave[(row0 - 16 * split + lq_t + 4 * e) * 17 + li_t] = x[e];
-                    }
                 }
             }
+            const bool last = j + 1 >= jend;                        // the first factoriser's last panel (rows > 0: not the matrix' last)
+            if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the meeting below then says: panel j and diagonal block j are complete in memory
             {   // (B) among the owners: every owner's rows of the solved panel are in LDS
                 if (CF_STAMPS && stamp_ok && nstamp < 100) stamps[nstamp++] = __builtin_amdgcn_s_memtime();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1533,83 +1541,37 @@ __device__ __forceinline__ void cp_factor_role(double* __restrict__ T, double* _
                 }
                 if (CF_STAMPS && stamp_ok && nstamp < 100) stamps[nstamp++] = __builtin_amdgcn_s_memtime();
             }
-            // the block columns this step's ranks run over: F's own up to the takeover step, the helpers' from it on
-            const bool took = j + 1 >= split;
-            const int c1 = took ? nb : split;
-            if (j + 1 == split && split < nb) {
-                // the takeover step: the helpers' blocks (every panel but this one applied) become this workgroup's trailing blocks
-                bool good = true;
-                if (lane == 0) good = cp_wait_word(sync + 3, (unsigned)CP_NH);
-                if (!__builtin_amdgcn_readfirstlane((int)good) && lane == 0) atomicOr(sync + 1, 4u);
-                if (CF_STAMPS && stamp_ok) stamps[100] = __builtin_amdgcn_s_memtime();
-                load_blocks(split, nb, true);
-                if (CF_STAMPS && stamp_ok) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamps[101] = __builtin_amdgcn_s_memtime(); }
-                // every panel but the last two applied: panel j-1 from Psave here, panel j with the step's own update below
-                static_for<0, CP_SLOTS>([&](auto Q) {
-                    constexpr int q = decltype(Q)::value;
-                    if (ow + 15 * q < cp_colblocks(split, nb, nb)) {
-                        const int bc = bc_[q];
-                        const double* pa = Psave + (16 * ((bc >> 8) - split) + li_t) * 17 + lq_t;
-                        const double* pb = Psave + (16 * ((bc & 255) - split) + li_t) * 17 + lq_t;
-                        double av[4], bv[4];
-#pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) { av[kk] = -pa[4 * kk]; bv[kk] = pb[4 * kk]; }
-#pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) blk[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], blk[q], 0, 0, 0);
-                    }
-                });
-                if (CF_STAMPS && stamp_ok) stamps[102] = __builtin_amdgcn_s_memtime();
+            if (last) {
+                // hand over: the second factoriser's last passive step waits for this panel; the inverse role for row block j
+                if (publisher && lane == 0) {
+                    __hip_atomic_store(sync + 2, (unsigned)j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(sync, (unsigned)j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                break;
             }
-            // (S4) this wave's active slots are [0, n34): ranks below R4 lie right of the next panel, the next ranks ARE the next panel
-            // (column j+1).  The next panel's blocks go first and leave for the other panel buffer -- except the diagonal one, which
-            // wave 0 updates and factors itself.  The diagonal block after that, (j+2, j+2), leaves a copy behind once it has this
-            // step's update: wave 0's input at the next step.
-            const int R4 = cp_colblocks(j + 2, c1, nb), R3 = cp_colblocks(j + 1, c1, nb);
-            const int n4 = R4 > ow ? (R4 - ow + 14) / 15 : 0;
-            const int n34 = R3 > ow ? (R3 - ow + 14) / 15 : 0;
-            const int R5 = cp_colblocks(j + 3, c1, nb);            // rank of block (j+2, j+2), the first of its column
-            const int qd = (j + 2 < c1 && R5 % 15 == ow) ? R5 / 15 : -1;
-            static_for<0, CP_SLOTS>([&](auto Q) {                  // next panel first (the highest active slots)
-                constexpr int q = CP_SLOTS - 1 - decltype(Q)::value;
-                if (q >= n4 && q < n34 && (bc_[q] >> 8) != (bc_[q] & 255)) {
-                    update(std::integral_constant<int, q>{});
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) nxt[(16 * (bc_[q] >> 8) + lq_t + 4 * e) * 17 + li_t] = blk[q][e];
-                }
-            });
-            static_for<0, CP_SLOTS>([&](auto Q) {
-                constexpr int q = decltype(Q)::value;
-                if (q < n4) {
-                    update(std::integral_constant<int, q>{});
-                    if (q == qd) {
-                        double* dp = Dpre + (j & 1) * (16 * 18);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) dp[(lq_t + 4 * e) * 18 + li_t] = blk[q][e];
-                    }
-                }
-            });
+            if (!(CP_SKIP & 2)) trailing(j);
         }
     }
     if (CF_STAMPS && stamp_ok) { if (nstamp < 100) stamps[nstamp++] = __builtin_amdgcn_s_memtime(); stamps[127] = nstamp; }
 }
 
-// grid: [0, groups) factorising, [groups, groups (1 + TI_WG)) inverse, [groups (1 + TI_WG), groups (1 + TI_WG + CP_NH)) helpers (when split < nb)
+// grid: [0, groups) first factorisers, [groups, groups (1 + TI_WG)) inverse, [groups (1 + TI_WG), groups (2 + TI_WG)) second factorisers (when split < nb)
 __global__ __launch_bounds__(1024) void cholesky_phased_kernel(double* __restrict__ T, double* __restrict__ Linv, int C, double* __restrict__ Winv,
                                                                unsigned* __restrict__ sync, int groups, int split)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int b = (int)blockIdx.x;
     if (b < groups) {
-        cp_factor_role(T + (int64_t)b * C * C, Linv + (int64_t)b * C * 16, C, sync + 16 * b, split, sm,
-                       reinterpret_cast<unsigned long long*>(Linv + 8192));
+        cp_factor_role(T + (int64_t)b * C * C, Linv + (int64_t)b * C * 16, C, sync + 16 * b, split, 0, sm,
+                       (CF_STAMPS && b == 0) ? reinterpret_cast<unsigned long long*>(Linv + 8192) : nullptr);
     } else if (b < groups * (1 + TI_WG)) {
         const int idx = b - groups, g = idx / TI_WG;
         tri_inverse_role(T + (int64_t)g * C * C, Linv + (int64_t)g * C * 16, Winv + (int64_t)g * C * C, C, idx % TI_WG, sync + 16 * g, sm);
     } else {
-        const int idx = b - groups * (1 + TI_WG), g = idx / CP_NH;
-        // (development stamps: 64 words per helper wave behind the factorising workgroup's 16 x 128)
-        cp_helper_role(T + (int64_t)g * C * C, C, sync + 16 * g, split, idx % CP_NH, sm,
-                       (CF_STAMPS && g == 0) ? reinterpret_cast<unsigned long long*>(Linv + 8192) + 16 * 128 + ((idx % CP_NH) * 16 + (threadIdx.x >> 6)) * 64 : nullptr);
+        const int g = b - groups * (1 + TI_WG);
+        // (development stamps of the second factoriser: behind the first one's 16 x 128 words)
+        cp_factor_role(T + (int64_t)g * C * C, Linv + (int64_t)g * C * 16, C, sync + 16 * g, split, 1, sm,
+                       (CF_STAMPS && g == 0) ? reinterpret_cast<unsigned long long*>(Linv + 8192) + 16 * 128 : nullptr);
     }
 }
 
@@ -2085,16 +2047,15 @@ hipError_t wc_launch_factor_fused(double* T, double* W, double* tmp, int C, int 
             int split = cp_split(nb);
             if (split_env >= 1 && split_env <= nb) split = split_env;
             // what a phase may hold (the owners' slots, the helpers' one block per wave); anything else runs in one phase, or on round 5's kernel
-            const bool fits2 = split < nb && cp_colblocks(1, split, nb) <= CP_MAXB && cp_colblocks(split + 1, nb, nb) <= CP_MAXB &&
-                               cp_colblocks(split, nb, nb) <= CP_NH * 16 && nb - split <= 10;
+            const bool fits2 = split >= 2 && split < nb && cp_colblocks(1, split, nb) <= CP_MAXB && cp_colblocks(split, nb, nb) <= CP_MAXB &&
+                               (nb - split) * 128 <= 2048;
             if (!fits2) split = nb;
             if (split < nb || cp_colblocks(1, nb, nb) <= CP_MAXB) {
                 size_t l2 = cp_factor_lds_doubles(C) * sizeof(double);
                 if (lds_role > l2) l2 = lds_role;
-                if (cp_helper_lds_doubles(C) * sizeof(double) > l2) l2 = cp_helper_lds_doubles(C) * sizeof(double);
                 e = hipFuncSetAttribute(reinterpret_cast<const void*>(cholesky_phased_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
                 if (e != hipSuccess) return e;
-                const int nwg = groups * (1 + TI_WG + (split < nb ? CP_NH : 0));
+                const int nwg = groups * (1 + TI_WG + (split < nb ? 1 : 0));
                 hipLaunchKernelGGL(cholesky_phased_kernel, dim3(nwg), dim3(1024), l2, st, T, tmp, C, W, rows, groups, split);
                 return hipGetLastError();
             }
