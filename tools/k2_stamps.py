@@ -13,20 +13,20 @@ g = torch.Generator(device='cpu'); g.manual_seed(1)
 x = torch.randn(M, C, generator=g).cuda()
 s, xtx = ops.stats(x)
 mu = torch.empty(C, device='cuda'); L = torch.empty(C, C, dtype=torch.float64, device='cuda'); W = torch.empty_like(L)
-ws = torch.zeros(max(lib.wc_factor_workspace_bytes(C, 1), 8 * (8192 + 32 * 128)), dtype=torch.uint8, device='cuda')
+ws = torch.zeros(max(lib.wc_factor_workspace_bytes(C, 1), 8 * (8192 + 64 * 128)), dtype=torch.uint8, device='cuda')
 for _ in range(3):
     _lib.check(lib.wc_factor_f64(s.data_ptr(), xtx.data_ptr(), M, C, 1, 1e-3, 0.99, 1, 1, None, None, mu.data_ptr(), None,
                                  L.data_ptr(), W.data_ptr(), ws.data_ptr(), ws.numel(), None), "factor")
 torch.cuda.synchronize()
 nb = C // 16
-split = nb - 10 if nb >= 14 else nb
-if os.environ.get("WC_K2_PHASE_SPLIT"): split = int(os.environ["WC_K2_PHASE_SPLIT"])
-allst = ws.view(torch.int64)[8192:8192 + 32 * 128].cpu().numpy().reshape(2, 16, 128)
+bounds = [0] + ([int(v) for v in os.environ["WC_K2_BOUNDS"].split(",")] if os.environ.get("WC_K2_BOUNDS") else ([nb // 4, nb * 9 // 16] if nb >= 14 else [])) + [nb]
+allst = ws.view(torch.int64)[8192:8192 + 64 * 128].cpu().numpy().reshape(4, 16, 128)
 for part, st in enumerate(allst):
     if not any(int(r[127]) > 0 for r in st): continue
-    jbeg = split if part else 0
-    print("---- factoriser %d (steps %d .. %d)%s" % (part + 1, jbeg, (nb if part or split == nb else split) - 1,
-          ": its first %d barrier pairs are the passive steps' (panel published / staged)" % (2 * split) if part else ""))
+    if part + 1 >= len(bounds): break
+    jbeg, jend = bounds[part], bounds[part + 1]
+    print("---- factoriser %d (steps %d .. %d)%s" % (part + 1, jbeg, jend - 1,
+          ": its first %d barrier pairs are the passive steps' (panel published / staged)" % (2 * jbeg) if part else ""))
     t0 = min(int(r[0]) for r in st if int(r[127]) > 0)
     for w in (0, 1, 4, 13, 15):
         row = st[w]; n = int(row[127]); t = (row[:n].astype(np.int64) - t0)
@@ -37,8 +37,8 @@ for part, st in enumerate(allst):
     # wave 0's phases per look-ahead (slots 40 + 5 (j - jbeg) + {0: next diagonal block solved + updated, in LDS; 1: its 16 columns loaded;
     # 2: factored + inverted; 3: LDS copies written}), relative to the release of barrier (A) of the step before
     row = st[0]; n = int(row[127]); t = row[:n].astype(np.int64) - t0
-    base = 2 * 2 * split if part else 0          # wave 0's stamps of the passive steps come first
-    for k in range(1, nb - jbeg):
+    base = 2 * 2 * jbeg          # wave 0's stamps of the passive steps come first
+    for k in range(1, jend - jbeg):
         if base + 2 * (k - 1) + 1 >= n or not row[40 + 5 * k + 2]: break
         rel = int(t[base + 2 * (k - 1) + 1]); ph = [int(row[40 + 5 * k + q]) - t0 - rel for q in range(4)]
         arrive = int(t[base + 2 * k]) - rel if base + 2 * k < n else -1

@@ -1164,7 +1164,6 @@ constexpr int CP_MAXB = 15 * CP_SLOTS;      // ... so a phase holds at most 75 b
 __host__ __device__ constexpr int cp_colblocks(int c, int c1, int nb)          // blocks (bi >= bj) of the block columns c .. c1-1
 { return c1 > c ? (c1 - c) * (2 * nb - c - c1 + 1) / 2 : 0; }
 // the block column where the helpers' part begins (nb: no helpers, one phase)
-__host__ __device__ constexpr int cp_split(int nb) { return nb >= 14 ? nb - 10 : nb; }       // (the helpers apply panels 0 .. split-3: below 14 block columns there is nothing for them to do)
 __host__ __device__ constexpr size_t cp_factor_lds_doubles(int C) { return (size_t)3 * C * 17 + 6 * 16 * 18 + 2; }
 
 __device__ __forceinline__ bool cp_wait_word(const unsigned* w, unsigned target)
@@ -1222,10 +1221,10 @@ __device__ __forceinline__ f64x4 cp_load_block_sc1(__amdgpu_buffer_rsrc_t r, int
                           asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                          \
                           if (CF_STAMPS && stamp_ok && nstamp < 100) stamps[nstamp++] = __builtin_amdgcn_s_memtime(); } while (0)
 
-// part 0: the first factoriser (steps 0 .. split-1; every step when split == nb).  part 1: the second one -- it holds the trailing blocks
-// of the block columns >= split from the start, applies panels 0 .. split-1 to them as the first one publishes them (the PASSIVE steps:
-// fetch rows >= 16 split of the solved panel, update) and is the factoriser from step split on.
-__device__ __forceinline__ void cp_factor_role(double* __restrict__ T, double* __restrict__ Linv, int C, unsigned* sync, int split, int part,
+// One factoriser of the relay: active in the steps [jbeg, jend), where it owns the trailing blocks of the block columns [max(jbeg, 1), jend)
+// (rows from the diagonal down to the matrix' last).  Before that it is PASSIVE: it applies the panels 0 .. jbeg-1 to those blocks as the
+// factorisers before it publish them (fetch rows >= 16 jbeg of the solved panel, update).  jbeg = 0: the first one; jend = nb: the last.
+__device__ __forceinline__ void cp_factor_role(double* __restrict__ T, double* __restrict__ Linv, int C, unsigned* sync, int jbeg, int jend,
                                                double* sm, unsigned long long* stamp_base)
 {
     double* Praw = sm;                          // [2][C][17]  the current / next panel as its owners hold it (row-major)
@@ -1241,16 +1240,15 @@ __device__ __forceinline__ void cp_factor_role(double* __restrict__ T, double* _
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lq = lane >> 4;
     const int nb = C >> 4;
-    const int jbeg = part ? split : 0, jend = part ? nb : split;        // the active steps
     const __amdgpu_buffer_rsrc_t rT = cp_rsrc(T), rLinv = cp_rsrc(Linv);
     const bool stamp_ok = CF_STAMPS && lane == 0 && stamp_base != nullptr;
     unsigned long long* stamps = stamp_base + wave * 128;
     int nstamp = 0;
     (void)stamps; (void)nstamp; (void)stamp_ok;
     if (tid == 0) cntB[0] = 0;
-    // a passive step's fetch: rows >= 16 split of the solved panel j -> Pn, 16 bytes per thread and load (all 16 waves)
+    // a passive step's fetch: rows >= 16 jbeg of the solved panel j -> Pn, 16 bytes per thread and load (all 16 waves)
     auto stage_panel = [&](int j) __attribute__((always_inline)) {
-        const int row0 = 16 * split, n16 = (nb - split) * 128;
+        const int row0 = 16 * jbeg, n16 = (nb - jbeg) * 128;
         const int e0 = tid, e1 = tid + 1024;
         f64x2 v0 = {0.0, 0.0}, v1 = {0.0, 0.0};
         if (e0 < n16) v0 = ld_sc1_x2(rT, (row0 + (e0 >> 3)) * C + 16 * j + 2 * (e0 & 7));
@@ -1308,18 +1306,18 @@ __device__ __forceinline__ void cp_factor_role(double* __restrict__ T, double* _
             }
             if (CF_STAMPS && stamp_ok) stamps[40 + 5 * (j - jbeg) + 3] = __builtin_amdgcn_s_memtime();
         };
-        if (part == 0) factor(0, nullptr);
+        if (jbeg == 0) factor(0, nullptr);
         else {
 #pragma unroll 1
-            for (int j = 0; j < split; ++j) {
+            for (int j = 0; j < jbeg; ++j) {
                 CP_BARRIER();                                          // (P1) panel j is complete in global memory
                 stage_panel(j);
                 CP_BARRIER();                                          // (P2) ... and its rows >= 16 split in Pn
-                if (j + 1 == split) {
-                    // the look-ahead into the first active step: block (split, split) with every update but panel j's waits in Dpre (the
-                    // passive step before left it there), its 16 rows of panel j are SOLVED already (the first factoriser's work)
-                    double* dp = Dpre + (split & 1) * (16 * 18);
-                    const double* px = Pn + (16 * split + li) * 17 + lq;
+                if (j + 1 == jbeg) {
+                    // the look-ahead into the first active step: block (jbeg, jbeg) with every update but panel j's waits in Dpre (the
+                    // passive step before left it there), its 16 rows of panel j are SOLVED already (the work of the factoriser before)
+                    double* dp = Dpre + (jbeg & 1) * (16 * 18);
+                    const double* px = Pn + (16 * jbeg + li) * 17 + lq;
                     f64x4 d4, d5 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                     for (int r = 0; r < 4; ++r) d4[r] = dp[(lq + 4 * r) * 18 + li];
@@ -1331,7 +1329,7 @@ __device__ __forceinline__ void cp_factor_role(double* __restrict__ T, double* _
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dp[(lq + 4 * r) * 18 + li] = d4[r];
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    factor(split, dp);
+                    factor(jbeg, dp);
                 }
             }
         }
@@ -1371,7 +1369,7 @@ __device__ __forceinline__ void cp_factor_role(double* __restrict__ T, double* _
         const bool publisher = wave == 4;                 // (on wave 0's SIMD: it has no row block to solve)
         const bool solver = (wave & 3) != 0;               // not on wave 0's SIMD
         const int sv = ow - (wave >> 2);                   // 0 .. 11 among the solvers
-        const int cb = part ? split : 1, ce = jend;        // this factoriser's trailing block columns [cb, ce)
+        const int cb = jbeg ? jbeg : 1, ce = jend;         // this factoriser's trailing block columns [cb, ce)
         int bc_[CP_SLOTS];
         f64x4 blk[CP_SLOTS];
         int li_t = li, lq_t = lq;       // per-step opaque copies of the lane constants (nothing built from them may be hoisted out of the step loop)
@@ -1464,7 +1462,7 @@ __device__ __forceinline__ void cp_factor_role(double* __restrict__ T, double* _
                 }
             }
         }
-        if (part == 0) {
+        if (jbeg == 0) {
             // panel 0 (block column 0 below its diagonal block) and block (1, 1) as they stand -> LDS
             for (int e = tid - 64; e < (C - 16) * 16; e += 960)
                 Praw[(16 + (e >> 4)) * 17 + (e & 15)] = T[(int64_t)(16 + (e >> 4)) * C + (e & 15)];
@@ -1473,7 +1471,7 @@ __device__ __forceinline__ void cp_factor_role(double* __restrict__ T, double* _
                     Dpre[16 * 18 + (e >> 4) * 18 + (e & 15)] = T[(int64_t)(16 + (e >> 4)) * C + 16 + (e & 15)];
         } else {
 #pragma unroll 1
-            for (int j = 0; j < split; ++j) {
+            for (int j = 0; j < jbeg; ++j) {
                 if (wave == 1) {
                     bool good = true;
                     if (lane == 0) good = cp_wait_word(sync + 2, (unsigned)j + 1);
@@ -1497,7 +1495,7 @@ __device__ __forceinline__ void cp_factor_role(double* __restrict__ T, double* _
             asm volatile("" : "+v"(li_t), "+v"(lq_t));
             if (publisher && lane == 0 && j > jbeg) {
                 __hip_atomic_store(sync, (unsigned)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (part == 0 && split < nb) __hip_atomic_store(sync + 2, (unsigned)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (jend < nb) __hip_atomic_store(sync + 2, (unsigned)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (a factoriser behind this one follows the panels)
             }
             if (publisher) publish_diag(j);
             const int j0 = 16 * j, g0 = j0 + 16, rows = C - g0;
@@ -1527,7 +1525,7 @@ __device__ __forceinline__ void cp_factor_role(double* __restrict__ T, double* _
                     for (int e = 0; e < 4; ++e) Pn[(row0 + lq_t + 4 * e) * 17 + li_t] = x[e];
                 }
             }
-            const bool last = j + 1 >= jend;                        // the first factoriser's last panel (rows > 0: not the matrix' last)
+            const bool last = j + 1 >= jend;                        // this factoriser's last panel (rows > 0: not the matrix' last)
             if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the meeting below then says: panel j and diagonal block j are complete in memory
             {   // (B) among the owners: every owner's rows of the solved panel are in LDS
                 if (CF_STAMPS && stamp_ok && nstamp < 100) stamps[nstamp++] = __builtin_amdgcn_s_memtime();
@@ -1542,7 +1540,7 @@ __device__ __forceinline__ void cp_factor_role(double* __restrict__ T, double* _
                 if (CF_STAMPS && stamp_ok && nstamp < 100) stamps[nstamp++] = __builtin_amdgcn_s_memtime();
             }
             if (last) {
-                // hand over: the second factoriser's last passive step waits for this panel; the inverse role for row block j
+                // hand over: the next factoriser's last passive step waits for this panel; the inverse role for row block j
                 if (publisher && lane == 0) {
                     __hip_atomic_store(sync + 2, (unsigned)j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(sync, (unsigned)j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1555,24 +1553,25 @@ __device__ __forceinline__ void cp_factor_role(double* __restrict__ T, double* _
     if (CF_STAMPS && stamp_ok) { if (nstamp < 100) stamps[nstamp++] = __builtin_amdgcn_s_memtime(); stamps[127] = nstamp; }
 }
 
-// grid: [0, groups) first factorisers, [groups, groups (1 + TI_WG)) inverse, [groups (1 + TI_WG), groups (2 + TI_WG)) second factorisers (when split < nb)
+// grid: [0, groups) first factorisers, [groups, groups (1 + TI_WG)) inverse, then the factorisers 2 .. nparts of every matrix.
+// bounds: the first steps of the factorisers 2, 3, 4, one byte each.
 __global__ __launch_bounds__(1024) void cholesky_phased_kernel(double* __restrict__ T, double* __restrict__ Linv, int C, double* __restrict__ Winv,
-                                                               unsigned* __restrict__ sync, int groups, int split)
+                                                               unsigned* __restrict__ sync, int groups, int nparts, int bounds)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int b = (int)blockIdx.x;
-    if (b < groups) {
-        cp_factor_role(T + (int64_t)b * C * C, Linv + (int64_t)b * C * 16, C, sync + 16 * b, split, 0, sm,
-                       (CF_STAMPS && b == 0) ? reinterpret_cast<unsigned long long*>(Linv + 8192) : nullptr);
-    } else if (b < groups * (1 + TI_WG)) {
+    const int b = (int)blockIdx.x, nb = C >> 4;
+    if (b >= groups && b < groups * (1 + TI_WG)) {
         const int idx = b - groups, g = idx / TI_WG;
         tri_inverse_role(T + (int64_t)g * C * C, Linv + (int64_t)g * C * 16, Winv + (int64_t)g * C * C, C, idx % TI_WG, sync + 16 * g, sm);
-    } else {
-        const int g = b - groups * (1 + TI_WG);
-        // (development stamps of the second factoriser: behind the first one's 16 x 128 words)
-        cp_factor_role(T + (int64_t)g * C * C, Linv + (int64_t)g * C * 16, C, sync + 16 * g, split, 1, sm,
-                       (CF_STAMPS && g == 0) ? reinterpret_cast<unsigned long long*>(Linv + 8192) + 16 * 128 : nullptr);
+        return;
     }
+    const int part = b < groups ? 0 : 1 + (b - groups * (1 + TI_WG)) / groups;
+    const int g = b < groups ? b : (b - groups * (1 + TI_WG)) % groups;
+    const int jbeg = part ? (bounds >> (8 * (part - 1))) & 255 : 0;
+    const int jend = part + 1 < nparts ? (bounds >> (8 * part)) & 255 : nb;
+    // (development stamps: 16 x 128 words per factoriser of matrix 0)
+    cp_factor_role(T + (int64_t)g * C * C, Linv + (int64_t)g * C * 16, C, sync + 16 * g, jbeg, jend, sm,
+                   (CF_STAMPS && g == 0) ? reinterpret_cast<unsigned long long*>(Linv + 8192) + part * 16 * 128 : nullptr);
 }
 
 // W = L^-1 from L and the inverses of its 16 x 16 diagonal blocks, one WAVE per block column j:
@@ -2043,20 +2042,27 @@ hipError_t wc_launch_factor_fused(double* T, double* W, double* tmp, int C, int 
         unsigned* rows = reinterpret_cast<unsigned*>(tmp + (size_t)groups * C * 16);     // zeroed by factor_prepare_kernel
         static const bool old_one = getenv("WC_K2_FUSED_R5") != nullptr;     // development A/B: round 5's one-workgroup factorisation
         if (!old_one) {
-            static const int split_env = getenv("WC_K2_PHASE_SPLIT") ? atoi(getenv("WC_K2_PHASE_SPLIT")) : -1;      // development: nb = no helpers
-            int split = cp_split(nb);
-            if (split_env >= 1 && split_env <= nb) split = split_env;
-            // what a phase may hold (the owners' slots, the helpers' one block per wave); anything else runs in one phase, or on round 5's kernel
-            const bool fits2 = split >= 2 && split < nb && cp_colblocks(1, split, nb) <= CP_MAXB && cp_colblocks(split, nb, nb) <= CP_MAXB &&
-                               (nb - split) * 128 <= 2048;
-            if (!fits2) split = nb;
-            if (split < nb || cp_colblocks(1, nb, nb) <= CP_MAXB) {
+            // the relay's stages: WC_K2_BOUNDS="4,9" (development) or the rule below; a stage that does not fit its owners' slots or the
+            // passive fetch -> one stage (or round 5's kernel when even that does not fit)
+            static const char* benv = getenv("WC_K2_BOUNDS");
+            int bnd[4] = {0, 0, 0, 0}, np = 1;
+            if (benv && *benv) {
+                const char* q = benv;
+                while (*q && np < 4) { const int v = atoi(q); if (v > bnd[np - 1] && v < nb) bnd[np++] = v; while (*q && *q != ',') ++q; if (*q == ',') ++q; }
+            } else if (nb >= 14) { bnd[1] = nb / 4; bnd[2] = nb * 9 / 16; np = 3; }
+            bool fits = true;
+            for (int k = 0; k < np; ++k) {
+                const int jb = bnd[k], je = k + 1 < np ? bnd[k + 1] : nb;
+                if (cp_colblocks(jb ? jb : 1, je, nb) > CP_MAXB || (jb && (nb - jb) * 128 > 2048)) fits = false;
+            }
+            if (!fits) { np = 1; fits = cp_colblocks(1, nb, nb) <= CP_MAXB; }
+            if (fits) {
                 size_t l2 = cp_factor_lds_doubles(C) * sizeof(double);
                 if (lds_role > l2) l2 = lds_role;
                 e = hipFuncSetAttribute(reinterpret_cast<const void*>(cholesky_phased_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
                 if (e != hipSuccess) return e;
-                const int nwg = groups * (1 + TI_WG + (split < nb ? 1 : 0));
-                hipLaunchKernelGGL(cholesky_phased_kernel, dim3(nwg), dim3(1024), l2, st, T, tmp, C, W, rows, groups, split);
+                const int nwg = groups * (np + TI_WG);
+                hipLaunchKernelGGL(cholesky_phased_kernel, dim3(nwg), dim3(1024), l2, st, T, tmp, C, W, rows, groups, np, bnd[1] | (bnd[2] << 8) | (bnd[3] << 16));
                 return hipGetLastError();
             }
         }
