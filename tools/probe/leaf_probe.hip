@@ -226,6 +226,62 @@ __device__ __forceinline__ void leaf_v3(const double* src, double* Lout, double*
     for (int c = 0; c < 16; ++c) { Lout[li * 17 + c] = (c <= li) ? a[c] : 0.0; Wout[c * 17 + li] = w[c]; }
 }
 
+
+// ---- V5 (round 6): V3 with a LEGAL pivot broadcast -- v_rsq_f64_dpp assembles but the hardware returns garbage (dpp_check below); the
+//      pivot travels through v_fmac_f64_dpp instead (p = 0 + bcast(a) * 1.0), half of it the same way, both beside the column's first update.
+template <int K, int K2, int K3>
+__device__ __forceinline__ void head3b(double& a1, double& a2, double& a3, double col, double& p, double& hp, double one, double half)
+{
+    asm volatile("v_fmac_f64_dpp %0, %5, -%5 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %5, -%5 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %2, %5, -%5 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %3, %0, %6 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %4, %0, %7 row_newbcast:%8 row_mask:0xf bank_mask:0xf"
+                 : "+v"(a1), "+v"(a2), "+v"(a3), "+v"(p), "+v"(hp) : "v"(col), "v"(one), "v"(half), "n"(K), "n"(K2), "n"(K3));
+}
+template <int K>
+__device__ __forceinline__ void head1b(double& a1, double col, double& p, double& hp, double one, double half)
+{
+    asm volatile("v_fmac_f64_dpp %0, %3, -%3 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_fmac_f64_dpp %1, %0, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %2, %0, %5 row_newbcast:%6 row_mask:0xf bank_mask:0xf"
+                 : "+v"(a1), "+v"(p), "+v"(hp) : "v"(col), "v"(one), "v"(half), "n"(K));
+}
+__device__ __forceinline__ void leaf_v5(const double* src, double* Lout, double* Wout, int li)
+{
+    double a[16], w[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) a[c] = src[li * 17 + c];
+    double half = 0.5, one = 1.0;
+    asm volatile("" : "+v"(half), "+v"(one));
+    double p = 0.0, hp = 0.0;
+    asm volatile("v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %2, %4 row_newbcast:0 row_mask:0xf bank_mask:0xf" : "+v"(p), "+v"(hp) : "v"(a[0]), "v"(one), "v"(half));
+    static_for<0, 16>([&](auto J) {
+        constexpr int jj = decltype(J)::value;
+        const double rn = __builtin_amdgcn_rsq(p);
+        const double t = hp * rn;
+        const double ua = a[jj] * rn;
+        const double c = __builtin_fma(-rn, t, 1.5);
+        a[jj] = ua * c;
+        const double rd = rn * c;
+        dpp_settle(a[jj]);
+        p = 0.0; hp = 0.0;
+        if constexpr (jj + 3 < 16) head3b<jj + 1, jj + 2, jj + 3>(a[jj + 1], a[jj + 2], a[jj + 3], a[jj], p, hp, one, half);
+        else if constexpr (jj + 1 < 16) {
+            head1b<jj + 1>(a[jj + 1], a[jj], p, hp, one, half);
+            if constexpr (jj + 2 < 16) fmac_nbcast<jj + 2>(a[jj + 2], a[jj], a[jj]);
+        }
+        static_for<jj + 4, 16>([&](auto K) { constexpr int k = decltype(K)::value; fmac_nbcast<k>(a[k], a[jj], a[jj]); });
+        double acc = (li == jj) ? -1.0 : 0.0;
+        static_for<0, jj>([&](auto K) { constexpr int k = decltype(K)::value; fmac_bcast<jj>(acc, a[k], w[k]); });
+        w[jj] = -acc * rd;
+    });
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { Lout[li * 17 + c] = (c <= li) ? a[c] : 0.0; Wout[c * 17 + li] = w[c]; }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------------
 template <int V>
 __global__ __launch_bounds__(1024) void leaf_kernel(const double* A, const double* P, double* L, double* W, double* X, unsigned long long* cyc,
@@ -247,6 +303,7 @@ __global__ __launch_bounds__(1024) void leaf_kernel(const double* A, const doubl
             if constexpr (V == 3) leaf_v1<false>(src, lo, wo, li);
             if constexpr (V == 4) leaf_v3<false>(src, lo, wo, li);
             if constexpr (V == 5) leaf_v3<true>(src, lo, wo, li);
+            if constexpr (V == 6) leaf_v5(src, lo, wo, li);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -355,6 +412,7 @@ int main()
         hipLaunchKernelGGL(leaf_kernel<2>, dim3(1), dim3(1024), 0, 0, dA, dP, dL, dW, dX, dc, 200, busy); check("V2 inverse + panel rows as payloads", busy, true, true);
         hipLaunchKernelGGL(leaf_kernel<4>, dim3(1), dim3(1024), 0, 0, dA, dP, dL, dW, dX, dc, 200, busy); check("V3 short chain, inverse rows", busy, false, true);
         hipLaunchKernelGGL(leaf_kernel<5>, dim3(1), dim3(1024), 0, 0, dA, dP, dL, dW, dX, dc, 200, busy); check("V4 short chain, inverse as payload", busy, false, true);
+        hipLaunchKernelGGL(leaf_kernel<6>, dim3(1), dim3(1024), 0, 0, dA, dP, dL, dW, dX, dc, 200, busy); check("V5 short chain, pivot through fmac_dpp", busy, false, true);
     }
     const char* names[] = {"16 independent v_fmac_f64_dpp", "16 independent v_fmac_f64", "16 dependent v_fmac_f64", "16 dependent v_fmac_f64_dpp (acc)",
                            "16 dependent v_mul_f64", "16 dependent v_rsq_f64", "16 independent v_rsq_f64", "16 dependent settle+v_mov_b64_dpp",

@@ -652,6 +652,34 @@ template <int K> __device__ __forceinline__ void fmac_bcast(double& acc, double 
 {
     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(K));
 }
+// acc -= (lane K of this lane's row).src * mul  (the negation rides on the source modifier)
+template <int K> __device__ __forceinline__ void fmac_nbcast(double& acc, double src, double mul)
+{
+    asm volatile("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(K));
+}
+// The head of a pivot step of the leaf (round 6, tools/probe/leaf_probe.hip V5): the three nearest columns take the update of column
+// `col`, then column K's pivot is broadcast -- p += bcast_K(a1) * 1.0, hp += bcast_K(a1) * 0.5 (p, hp zero on entry) -- through
+// v_fmac_f64_dpp: the two updates in between are the DPP read's wait states, and no v_mov_b64_dpp (29 cycles of the dependent chain) is
+// needed.  (v_rsq_f64_dpp would read the pivot directly and assembles, but the hardware returns garbage: probe's dpp_check.)
+template <int K, int K2, int K3>
+__device__ __forceinline__ void leaf_head3(double& a1, double& a2, double& a3, double col, double& p, double& hp, double one, double half)
+{
+    asm volatile("v_fmac_f64_dpp %0, %5, -%5 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %5, -%5 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %2, %5, -%5 row_newbcast:%10 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %3, %0, %6 row_newbcast:%8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %4, %0, %7 row_newbcast:%8 row_mask:0xf bank_mask:0xf"
+                 : "+v"(a1), "+v"(a2), "+v"(a3), "+v"(p), "+v"(hp) : "v"(col), "v"(one), "v"(half), "n"(K), "n"(K2), "n"(K3));
+}
+template <int K>
+__device__ __forceinline__ void leaf_head1(double& a1, double col, double& p, double& hp, double one, double half)
+{
+    asm volatile("v_fmac_f64_dpp %0, %3, -%3 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_fmac_f64_dpp %1, %0, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %2, %0, %5 row_newbcast:%6 row_mask:0xf bank_mask:0xf"
+                 : "+v"(a1), "+v"(p), "+v"(hp) : "v"(col), "v"(one), "v"(half), "n"(K));
+}
 // two wait states between the write of v and every DPP read that follows ("modifies" v, so its readers are ordered behind it)
 __device__ __forceinline__ void dpp_settle(double& v) { asm("s_nop 1" : "+v"(v)); }
 template <int B, int E, typename F> __device__ __forceinline__ void static_for(F&& f)
@@ -1164,7 +1192,7 @@ constexpr int CP_MAXB = 15 * CP_SLOTS;      // ... so a phase holds at most 75 b
 __host__ __device__ constexpr int cp_colblocks(int c, int c1, int nb)          // blocks (bi >= bj) of the block columns c .. c1-1
 { return c1 > c ? (c1 - c) * (2 * nb - c - c1 + 1) / 2 : 0; }
 // the block column where the helpers' part begins (nb: no helpers, one phase)
-__host__ __device__ constexpr size_t cp_factor_lds_doubles(int C) { return (size_t)3 * C * 17 + 6 * 16 * 18 + 2; }
+__host__ __device__ constexpr size_t cp_factor_lds_doubles(int C) { return (size_t)3 * C * 17 + 6 * 16 * 18 + 2; }       // (+ two counter words)
 
 __device__ __forceinline__ bool cp_wait_word(const unsigned* w, unsigned target)
 {
@@ -1275,18 +1303,33 @@ __device__ __forceinline__ void cp_factor_role(double* __restrict__ T, double* _
             }
             if (CF_STAMPS && stamp_ok) { if (src) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                                          stamps[40 + 5 * (j - jbeg) + 1] = __builtin_amdgcn_s_memtime(); }
+            // Round 6 (probe V5: 3 720 -> 3 070 cycles alone on its SIMD): the pivot column is scaled by the raw rsq first and by the Newton
+            // factor after (a * rn runs beside the Newton step, not behind it); lane jj's a[jj] IS the pivot, no select; the negation rides
+            // on the FMA's source modifier; the next pivot's broadcast is issued behind the first three updates of this one (leaf_head3).
+            double half = 0.5, one = 1.0;
+            asm volatile("" : "+v"(half), "+v"(one));
+            double p = 0.0, hp = 0.0;
+            asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %1, %2, %4 row_newbcast:0 row_mask:0xf bank_mask:0xf" : "+v"(p), "+v"(hp) : "v"(a[0]), "v"(one), "v"(half));
             static_for<0, 16>([&](auto J) {
                 constexpr int jj = decltype(J)::value;
                 if (CP_SKIP & 8) { w[jj] = a[jj]; return; }
-                const double p = row_bcast<jj>(a[jj]);
-                double rd = __builtin_amdgcn_rsq(p);
-                rd = rd * (1.5 - 0.5 * p * rd * rd);
-                a[jj] = a[jj] * rd;                                     // (lane jj's a[jj] IS the pivot)
+                const double rn = __builtin_amdgcn_rsq(p);
+                const double t = hp * rn;
+                const double ua = a[jj] * rn;
+                const double c = __builtin_fma(-rn, t, 1.5);          // one Newton step: rd = rn (1.5 - 0.5 p rn^2)
+                a[jj] = ua * c;
+                const double rd = rn * c;
                 dpp_settle(a[jj]);
-                const double nj = -a[jj];
-                static_for<jj + 1, 16>([&](auto K) {
+                p = 0.0; hp = 0.0;
+                if constexpr (jj + 3 < 16) leaf_head3<jj + 1, jj + 2, jj + 3>(a[jj + 1], a[jj + 2], a[jj + 3], a[jj], p, hp, one, half);
+                else if constexpr (jj + 1 < 16) {
+                    leaf_head1<jj + 1>(a[jj + 1], a[jj], p, hp, one, half);
+                    if constexpr (jj + 2 < 16) fmac_nbcast<jj + 2>(a[jj + 2], a[jj], a[jj]);
+                }
+                static_for<jj + 4, 16>([&](auto K) {
                     constexpr int k = decltype(K)::value;
-                    fmac_bcast<k>(a[k], a[jj], nj);                    // a[li][k] -= l[k][jj] * l[li][jj]
+                    fmac_nbcast<k>(a[k], a[jj], a[jj]);                // a[li][k] -= l[k][jj] * l[li][jj]
                 });
                 double acc = (li == jj) ? -1.0 : 0.0;                  // lane jj: w = rd; lanes above jj: the sum is zero by itself
                 static_for<0, jj>([&](auto K) {
@@ -1330,6 +1373,9 @@ __device__ __forceinline__ void cp_factor_role(double* __restrict__ T, double* _
                     for (int r = 0; r < 4; ++r) dp[(lq + 4 * r) * 18 + li] = d4[r];
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     factor(jbeg, dp);
+                    // (Measured and dropped: the owner waves on this SIMD holding their share of this step's update back until the leaf is
+                    // done -- f64 MFMAs beside it stretch the leaf from 2 600 to ~6 000 cycles here -- made K2 2 us SLOWER: their blocks then
+                    // finish last.)
                 }
             }
         }
