@@ -317,8 +317,13 @@ def test_history_scaled_split_outside_its_window_is_split_again_with_the_measure
     y = torch.where(x > 0, x * 1.0e-5, x * 50.0)
     C.split_planes(x, relu=True, site=site2)
     gr = C.split_planes(y, relu=True, site=site2)
+    yr = y.clamp_min(0)
+    assert _redo_count(site2) == 1
+    assert float((_back(gr) - yr.double()).abs().max() / yr.abs().max()) < 2.0 ** -20
+    # (the two-launch form takes its scale from max |y| BEFORE the ReLU -- 225 here -- and leaves this positive part 2^-9 of it: the
+    # second pass scales for what is actually split)
     ref = C.split_planes(y, relu=True)
-    assert torch.equal(gr[0], ref[0]) and torch.equal(gr[1], ref[1]) and _redo_count(site2) == 1
+    assert float((_back(ref) - yr.double()).abs().max() / yr.abs().max()) > 2.0 ** -20
 
 
 @pytest.mark.gpu
