@@ -549,8 +549,13 @@ int wc_conv_split_colsum_f32(const float* x, int64_t n, int relu, void* hi, void
  * scaled maximum fell outside [2^-5, 65504) -- the previous tensor was all zero (a saturated hinge critic), a growth beyond 255-fold, a
  * shrink beyond 4096-fold -- splits the tensor again with the MEASURED scale (the bits of wc_conv_split_f32) and counts the event in word
  * WC_CONV_HIST_REDO of `hist`; inside the window it returns at once.  Capturable, no host synchronisation, never quietly wrong.
- * bootstrap != 0 (the site's first call): the two-launch form with the measured maximum, which seeds the record.  Calls of one site must
- * be ordered (one stream, or events).
+ * The second launch costs ~2.3 us per call (0.56 ms of the 18-ms CIFAR-10 step when every split of the step takes it: as much as the
+ * history saves), so the caller chooses per call: bit 1 of `bootstrap` set = no second launch.  The shipped layers take it for the OUTPUT
+ * GRADIENTS (the tensors that do go to zero and swing by orders of magnitude) and not for the layer inputs.  Without it a call is still
+ * exact after all-zero tensors (the record carries the maximum a call assumed: zeros leave the site's scale where it was), loud above a
+ * 255-fold growth (inf), and short of bits for ONE call after a shrink beyond 4096-fold.
+ * bit 0 of `bootstrap` (the site's first call): the two-launch form with the measured maximum, which seeds the record.  Calls of one
+ * site must be ordered (one stream, or events).
  * colsum_partials / C as in wc_conv_split_colsum_f32 (nullable).  Replaces the absmax pass of wc_conv_split_f32 (~130 launches of
  * 3-30 us per G+D step; reference call sites: every Conv2D of discriminator.py:41-54 / generator.py:142-158 as in wc_conv_f16x3). */
 #define WC_CONV_HIST_FLOATS (4 * 512 + 16)

@@ -281,49 +281,75 @@ def test_history_scaled_split_outside_its_window_is_split_again_with_the_measure
     """Round 6: the previous call's maximum can be wrong in three ways -- the tensor grew more than 255-fold
     (round 5: inf in the planes, NaN in the weights one optimizer step later, no redo), it shrank more than 4096-fold (round 5: the lo plane
     in fp16's subnormals, quietly fewer bits), or the previous tensor was ALL ZERO (round 5: scale 1.0, whatever the next tensor is -- a
-    hinge critic whose margins are all met hands back exactly-zero gradients).  The gated second launch sees the tensor's own maximum in
-    the record and splits again with the measured scale: the planes are then the two-launch form's, bit for bit, and the site's counter
-    says the second pass ran.  Inside the window it does not run."""
+    hinge critic whose margins are all met hands back exactly-zero gradients).  The output gradients (role 'g') take a gated second launch
+    that sees the tensor's own maximum in the record and splits again with the measured scale: the planes are then the two-launch form's,
+    bit for bit, and the site's counter says the second pass ran.  Inside the window it does not run."""
     from wc_gan_amd import conv as C
     torch.manual_seed(4)
     site = _Site()
     x = torch.randn(8, 16, 16, 128, device='cuda')
-    C.split_planes(x, site=site)
-    assert _redo_count(site) == 0
-    ok = C.split_planes(x * 4.0, site=site)                        # inside the window: history scale, no second pass
-    assert _redo_count(site) == 0 and float(ok[2][0]) != float(C.split_planes(x * 4.0)[2][0])
+    sp = lambda t, **kw: C.split_planes(t, site=site, role='g', **kw)
+    rc = lambda s=site: _redo_count(s, 'g')
+    sp(x)
+    assert rc() == 0
+    ok = sp(x * 4.0)                                               # inside the window: history scale, no second pass
+    assert rc() == 0 and float(ok[2][0]) != float(C.split_planes(x * 4.0)[2][0])
     def exact(t, got):
         ref = C.split_planes(t)
         return torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]) and torch.equal(got[2][:1], ref[2][:1])
-    big = C.split_planes(x * 12000.0, site=site)                    # x 3000 from one call to the next
-    assert bool(torch.isfinite(big[0].float()).all()) and exact(x * 12000.0, big) and _redo_count(site) == 1
-    small = C.split_planes(x * 0.12, site=site)                     # / 100000
-    assert exact(x * 0.12, small) and _redo_count(site) == 2
+    big = sp(x * 12000.0)                                          # x 3000 from one call to the next
+    assert bool(torch.isfinite(big[0].float()).all()) and exact(x * 12000.0, big) and rc() == 1
+    small = sp(x * 0.12)                                           # / 100000
+    assert exact(x * 0.12, small) and rc() == 2
     assert float((_back(small) - (x * 0.12).double()).abs().max() / (x * 0.12).abs().max()) < 2.0 ** -20
     # zeros, then a tensor of size 1e-4: 2^-20 of its maximum
-    z = C.split_planes(torch.zeros_like(x), site=site)
-    assert _redo_count(site) == 2 and not bool(z[0].any()) and not bool(z[1].any())
-    z2 = C.split_planes(torch.zeros_like(x), site=site)            # zeros after zeros: nothing to redo either
-    assert _redo_count(site) == 2 and not bool(z2[0].any())
-    tiny = x * 1.0e-4
-    got = C.split_planes(tiny, site=site)
-    assert exact(tiny, got) and _redo_count(site) == 3
+    z = sp(torch.zeros_like(x))
+    assert rc() == 2 and not bool(z[0].any()) and not bool(z[1].any())
+    z2 = sp(torch.zeros_like(x))                                   # zeros after zeros: nothing to redo either
+    assert rc() == 2 and not bool(z2[0].any())
+    tiny = x * 1.0e-4                                              # (0.12 / 1e-4 = 1200-fold below what the site last saw: inside the window)
+    got = sp(tiny)
+    assert rc() == 2
     assert float((_back(got) - tiny.double()).abs().max() / tiny.abs().max()) < 2.0 ** -20
-    nxt = C.split_planes(tiny * 2.0, site=site)                    # the record now holds the measured maximum: history again
-    assert _redo_count(site) == 3
-    assert float((_back(nxt) - (tiny * 2.0).double()).abs().max() / (tiny * 2.0).abs().max()) < 2.0 ** -20
+    sp(torch.zeros_like(x))
+    tinier = x * 1.0e-9                                            # ... and 1e5-fold below it: the second pass
+    got = sp(tinier)
+    assert exact(tinier, got) and rc() == 3
+    assert float((_back(got) - tinier.double()).abs().max() / tinier.abs().max()) < 2.0 ** -20
+    nxt = sp(tinier * 2.0)                                         # the record now holds the measured maximum: history again
+    assert rc() == 3
+    assert float((_back(nxt) - (tinier * 2.0).double()).abs().max() / (tinier * 2.0).abs().max()) < 2.0 ** -20
     # with the ReLU in the split: the maximum that counts is the one of what is split (a tensor whose positive part is tiny)
     site2 = _Site()
     y = torch.where(x > 0, x * 1.0e-5, x * 50.0)
-    C.split_planes(x, relu=True, site=site2)
-    gr = C.split_planes(y, relu=True, site=site2)
+    C.split_planes(x, relu=True, site=site2, role='g')
+    gr = C.split_planes(y, relu=True, site=site2, role='g')
     yr = y.clamp_min(0)
-    assert _redo_count(site2) == 1
+    assert _redo_count(site2, 'g') == 1
     assert float((_back(gr) - yr.double()).abs().max() / yr.abs().max()) < 2.0 ** -20
     # (the two-launch form takes its scale from max |y| BEFORE the ReLU -- 225 here -- and leaves this positive part 2^-9 of it: the
     # second pass scales for what is actually split)
     ref = C.split_planes(y, relu=True)
     assert float((_back(ref) - yr.double()).abs().max() / yr.abs().max()) > 2.0 ** -20
+
+
+@pytest.mark.gpu
+def test_history_scaled_split_of_a_layer_input_survives_all_zero_tensors_without_the_second_launch():
+    """The layer inputs (role 'x') do not take the second launch (+2.3 us per call: every split of the step would give back what the history
+    saves): an all-zero tensor leaves the site's scale where it was -- the record carries the maximum a call assumed -- so the tensor after
+    it, and after any number of them, is split to 2^-20 of its maximum as long as it lies within the window of the last non-zero one."""
+    from wc_gan_amd import conv as C
+    torch.manual_seed(9)
+    site = _Site()
+    x = torch.randn(8, 16, 16, 128, device='cuda')
+    C.split_planes(x, site=site)
+    for k in range(3):
+        z = C.split_planes(torch.zeros_like(x), site=site)
+        assert not bool(z[0].any()) and not bool(z[1].any())
+        t = x * (0.5 ** k) * 3.0
+        got = C.split_planes(t, site=site)
+        assert float((_back(got) - t.double()).abs().max() / t.abs().max()) < 2.0 ** -20, k
+    assert _redo_count(site) == 0
 
 
 @pytest.mark.gpu
@@ -333,17 +359,17 @@ def test_history_scaled_split_second_pass_inside_a_graph():
     torch.manual_seed(8)
     site = _Site()
     x = torch.randn(8, 16, 16, 128, device='cuda')
-    C.split_planes(x, site=site)
+    C.split_planes(x, site=site, role='g')
     buf = torch.empty_like(x)
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
-        out = C.split_planes(buf, site=site)
-    for factor, redo in ((2.0, 0), (0.0, 0), (1.0e-3, 1), (3.0e-3, 0), (40.0, 1), (40.0, 0)):
-        before = _redo_count(site)
+        out = C.split_planes(buf, site=site, role='g')
+    for factor, redo in ((2.0, 0), (0.0, 0), (1.0e-4, 1), (3.0e-4, 0), (40.0, 1), (40.0, 0)):
+        before = _redo_count(site, 'g')
         buf.copy_(x * factor)
         graph.replay()
         torch.cuda.synchronize()
-        assert _redo_count(site) - before == redo, (factor, redo)
+        assert _redo_count(site, 'g') - before == redo, (factor, redo)
         if factor:
             assert float((_back(out) - buf.double()).abs().max() / buf.abs().max()) < 2.0 ** -20, factor
             assert bool(torch.isfinite(out[0].float()).all())

@@ -8,7 +8,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NAMES = {0: "as shipped", 1: "no stores", 2: "no MFMA", 8: "no table loads (zero table)", 16: "no mask words",
          3: "no stores, no MFMA", 10: "no MFMA, no table", 26: "loads + stores only (no MFMA / table / mask; the epilogue's scale-and-add stays)",
          27: "loads only (and the hand-off counters)", 18: "no MFMA, no mask", 24: "no table, no mask",
-         64: "NOT an ablation: tile 3 requested in the prologue (-DWC_SPLIT_PRE3=1)"}
+         64: "NOT an ablation: tile 3 requested in the prologue (-DWC_SPLIT_PRE3=1)",
+         128: "table walked from a per-workgroup k-step (WRONG results)", 130: "no MFMA, table walked from a per-workgroup k-step"}
 child = r'''
 import sys, torch
 sys.path.insert(0, %r)
@@ -58,7 +59,9 @@ print("K3 min %%5.1f median %%5.1f us | stream copy (same rule, same process) mi
 libs = []
 for lib in glob.glob(os.path.join(ROOT, "wc_gan_amd", "csrc", "build", "var", "lib_k3*.so")):
     tag = os.path.basename(lib)[len("lib_k3"):-3]
-    libs.append((0 if tag == "base" else 64 if tag == "pre3" else int(tag.replace("abl", "")), lib))
+    trot = 128 if tag.endswith("trot") else 0           # (round 6: -DWC_SPLIT_TROT=1, the table walked from a different k-step by every workgroup)
+    tag = tag[:-4] if trot else tag
+    libs.append((trot + (0 if tag in ("base", "") else 64 if tag == "pre3" else int(tag.replace("abl", ""))), lib))
 for bits, lib in sorted(libs):
     try:
         r = subprocess.run([sys.executable, "-c", child, lib], capture_output=True, text=True, timeout=150)

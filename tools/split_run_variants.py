@@ -20,7 +20,7 @@ A, At, plan = ops.color(W, gamma, xs.scale)
 yref = ops.apply(x, mu, A, b, None, fast=False)
 be = ops.split_bias(A, b, xs, mu)
 lib = _lib.load()
-dbg = torch.zeros(256 * 8 * 8, dtype=torch.int64, device='cuda')
+dbg = torch.zeros(256 * 8 * 16, dtype=torch.int64, device='cuda')
 stamps = "STAMPS" in sys.argv[1]
 if stamps:
     lib.wc_dev_split_dbg.argtypes = [ctypes.c_void_p]; lib.wc_dev_split_dbg(dbg.data_ptr())
@@ -35,7 +35,7 @@ for rep in range(25):       # one launch at a time behind a register-only spin (
 ts.sort()
 print("apply (ReLU + mask) us: min %%.1f median %%.1f max %%.1f   max err vs exact %%.2e" %% (ts[0], ts[len(ts) // 2], ts[-1], err))
 if stamps:
-    d = dbg.view(256, 8, 8).cpu().double()
+    d = dbg.view(256, 8, 16).cpu().double()
     t0 = d[..., 4].min()
     print("  timeline (us from the first workgroup's start): last start %%.2f | loop starts %%.2f .. %%.2f | ends %%.2f .. %%.2f" %% (
         (d[..., 4].max() - t0) / 100, (d[..., 5].min() - t0) / 100, (d[..., 5].max() - t0) / 100, (d[..., 6].min() - t0) / 100, (d[..., 6].max() - t0) / 100))
@@ -45,6 +45,15 @@ if stamps:
     f = lambda t: "mean %%.0f min %%.0f max %%.0f" %% (t.mean(), t.min(), t.max())
     print("  per wave, whole tile loop (s_memtime ticks): wait+dma-issue", f(w), "| k-loop", f(l), "| stores", f(st), "| total", f(tot))
     print("  waves 0-3 total", f(tot[:, :4]), "| waves 4-7 total", f(tot[:, 4:]))
+    ghz = tot / ((d[..., 6] - d[..., 5]) * 10.0)          # s_memtime ticks of the tile loop over its s_memrealtime span (100 MHz, chip-wide)
+    print("  shader clock over the tile loop (ticks / wall time): mean %%.3f GHz  min %%.3f  max %%.3f" %% (ghz.mean(), ghz.min(), ghz.max()))
+    # the prologue and tile 0 (round 6): cycles after the wave's first vector-memory instruction
+    pr = d[..., 8:16]; base = pr[..., 0:1]
+    names = ["my pieces of tile 0 landed", "tile 0 landed for all eight waves (first MFMA may issue)", "table k-step 0 landed", "table, last k-step landed",
+             "my pieces of tile 1 landed", "tile 1 landed for all (tile 1's loop begins)", "tile 2's loop begins"]
+    for i, nm in enumerate(names):
+        v = (pr[..., i + 1] - base[..., 0])[pr[..., i + 1] > 0]
+        if v.numel(): print("    %%-58s mean %%6.0f  min %%6.0f  max %%6.0f cycles" %% (nm, v.mean(), v.min(), v.max()))
 ''' % ROOT
 shape = sys.argv[1:4] if len(sys.argv) > 3 else ["128", "32", "256"]
 for lib in sorted(glob.glob(os.path.join(ROOT, "wc_gan_amd", "csrc", "build", "var", "lib_*.so"))):

@@ -156,6 +156,15 @@ HIST_FLOATS = 4 * 512 + 16     # include/wc_hip.h WC_CONV_HIST_FLOATS
 HIST_REDO = 4 * 512            # WC_CONV_HIST_REDO: uint32 count of the gated second passes a site has taken
 
 
+# The gated second pass of the history-scaled split (include/wc_hip.h, wc_conv_split_hist_f32): WC_SPLIT_HIST_REDO = 1 (default) for the
+# output gradients only, 2 for every split, 0 for none.  (Every split of the step: +0.56 ms of 18 -- what the history saves.)
+_REDO_MODE = os.environ.get('WC_SPLIT_HIST_REDO', '1')
+
+
+def _guarded(role):
+    return _REDO_MODE == '2' or (_REDO_MODE != '0' and role == 'g')
+
+
 def _site_hist(site, role, device):
     """[record (HIST_FLOATS floats on the device: two arrays of per-workgroup (maximum, tag) pairs), seeded?] of a call site:
     `site` is the layer object that owns the convolution (state lives in its __dict__, not in a parameter or buffer: no checkpoint entry --
@@ -187,7 +196,7 @@ def split_planes(x, relu=False, colsum=False, site=None, role='x'):
         C = x.shape[-1]
         part = torch.empty((512, C), dtype=torch.float32, device=x.device) if colsum else None
         _lib.check(lib.wc_conv_split_hist_f32(_ptr(x), x.numel(), 1 if relu else 0, _ptr(hi), _ptr(lo), _ptr(scale), _ptr(part), C if colsum else 0,
-                                              _ptr(h[0]), 0 if h[1] else 1, _stream()), "wc_conv_split_hist_f32")
+                                              _ptr(h[0]), (0 if h[1] else 1) | (0 if _guarded(role) else 2), _stream()), "wc_conv_split_hist_f32")
         h[1] = True
         return (hi, lo, scale, part) if colsum else (hi, lo, scale)
     if not colsum:

@@ -407,6 +407,18 @@ __global__ __launch_bounds__(kAmaxBlocks) void conv_hist_seed_kernel(float* __re
     f32x2h a = {m, __builtin_bit_cast(float, 1u)}, b = {0.f, __builtin_bit_cast(float, 0u)};
     *reinterpret_cast<f32x2h*>(hist + 2 * threadIdx.x) = a;
     *reinterpret_cast<f32x2h*>(hist + kHistArray + 2 * threadIdx.x) = b;
+    // the carried maximum (round 6: what a call falls back on when the call before saw an all-zero tensor), both parities
+    __shared__ float red[kAmaxBlocks / 64];
+    float mm = m;
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mm = fmaxf(mm, __shfl_xor(mm, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < kAmaxBlocks / 64; ++i) t = fmaxf(t, red[i]);
+        hist[2 * kHistArray + 2] = t; hist[2 * kHistArray + 3] = t;
+    }
 }
 
 __global__ __launch_bounds__(256) void conv_split_hist_kernel(const float* __restrict__ x, int64_t n4, int relu, _Float16* __restrict__ hi,
@@ -442,8 +454,13 @@ __global__ __launch_bounds__(256) void conv_split_hist_kernel(const float* __res
     // the complete array with the larger tag (one of the two always is: the launch in flight writes the other one)
     const int src = (ok1 && (!ok0 || thi[1] > thi[0])) ? 1 : 0;
     const int tag = (src ? thi[1] : thi[0]) + 1;
-    const float s = scale_for((src ? mx[1] : mx[0]) * kHistMargin);
-    if (blockIdx.x == 0 && threadIdx.x == 0) scale_out[0] = s;
+    // Round 6: an all-zero tensor says nothing about the next one (a hinge critic whose margins are all met hands back exactly-zero
+    // gradients; round 5 then split the next tensor with scale 1.0, whatever it held).  The site's scale stays where it was instead: every
+    // call leaves the maximum it ASSUMED in a word of the record (one per array parity: this call reads the one the call before wrote).
+    const float prev = src ? mx[1] : mx[0];
+    const float assumed = prev > 0.f ? prev : hist[2 * kHistArray + 2 + src];
+    const float s = scale_for(assumed * kHistMargin);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { scale_out[0] = s; hist[2 * kHistArray + 2 + (1 - src)] = assumed; }
     float m = 0.f;
     f32x4 cs = {0.f, 0.f, 0.f, 0.f};
     for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
@@ -507,7 +524,7 @@ __global__ __launch_bounds__(256) void conv_split_redo_kernel(const float* __res
             tg[arr] = max(tg[arr], __shfl_xor(tg[arr], o));
         }
     const int now = tg[1] > tg[0] ? 1 : 0;
-    const float own = mx[now], assumed = mx[1 - now];
+    const float own = mx[now], assumed = hist[2 * kHistArray + 2 + now];       // (what the split assumed: it left the value here)
     const float s_used = scale_for(assumed * kHistMargin);
     const float top = own * s_used;                // the scaled maximum the planes were written with
     // (a NaN maximum never reaches here: fmaxf drops NaN operands; a tensor holding inf has own = inf -> no finite scale exists, leave it loud)
@@ -1192,7 +1209,7 @@ int wc_conv_split_hist_f32(const float* x, int64_t n, int relu, void* hi, void* 
     hipStream_t st = (hipStream_t)stream;
     if (!x || !hi || !lo || !scale || !hist || n <= 0 || (n & 3)) return WC_ERR_ARG;
     if (colsum_partials && (C <= 0 || (C & 3) || 256 % (C >> 2) != 0 || n % C != 0)) return WC_ERR_SHAPE;
-    if (bootstrap) {       // the site's first call: the measured maximum (the two-launch form, bit for bit), left in the record
+    if (bootstrap & 1) {   // the site's first call: the measured maximum (the two-launch form, bit for bit), left in the record
         hipLaunchKernelGGL(conv_absmax_kernel, dim3(kAmaxBlocks), dim3(256), 0, st, x, n / 4, n, hist, colsum_partials, colsum_partials ? C >> 2 : 0);
         hipLaunchKernelGGL(conv_split_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, x, n / 4, (const float*)hist, relu, (_Float16*)hi,
                            (_Float16*)lo, scale);
@@ -1202,10 +1219,12 @@ int wc_conv_split_hist_f32(const float* x, int64_t n, int relu, void* hi, void* 
     // always kAmaxBlocks workgroups: they are the partial rows conv_wrw_reduce_kernel adds up
     hipLaunchKernelGGL(conv_split_hist_kernel, dim3(kAmaxBlocks), dim3(256), 0, st, x, n / 4, relu, (_Float16*)hi, (_Float16*)lo, scale,
                        hist, colsum_partials, colsum_partials ? C >> 2 : 0);
-    static const bool redo = !(getenv("WC_SPLIT_HIST_REDO") && getenv("WC_SPLIT_HIST_REDO")[0] == '0');      // development A/B only: "0" = round 5's unguarded form
-    if (redo)
-        hipLaunchKernelGGL(conv_split_redo_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, x, n / 4, relu, (_Float16*)hi, (_Float16*)lo,
-                           scale, hist);
+    if (!(bootstrap & 2)) {
+        // (a small grid: inside the window -- the usual case -- the launch is 64 workgroups reading 8 KB each and returning; outside it they
+        // stride over the tensor)
+        const unsigned g2 = grid_for(n / 4) < 64u ? grid_for(n / 4) : 64u;
+        hipLaunchKernelGGL(conv_split_redo_kernel, dim3(g2), dim3(256), 0, st, x, n / 4, relu, (_Float16*)hi, (_Float16*)lo, scale, hist);
+    }
     return (int)hipGetLastError();
 }
 

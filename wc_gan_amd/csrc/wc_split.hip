@@ -60,6 +60,12 @@
 #ifndef WC_SPLIT_PRE3
 #define WC_SPLIT_PRE3 0     // 1 (one table for the launch, >= 6 tiles): tile 3's pieces are requested in the prologue with tiles 0-2 (its buffer is free from the start)
 #endif                      // instead of from tile 0's k-step 1, which waits for the table's first fragments: 128 instead of 96 KiB per CU in flight while the table arrives
+#ifndef WC_SPLIT_D0FIRST
+#define WC_SPLIT_D0FIRST 0
+#endif
+#ifndef WC_SPLIT_TROT
+#define WC_SPLIT_TROT 0
+#endif
 #ifndef WC_SPLIT_ABL
 #define WC_SPLIT_ABL 0       // development ablation bits (wrong results, times only; tools/k3_ablations.py): 1 no stores (the hand-counted waits
                              // adjusted: the DMA waits stay real), 2 no MFMA, 4 linear (unswizzled) DMA source, 8 no table loads (a zero table),
@@ -199,6 +205,7 @@ __global__ __launch_bounds__(512, 1) void apply_split_kernel(SplitApplyArgs a)
     volatile int* const cnt = reinterpret_cast<volatile int*>(smem + NBUF * TILE);
 
     unsigned long long rt_in = 0;
+    unsigned long long pro_[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // WC_SPLIT_STAMPS: the prologue and tile 0, s_memtime
     if (WC_SPLIT_STAMPS) rt_in = __builtin_amdgcn_s_memrealtime();
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -318,10 +325,16 @@ __global__ __launch_bounds__(512, 1) void apply_split_kernel(SplitApplyArgs a)
             cur_slot = slot;
             return;
         }
+#if WC_SPLIT_TROT        // development (WRONG results, times only): every workgroup walks the table from a different k-step -- do 256 CUs reading the same
+        // lines in the same order at the same moment queue up at the same L2 channels?
+        const int rot = (int)((blockIdx.x * 5u) & (unsigned)(KS - 1));
+#else
+        const int rot = 0;
+#endif
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(bhi[s]) : "v"(tb_lane), "s"(ph + 1024 * s) : "memory");
-            asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(blo[s]) : "v"(tb_lane), "s"(pl + 1024 * s) : "memory");
+            asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(bhi[s]) : "v"(tb_lane), "s"(ph + 1024 * ((s + rot) & (KS - 1))) : "memory");
+            asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(blo[s]) : "v"(tb_lane), "s"(pl + 1024 * ((s + rot) & (KS - 1))) : "memory");
         }
         asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(cscale[0]) : "v"(col_b), "s"(pc) : "memory");
         asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2 offset:64" : "=v"(cscale[1]) : "v"(col_b), "s"(pc) : "memory");
@@ -345,8 +358,15 @@ __global__ __launch_bounds__(512, 1) void apply_split_kernel(SplitApplyArgs a)
     // (every wave waits for the same "tile landed" event), so the matrix pipe idled through 1 500 of every 4 600 cycles
     // while both were storing.  Fewer tiles (the small sites): everything drains per tile, stores at the end of the tile.
     const bool def_mode = n >= 6;
+    if (WC_SPLIT_STAMPS) pro_[0] = __builtin_amdgcn_s_memtime();      // in front of the first vector-memory instruction
     if (!ASYNC_TABLE) load_b(a.slot[((int64_t)tile_of(0) * TR) / a.HW]);      // (drained: in front of the DMAs, whose counts start here)
     dma_tile(0);
+#if WC_SPLIT_D0FIRST
+    // Round 6 (stamps, profiles/r6_k3_prologue_stamps.txt): with the table's 36 loads per wave queued right behind D0, a wave's pieces of
+    // tile 0 land 8 000 cycles after its first vector-memory instruction -- 4 300 without the table: 256 KiB per workgroup share the CU's
+    // 64 B/clk return path with the 32 KiB everybody is waiting for.  Tile 0 alone first, the table behind it.
+    if (ASYNC_TABLE && def_mode) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     if (ASYNC_TABLE) load_b(0);
     if (n > 1) dma_tile(1);
     if (n > 2) dma_tile(2);
@@ -357,6 +377,7 @@ __global__ __launch_bounds__(512, 1) void apply_split_kernel(SplitApplyArgs a)
     else if (n > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     touch_b();                                    // (unconditional: a tie in one branch only doubles the table's registers at the merge)
+    if (WC_SPLIT_STAMPS) pro_[1] = __builtin_amdgcn_s_memtime();      // my pieces of tile 0 have landed
     arrive(0);                                    // my pieces of tile 0
 
     const int rbase = rg * 32;
@@ -413,7 +434,7 @@ __global__ __launch_bounds__(512, 1) void apply_split_kernel(SplitApplyArgs a)
         if (WC_SPLIT_STAMPS) c0_ = __builtin_amdgcn_s_memtime();
         wait_for(0, 8 * (t + 1));                  // tile t has landed for all eight waves
         unsigned long long c1_ = 0;
-        if (WC_SPLIT_STAMPS) { c1_ = __builtin_amdgcn_s_memtime(); t_wait += c1_ - c0_; }
+        if (WC_SPLIT_STAMPS) { c1_ = __builtin_amdgcn_s_memtime(); t_wait += c1_ - c0_; if (FIRST_) pro_[2] = c1_; if (t == 1) pro_[6] = c1_; if (t == 2) pro_[7] = c1_; }
         int rb[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) rb[j] = rd_base[j];
@@ -436,6 +457,7 @@ __global__ __launch_bounds__(512, 1) void apply_split_kernel(SplitApplyArgs a)
                 // DMAs of tiles 1 and 2 and, behind step DSTEP, of tile 3).  No "+v" ties: redefining 128 table registers inside one
                 // of the tile bodies cost 60 VGPRs and spills; the scheduling barrier keeps the k-step's MFMAs behind the wait
                 asm volatile("s_waitcnt vmcnt(%0)" :: "n"(12 + 4 * (KS32 - 1 - s) + ((PRE3 || s > DSTEP) ? 4 : 0)) : "memory");
+                if (WC_SPLIT_STAMPS && (s == 0 || s == KS32 - 1)) pro_[s == 0 ? 3 : 4] = __builtin_amdgcn_s_memtime();      // table k-step 0 / the last one has landed
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
@@ -454,6 +476,7 @@ __global__ __launch_bounds__(512, 1) void apply_split_kernel(SplitApplyArgs a)
                 }
                 if (PUB_ >= 0 && g == (FIRST_ ? G - 6 : WC_SPLIT_PUB_GAP)) {      // my pieces of tile t+1 have landed: publish (tile 0: behind the table)
                     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PUB_) : "memory");
+                    if (WC_SPLIT_STAMPS && FIRST_) pro_[5] = __builtin_amdgcn_s_memtime();      // my pieces of tile 1 have landed (waited for behind the table)
                     arrive(0);
                 }
                 if (DMA_ && g == 12 * DSTEP) {      // tile t-1 read by all: its buffer takes tile t+3
@@ -593,9 +616,11 @@ __global__ __launch_bounds__(512, 1) void apply_split_kernel(SplitApplyArgs a)
 #endif
     }
     if (WC_SPLIT_STAMPS && a.dbg && lane == 0) {
-        unsigned long long* d = a.dbg + ((int64_t)blockIdx.x * 8 + wave) * 8;
+        unsigned long long* d = a.dbg + ((int64_t)blockIdx.x * 8 + wave) * 16;
         d[0] = t_wait; d[1] = t_loop; d[2] = t_store; d[3] = __builtin_amdgcn_s_memtime() - k0_;
         d[4] = rt_in; d[5] = rt_loop; d[6] = __builtin_amdgcn_s_memrealtime();      // 100 MHz, chip-wide
+#pragma unroll
+        for (int i = 0; i < 8; ++i) d[8 + i] = pro_[i];
     }
 
     // Exact redo of every tile that STRADDLES samples of different slots (HW not a multiple of the tile): the MFMA pass used
