@@ -359,7 +359,12 @@ def roofline_apply(dev):
             "k3_kernels": k3, "site_stages": stages,
             "forward_site_us": round(t_site * 1e6, 1),
             "forward_site_route": "layer object (hipGraph replay of 10 calls), training mode, input " + ("on planes" if on_planes else "fp32") + " (producer not included: it replaces the block's residual add, timed below)",
-            "forward_site_frac_of_peak": round(3 * xb / t_site / 1e9 / HBM_PEAK_GBS, 4),
+            # the site alone moves 2 M C 4 bytes since the producer carries K1 (one read of x on planes + the write of y, counted
+            # as fp32); rounds 1-4 divided 3 M C 4 by a site that made all three passes.  With the producer: its two reads and one write of the
+            # sum (the shortcut at a quarter of the rows: 2.25 M C 4) + the site's 2 M C 4 = 4.25 M C 4.
+            "forward_site_frac_of_peak": round((2 if fused_k1 else 3) * xb / t_site / 1e9 / HBM_PEAK_GBS, 4),
+            "forward_site_bytes_counted": ("2 M C 4 (K1 rides on the producer's pass)" if fused_k1 else "3 M C 4"),
+            "forward_site_plus_producer_frac_of_peak": round(4.25 * xb / (t_site + t_prod) / 1e9 / HBM_PEAK_GBS, 4),
             "forward_site_fp32_input_us": round(t_site32 * 1e6, 1),
             "producer_us": {"residual add as the layers run it": round(t_prod * 1e6, 1), "residual add -> planes only (round 4)": round(t_prod_r4 * 1e6, 1),
                             "residual add -> fp32 (HIP)": round(t_prod32 * 1e6, 1), "torch broadcast add (rounds 1-3)": round(t_torch_add * 1e6, 1)},
