@@ -60,6 +60,33 @@ typedef void* wc_stream_t;        /* hipStream_t */
 int         wc_abi_version(void);
 const char* wc_error_string(int code);
 
+/* ==== THE BOUNDARY (round 6) ==========================================================================================
+ * SURVEY.md section 8b sketches the C ABI a replacement must export as `stats / factor / apply / bwd x 3 / workspace`.  That is this list:
+ * ten functions (the seven stages + colouring glue) and their workspace sizers.  A binding that implements only these (INTEGRATION.md
+ * section 3, the TF1/Keras-side stub) runs every layer of generator.py:13-90 -- forward, backward, train and eval mode, all colouring
+ * variants -- to the parity bar; oracle/wc_cpu.cpp exports each of them with a `_cpu` suffix (the conformance twin SURVEY asks for),
+ * and tests/test_abi.py checks both.
+ *
+ *   wc_stats_f32        K1   raw moments                         DecorelationNormalization.call (generator.py:24, 26)
+ *   wc_factor_f64       K2   mu, L = chol((1-eps) Sigma + eps I), W = L^-1, moving statistics
+ *   wc_color_f32             A_k = W^T Gamma_k                   Conv2D 1x1 / ConditionalConv11 / FactorizedConv11 (generator.py:49-78)
+ *   wc_group_bias_f32        b_k = beta_k - mu A_k (grouped batches)
+ *   wc_apply_f32        K3   y = (x - mu) A[slot] + b[slot]       (wc_apply_act_f32: the same with the block's ReLU in the epilogue)
+ *   wc_bwd_reduce_f32   K4   R = f^T gy, column sums             autodiff of the above
+ *   wc_bwd_factor_f64   K5   the C x C adjoint chain
+ *   wc_bwd_apply_f32    K6   dx = [gy | f] [A^T ; S] - mean
+ *   wc_*_workspace_bytes     the sizers of the eight above
+ *
+ * EVERYTHING ELSE in this header is an EXTENSION: a fusion or a data-format route of the same stages that the shipped torch layers take
+ * where the shape allows (pre-split fp16 planes, the residual add as producer, bit masks, K1 + K2 in one call, the harness' convolutions
+ * and spectral norm).  Each extension's comment names the core sequence it equals, each is parity-tested against that sequence or the
+ * oracle, and none is needed for a drop-in: a caller that never heard of them loses speed, not results.  No new extension enters without
+ * one leaving (ABI 8 retired nothing and added none).  The list below is what tests/test_abi.py parses. */
+#define WC_CORE_API "wc_stats_f32 wc_factor_f64 wc_color_f32 wc_group_bias_f32 wc_apply_f32 wc_apply_act_f32 " \
+                    "wc_bwd_reduce_f32 wc_bwd_factor_f64 wc_bwd_apply_f32 " \
+                    "wc_stats_workspace_bytes wc_factor_workspace_bytes wc_color_workspace_bytes wc_apply_workspace_bytes " \
+                    "wc_bwd_reduce_workspace_bytes wc_bwd_factor_workspace_bytes wc_bwd_apply_workspace_bytes"
+
 /* K1 + K2 in one call (ABI 4): wc_stats_f32 followed by wc_factor_f64(training = 1) for the caller that does not need the moments
  * themselves -- per-replica statistics, the reference's behaviour (sync-WC all-reduces (sum, xtx) between the two and keeps the
  * separate entries).  Same arguments and results as that pair; the K1 tail's slab reduction and the K2 head's bookkeeping run as ONE

@@ -29,6 +29,27 @@ def test_header_and_binding_table_agree():
     assert declared_symbols() == sorted(_lib.SIGNATURES)
 
 
+def test_the_core_boundary_is_the_surveys_list_and_has_its_cpu_twin(lib):
+    """include/wc_hip.h names THE boundary -- SURVEY.md section 8b's `stats / factor / apply / bwd x 3 / workspace` -- as
+    WC_CORE_API; every entry is declared and exported, the compute entries have their `_cpu` conformance twin in oracle/libwc_cpu.so, and
+    the list stays a list one can bind by hand (the rest of the header are extensions: fusions and data-format routes of the same stages)."""
+    src = open(HEADER).read()
+    m = re.search(r'#define WC_CORE_API((?:\s*"[^"]*"\s*\\?\n?)+)', src)
+    assert m, "WC_CORE_API not found"
+    core = " ".join(re.findall(r'"([^"]*)"', m.group(1))).split()
+    assert len(core) == len(set(core)) and 8 <= len(core) <= 16
+    stages = [n for n in core if not n.endswith("_workspace_bytes")]
+    assert {"wc_stats_f32", "wc_factor_f64", "wc_apply_f32", "wc_bwd_reduce_f32", "wc_bwd_factor_f64", "wc_bwd_apply_f32"} <= set(stages)
+    declared = set(declared_symbols())
+    for name in core:
+        assert name in declared and hasattr(lib, name), name
+    twin = os.path.join(ROOT, "oracle", "libwc_cpu.so")
+    if os.path.exists(twin):
+        cpu = ctypes.CDLL(twin)
+        for name in stages:
+            assert hasattr(cpu, name + "_cpu"), name + "_cpu"
+
+
 def test_every_declared_symbol_is_exported(lib):
     for name in declared_symbols():
         assert hasattr(lib, name), name

@@ -182,15 +182,18 @@ def test_generator_images_and_gradients_with_and_without_the_handoff():
     # gradients of size 1e3 -- and the two routes agree only to the last bit or two of each activation (a value whose lo term falls
     # into fp16's subnormal range under one scale and not under the other: 1-ulp differences from blocks.2.conv2 on, measured round 5),
     # so those are bounded by 2e-6 of the largest gradient's maximum instead, as in test_producer_gpu.py.
+    # that looser bound is for THOSE parameters only -- the biases (every '.bias' of a convolution: each sits in front of a WC
+    # site or is a shortcut's) -- every other gradient keeps 2e-5 of its own maximum, so a hand-off regression in a small-gradient weight
+    # cannot hide behind the largest gradient of the model.
     names = ["img"] + [n for n, p in G.named_parameters() if p.requires_grad]
     top = max(float(b.abs().max()) for b in out[1][1:])
-    worst, bad = 0.0, {}
+    bad = {}
     for n, a, b in zip(names, *out):
         d = float((a - b).abs().max())
         rel_own, rel_top = d / max(float(b.abs().max()), 1e-30), d / top
-        if rel_own > 2e-5 and (n == "img" or rel_top > 2e-6):
+        zero_in_exact_arithmetic = n.endswith(".bias") and "conv" in n
+        if rel_own > 2e-5 and not (zero_in_exact_arithmetic and rel_top <= 2e-6):
             bad[n] = (rel_own, rel_top)
-        worst = max(worst, rel_own if n == "img" else min(rel_own, rel_top * 10))
     assert not bad, bad
 
 

@@ -533,7 +533,7 @@ __global__ __launch_bounds__(512, 1) void resadd_xtx_kernel(ResXtxArgs a)
                 m = __builtin_fmaxf(__builtin_fmaxf(m, fabsf(g[p][0])), fabsf(g[p][1]));
                 m = __builtin_fmaxf(__builtin_fmaxf(m, fabsf(g[p][2])), fabsf(g[p][3]));
             }
-            if (!(m <= kResGuard)) {        // (a NaN raises the gate too; pass 2 then leaves the NaN in the planes: loud)
+            if (!(m <= kResGuard)) {        // (a NaN does NOT raise the gate -- fmaxf drops NaN operands, m never is one -- and needs none: it goes into the planes as it is, loud)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float mj = 0.f;
@@ -812,6 +812,7 @@ hipError_t wc_launch_resadd(const float* h, const float* s, int64_t N, int64_t H
 bool wc_resadd_xtx_supported(int64_t N, int64_t H, int64_t W, int C, int up, int groups)
 {
     if (!(C == 128 || C == 256) || !up || groups <= 0 || (N % groups) != 0 || (W % 8) != 0 || (H % 2) != 0) return false;
+    if (N * H * W < 256) return false;      // (rx_sample strides over M / 256 rows: ADVICE r5)
     int nsplit, ntypes; int64_t rps;
     return wc_fast_xty_plan(groups, (N / groups) * H * W, C, groups > 1, 0, &nsplit, &rps, &ntypes) > 0;
 }
