@@ -2105,8 +2105,12 @@ hipError_t wc_launch_factor_fused(double* T, double* W, double* tmp, int C, int 
             if (fits) {
                 size_t l2 = cp_factor_lds_doubles(C) * sizeof(double);
                 if (lds_role > l2) l2 = lds_role;
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(cholesky_phased_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
-                if (e != hipSuccess) return e;
+                static size_t l2_set = 0;        // (once per size: the attribute call is not free, and not needed again)
+                if (l2 > l2_set) {
+                    e = hipFuncSetAttribute(reinterpret_cast<const void*>(cholesky_phased_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+                    if (e != hipSuccess) return e;
+                    l2_set = l2;
+                }
                 const int nwg = groups * (np + TI_WG);
                 hipLaunchKernelGGL(cholesky_phased_kernel, dim3(nwg), dim3(1024), l2, st, T, tmp, C, W, rows, groups, np, bnd[1] | (bnd[2] << 8) | (bnd[3] << 16));
                 return hipGetLastError();
