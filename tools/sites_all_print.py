@@ -41,3 +41,9 @@ if k < len(per):
     print("launches of ONE forward + backward call of the same site:")
     t0 = int(b[2 * n]['Start_Timestamp'])
     for r in b[2 * n:]: print("  %-90s start %7.1f dur %6.1f" % (r['Kernel_Name'][:88], (int(r['Start_Timestamp']) - t0) / 1e3, (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3))
+for k, title in ((0, "the smallest site (cifar10 uncond block1.bn1, 128 x 4 x 4 x 256)"), (4, "cifar10 uncond block3.bn1 (128 x 16 x 16 x 256, planes)")):
+    if k < len(per):
+        b = per[k][1]; n = len(b) // 3
+        print("launches of ONE forward + backward call of %s:" % title)
+        t0 = int(b[2 * n]['Start_Timestamp'])
+        for r in b[2 * n:]: print("  %-90s start %7.1f dur %6.1f" % (r['Kernel_Name'][:88], (int(r['Start_Timestamp']) - t0) / 1e3, (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3))

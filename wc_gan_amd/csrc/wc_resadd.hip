@@ -44,6 +44,20 @@ __device__ __forceinline__ unsigned pk_rne2r(float a, float b)
 
 constexpr float kResGuard = 60000.0f;
 
+// The tensors these kernels write (planes, the fp32 sum) are streams far larger than the L2s that nobody reads before the launch ends: they leave
+// as NON-TEMPORAL stores (round 6: the fused producer 86.5 -> 75.9 us per call at 128 x 32 x 32 x 256 -- a wave's loads and stores retire on one
+// in-order counter, so a store that is acknowledged sooner also releases the rows requested behind it).  WC_RX_NT=0: plain stores, for A/B.
+#ifndef WC_RX_NT
+#define WC_RX_NT 1
+#endif
+template <typename V>
+__device__ __forceinline__ void st_stream(V* p, V v)
+{
+    if (WC_RX_NT) __builtin_nontemporal_store(v, p); else *p = v;
+}
+typedef unsigned u32x2r __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4r __attribute__((ext_vector_type(4)));
+
 struct ResAddArgs {
     const float* h; const float* s;        // h [N][H][W][C]; s [N][H >> up][W >> up][C] (nullable: out = h)
     int64_t M;                             // N * H * W
@@ -196,8 +210,8 @@ __global__ __launch_bounds__(256) void resadd_kernel(ResAddArgs a)
     auto advance = [&](int64_t& r, int& g) { r += drow; g += dcg; if (g >= C8) { g -= C8; ++r; } };
     auto emit = [&](int64_t e, f32x4 v0, f32x4 v1) __attribute__((always_inline)) {
         if (F32) {
-            *reinterpret_cast<f32x4*>(a.x32 + e) = v0;
-            *reinterpret_cast<f32x4*>(a.x32 + e + 4) = v1;
+            st_stream(reinterpret_cast<f32x4*>(a.x32 + e), v0);
+            st_stream(reinterpret_cast<f32x4*>(a.x32 + e + 4), v1);
         }
         if (SPLIT) {
             float g[8];
@@ -217,8 +231,8 @@ __global__ __launch_bounds__(256) void resadd_kernel(ResAddArgs a)
                 asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hw[j]), "v"(g[2 * j + 1]));
                 lw[j] = pk_rne2r(r0, r1);
             }
-            *reinterpret_cast<uint4*>(a.hi + e) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
-            *reinterpret_cast<uint4*>(a.lo + e) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+            st_stream(reinterpret_cast<u32x4r*>(a.hi + e), u32x4r{hw[0], hw[1], hw[2], hw[3]});
+            st_stream(reinterpret_cast<u32x4r*>(a.lo + e), u32x4r{lw[0], lw[1], lw[2], lw[3]});
         }
     };
     for (int64_t i = i0; i < n8; i += 2 * step) {
@@ -523,7 +537,7 @@ __global__ __launch_bounds__(512, 1) void resadd_xtx_kernel(ResXtxArgs a)
         for (int p = 0; p < 8; ++p) {
             f32x4 v = xr[p];
             if (has_s && !(WC_RX_ABL & 2)) v += sr[p >> 1];
-            if (F32 && st_hi) *reinterpret_cast<f32x4*>(a.r.x32 + (row0 + p) * C + 4 * c4) = v;
+            if (F32 && st_hi) st_stream(reinterpret_cast<f32x4*>(a.r.x32 + (row0 + p) * C + 4 * c4), v);
             g[p] = v * scl + ncs;
         }
         if (!REDO) {        // the saturation test: the stage's maximum against the guard; the per-channel maxima only behind it (rare)
@@ -585,11 +599,11 @@ __global__ __launch_bounds__(512, 1) void resadd_xtx_kernel(ResXtxArgs a)
         } else if (!(WC_RX_ABL & 1)) {
             if (st_hi) {
 #pragma unroll
-                for (int p = 0; p < 8; ++p) *reinterpret_cast<uint2*>(a.r.hi + (row0 + p) * C + 4 * c4) = make_uint2(H[p][0], H[p][1]);
+                for (int p = 0; p < 8; ++p) st_stream(reinterpret_cast<u32x2r*>(a.r.hi + (row0 + p) * C + 4 * c4), u32x2r{H[p][0], H[p][1]});
             }
             if (st_lo) {
 #pragma unroll
-                for (int p = 0; p < 8; ++p) *reinterpret_cast<uint2*>(a.r.lo + (row0 + p) * C + 4 * c4) = make_uint2(Lw[p][0], Lw[p][1]);
+                for (int p = 0; p < 8; ++p) st_stream(reinterpret_cast<u32x2r*>(a.r.lo + (row0 + p) * C + 4 * c4), u32x2r{Lw[p][0], Lw[p][1]});
             }
         }
 #pragma unroll
