@@ -454,7 +454,8 @@ int    wc_bwd_apply_xsplit_f32(const float* gy, const void* relu_mask /*nullable
                                float* dx, void* ws, size_t ws_bytes, wc_stream_t stream);
 
 /* K5: dgamma[k] = W R[k];  and, when training != 0, the statistics path
- *     Wbar = sum_k Gamma_k R_k^T;  Lbar = -tril(W^T Wbar W^T);  P = Phi(L^T Lbar);
+ *     Wbar = sum_k Gamma_k R_k^T;  Lbar = -tril(W^T Wbar W^T);  P = Phi(L^T Lbar)  [computed as -Phi(Wbar W^T): L^T W^T = I and
+ *     the strictly upper part of W^T Wbar W^T never reaches Phi's triangle -- one product instead of three; L itself is not read];
  *     S = 2(1-eps)/(M-ddof) sym(W^T P W)  (float32, C x C);   gmean = (1/M) sum_k gsum_k A_k^T  (C).
  * gamma == NULL means Gamma = I.  dgamma / dbeta may be NULL (that output is skipped).  S and gmean are
  * untouched when training == 0. */

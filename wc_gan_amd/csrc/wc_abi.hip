@@ -1033,7 +1033,7 @@ int wc_bwd_factor_f64(const double* R, const double* gsum, const double* W, cons
                       void* ws, size_t ws_bytes, wc_stream_t stream)
 {
     if (!R || !gsum || !W || !ws) return WC_ERR_NULL;
-    if (training && (!L || !A || !S || !gmean)) return WC_ERR_NULL;
+    if (training && (!L || !A || !S || !gmean)) return WC_ERR_NULL;        // (L: part of the contract, not read since round 6 -- see the chain below)
     if (bad_channels(C)) return WC_ERR_CHANNELS;
     if (Kc <= 0 || (!gamma && Kc != 1) || (training && M <= ddof)) return WC_ERR_SHAPE;
     if (ws_bytes < wc_bwd_factor_workspace_bytes(C, Kc)) return WC_ERR_WORKSPACE;
@@ -1082,28 +1082,24 @@ int wc_bwd_factor_f64(const double* R, const double* gsum, const double* W, cons
     } else {                                        // Gamma = I: Wbar = R^T, read through swapped strides
         Wbar = R; wb_rs = 1; wb_cs = C;
     }
-    {   // U1 = W^T Wbar
-        WcGemm g = sq(W, 0, 1, C, Wbar, 0, wb_rs, wb_cs, buf1, 0, 1.0, WC_EPI_NONE);
-        WC_TRY(wc_launch_gemm(g, st));
-    }
-    {   // Lbar = -tril(U1 W^T)
-        WcGemm g = sq(buf1, 0, C, 1, W, 0, 1, C, buf2, 0, -1.0, WC_EPI_TRIL);
-        WC_TRY(wc_launch_gemm(g, st));
-    }
-    {   // P = Phi(L^T Lbar)
-        WcGemm g = sq(L, 0, 1, C, buf2, 0, C, 1, buf0, 0, 1.0, WC_EPI_PHI);
+    // The Cholesky step of the chain in ONE product (round 6).  The textbook form -- Lbar = -tril(W^T Wbar W^T), P = Phi(L^T Lbar): three dependent
+    // products -- collapses: L^T is upper triangular, so the strictly upper part of Y = W^T Wbar W^T contributes nothing on or below the diagonal of
+    // L^T Y, i.e. Phi(L^T tril(Y)) = Phi(L^T Y), and L^T W^T = (W L)^T = I: P = -Phi(Wbar W^T).  Same quantity (to the 6e-13 of K2's W L = I), two
+    // launches of ~8 us fewer on the backward's critical path of every site; L is not read any more.
+    {   // P = -Phi(Wbar W^T)
+        WcGemm g = sq(Wbar, 0, wb_rs, wb_cs, W, 0, 1, C, buf1, 0, -1.0, WC_EPI_PHI);
         WC_TRY(wc_launch_gemm(g, st));
     }
     {   // Q1 = W^T P
-        WcGemm g = sq(W, 0, 1, C, buf0, 0, C, 1, buf1, 0, 1.0, WC_EPI_NONE);
+        WcGemm g = sq(W, 0, 1, C, buf1, 0, C, 1, buf2, 0, 1.0, WC_EPI_NONE);
         WC_TRY(wc_launch_gemm(g, st));
     }
     {   // Q2 = Q1 W
-        WcGemm g = sq(buf1, 0, C, 1, W, 0, C, 1, buf2, 0, 1.0, WC_EPI_NONE);
+        WcGemm g = sq(buf2, 0, C, 1, W, 0, C, 1, buf0, 0, 1.0, WC_EPI_NONE);
         WC_TRY(wc_launch_gemm(g, st));
     }
     const double scale = 2.0 * (1.0 - eps) / (double)(M - ddof);
-    WC_TRY(wc_launch_bwd_tail(buf2, C, scale, S, gsum, A, Kc, M, gmean, dbeta, st));      // S, gmean, dbeta
+    WC_TRY(wc_launch_bwd_tail(buf0, C, scale, S, gsum, A, Kc, M, gmean, dbeta, st));      // S, gmean, dbeta
     return WC_OK;
 }
 
