@@ -1,6 +1,6 @@
 # Round 6 evidence on one box: the GPU suite, K2's pipe check (both kernels + stage boundaries), every site under rocprofv3, the bench line.
 cd "$GRAFT_REPO_ROOT"; R=$PWD; mkdir -p gpurun_out
-timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | grep -v amdgpu.ids | tail -15 > gpurun_out/r6_gpu_suite.txt
+timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "amdgpu.ids\|version\|Hostname\|Librccl" | tail -12 > gpurun_out/r6_gpu_suite.txt
 { echo "K2 per call (tools/k2_pipe_check.py: ops.factor = K1 tail + prepare + factor + inverse; W L = I residual over 10 repeats; best of 5 back-to-back loops of 30 calls), round 6 default: cholesky_phased_kernel, a relay of three factorising workgroups at C = 256"
   python tools/k2_pipe_check.py 10 2>&1 | grep -v amdgpu.ids
   echo; echo "the same with WC_K2_FUSED_R5=1: round 5's one-workgroup factorisation (cholesky_fused_kernel, with this round's row-major panel)"
