@@ -32,6 +32,9 @@ __device__ __forceinline__ unsigned pk_rne(float a, float b)
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
 }
 constexpr float kGuard = 60000.0f;
+#ifndef XTY_ROLE31
+#define XTY_ROLE31 1    // K4 on planes, quadrant form: the waves that stage X (one v_perm per image word) own three blocks of their block row, the waves that
+#endif                  // stage and convert gy one -- see the stage loop.  0: two blocks each (rounds 4-5), for A/B
 #ifndef XTY_STAMPS
 #define XTY_STAMPS 0      // development: s_memtime stamps of wave 0 / workgroup 0 behind the partials (the caller adds 2 KiB to the workspace)
 #endif
@@ -229,14 +232,17 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
         st_off[j] = op * 2 * IMG + c * (R * 2) + ((rgrp ^ swz(c)) * 16);
     }
 
-    f32x4 xr[8];
+    f32x4 xr0[8];           // (the rows of one stage on their way; ROLE31 keeps a second set: two stages in flight)
     f32x4 yr[RELU == 1 ? 8 : 1];
-    uint4 ym = {0u, 0u, 0u, 0u};
+    uint4 ym0 = {0u, 0u, 0u, 0u};
     const bool y_wave = RELU && __builtin_amdgcn_readfirstlane(op) != 0;       // waves 4-7 stage Y (wave-uniform: a scalar branch)
     const bool x_wave = XPL && (XTY_YPL_ABL || __builtin_amdgcn_readfirstlane(op) == 0);        // waves 0-3 stage X (wave-uniform: a scalar branch)
-    auto stage_load = [&](int st) {
+    // (RL: 0 = the wave's role is a run-time value, as in every form but ROLE31; 1 = an X wave, 2 = a Y wave at compile time -- each role's loop
+    //  then holds only its own staging code and registers)
+    auto stage_load = [&](int st, auto RL_, f32x4 (&xr)[8], uint4& ym) __attribute__((always_inline)) {
+        constexpr int RL = decltype(RL_)::value;
         const int64_t off = (r0 + (int64_t)st * R + rgrp * 8) * C + cbase + 4 * c4;
-        if (XPL && x_wave) {        // 4 channels of 8 rows from each plane: xr[p] = (hi word 0, hi word 1, lo word 0, lo word 1) of row p
+        if (XPL && (RL == 1 || (RL == 0 && x_wave))) {        // 4 channels of 8 rows from each plane: xr[p] = (hi word 0, hi word 1, lo word 0, lo word 1) of row p
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
                 const uint2 h = *reinterpret_cast<const uint2*>(a.Xhi + off + p * C), l = *reinterpret_cast<const uint2*>(a.Xlo + off + p * C);
@@ -247,11 +253,11 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
         const float* base = src + off;
 #pragma unroll
         for (int p = 0; p < 8; ++p) xr[p] = ldg4(base + p * C);
-        if (RELU == 1 && y_wave) {
+        if (RELU == 1 && (RL == 2 || (RL == 0 && y_wave))) {
 #pragma unroll
             for (int p = 0; p < 8; ++p) yr[RELU == 1 ? p : 0] = ldg4(a.Yrelu + off + p * C);
         }
-        if (RELU == 2 && y_wave) {      // rows row0 .. row0 + 7 (row0 a multiple of 8): byte (row0 % 32) / 8 of the 32-row block's words
+        if (RELU == 2 && (RL == 2 || (RL == 0 && y_wave))) {      // rows row0 .. row0 + 7 (row0 a multiple of 8): byte (row0 % 32) / 8 of the 32-row block's words
             const int64_t row0 = r0 + (int64_t)st * R + rgrp * 8;
             ym = *reinterpret_cast<const uint4*>(a.Ymask + (row0 >> 5) * C + cbase + 4 * c4);
             const int sh = (int)(row0 & 31);
@@ -279,9 +285,10 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
     // IEEE fp32 FMAs (round to nearest even: unbiased) and the combine takes the diagonal from there.
     const bool want_dfix = !TWO && a.dfix != nullptr && type == a.ntypes - 1;
     double lsq[4] = {0.0, 0.0, 0.0, 0.0};      // per stage: a fresh 8-term fp32 chain, folded into float64
-    auto stage_write = [&](int buf, int st_of_data) {
+    auto stage_write = [&](int buf, int st_of_data, auto RL_, f32x4 (&xr)[8], uint4& ym) __attribute__((always_inline)) {
+        constexpr int RL = decltype(RL_)::value;
         char* img = smem + buf * (NOP * 2 * IMG);
-        if (XPL && x_wave) {        // transpose by byte permutes: channel j of rows (2 pp, 2 pp + 1) = half j & 1 of word j >> 1 of the two rows
+        if (XPL && (RL == 1 || (RL == 0 && x_wave))) {        // transpose by byte permutes: channel j of rows (2 pp, 2 pp + 1) = half j & 1 of word j >> 1 of the two rows
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const unsigned sel = (j & 1) ? 0x07060302u : 0x05040100u;
@@ -299,7 +306,7 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
             return;
         }
         f32x4 g[8];
-        if (RELU && y_wave) {
+        if (RELU && (RL == 2 || (RL == 0 && y_wave))) {
             if (RELU == 2) {
                 const unsigned mw[4] = {ym.x, ym.y, ym.z, ym.w};
 #pragma unroll
@@ -376,12 +383,15 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
         b_base[b] = (TWO ? 2 * IMG : 0) + cb * (R * 2) + ((lh ^ swz(cb)) << 4);
     }
 
-    if (nst > 0) {
-        stage_load(0);
-        stage_write(0, 0);
-        if (nst > 1) stage_load(1);
+    using RL0 = std::integral_constant<int, 0>;
+    constexpr bool ROLE31 = XTY_ROLE31 && QUAD && (XPL || RELU == 2) && !XTY_YPL_ABL && !XTY_STAMPS;      // (fp32 x with the bit mask: both roles convert -- two blocks
+                                                                                                           //  and two sets each: 103 -> 98 us; without a mask the old loop is as fast: 81 against 83)
+    if (!ROLE31 && nst > 0) {
+        stage_load(0, RL0{}, xr0, ym0);
+        stage_write(0, 0, RL0{}, xr0, ym0);
+        if (nst > 1) stage_load(1, RL0{}, xr0, ym0);
     }
-    __syncthreads();
+    if (!ROLE31) __syncthreads();
     const bool stamp_ok = XTY_STAMPS && tid == 0 && blockIdx.x == 0;
     unsigned long long* stamps = reinterpret_cast<unsigned long long*>(a.P + (int64_t)a.nslab * C * C);     // just past P: stamp builds get a larger workspace
     int nstamp = 0;
@@ -393,12 +403,12 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
     // ahead: 89 -> 100 us.  Reading the A fragments once for a wave's blocks of the same block row (12 -> 9 ds_read_b128 per
     // k-step): no change, +18 spilled registers.)
     f32x16 acc[BW];
-    for (int st = 0; st < nst; ++st) {
+    for (int st = 0; !ROLE31 && st < nst; ++st) {
         const int cur = st & 1;
         XS();
-        if (st + 1 < nst) stage_write(cur ^ 1, st + 1);
+        if (st + 1 < nst) stage_write(cur ^ 1, st + 1, RL0{}, xr0, ym0);
         XS();
-        if (st + 2 < nst) stage_load(st + 2);
+        if (st + 2 < nst) stage_load(st + 2, RL0{}, xr0, ym0);
         XS();
         // the fp32 accumulators live for one stage only (their first MFMA takes a zero operand: no zeroing pass, and the 16 BW
         // registers are free while the next stage is converted)
@@ -503,9 +513,128 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
 
     // partial blocks out, scales undone exactly (powers of two)
     double* P = a.P + z * (int64_t)C * C;
+    if constexpr (ROLE31) {
+        // K4 on planes, quadrant form, round 6.  The four waves that stage X have almost nothing to convert (one v_perm_b32 per image word), the four
+        // that stage gy mask, scale, range-test and split every element: with two blocks per wave the stage lasted as long as a Y wave's conversion
+        // PLUS its two chains, while its SIMD partner -- an X wave -- had long finished (the clock probe and the planes ablation).  So
+        // wave w < 4 owns blocks (w, 0), (w, 1), (w, 2) of the quadrant -- one A fragment pair for three chains -- and wave w + 4 owns (w, 3): the
+        // matrix work of a SIMD is what it was, the Y wave's critical path is a third shorter.  Each role runs its own copy of the stage loop (the
+        // same barriers), so the X role's 144 accumulator registers never meet the Y role's conversion registers.  Block by block the same chains:
+        // the partials are bit-identical to the two-blocks-per-wave form.
+        auto role = [&](auto NBW_, auto RL_) __attribute__((always_inline)) {
+            constexpr int NBW = decltype(NBW_)::value;
+            using RLt = decltype(RL_);
+            constexpr int jl0 = RLt::value == 1 ? 0 : 4 - NBW;                            // (the Y role's blocks are the last of the row)
+            const int ilr = wave & 3;
+            double s64[NBW][16];
+#pragma unroll
+            for (int b = 0; b < NBW; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s64[b][r] = 0.0;
+            const int ca = ilr * 32 + l31;
+            const int a_b = ca * (R * 2) + ((lh ^ swz(ca)) << 4);
+            int b_b[NBW];
+#pragma unroll
+            for (int b = 0; b < NBW; ++b) {
+                const int cb = (jl0 + b) * 32 + l31;
+                b_b[b] = 2 * IMG + cb * (R * 2) + ((lh ^ swz(cb)) << 4);
+            }
+            // TWO stages of rows in flight (set A = xr0, set B = xr1, alternating): a stage's loads used to have the matrix phase of ONE stage to
+            // land (~1 us against a loaded memory latency of two) and every stage began with a wait -- K4 was latency-bound at 2.9 us per stage
+            // where its vector + matrix work is 0.8.  Every trip issues the same loads (past the end: the last stage's rows again, an L2 hit nobody
+            // reads), so the compiler's vmcnt for "this set has landed" leaves the other set's loads in flight (see resadd_xtx_kernel's history).
+            f32x4 xr1[8];
+            uint4 ym1 = {0u, 0u, 0u, 0u};
+            const int last = nst - 1;
+            auto clampst = [&](int st) { return st < last ? st : last; };
+            auto stage_body = [&](int st) __attribute__((always_inline)) {
+                const int cur = st & 1;
+                const int kbuf = cur << 16;
+                auto frag = [&](int base, int ks, int lo) __attribute__((always_inline)) {
+                    return *reinterpret_cast<const f16x8*>(smem + (base ^ ((ks << 5) | kbuf)) + lo * IMG);
+                };
+                // (the X role's blocks two at a time, then the third: three chains side by side need 48 accumulator registers that the second set of
+                //  rows has taken)
+                constexpr int G2 = NBW >= 2 && NBW < 3 ? 2 : (NBW == 3 ? 3 : 1);
+                auto chains = [&](auto B0_, auto NB_) __attribute__((always_inline)) {
+                    constexpr int b0 = decltype(B0_)::value, nbk = decltype(NB_)::value;
+                    f32x16 ac[nbk];
+#pragma unroll
+                    for (int b = 0; b < nbk; ++b)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) ac[b][r] = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        const f16x8 ah = frag(a_b, ks, 0), al = frag(a_b, ks, 1);
+#pragma unroll
+                        for (int b = 0; b < nbk; ++b) {
+                            const f16x8 bh = frag(b_b[b0 + b], ks, 0), bl = frag(b_b[b0 + b], ks, 1);
+                            ac[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, ac[b], 0, 0, 0);
+                            ac[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, ac[b], 0, 0, 0);
+                            ac[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, ac[b], 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int b = 0; b < nbk; ++b)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) s64[b0 + b][r] = __builtin_fma((double)ac[b][r], 1.0, s64[b0 + b][r]);
+                };
+                chains(std::integral_constant<int, 0>{}, std::integral_constant<int, G2>{});
+                if constexpr (NBW > G2) chains(std::integral_constant<int, G2>{}, std::integral_constant<int, NBW - G2>{});
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            };
+            // (the X role with three blocks has no room for a second set: its plane rows keep one stage in flight, the Y role's fp32 rows two)
+            constexpr bool TWOSETS = XTY_ROLE31 == 2 || RLt::value == 2 || !XPL;
+            if constexpr (TWOSETS) {
+                if (nst > 0) {
+                    stage_load(0, RLt{}, xr0, ym0);
+                    stage_load(clampst(1), RLt{}, xr1, ym1);
+                    stage_write(0, 0, RLt{}, xr0, ym0);
+                    stage_load(clampst(2), RLt{}, xr0, ym0);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                for (int st = 0; st < nst; st += 2) {
+                    // even stage: set B holds stage st + 1, set A stage st + 2
+                    if (st + 1 < nst) stage_write((st & 1) ^ 1, st + 1, RLt{}, xr1, ym1);
+                    stage_load(clampst(st + 3), RLt{}, xr1, ym1);
+                    stage_body(st);
+                    if (st + 1 >= nst) break;
+                    // odd stage: set A holds stage st + 2, set B stage st + 3
+                    if (st + 2 < nst) stage_write(st & 1, st + 2, RLt{}, xr0, ym0);
+                    stage_load(clampst(st + 4), RLt{}, xr0, ym0);
+                    stage_body(st + 1);
+                }
+            } else {
+                if (nst > 0) {
+                    stage_load(0, RLt{}, xr0, ym0);
+                    stage_write(0, 0, RLt{}, xr0, ym0);
+                    if (nst > 1) stage_load(1, RLt{}, xr0, ym0);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                for (int st = 0; st < nst; ++st) {
+                    if (st + 1 < nst) stage_write((st & 1) ^ 1, st + 1, RLt{}, xr0, ym0);
+                    if (st + 2 < nst) stage_load(st + 2, RLt{}, xr0, ym0);      // (one set: the wait for it is a wait for everything anyway)
+                    stage_body(st);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < NBW; ++b) {
+                const int j = (qj * (NB / 2) + jl0 + b) * 32 + l31;
+                const double isj = 1.0 / (double)a.sy[j];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = (qi * (NB / 2) + ilr) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    P[(int64_t)i * C + j] = s64[b][r] * isj / (double)a.sx[i];
+                }
+            }
+        };
+        constexpr int NBX = (XPL && XTY_ROLE31 != 2) ? 3 : 2;          // (XTY_ROLE31 == 2, development: two blocks per wave on planes too)
+        if (__builtin_amdgcn_readfirstlane(op) == 0) role(std::integral_constant<int, NBX>{}, std::integral_constant<int, 1>{});
+        else role(std::integral_constant<int, 4 - NBX>{}, std::integral_constant<int, 2>{});
+    }
 #pragma unroll
     for (int b = 0; b < BW; ++b) {
-        if (!live[b]) continue;
+        if (ROLE31 || !live[b]) continue;
         const int j = jb[b] * 32 + l31;
         const double isj = 1.0 / (double)(TWO ? a.sy[j] : a.sx[j]);
 #pragma unroll
