@@ -384,7 +384,7 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
     }
 
     using RL0 = std::integral_constant<int, 0>;
-    constexpr bool ROLE31 = XTY_ROLE31 && QUAD && (XPL || RELU == 2) && !XTY_YPL_ABL && !XTY_STAMPS;      // (fp32 x with the bit mask: both roles convert -- two blocks
+    constexpr bool ROLE31 = XTY_ROLE31 && QUAD && (XPL || RELU == 2) && !XTY_YPL_ABL && !XTY_STAMPS;      // (tried on the C = 128 planes form -- one 4 x 4 block grid, a quadrant's geometry: 47.1 -> 48.8 / 66.2 -> 68.7 us per stage, not taken)      // (fp32 x with the bit mask: both roles convert -- two blocks
                                                                                                            //  and two sets each: 103 -> 98 us; without a mask the old loop is as fast: 81 against 83)
     if (!ROLE31 && nst > 0) {
         stage_load(0, RL0{}, xr0, ym0);
