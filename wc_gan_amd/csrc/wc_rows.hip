@@ -638,7 +638,9 @@ int wc_xty_plan(int64_t N, int64_t HW, int C, int per_sample, int sym, int* nspl
 {
     const int nb = (C + BM - 1) / BM;
     const int64_t target = 512;                       // ~2 workgroups per CU (the fp64 flush registers cap it at 2)
-    const int64_t min_rows = 256;
+    // (round 6: the smallest sites -- 4 x 4 pixels, 2 048 rows, the exact float64 kernel -- as slabs of ONE 128-row chunk: 160 workgroups instead
+    //  of 80 on a chip of 256 CUs; above 4 096 rows the slabs' float64 partials would double what the tail reads for nothing)
+    const int64_t min_rows = (per_sample ? HW : N * HW) <= 4096 ? 128 : 256;
     const int ntiles = sym ? nb * (nb + 1) / 2 : nb * nb;
     if (per_sample) {
         int64_t want = (target + N * ntiles - 1) / (N * ntiles);         // slabs per sample
