@@ -526,14 +526,14 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
             using RLt = decltype(RL_);
             constexpr int jl0 = RLt::value == 1 ? 0 : 4 - NBW;                            // (the Y role's blocks are the last of the row)
             const int ilr = wave & 3;
-            double s64[NBW][16];
+            double s64[NBW > 0 ? NBW : 1][16];
 #pragma unroll
             for (int b = 0; b < NBW; ++b)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s64[b][r] = 0.0;
             const int ca = ilr * 32 + l31;
             const int a_b = ca * (R * 2) + ((lh ^ swz(ca)) << 4);
-            int b_b[NBW];
+            int b_b[NBW > 0 ? NBW : 1];
 #pragma unroll
             for (int b = 0; b < NBW; ++b) {
                 const int cb = (jl0 + b) * 32 + l31;
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
                 };
                 // (the X role's blocks two at a time, then the third: three chains side by side need 48 accumulator registers that the second set of
                 //  rows has taken)
-                constexpr int G2 = NBW >= 2 && NBW < 3 ? 2 : (NBW == 3 ? 3 : 1);
+                constexpr int G2 = (NBW == 2 || NBW == 4) ? 2 : (NBW == 3 ? 3 : 1);
                 auto chains = [&](auto B0_, auto NB_) __attribute__((always_inline)) {
                     constexpr int b0 = decltype(B0_)::value, nbk = decltype(NB_)::value;
                     f32x16 ac[nbk];
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) s64[b0 + b][r] = __builtin_fma((double)ac[b][r], 1.0, s64[b0 + b][r]);
                 };
-                chains(std::integral_constant<int, 0>{}, std::integral_constant<int, G2>{});
+                if constexpr (NBW > 0) chains(std::integral_constant<int, 0>{}, std::integral_constant<int, G2>{});
                 if constexpr (NBW > G2) chains(std::integral_constant<int, G2>{}, std::integral_constant<int, NBW - G2>{});
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             };
@@ -628,7 +628,7 @@ __global__ __launch_bounds__(512, 1) void xty_f16x3_kernel(FastXtyArgs a)
                 }
             }
         };
-        constexpr int NBX = (XPL && XTY_ROLE31 != 2) ? 3 : 2;          // (XTY_ROLE31 == 2, development: two blocks per wave on planes too)
+        constexpr int NBX = (XPL && XTY_ROLE31 == 3) ? 4 : (XPL && XTY_ROLE31 != 2) ? 3 : 2;          // (XTY_ROLE31 == 2 / 3, development: two / four blocks per X wave on planes)
         if (__builtin_amdgcn_readfirstlane(op) == 0) role(std::integral_constant<int, NBX>{}, std::integral_constant<int, 1>{});
         else role(std::integral_constant<int, 4 - NBX>{}, std::integral_constant<int, 2>{});
     }
