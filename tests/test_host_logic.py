@@ -1,4 +1,6 @@
 """CPU tests of the Python host mirror: create_norm alphabets, sub-layer naming, coloring tables."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -340,3 +342,22 @@ def test_discriminator_keyword_defaults_are_the_references():
     out, cls_out = D(torch.zeros(2, 8, 8, 3))
     assert out.shape == (2, 1) and cls_out.shape == (2, 10)
     assert type(D.cls_out) is torch.nn.Linear                          # plain Dense class head, discriminator.py:74
+
+
+def test_ranks_that_share_a_gpu_get_the_k2_form_without_an_in_launch_wait(monkeypatch):
+    """_lib.shared_gpu_guard: more local ranks than visible devices -> WC_K2_TWO_LAUNCH=1 before the library reads its environment; one rank per
+    device, a single process, or an explicit setting: nothing is touched ("Abstractions": the user no longer has to know the switch)."""
+    from wc_gan_amd import _lib
+    monkeypatch.delenv("WC_K2_TWO_LAUNCH", raising=False)
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    assert _lib.shared_gpu_guard(device_count=1) is False and "WC_K2_TWO_LAUNCH" not in os.environ
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert _lib.shared_gpu_guard(device_count=8) is False and "WC_K2_TWO_LAUNCH" not in os.environ
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "2")
+    assert _lib.shared_gpu_guard(device_count=1) is True and os.environ["WC_K2_TWO_LAUNCH"] == "1"
+    assert _lib.shared_gpu_guard(device_count=1) is False and os.environ["WC_K2_TWO_LAUNCH"] == "1"      # explicit now: left alone
+    monkeypatch.setenv("WC_K2_TWO_LAUNCH", "0")
+    assert _lib.shared_gpu_guard(device_count=1) is False and "WC_K2_TWO_LAUNCH" not in os.environ           # "0" = the one-launch form, by request
+    monkeypatch.delenv("WC_K2_TWO_LAUNCH", raising=False)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "two")
+    assert _lib.shared_gpu_guard(device_count=1) is False

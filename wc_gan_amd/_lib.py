@@ -184,6 +184,35 @@ class WcHipError(RuntimeError):
     pass
 
 
+def shared_gpu_guard(device_count=None) -> bool:
+    """K2's one-launch forms (the relay, and rounds 2-5's kernel with the inverse inside) wait -- bounded -- for workgroups of their own
+    launch: fine when the process has the GPU, wrong when several ranks TIME-SLICE one GPU (a waiting workgroup can be switched out
+    with the one it waits for; the wait runs out, W holds NaN and only WC_CHECK_K2=1 would say so).  The two-launch form has no such
+    wait.  Until round 6 the user had to know the switch; now a launcher that puts more local ranks on the node than there are visible
+    devices (LOCAL_WORLD_SIZE > device count) selects it here, before the library reads its environment.  An explicit
+    WC_K2_TWO_LAUNCH (0 or 1) is left alone.  Returns whether the switch was set by this call."""
+    if "WC_K2_TWO_LAUNCH" in os.environ:
+        if os.environ["WC_K2_TWO_LAUNCH"] == "0":       # (the C side tests for presence: "0" means "not set")
+            del os.environ["WC_K2_TWO_LAUNCH"]
+        return False
+    try:
+        ranks = int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1)
+    except ValueError:
+        ranks = 1
+    if ranks <= 1:
+        return False
+    if device_count is None:
+        try:
+            import torch
+            device_count = torch.cuda.device_count()      # (does not initialise the GPU)
+        except Exception:
+            device_count = 0
+    if device_count and ranks > device_count:
+        os.environ["WC_K2_TWO_LAUNCH"] = "1"
+        return True
+    return False
+
+
 def load() -> ctypes.CDLL:
     """Load libwc_hip.so (once).  Raises if it has not been built -- no fallback."""
     global _lib
@@ -192,6 +221,7 @@ def load() -> ctypes.CDLL:
     # torch first: libwc_hip.so must bind to the HIP runtime torch has loaded (same streams, same
     # allocations); loading it before torch pulls in a second runtime that sees no device
     import torch  # noqa: F401
+    shared_gpu_guard()
     if not os.path.exists(LIB_PATH):
         raise WcHipError(
             f"{LIB_PATH} is missing: build it with `python -m wc_gan_amd.build` "
