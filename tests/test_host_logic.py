@@ -353,7 +353,11 @@ def test_ranks_that_share_a_gpu_get_the_k2_form_without_an_in_launch_wait(monkey
     assert _lib.shared_gpu_guard(device_count=1) is False and "WC_K2_TWO_LAUNCH" not in os.environ
     monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
     assert _lib.shared_gpu_guard(device_count=8) is False and "WC_K2_TWO_LAUNCH" not in os.environ
+    for k in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"): monkeypatch.delenv(k, raising=False)
     monkeypatch.setenv("LOCAL_WORLD_SIZE", "2")
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1")
+    assert _lib.shared_gpu_guard(device_count=1) is False and "WC_K2_TWO_LAUNCH" not in os.environ           # devices masked per rank: no verdict
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
     assert _lib.shared_gpu_guard(device_count=1) is True and os.environ["WC_K2_TWO_LAUNCH"] == "1"
     assert _lib.shared_gpu_guard(device_count=1) is False and os.environ["WC_K2_TWO_LAUNCH"] == "1"      # explicit now: left alone
     monkeypatch.setenv("WC_K2_TWO_LAUNCH", "0")

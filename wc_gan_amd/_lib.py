@@ -201,6 +201,8 @@ def shared_gpu_guard(device_count=None) -> bool:
         ranks = 1
     if ranks <= 1:
         return False
+    if any(os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES")):
+        return False        # (a launcher that masks devices per rank: the count seen here says nothing about sharing)
     if device_count is None:
         try:
             import torch
