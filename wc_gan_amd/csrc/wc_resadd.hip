@@ -278,6 +278,9 @@ __global__ __launch_bounds__(256) void resadd_kernel(ResAddArgs a)
 // The partials P / colsum / dfix go where wc_whiten_split_f16x2's tail expects them (wc_whiten_presummed_f16x2 runs that tail), so the
 // site's K1 launch does not exist.  Saturation: as resadd_kernel -- the channel's true maximum is recorded, the gated second launch
 // redoes planes AND partials with the lowered scales.
+#ifndef WC_RX_STAGGER
+#define WC_RX_STAGGER 1      // 0: every wave converts first (round 5)
+#endif
 #ifndef WC_RX_ABL
 #define WC_RX_ABL 0      // development ablation bits (wrong results, times only): 1 no plane stores, 2 no shortcut rows, 4 no MFMAs, 8 no float64 flush, 16 the planes as 16-byte stores (misplaced)
 #endif
@@ -513,13 +516,26 @@ __global__ __launch_bounds__(512, 1) void resadd_xtx_kernel(ResXtxArgs a)
     // up = 1 they add 4 consecutive source pixels of s, each twice
     f32x4 xr[8], sr[4];
     constexpr bool has_s = true;                         // (the launcher refuses a call without a shortcut: every block of the generators has one)
-    auto stage_load = [&](int st) {
+    // (what the stage lambdas need of the arguments, as scalars: with the stage loop instantiated per order of its halves -- `run` below -- the
+    //  lambdas are captured a second time, and an argument STRUCT reached through two captures is materialised in scratch memory)
+    const float* const g_h = a.r.h; const float* const g_s = a.r.s; float* const g_x32 = a.r.x32;
+    _Float16* const g_hi = a.r.hi; _Float16* const g_lo = a.r.lo;
+    const int g_up = a.r.up, g_H = a.r.H, g_W = a.r.W;
+    const unsigned g_magHW = a.r.magHW, g_shHW = a.r.shHW, g_magW = a.r.magW, g_shW = a.r.shW;
+    auto src_row_l = [&](unsigned row) __attribute__((always_inline)) -> int64_t {        // src_row() on the scalars
+        if (!g_up) return row;
+        const unsigned HWp = (unsigned)g_H * (unsigned)g_W;
+        const unsigned n = __umulhi(row, g_magHW) >> g_shHW, rem = row - n * HWp;
+        const unsigned y = __umulhi(rem, g_magW) >> g_shW, x = rem - y * (unsigned)g_W;
+        return ((int64_t)n * (g_H >> 1) + (y >> 1)) * (g_W >> 1) + (x >> 1);
+    };
+    auto stage_load = [&](int st) __attribute__((always_inline)) {
         const int64_t row0 = r0 + (int64_t)st * R + rgrp * 8;
-        const float* base = a.r.h + row0 * C + 4 * c4;
+        const float* base = g_h + row0 * C + 4 * c4;
 #pragma unroll
         for (int p = 0; p < 8; ++p) xr[p] = *reinterpret_cast<const f32x4*>(base + p * C);
         if (has_s && !(WC_RX_ABL & 2)) {
-            const float* sb = a.r.s + src_row(a.r, (unsigned)row0) * C + 4 * c4;
+            const float* sb = g_s + src_row_l((unsigned)row0) * C + 4 * c4;
 #pragma unroll
             for (int p = 0; p < 4; ++p) sr[p] = *reinterpret_cast<const f32x4*>(sb + p * C);
         }
@@ -528,7 +544,7 @@ __global__ __launch_bounds__(512, 1) void resadd_xtx_kernel(ResXtxArgs a)
     const bool want_dfix = a.dfix != nullptr && type == a.ntypes - 1;
     // which plane this workgroup stores: with two types of a slab each takes one (both hold every word); one type stores both
     const bool st_hi = a.ntypes == 1 || type == 0, st_lo = a.ntypes == 1 || type == 1;
-    auto stage_write = [&](int buf, int st_of_data) {
+    auto stage_write = [&](int buf, int st_of_data) __attribute__((always_inline)) {
         char* img = smem + buf * (2 * IMG);
         const int64_t row0 = r0 + (int64_t)st_of_data * R + rgrp * 8;
         const f32x4 scl = *reinterpret_cast<const f32x4*>(sc_sh + 4 * c4), ncs = *reinterpret_cast<const f32x4*>(nc_sh + 4 * c4);
@@ -537,7 +553,7 @@ __global__ __launch_bounds__(512, 1) void resadd_xtx_kernel(ResXtxArgs a)
         for (int p = 0; p < 8; ++p) {
             f32x4 v = xr[p];
             if (has_s && !(WC_RX_ABL & 2)) v += sr[p >> 1];
-            if (F32 && st_hi) st_stream(reinterpret_cast<f32x4*>(a.r.x32 + (row0 + p) * C + 4 * c4), v);
+            if (F32 && st_hi) st_stream(reinterpret_cast<f32x4*>(g_x32 + (row0 + p) * C + 4 * c4), v);
             g[p] = v * scl + ncs;
         }
         if (!REDO) {        // the saturation test: the stage's maximum against the guard; the per-channel maxima only behind it (rare)
@@ -590,20 +606,20 @@ __global__ __launch_bounds__(512, 1) void resadd_xtx_kernel(ResXtxArgs a)
         if (WC_RX_ABL & 16) {        // timing only: the same bytes as four 16-byte stores per plane (rows p, p + 1 are 1 KiB contiguous; data misplaced)
             if (st_hi) {
 #pragma unroll
-                for (int p = 0; p < 8; p += 2) *reinterpret_cast<uint4*>(a.r.hi + (row0 + p) * C + 8 * c4) = make_uint4(H[p][0], H[p][1], H[p + 1][0], H[p + 1][1]);
+                for (int p = 0; p < 8; p += 2) *reinterpret_cast<uint4*>(g_hi + (row0 + p) * C + 8 * c4) = make_uint4(H[p][0], H[p][1], H[p + 1][0], H[p + 1][1]);
             }
             if (st_lo) {
 #pragma unroll
-                for (int p = 0; p < 8; p += 2) *reinterpret_cast<uint4*>(a.r.lo + (row0 + p) * C + 8 * c4) = make_uint4(Lw[p][0], Lw[p][1], Lw[p + 1][0], Lw[p + 1][1]);
+                for (int p = 0; p < 8; p += 2) *reinterpret_cast<uint4*>(g_lo + (row0 + p) * C + 8 * c4) = make_uint4(Lw[p][0], Lw[p][1], Lw[p + 1][0], Lw[p + 1][1]);
             }
         } else if (!(WC_RX_ABL & 1)) {
             if (st_hi) {
 #pragma unroll
-                for (int p = 0; p < 8; ++p) st_stream(reinterpret_cast<u32x2r*>(a.r.hi + (row0 + p) * C + 4 * c4), u32x2r{H[p][0], H[p][1]});
+                for (int p = 0; p < 8; ++p) st_stream(reinterpret_cast<u32x2r*>(g_hi + (row0 + p) * C + 4 * c4), u32x2r{H[p][0], H[p][1]});
             }
             if (st_lo) {
 #pragma unroll
-                for (int p = 0; p < 8; ++p) st_stream(reinterpret_cast<u32x2r*>(a.r.lo + (row0 + p) * C + 4 * c4), u32x2r{Lw[p][0], Lw[p][1]});
+                for (int p = 0; p < 8; ++p) st_stream(reinterpret_cast<u32x2r*>(g_lo + (row0 + p) * C + 4 * c4), u32x2r{Lw[p][0], Lw[p][1]});
             }
         }
 #pragma unroll
@@ -620,11 +636,6 @@ __global__ __launch_bounds__(512, 1) void resadd_xtx_kernel(ResXtxArgs a)
         }
     };
 
-    double acc64[BW][16];
-#pragma unroll
-    for (int b = 0; b < BW; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc64[b][r] = 0.0;
     int a_base[BW], b_base[BW];
 #pragma unroll
     for (int b = 0; b < BW; ++b) {
@@ -639,66 +650,93 @@ __global__ __launch_bounds__(512, 1) void resadd_xtx_kernel(ResXtxArgs a)
         if (nst > 1) stage_load(1);
     }
     __syncthreads();
-    f32x16 acc[BW];
-    for (int st = 0; st < nst; ++st) {
-        const int cur = st & 1;
-        if (st + 1 < nst) stage_write(cur ^ 1, st + 1);
-        if (st + 2 < nst) stage_load(st + 2);
+    double* P = a.P + z * (int64_t)C * C;
+    // The stage loop, once per ORDER of its two halves (round 6; MI355X_MICROARCH.md: "two waves that run the same program with one barrier per
+    // block: try a stagger").  Waves 0-3 convert the next stage and then multiply the current one (MF = false: the loop as it was); their SIMD
+    // partners 4-7 multiply FIRST and convert afterwards (MF = true) -- both orders are legal inside a stage, the conversion writes the other
+    // buffer -- so a SIMD's vector pipe and its matrix pipe are wanted by different waves at the same time.  The kernel stands at 256 registers
+    // with three blocks per wave; waves 4-7 never have more than NBK = 2 (C = 256: the balanced split) or any at all (C = 128), and their copy of
+    // the loop is compiled for that many: that is where the registers for holding a stage's rows across the matrix half come from.
+    auto run = [&](auto MF_, auto NBK_) __attribute__((always_inline)) {
+        constexpr bool MF = decltype(MF_)::value;
+        constexpr int NBK = decltype(NBK_)::value;              // block slots of this copy
+        double acc64[NBK > 0 ? NBK : 1][16];
 #pragma unroll
-        for (int b = 0; b < BW; ++b)
+        for (int b = 0; b < NBK; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
-        const int kbuf = cur << 16;
-        auto frag = [&](int base, int ks, int lo) __attribute__((always_inline)) {
-            return *reinterpret_cast<const f16x8*>(smem + (base ^ ((ks << 5) | kbuf)) + lo * IMG);
-        };
-        auto products = [&](auto ALL_, auto NL_) __attribute__((always_inline)) {
-            constexpr bool ALL = decltype(ALL_)::value;
-            constexpr int NL = decltype(NL_)::value;
+            for (int r = 0; r < 16; ++r) acc64[b][r] = 0.0;
+        for (int st = 0; st < nst; ++st) {
+            const int cur = st & 1;
+            if (!MF) {
+                if (st + 1 < nst) stage_write(cur ^ 1, st + 1);
+                if (st + 2 < nst) stage_load(st + 2);
+            }
+            if constexpr (NBK > 0) {
+                f32x16 acc[NBK];
+#pragma unroll
+                for (int b = 0; b < NBK; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+                const int kbuf = cur << 16;
+                auto frag = [&](int base, int ks, int lo) __attribute__((always_inline)) {
+                    return *reinterpret_cast<const f16x8*>(smem + (base ^ ((ks << 5) | kbuf)) + lo * IMG);
+                };
+                auto products = [&](auto ALL_, auto NL_) __attribute__((always_inline)) {
+                    constexpr bool ALL = decltype(ALL_)::value;
+                    constexpr int NL = decltype(NL_)::value;
 #pragma unroll 4
-            for (int ks = 0; ks < KS; ++ks) {
+                    for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-                for (int b = 0; b < NL; ++b) {
-                    if (!ALL && !live[b]) continue;
-                    const f16x8 ah = frag(a_base[b], ks, 0), al = frag(a_base[b], ks, 1);
-                    const f16x8 bh = frag(b_base[b], ks, 0), bl = frag(b_base[b], ks, 1);
-                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[b], 0, 0, 0);
-                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[b], 0, 0, 0);
-                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[b], 0, 0, 0);
+                        for (int b = 0; b < NL; ++b) {
+                            if (!ALL && !live[b]) continue;
+                            const f16x8 ah = frag(a_base[b], ks, 0), al = frag(a_base[b], ks, 1);
+                            const f16x8 bh = frag(b_base[b], ks, 0), bl = frag(b_base[b], ks, 1);
+                            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[b], 0, 0, 0);
+                            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[b], 0, 0, 0);
+                            acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[b], 0, 0, 0);
+                        }
+                    }
+                };
+                const bool all_here = NBK == BW ? all_live : two_live;          // every slot of this copy live (a scalar per wave)
+                if (WC_RX_ABL & 4) {}
+                else if (all_here) products(std::true_type{}, std::integral_constant<int, NBK>{});
+                else if (NBK == BW && two_live) products(std::true_type{}, std::integral_constant<int, NBK < 2 ? NBK : 2>{});
+                else if (any_live) products(std::false_type{}, std::integral_constant<int, NBK>{});
+                if (WC_RX_ABL & 8) {}
+                else if (NBK == BW && two_live) {
+#pragma unroll
+                    for (int b = 0; b < (NBK < 2 ? NBK : 2); ++b)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc64[b][r] += (double)acc[b][r];
+                } else if (any_live) {
+#pragma unroll
+                    for (int b = 0; b < NBK; ++b)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc64[b][r] += (double)acc[b][r];
                 }
             }
-        };
-        if (WC_RX_ABL & 4) {}
-        else if (all_live) products(std::true_type{}, std::integral_constant<int, BW>{});
-        else if (two_live) products(std::true_type{}, std::integral_constant<int, 2>{});
-        else if (any_live) products(std::false_type{}, std::integral_constant<int, BW>{});
-        if (WC_RX_ABL & 8) {}
-        else if (two_live) {
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc64[b][r] += (double)acc[b][r];
-        } else if (any_live) {
-#pragma unroll
-            for (int b = 0; b < BW; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc64[b][r] += (double)acc[b][r];
+            if (MF) {
+                if (st + 1 < nst) stage_write(cur ^ 1, st + 1);
+                if (st + 2 < nst) stage_load(st + 2);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    }
-
-    double* P = a.P + z * (int64_t)C * C;
 #pragma unroll
-    for (int b = 0; b < BW; ++b) {
-        if (!live[b]) continue;
-        const int j = jb[b] * 32 + l31;
-        const double isj = 1.0 / (double)sc_sh[j];
+        for (int b = 0; b < NBK; ++b) {
+            if (!live[b]) continue;
+            const int j = jb[b] * 32 + l31;
+            const double isj = 1.0 / (double)sc_sh[j];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = ib[b] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            P[(int64_t)i * C + j] = acc64[b][r] * isj / (double)sc_sh[i];
+            for (int r = 0; r < 16; ++r) {
+                const int i = ib[b] * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                P[(int64_t)i * C + j] = acc64[b][r] * isj / (double)sc_sh[i];
+            }
         }
-    }
+    };
+    constexpr int NBK_B = BAL ? 2 : 0;            // waves 4-7: two blocks each (C = 256, balanced) | none ((type * 8 + wave) * 3 >= 10 at C = 128)
+    static_assert(BAL || (4 * BW >= NBLK), "C = 128: waves 4-7 own no block");
+    if (WC_RX_STAGGER && wave >= 4) run(std::true_type{}, std::integral_constant<int, NBK_B>{});
+    else run(std::false_type{}, std::integral_constant<int, BW>{});
     // column sums / the diagonal: the row groups' per-thread sums are already in LDS, thread (rgrp, c4) at slot tid = rgrp * C4 + c4
     __syncthreads();
     if (want_csum) {
